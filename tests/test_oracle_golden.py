@@ -1,0 +1,167 @@
+"""Pin the CPU oracle against the reference's own test vectors.
+
+* tests/golden/case_test_vectors.json  <- /root/reference/tests/case_test.py
+* tests/golden/lj3d_valid.npz          <- /root/reference/tests/3D_LJ_3_1214every1/valid.h5
+  with the "CheatingModel" protocol of /root/reference/tests/rollout_test.py:92-195.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import lb_oracle as O
+
+
+@pytest.fixture(scope="module")
+def vec(golden_dir):
+    with open(os.path.join(golden_dir, "case_test_vectors.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module", params=["float32", "float64"])
+def case_and_data(request, vec):
+    md = vec["metadata"]
+    bounds = np.array(md["bounds"])
+    box = bounds[:, 1] - bounds[:, 0]
+    case = O.case_builder(box, md, vec["input_seq_length"], vec["cfg_neighbors"],
+                          vec["cfg_model"], noise_std=vec["noise_std"], dtype=request.param)
+    pos = np.array(vec["position_data"])
+    pt = np.array(vec["particle_types"])
+    return case, pos, pt
+
+
+def test_allocate_matches_case_test(case_and_data, vec):
+    case, pos, pt = case_and_data
+    exp = vec["expected"]
+    _, features, target, nbrs = case.allocate(None, (pos, pt))
+    # case_test.py:77-82 - exact neighbor idx, in the reference's edge ORDER
+    assert (nbrs.idx == np.array(exp["neighbors_idx"])).all()
+    assert not nbrs.did_buffer_overflow
+    # case_test.py:86-100
+    assert np.isclose(target["vel"], np.array(exp["target_vel"])).all()
+    assert np.isclose(target["acc"], np.array(exp["target_acc"]), atol=1e-7).all()
+    # case_test.py:102-114
+    assert np.isclose(features["vel_hist"], np.array(exp["vel_hist"]), atol=1e-7).all()
+    # case_test.py:116-137
+    r0 = vec["metadata"]["default_connectivity_radius"]
+    nd = np.array(exp["most_recent_displacement"]) / r0
+    assert np.isclose(features["rel_disp"], nd, atol=1e-6).all()
+    assert np.isclose(features["rel_dist"], ((nd**2).sum(-1, keepdims=True)) ** 0.5, atol=1e-6).all()
+
+
+def test_preprocess_equals_allocate(case_and_data):
+    # case_test.py:139-148
+    case, pos, pt = case_and_data
+    _, _, _, nbrs = case.allocate(None, (pos, pt))
+    _, _, _, nbrs2 = case.preprocess(None, (pos, pt), 0.0, nbrs, 0)
+    assert (nbrs.idx == nbrs2.idx).all()
+
+
+def test_preprocess_unroll(case_and_data, vec):
+    # case_test.py:150-163
+    case, pos, pt = case_and_data
+    _, _, _, nbrs = case.allocate(None, (pos, pt))
+    _, _, target, _ = case.preprocess(None, (pos, pt), 0.0, nbrs, 1)
+    assert np.isclose(target["acc"], np.array(vec["expected"]["target_acc_unroll1"]), atol=1e-7).all()
+
+
+def test_integrate(case_and_data, vec):
+    # case_test.py:195-206 (periodic wrap: 0.9 + 0.3 -> 0.2)
+    case, pos, pt = case_and_data
+    acc = {"acc": np.array(vec["expected"]["integrate_acc"])}
+    new_pos = case.integrate(acc, pos[:, :3])
+    assert np.isclose(new_pos, pos[:, 3]).all()
+
+
+def _lj(golden_dir):
+    d = np.load(os.path.join(golden_dir, "lj3d_valid.npz"))
+    with open(os.path.join(golden_dir, "lj3d_metadata.json")) as f:
+        md = json.load(f)
+    return d["position"], d["particle_type"], md
+
+
+@pytest.mark.parametrize("n_extrap_steps", [0, 5, 10])
+def test_lj_cheating_model_rollout(golden_dir, n_extrap_steps):
+    """rollout_test.py:68-195.  H5Dataset(split=valid, isl=3, extra=100).get_trajectory(0)
+    = frames [0, 103) transposed to (N, T, dim) (data/data.py:199-225)."""
+    position, ptype, md = _lj(golden_dir)
+    isl, n_rollout = 3, 100
+    positions = np.transpose(position[: isl + n_rollout], (1, 0, 2)).astype(np.float64)
+    bounds = np.array(md["bounds"])
+    box = bounds[:, 1] - bounds[:, 0]
+    disp, shift = O.space_periodic(box)
+    stats = O.get_dataset_stats(md, False, 0.0)
+    case = O.case_builder(box, md, isl, noise_std=0.0)
+
+    vels = disp(positions[:, 1:], positions[:, :-1])
+    accs = vels[:, 1:] - vels[:, :-1]
+    a = stats["acceleration"]
+    accs = (accs - a["mean"]) / a["std"]
+
+    # "proof that the above model works" (rollout_test.py:132-140)
+    pred_pos = shift(positions[:, isl - 1], vels[:, isl - 2] + (a["mean"] + accs[:, isl - 2] * a["std"]))
+    assert np.isclose(pred_pos.astype(np.float32), positions[:, isl], atol=1e-6).all()
+
+    def cheating_apply(params, state, sample):
+        i = state["counter"]
+        return {"acc": accs[:, min(i, accs.shape[1] - 1)]}, {"counter": i + 1}  # JAX clamps OOB
+
+    _, nbrs = case.allocate_eval((positions[:, :isl], ptype))
+    # box 5, r_c 3 -> cutoff >= box/3 -> no cell list (all-pairs candidate branch)
+    assert nbrs.cell_capacity is None
+    preds, metrics, _ = O.eval_batched_rollout(
+        cheating_apply, case, None, {"counter": isl - 2}, (positions[None], ptype[None]), nbrs,
+        n_rollout_steps=n_rollout, t_window=isl, n_extrap_steps=n_extrap_steps)
+    assert preds.shape[1] == n_rollout + n_extrap_steps
+    assert np.isclose(metrics[0]["mse"].mean(), 0.0, atol=1e-6)
+    full = np.concatenate([np.transpose(positions[:, :isl], (1, 0, 2)), preds[0]], axis=0)
+    gt = np.transpose(positions, (1, 0, 2))
+    assert np.isclose(full[100, 0], gt[100, 0], atol=1e-6).all()
+    assert "mse20" in metrics[0] and metrics[0]["mse20"].shape == (20,)
+    assert "mse100" not in metrics[0]  # only ranges strictly shorter than T (metrics.py:94-96)
+
+
+def test_neighbor_list_celllist_matches_bruteforce():
+    """Cell-list candidates + prune == brute-force all-pairs set (periodic, 2D and 3D)."""
+    rng = np.random.default_rng(0)
+    for dim, n, box, rc in [(2, 400, [1.0, 1.0], 0.08), (3, 500, [1.0, 2.0, 1.5], 0.21)]:
+        box = np.array(box)
+        pos = rng.uniform(0, 1, size=(n, dim)) * box
+        disp, _ = O.space_periodic(box)
+        nl = O.neighbor_list(disp, box, rc, 1.25).allocate(pos)
+        assert nl.cell_capacity is not None
+        got = O.canonical_edges(nl.idx, n)
+        d2 = (disp(pos[:, None, :], pos[None, :, :]) ** 2).sum(-1)  # [sender i, candidate j]
+        s, r = np.nonzero(d2 < rc * rc)
+        want = np.stack([r, s]).astype(np.int32)
+        want = want[:, np.lexsort((want[1], want[0]))]
+        assert got.shape == want.shape and (got == want).all()
+        assert nl.max_occupancy == int(nl.occupancy * 1.25)
+        # update with the frozen capacities reproduces the list; moving particles closer overflows
+        nl2 = nl.update(pos)
+        assert (nl2.idx == nl.idx).all() and not nl2.did_buffer_overflow
+        squeezed = pos * 0.5
+        assert nl.update(squeezed).did_buffer_overflow
+
+
+def test_gns_shapes_and_padding_invariance():
+    """Padded edges (id = N) must not change node outputs."""
+    rng = np.random.default_rng(1)
+    n, dim, rc = 300, 2, 0.11
+    box = np.array([1.0, 1.0])
+    md = dict(periodic_boundary_conditions=[True, True], default_connectivity_radius=rc,
+              bounds=[[0, 1], [0, 1]], num_particles_max=n, acc_mean=[0, 0], acc_std=[1e-3, 1e-3],
+              vel_mean=[0, 0], vel_std=[5e-3, 5e-3])
+    case = O.case_builder(box, md, 6)
+    p0 = rng.uniform(0, 1, size=(n, 1, dim))
+    pos = np.mod(p0 + np.cumsum(rng.normal(0, 2e-3, size=(n, 6, dim)), axis=1), 1.0)
+    pt = np.zeros(n, np.int32)
+    feats, nbrs = case.allocate_eval((pos, pt))
+    assert feats["vel_hist"].shape == (n, 10) and feats["rel_disp"].shape[1] == 2
+    params = O.gns_init(np.random.default_rng(2), node_in=10, edge_in=3, particle_dimension=dim,
+                        num_mp_steps=3)
+    a = O.gns_apply(params, feats, pt, num_mp_steps=3)["acc"]
+    b = O.gns_apply(params, feats, pt, num_mp_steps=3, skip_padding=True)["acc"]
+    assert a.shape == (n, dim) and a.dtype == np.float32
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-6)
