@@ -1,0 +1,214 @@
+/*
+ * lbhip.h - C ABI of liblbhip.so: the MI355X (gfx950) rollout engine that sits behind
+ * LagrangeBench's case_setup / models.GNS / evaluate.rollout Python API.
+ *
+ * The reference (tumaer/lagrangebench) is pure Python/JAX and has no FFI of its own; each
+ * entry point below replaces the reference function named in its comment (paths relative to
+ * the reference repo root).  A maintainer binds them with ctypes - see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer suffixed _dev is DEVICE memory owned by the caller (e.g. a torch tensor);
+ *     the library owns only its opaque handles and internal scratch.
+ *   - all work is enqueued on the hipStream_t given to lb_engine_create(); only the calls
+ *     documented as "host-synchronous" block.
+ *   - return value: 0 = LB_OK, < 0 = error (lb_strerror()).  Neighbor-list overflow is NOT an
+ *     error: like the reference (evaluate/rollout.py:134-151) it is a flag the driver polls.
+ *   - positions/targets are fp64 (the reference's default dtype, defaults.py:22); network
+ *     inputs/outputs are fp32 (runner.py:71-72).  Indices are int32.
+ *   - B independent trajectories ("batch", the reference's vmap axis rollout.py:226-228) of
+ *     N particles each are processed as one disjoint graph of B*N nodes.
+ */
+#ifndef LBHIP_H
+#define LBHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LB_OK 0
+#define LB_ERR_ARG (-1)         /* bad argument / unsupported configuration            */
+#define LB_ERR_HIP (-2)         /* a HIP runtime call failed (message via lb_strerror) */
+#define LB_ERR_STATE (-3)       /* call order violated (e.g. update before allocate)   */
+#define LB_ERR_DENSITY (-4)     /* a cell stencil / row exceeds the LDS tile bounds    */
+#define LB_ERR_UNSUPPORTED (-5) /* valid in the reference, not built yet               */
+
+#define LB_FORCE_NONE 0
+#define LB_FORCE_PIECEWISE 1 /* f = pos[axis] > split ? f_hi : f_lo (RPF body force, DAM gravity) */
+#define LB_FORCE_BUFFER 2    /* caller supplies (B,N,dim) fp64 every step via lb_set_force()       */
+
+typedef struct lb_engine lb_engine;
+typedef struct lb_gns lb_gns;
+
+/* What case_builder(box, metadata, input_seq_length, cfg_neighbors, cfg_model, noise_std,
+ * external_force_fn, dtype) closes over: case_setup/case.py:62-140.  Normalisation stats are the
+ * OUTPUT of get_dataset_stats (data/utils.py:9-45), i.e. noise already folded into std. */
+typedef struct lb_case_desc {
+  int32_t dim;          /* 2 or 3 */
+  int32_t n_particles;  /* N per trajectory (metadata["num_particles_max"]) */
+  int32_t batch;        /* B trajectories advanced together */
+  int32_t isl;          /* input_seq_length (>= 2) */
+  int32_t periodic;     /* any(metadata["periodic_boundary_conditions"]) - case.py:104-108 */
+  int32_t has_bound;    /* "bound" node feature: not any(pbc) - features.py:87-103 */
+  int32_t has_vel_mag;  /* cfg_model.magnitude_features - features.py:80-85 */
+  int32_t force_kind;   /* LB_FORCE_* : external_force_fn - features.py:105-107 */
+  int32_t force_axis;
+  int32_t reserved0;
+  double box[3];
+  double r_cutoff;      /* metadata["default_connectivity_radius"] */
+  double capacity_multiplier; /* cfg_neighbors.multiplier */
+  double vel_mean[3], vel_std[3], acc_mean[3], acc_std[3];
+  double bound_lo[3], bound_hi[3]; /* metadata["bounds"] */
+  double force_split;
+  double force_lo[3], force_hi[3];
+} lb_case_desc;
+
+/* GNS hyper-parameters: models/gns.py:36-63 (runner.py:205-216). */
+typedef struct lb_gns_desc {
+  int32_t latent_size;        /* 128 (GNS-10-128); 64 not built yet */
+  int32_t blocks_per_step;    /* num_mlp_layers; only 2 is built */
+  int32_t num_mp_steps;
+  int32_t embedding_size;     /* particle_type_embedding_size (16) */
+  int32_t num_particle_types; /* NodeType.SIZE = 9; <= 1 disables the embedding */
+  int32_t node_in;            /* feature width WITHOUT the embedding: K*dim [+K] [+2dim] [+dim] */
+  int32_t edge_in;            /* dim + 1 */
+  int32_t out_dim;            /* particle_dimension */
+} lb_gns_desc;
+
+const char* lb_strerror(int code);
+const char* lb_last_error(void);
+int lb_version(void);
+
+/* ---- engine / state ------------------------------------------------------------------ */
+
+/* case_builder(...) - case_setup/case.py:62.  stream = hipStream_t (NULL = default stream). */
+int lb_engine_create(const lb_case_desc* desc, void* hip_stream, lb_engine** out);
+void lb_engine_destroy(lb_engine* eng);
+
+/* sample[1] of the reference's (pos, particle_type) tuple: (B,N) int32. */
+int lb_set_particle_type(lb_engine* eng, const int32_t* ptype_dev);
+
+/* LB_FORCE_BUFFER only: (B,N,dim) fp64 = vmap(external_force_fn)(most_recent_position). */
+int lb_set_force(lb_engine* eng, const double* force_dev);
+
+/* Load the position window sample[0][:, t0:t0+isl] from a (B,N,T,dim) fp64 trajectory
+ * (the layout H5Dataset.get_trajectory returns, data/data.py:199-225) into the engine's SoA
+ * ring, and reset the step counter to `step` (normally 0).  rollout.py:113. */
+int lb_load_window(lb_engine* eng, const double* traj_dev, int32_t T, int32_t t0, int32_t step);
+
+/* Copy the current window back out as (B,N,isl,dim) fp64 (oldest frame first). */
+int lb_read_window(lb_engine* eng, double* win_out_dev);
+
+/* ---- neighbor list: jax_sph.jax_md.partition.neighbor_list (3rd party) ----------------
+ * constructed case.py:120-130; used .allocate case.py:184-186, .update case.py:188-190. */
+
+/* neighbor_fn.allocate(most_recent_position): HOST-SYNCHRONOUS sizing.  Builds the list for the
+ * current window's newest frame, then freezes cell_capacity = int(max cell occupancy * mult)
+ * and E_cap = int(max_b occupancy_b * mult) (clamped like jax-md).  Outputs may be NULL. */
+int lb_nl_allocate(lb_engine* eng, int32_t* cell_capacity_out, int32_t* e_cap_out,
+                   int32_t* occupancy_out /* [B] host */);
+
+/* Pin the frozen capacities explicitly (e.g. to mirror a reference NeighborList). */
+int lb_nl_set_capacity(lb_engine* eng, int32_t cell_capacity, int32_t e_cap);
+
+/* neighbors.update(most_recent_position): asynchronous rebuild with the frozen capacities.
+ * Sets the per-trajectory did_buffer_overflow flags (read them with lb_nl_read_flags). */
+int lb_nl_update(lb_engine* eng);
+
+/* did_buffer_overflow per trajectory -> (B,) int32 device buffer (async copy). */
+int lb_nl_read_flags(lb_engine* eng, int32_t* overflow_out_dev);
+
+/* NeighborList.idx in the reference's format: (B, 2, E_cap) int32, row 0 receivers, row 1
+ * senders, trajectory-local ids, padding = N (features.py:110).  Edge ORDER is the engine's
+ * canonical one - sorted by (receiver, sender) - not jax-md's slot order.  n_edges_out_dev
+ * (B,) int32 gets the real edge counts (may be NULL). */
+int lb_nl_read_idx(lb_engine* eng, int32_t* idx_out_dev, int32_t* n_edges_out_dev);
+
+/* ---- features: feature_transform - case_setup/features.py:47-126 ---------------------- */
+
+/* Node features as fp64 in reference column order:
+ *   vel_hist (B,N,K*dim) time-major; vel_mag (B,N,K) or NULL; bound (B,N,2*dim) or NULL;
+ *   force (B,N,dim) or NULL. */
+int lb_node_features(lb_engine* eng, double* vel_hist_out_dev, double* vel_mag_out_dev,
+                     double* bound_out_dev, double* force_out_dev);
+
+/* Edge features of the CURRENT list in lb_nl_read_idx order: rel_disp (B,E_cap,dim) and
+ * rel_dist (B,E_cap,1) fp64.  Padded rows hold what the reference's clamped gather produces
+ * (disp(pos[N-1], pos[N-1]) = 0). */
+int lb_edge_features(lb_engine* eng, double* rel_disp_out_dev, double* rel_dist_out_dev);
+
+/* ---- model: GNS - models/gns.py:35-171 ------------------------------------------------ */
+
+/* Weights are fp32 HOST arrays in haiku layout (Linear w is (in,out) row-major), concatenated in
+ * module creation order:
+ *   [embed (types,emb)] then for each MLP in order enc_node, enc_edge, (proc_k_edge, proc_k_node)
+ *   for k < num_mp_steps, decoder:  w0, b0, w1, b1, [ln_scale, ln_offset]  (decoder: no LN).
+ * n_floats is the total length (checked). */
+int lb_gns_create(lb_engine* eng, const lb_gns_desc* desc, const float* weights_host,
+                  int64_t n_floats, lb_gns** out);
+void lb_gns_destroy(lb_gns* gns);
+
+/* model.apply(params, state, (features, particle_type)) -> {"acc": (B,N,dim) fp32}
+ * (rollout.py:59) on the engine's current window and neighbor list. */
+int lb_gns_forward(lb_engine* eng, lb_gns* gns, float* acc_out_dev);
+
+/* Debug/parity taps: node latents after the encoder and after each MP step
+ * ((num_mp_steps+1), B*N, latent) fp32, or NULL. */
+int lb_gns_set_tap(lb_gns* gns, float* node_latents_out_dev);
+
+/* ---- integrator + driver -------------------------------------------------------------- */
+
+/* _forward_eval minus the model call - rollout.py:61-73 with case.integrate (case.py:230-259):
+ * next = shift(p[-1], disp(p[-1], p[-2]) + acc_mean + acc*acc_std); kinematic particles
+ * (utils.py:28-35) take target (B,N,dim) fp64 instead; the window advances by one frame and
+ * the step counter increments.  If pred_out_dev != NULL the new frame is also written to
+ * pred_out_dev[b][step][:][:] of a (B,pred_T,N,dim) buffer (rollout.py:165-167). */
+int lb_integrate(lb_engine* eng, const float* acc_dev, const double* target_dev,
+                 double* pred_out_dev, int32_t pred_T);
+
+/* case.integrate(normalized_in, position_sequence) alone - case.py:230-259 - stateless:
+ * mode 0 "acc": shift(p[-1], disp(p[-1],p[-2]) + acc_mean + pred*acc_std);
+ * mode 1 "vel": shift(p[-1], vel_mean + pred*vel_std).  ("pos" is the identity: host side.)
+ * pred (B,N,dim) fp32; pos_seq (B,N,T,dim) fp64 (last two frames used); out (B,N,dim) fp64. */
+int lb_case_integrate(lb_engine* eng, int32_t mode, const float* pred_dev, const double* pos_seq_dev,
+                      int32_t T, double* next_out_dev);
+
+/* _eval_batched_rollout's step loop - rollout.py:125-169 - fully on the device:
+ * for step in [0, n_steps): nl_update -> features -> GNS -> integrate -> store prediction.
+ * traj_dev (B,N,T,dim) fp64 supplies the initial window (frames [0,isl)) and the kinematic
+ * targets (frame isl+step, clamped to T-1 as JAX clamps the gather, rollout.py:159).
+ * HOST-SYNCHRONOUS at the end.  On neighbor overflow it re-allocates (allocate_eval semantics,
+ * rollout.py:139-151) and resumes from the overflowed step; *n_realloc_out counts that. */
+int lb_rollout(lb_engine* eng, lb_gns* gns, const double* traj_dev, int32_t T, int32_t n_steps,
+               double* pred_out_dev, int32_t* n_realloc_out);
+
+/* MetricsComputer.mse / .mae per step - evaluate/metrics.py:139-147: mean over (N,dim) of
+ * disp(pred,target)^2 (|.|) with the case's displacement.  Both rollouts are (B,T,N,dim) fp64,
+ * the layout metrics_computer receives (rollout.py:171-176).  Outputs (B,n_steps) fp64,
+ * either may be NULL. */
+int lb_metrics(lb_engine* eng, const double* pred_dev, int32_t pred_T, const double* target_dev,
+               int32_t target_T, int32_t n_steps, double* mse_out_dev, double* mae_out_dev);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------ */
+
+/* Enable per-kernel-class HIP-event timing on the engine stream.  Classes: see lb_timer_name. */
+int lb_timers_enable(lb_engine* eng, int32_t on);
+int lb_timers_reset(lb_engine* eng);
+int32_t lb_timer_count(void);
+const char* lb_timer_name(int32_t cls);
+/* Accumulated milliseconds and launch count of one class (host-synchronous). */
+int lb_timer_get(lb_engine* eng, int32_t cls, double* ms_out, int64_t* launches_out);
+
+/* Current totals: real edges over all trajectories, E_cap, cell capacity (host-synchronous). */
+int lb_stats(lb_engine* eng, int64_t* n_edges_total, int32_t* e_cap, int32_t* cell_capacity);
+
+/* Stand-alone jraph.segment_sum(messages, receivers, N) on the CURRENT list (gns.py:117-119):
+ * msg (E_total,D) fp32 in engine edge order -> out (B*N,D) fp32.  Used by tests and by the
+ * aggregation-roofline leg of bench.py. */
+int lb_segment_sum(lb_engine* eng, const float* msg_dev, float* out_dev, int32_t D);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBHIP_H */

@@ -1,0 +1,656 @@
+// lb_api.hip - the C ABI of liblbhip.so (include/lbhip.h): engine object, buffers, weight
+// packing, the device-resident rollout driver and the HIP-event timers used by bench.py.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "lb_internal.h"
+
+thread_local std::string g_lb_err;
+
+int lb_fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_lb_err = buf;
+  return code;
+}
+
+extern "C" const char* lb_strerror(int code) {
+  switch (code) {
+    case LB_OK: return "ok";
+    case LB_ERR_ARG: return "bad argument";
+    case LB_ERR_HIP: return "HIP runtime error";
+    case LB_ERR_STATE: return "call order violated";
+    case LB_ERR_DENSITY: return "cell stencil / row exceeds LDS tile bounds";
+    case LB_ERR_UNSUPPORTED: return "not built yet";
+    default: return "unknown";
+  }
+}
+extern "C" const char* lb_last_error(void) { return g_lb_err.c_str(); }
+extern "C" int lb_version(void) { return 100; }
+
+// ---------------------------------------------------------------------------------- timers
+static const char* k_timer_names[LB_T_COUNT] = {
+    "cells", "neighbors", "node_features", "enc_node", "enc_edge", "edge_mlp",
+    "aggregate", "node_mlp", "decoder", "integrate", "misc"};
+
+static hipEvent_t lb_get_event(lb_engine* e) {
+  if (!e->epool.empty()) {
+    hipEvent_t ev = e->epool.back();
+    e->epool.pop_back();
+    return ev;
+  }
+  hipEvent_t ev;
+  (void)hipEventCreate(&ev);
+  return ev;
+}
+
+void lb_tic(lb_engine* e, int cls) {
+  if (!e->timers_on) return;
+  lb_timer_rec r;
+  r.a = lb_get_event(e);
+  r.b = lb_get_event(e);
+  r.cls = cls;
+  (void)hipEventRecord(r.a, e->stream);
+  e->trecs.push_back(r);
+}
+
+void lb_toc(lb_engine* e) {
+  if (!e->timers_on || e->trecs.empty()) return;
+  (void)hipEventRecord(e->trecs.back().b, e->stream);
+}
+
+static void lb_timers_collect(lb_engine* e) {
+  if (e->trecs.empty()) return;
+  (void)hipStreamSynchronize(e->stream);
+  for (auto& r : e->trecs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      e->t_ms[r.cls] += ms;
+      e->t_n[r.cls] += 1;
+    }
+    e->epool.push_back(r.a);
+    e->epool.push_back(r.b);
+  }
+  e->trecs.clear();
+}
+
+extern "C" int lb_timers_enable(lb_engine* e, int32_t on) {
+  if (!e) return lb_fail(LB_ERR_ARG, "null engine");
+  lb_timers_collect(e);
+  e->timers_on = on != 0;
+  return LB_OK;
+}
+extern "C" int lb_timers_reset(lb_engine* e) {
+  if (!e) return lb_fail(LB_ERR_ARG, "null engine");
+  lb_timers_collect(e);
+  for (int i = 0; i < LB_T_COUNT; ++i) {
+    e->t_ms[i] = 0;
+    e->t_n[i] = 0;
+  }
+  return LB_OK;
+}
+extern "C" int32_t lb_timer_count(void) { return LB_T_COUNT; }
+extern "C" const char* lb_timer_name(int32_t cls) {
+  return (cls >= 0 && cls < LB_T_COUNT) ? k_timer_names[cls] : "";
+}
+extern "C" int lb_timer_get(lb_engine* e, int32_t cls, double* ms_out, int64_t* launches_out) {
+  if (!e || cls < 0 || cls >= LB_T_COUNT) return lb_fail(LB_ERR_ARG, "bad timer class");
+  lb_timers_collect(e);
+  if (ms_out) *ms_out = e->t_ms[cls];
+  if (launches_out) *launches_out = e->t_n[cls];
+  return LB_OK;
+}
+
+// ---------------------------------------------------------------------------------- engine
+template <typename T>
+static int lb_alloc(T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  LB_HIP(hipMalloc((void**)p, n * sizeof(T)));
+  return LB_OK;
+}
+#define LB_TRY(x)          \
+  do {                     \
+    int _rc = (x);         \
+    if (_rc) return _rc;   \
+  } while (0)
+
+extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engine** out) {
+  if (!d || !out) return lb_fail(LB_ERR_ARG, "null argument");
+  if (d->dim != 2 && d->dim != 3) return lb_fail(LB_ERR_ARG, "dim must be 2 or 3 (got %d)", d->dim);
+  if (d->n_particles < 1 || d->batch < 1 || d->isl < 2)
+    return lb_fail(LB_ERR_ARG, "need n_particles>=1, batch>=1, isl>=2");
+  if (!(d->r_cutoff > 0)) return lb_fail(LB_ERR_ARG, "r_cutoff must be > 0");
+  if ((int64_t)d->n_particles * d->batch > (int64_t)1 << 30)
+    return lb_fail(LB_ERR_ARG, "B*N too large for int32 node ids");
+  lb_engine* e = new lb_engine();
+  e->desc = *d;
+  e->stream = (hipStream_t)hip_stream;
+  e->BN = (int64_t)d->n_particles * d->batch;
+  e->timers_on = false;
+  for (int i = 0; i < LB_T_COUNT; ++i) e->t_ms[i] = 0, e->t_n[i] = 0;
+  lb_geom& g = e->g;
+  memset(&g, 0, sizeof(g));
+  g.dim = d->dim;
+  g.N = d->n_particles;
+  g.B = d->batch;
+  g.isl = d->isl;
+  g.periodic = d->periodic != 0;
+  g.has_bound = d->has_bound != 0;
+  g.has_vel_mag = d->has_vel_mag != 0;
+  g.force_kind = d->force_kind;
+  g.force_axis = d->force_axis;
+  g.rc = d->r_cutoff;
+  g.rc2 = d->r_cutoff * d->r_cutoff;
+  // jax-md partition.py: box and cell_size are float32; cell list only if cutoff < box/3.
+  bool use_cells = true;
+  for (int k = 0; k < d->dim; ++k) {
+    const float b32 = (float)d->box[k];
+    if (!((float)d->r_cutoff < b32 / 3.0f)) use_cells = false;
+  }
+  g.use_cell_list = use_cells;
+  g.ncells = 1;
+  for (int k = 0; k < 3; ++k) {
+    g.ncell[k] = 1;
+    g.cell_size[k] = 1.0;
+    g.box[k] = k < d->dim ? d->box[k] : 1.0;
+    g.half_box[k] = g.box[k] * 0.5;
+    g.vel_mean[k] = d->vel_mean[k];
+    g.vel_std[k] = d->vel_std[k];
+    g.acc_mean[k] = d->acc_mean[k];
+    g.acc_std[k] = d->acc_std[k];
+    g.bound_lo[k] = d->bound_lo[k];
+    g.bound_hi[k] = d->bound_hi[k];
+    g.force_lo[k] = d->force_lo[k];
+    g.force_hi[k] = d->force_hi[k];
+  }
+  g.force_split = d->force_split;
+  if (use_cells) {
+    for (int k = 0; k < d->dim; ++k) {
+      const float b32 = (float)d->box[k];
+      const float cps = floorf(b32 / (float)d->r_cutoff);
+      g.ncell[k] = (int)cps;
+      g.cell_size[k] = (double)(b32 / cps);
+      g.ncells *= g.ncell[k];
+    }
+    g.nstencil = d->dim == 2 ? 9 : 27;
+  } else {
+    g.nstencil = 1;
+    // all-pairs candidates: one "cell" per trajectory, staged whole in LDS
+    if (d->n_particles > LB_MAX_STENCIL_CAND) {
+      delete e;
+      return lb_fail(LB_ERR_UNSUPPORTED,
+                     "box < 3*r_cutoff (no cell list) supports at most %d particles",
+                     LB_MAX_STENCIL_CAND);
+    }
+    for (int k = 0; k < d->dim; ++k) g.cell_size[k] = 1e300;  // every particle -> cell 0
+  }
+  const int K = d->isl - 1;
+  g.node_in = K * d->dim + (g.has_vel_mag ? K : 0) + (g.has_bound ? 2 * d->dim : 0) +
+              (g.force_kind != LB_FORCE_NONE ? d->dim : 0);
+  g.kpad = 64;  // refined by lb_gns_create (32 or 64)
+
+  const int64_t BN = e->BN;
+  const size_t nc = (size_t)g.B * g.ncells;
+  int rc = LB_OK;
+  auto A = [&](int r) { if (!rc) rc = r; };
+  A(lb_alloc(&e->win, (size_t)d->isl * d->dim * BN));
+  A(lb_alloc(&e->ptype, (size_t)BN));
+  A(lb_alloc(&e->ctrl, 1));
+  A(lb_alloc(&e->cell_of, (size_t)BN));
+  A(lb_alloc(&e->cell_count, 2 * nc));  // cell_count | cell_fill contiguous (one memset)
+  A(lb_alloc(&e->cell_start, nc + 1));
+  A(lb_alloc(&e->cell_part, (size_t)BN));
+  A(lb_alloc(&e->deg, (size_t)BN));
+  A(lb_alloc(&e->row_ptr, (size_t)BN + 1));
+  A(lb_alloc(&e->overflow, (size_t)g.B));
+  A(lb_alloc(&e->nedges_b, (size_t)g.B));
+  A(lb_alloc(&e->acc, (size_t)BN * 4));
+  if (rc) { lb_engine_destroy(e); return rc; }
+  e->cell_fill = e->cell_count + nc;
+  if (hipHostMalloc((void**)&e->ctrl_host, sizeof(lb_ctrl)) != hipSuccess) {
+    lb_engine_destroy(e);
+    return lb_fail(LB_ERR_HIP, "hipHostMalloc failed");
+  }
+  lb_ctrl c0;
+  memset(&c0, 0, sizeof(c0));
+  c0.overflow_step = -1;
+  if (hipMemcpy(e->ctrl, &c0, sizeof(c0), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(e->ptype, 0, sizeof(int32_t) * BN) != hipSuccess ||
+      hipMemset(e->row_ptr, 0, sizeof(int32_t) * (BN + 1)) != hipSuccess) {
+    lb_engine_destroy(e);
+    return lb_fail(LB_ERR_HIP, "engine init copies failed");
+  }
+  *out = e;
+  return LB_OK;
+}
+
+extern "C" void lb_engine_destroy(lb_engine* e) {
+  if (!e) return;
+  lb_timers_collect(e);
+  for (auto ev : e->epool) (void)hipEventDestroy(ev);
+  void* bufs[] = {e->win, e->ptype, e->force, e->ctrl, e->cell_of, e->cell_count, e->cell_start,
+                  e->cell_part, e->deg, e->row_ptr, e->senders, e->receivers, e->efeat, e->efeat64,
+                  e->overflow, e->nedges_b, e->xnode, e->nlat, e->agg, e->psr, e->elat, e->msg,
+                  e->acc};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (e->ctrl_host) (void)hipHostFree(e->ctrl_host);
+  delete e;
+}
+
+// Edge-sized buffers grow geometrically; contents are not preserved (rebuilt every step).
+int lb_ensure_edges(lb_engine* e, int64_t need) {
+  if (need <= e->e_alloc && e->senders) return LB_OK;
+  LB_HIP(hipStreamSynchronize(e->stream));
+  int64_t n = std::max<int64_t>(need + need / 8 + 1024, 4096);
+  void* old[] = {e->senders, e->receivers, e->efeat, e->efeat64, e->elat, e->msg};
+  for (void* b : old)
+    if (b) (void)hipFree(b);
+  e->senders = e->receivers = nullptr;
+  e->efeat = nullptr;
+  e->efeat64 = nullptr;
+  e->elat = e->msg = nullptr;
+  LB_TRY(lb_alloc(&e->senders, (size_t)n));
+  LB_TRY(lb_alloc(&e->receivers, (size_t)n));
+  LB_TRY(lb_alloc(&e->efeat, (size_t)n * 8));
+  LB_TRY(lb_alloc(&e->efeat64, (size_t)n * 4));
+  LB_TRY(lb_alloc(&e->elat, (size_t)n * LB_D));
+  LB_TRY(lb_alloc(&e->msg, (size_t)n * LB_D));
+  e->e_alloc = n;
+  return LB_OK;
+}
+
+extern "C" int lb_set_particle_type(lb_engine* e, const int32_t* ptype_dev) {
+  if (!e || !ptype_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  LB_HIP(hipMemcpyAsync(e->ptype, ptype_dev, sizeof(int32_t) * e->BN, hipMemcpyDeviceToDevice,
+                        e->stream));
+  return LB_OK;
+}
+
+extern "C" int lb_set_force(lb_engine* e, const double* force_dev) {
+  if (!e || !force_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  if (e->g.force_kind != LB_FORCE_BUFFER)
+    return lb_fail(LB_ERR_STATE, "engine was not created with LB_FORCE_BUFFER");
+  if (!e->force) LB_TRY(lb_alloc(&e->force, (size_t)e->BN * e->g.dim));
+  LB_HIP(hipMemcpyAsync(e->force, force_dev, sizeof(double) * e->BN * e->g.dim,
+                        hipMemcpyDeviceToDevice, e->stream));
+  return LB_OK;
+}
+
+extern "C" int lb_load_window(lb_engine* e, const double* traj_dev, int32_t T, int32_t t0,
+                              int32_t step) {
+  if (!e || !traj_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  if (t0 < 0 || t0 + e->g.isl > T) return lb_fail(LB_ERR_ARG, "window [%d,%d) outside T=%d", t0, t0 + e->g.isl, T);
+  return lbk_load_window(e, traj_dev, T, t0, step);
+}
+
+extern "C" int lb_read_window(lb_engine* e, double* out) {
+  if (!e || !out) return lb_fail(LB_ERR_ARG, "null argument");
+  return lbk_read_window(e, out);
+}
+
+// --------------------------------------------------------------------------- neighbor list
+static int lb_check_density(lb_engine* e) {
+  if (e->ctrl_host->density_error)
+    return lb_fail(LB_ERR_DENSITY,
+                   "neighbor search: %s (limits: %d stencil candidates, %d neighbors per particle)",
+                   e->ctrl_host->density_error == 1 ? "3^dim-cell stencil too populated"
+                                                    : "a particle has too many neighbors",
+                   LB_MAX_STENCIL_CAND, LB_MAX_ROW);
+  return LB_OK;
+}
+
+extern "C" int lb_nl_allocate(lb_engine* e, int32_t* cell_capacity_out, int32_t* e_cap_out,
+                              int32_t* occupancy_out) {
+  if (!e) return lb_fail(LB_ERR_ARG, "null engine");
+  // clear the poison + thaw the capacities: this is an allocation, not an update
+  lb_ctrl* h = e->ctrl_host;
+  LB_HIP(hipMemcpyAsync(h, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, e->stream));
+  LB_HIP(hipStreamSynchronize(e->stream));
+  h->overflow_step = -1;
+  h->density_error = 0;
+  LB_HIP(hipMemcpyAsync(e->ctrl, h, sizeof(lb_ctrl), hipMemcpyHostToDevice, e->stream));
+  e->cell_capacity = 0;
+  e->e_cap = 0;
+  LB_TRY(lbk_nl_build(e, true));
+  std::vector<int32_t> occ(e->g.B);
+  LB_HIP(hipMemcpyAsync(h, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, e->stream));
+  LB_HIP(hipMemcpyAsync(occ.data(), e->nedges_b, sizeof(int32_t) * e->g.B, hipMemcpyDeviceToHost,
+                        e->stream));
+  LB_HIP(hipStreamSynchronize(e->stream));
+  LB_TRY(lb_check_density(e));
+  const double mult = e->desc.capacity_multiplier > 0 ? e->desc.capacity_multiplier : 1.25;
+  // jax-md: cell_capacity = int(max_cell_occupancy * multiplier)
+  e->cell_capacity = e->g.use_cell_list ? (int)(h->max_cell_occ * mult) : 0;
+  int32_t occ_max = 0;
+  for (int b = 0; b < e->g.B; ++b) occ_max = std::max(occ_max, occ[b]);
+  // jax-md: max_occupancy = int(occupancy * multiplier), clamped to the candidate count and N^2
+  int64_t ecap = (int64_t)(occ_max * mult);
+  const int64_t N = e->g.N;
+  int64_t cand = e->g.use_cell_list ? N * e->g.nstencil * std::max(e->cell_capacity, 1) : N * N;
+  ecap = std::min(ecap, cand);
+  ecap = std::min(ecap, N * N);
+  if (ecap * e->g.B > (int64_t)1 << 30) return lb_fail(LB_ERR_ARG, "B*E_cap exceeds int32 range");
+  e->e_cap = (int32_t)std::max<int64_t>(ecap, 1);
+  LB_TRY(lb_ensure_edges(e, (int64_t)e->e_cap * e->g.B));
+  if (cell_capacity_out) *cell_capacity_out = e->cell_capacity;
+  if (e_cap_out) *e_cap_out = e->e_cap;
+  if (occupancy_out) memcpy(occupancy_out, occ.data(), sizeof(int32_t) * e->g.B);
+  return LB_OK;
+}
+
+extern "C" int lb_nl_set_capacity(lb_engine* e, int32_t cell_capacity, int32_t e_cap) {
+  if (!e || e_cap < 1) return lb_fail(LB_ERR_ARG, "bad capacity");
+  e->cell_capacity = cell_capacity;
+  e->e_cap = e_cap;
+  return lb_ensure_edges(e, (int64_t)e_cap * e->g.B);
+}
+
+extern "C" int lb_nl_update(lb_engine* e) {
+  if (!e) return lb_fail(LB_ERR_ARG, "null engine");
+  if (e->e_cap <= 0) return lb_fail(LB_ERR_STATE, "lb_nl_update before lb_nl_allocate");
+  return lbk_nl_build(e, true);
+}
+
+extern "C" int lb_nl_read_flags(lb_engine* e, int32_t* overflow_out_dev) {
+  if (!e || !overflow_out_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  LB_HIP(hipMemcpyAsync(overflow_out_dev, e->overflow, sizeof(int32_t) * e->g.B,
+                        hipMemcpyDeviceToDevice, e->stream));
+  return LB_OK;
+}
+
+extern "C" int lb_nl_read_idx(lb_engine* e, int32_t* idx_out_dev, int32_t* n_edges_out_dev) {
+  if (!e || !idx_out_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  if (e->e_cap <= 0) return lb_fail(LB_ERR_STATE, "no neighbor list allocated");
+  return lbk_nl_export(e, idx_out_dev, n_edges_out_dev);
+}
+
+extern "C" int lb_node_features(lb_engine* e, double* vel_hist, double* vel_mag, double* bound,
+                                double* force) {
+  if (!e || !vel_hist) return lb_fail(LB_ERR_ARG, "null argument");
+  if (e->g.force_kind == LB_FORCE_BUFFER && !e->force)
+    return lb_fail(LB_ERR_STATE, "LB_FORCE_BUFFER engine: call lb_set_force first");
+  return lbk_node_features(e, nullptr, nullptr, 0, 0, vel_hist, e->g.has_vel_mag ? vel_mag : nullptr,
+                           e->g.has_bound ? bound : nullptr,
+                           e->g.force_kind != LB_FORCE_NONE ? force : nullptr);
+}
+
+extern "C" int lb_edge_features(lb_engine* e, double* rel_disp, double* rel_dist) {
+  if (!e || !rel_disp || !rel_dist) return lb_fail(LB_ERR_ARG, "null argument");
+  if (e->e_cap <= 0) return lb_fail(LB_ERR_STATE, "no neighbor list allocated");
+  return lbk_edge_features_export(e, rel_disp, rel_dist);
+}
+
+extern "C" int lb_stats(lb_engine* e, int64_t* n_edges_total, int32_t* e_cap, int32_t* cell_capacity) {
+  if (!e) return lb_fail(LB_ERR_ARG, "null engine");
+  LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, e->stream));
+  LB_HIP(hipStreamSynchronize(e->stream));
+  if (n_edges_total) *n_edges_total = e->ctrl_host->n_edges_unclamped;
+  if (e_cap) *e_cap = e->e_cap;
+  if (cell_capacity) *cell_capacity = e->cell_capacity;
+  return LB_OK;
+}
+
+extern "C" int lb_segment_sum(lb_engine* e, const float* msg_dev, float* out_dev, int32_t D) {
+  if (!e || !msg_dev || !out_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  lb_tic(e, LB_T_AGGREGATE);
+  int rc = lbk_segment_sum(e, msg_dev, out_dev, D);
+  lb_toc(e);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------- GNS
+extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w, int64_t n_floats,
+                             lb_gns** out) {
+  if (!e || !d || !w || !out) return lb_fail(LB_ERR_ARG, "null argument");
+  if (d->latent_size != LB_D) return lb_fail(LB_ERR_UNSUPPORTED, "latent_size %d not built (128 only)", d->latent_size);
+  if (d->blocks_per_step != 2) return lb_fail(LB_ERR_UNSUPPORTED, "blocks_per_step %d not built (2 only)", d->blocks_per_step);
+  if (d->out_dim != e->g.dim) return lb_fail(LB_ERR_ARG, "out_dim %d != case dim %d", d->out_dim, e->g.dim);
+  if (d->node_in != e->g.node_in) return lb_fail(LB_ERR_ARG, "node_in %d != case feature width %d", d->node_in, e->g.node_in);
+  if (d->edge_in != e->g.dim + 1) return lb_fail(LB_ERR_ARG, "edge_in %d != dim+1", d->edge_in);
+  if (d->num_mp_steps < 0 || d->num_mp_steps > 64) return lb_fail(LB_ERR_ARG, "bad num_mp_steps");
+  const int D = LB_D, L = d->num_mp_steps;
+  const bool has_emb = d->num_particle_types > 1;
+  const int emb = has_emb ? d->embedding_size : 0;
+  const int nin = d->node_in + emb;
+  if (nin > 64) return lb_fail(LB_ERR_UNSUPPORTED, "node input width %d > 64 not built", nin);
+  const int kpad = nin <= 32 ? 32 : 64;
+
+  // expected blob length
+  auto mlp_len = [&](int in, int outw, bool ln) -> int64_t {
+    return (int64_t)in * D + D + (int64_t)D * outw + outw + (ln ? 2 * outw : 0);
+  };
+  int64_t expect = (has_emb ? (int64_t)d->num_particle_types * emb : 0) + mlp_len(nin, D, true) +
+                   mlp_len(d->edge_in, D, true) +
+                   (int64_t)L * (mlp_len(3 * D, D, true) + mlp_len(2 * D, D, true)) +
+                   mlp_len(D, d->out_dim, false);
+  if (expect != n_floats)
+    return lb_fail(LB_ERR_ARG, "weight blob has %lld floats, expected %lld", (long long)n_floats, (long long)expect);
+
+  std::vector<float> host;
+  auto put = [&](const float* src, size_t n) -> size_t {
+    size_t off = host.size();
+    off = (off + 63) & ~(size_t)63;  // 256-byte alignment of every block
+    host.resize(off + n, 0.f);
+    if (src) memcpy(host.data() + off, src, n * sizeof(float));
+    return off;
+  };
+  auto put_packed = [&](const float* src, int K, int M, int Kp, int Mp) -> size_t {
+    std::vector<float> tmp((size_t)Kp * Mp);
+    lb_pack_weight(src, K, M, Kp, Mp, tmp.data());
+    return put(tmp.data(), tmp.size());
+  };
+  struct Off { size_t w0, b0, w1, b1, lns, lno; bool ln; };
+  const float* p = w;
+  size_t off_embed = 0;
+  if (has_emb) {
+    off_embed = put(p, (size_t)d->num_particle_types * emb);
+    p += (size_t)d->num_particle_types * emb;
+  }
+  // generic 2-layer MLP reader; k0pad = padded K of layer 0; outp = padded out width
+  auto read_mlp = [&](int in, int k0pad, int outw, int outp, bool ln) -> Off {
+    Off o{};
+    o.w0 = put_packed(p, in, D, k0pad, D); p += (size_t)in * D;
+    o.b0 = put(p, D); p += D;
+    o.w1 = put_packed(p, D, outw, D, outp); p += (size_t)D * outw;
+    {
+      std::vector<float> b(outp, 0.f);
+      memcpy(b.data(), p, sizeof(float) * outw);
+      o.b1 = put(b.data(), outp);
+      p += outw;
+    }
+    o.ln = ln;
+    if (ln) {
+      o.lns = put(p, outw); p += outw;
+      o.lno = put(p, outw); p += outw;
+    }
+    return o;
+  };
+  Off o_enc_node = read_mlp(nin, kpad, D, D, true);
+  Off o_enc_edge = read_mlp(d->edge_in, 8, D, D, true);
+  std::vector<Off> o_pe(L), o_pn(L);
+  std::vector<size_t> o_pw(L), o_pb(L);
+  for (int k = 0; k < L; ++k) {
+    // edge MLP: w0 is (3D, D) over [sender | receiver | edge] (gns.py:97-100)
+    const float* w0 = p;
+    const float* b0 = p + (size_t)3 * D * D;
+    // projection for the node kernel: (D, 2D) = [Ws | Wr], bias [0 | b0]
+    {
+      std::vector<float> wsr((size_t)D * 2 * D);
+      for (int kk = 0; kk < D; ++kk)
+        for (int m = 0; m < D; ++m) {
+          wsr[(size_t)kk * 2 * D + m] = w0[(size_t)kk * D + m];
+          wsr[(size_t)kk * 2 * D + D + m] = w0[(size_t)(D + kk) * D + m];
+        }
+      o_pw[k] = put_packed(wsr.data(), D, 2 * D, D, 2 * D);
+      std::vector<float> bb(2 * D, 0.f);
+      memcpy(bb.data() + D, b0, sizeof(float) * D);
+      o_pb[k] = put(bb.data(), 2 * D);
+    }
+    Off o{};
+    o.w0 = put_packed(w0 + (size_t)2 * D * D, D, D, D, D);  // edge rows only
+    o.b0 = put(b0, D);
+    p += (size_t)3 * D * D + D;
+    o.w1 = put_packed(p, D, D, D, D); p += (size_t)D * D;
+    o.b1 = put(p, D); p += D;
+    o.ln = true;
+    o.lns = put(p, D); p += D;
+    o.lno = put(p, D); p += D;
+    o_pe[k] = o;
+    o_pn[k] = read_mlp(2 * D, 2 * D, D, D, true);
+  }
+  Off o_dec = read_mlp(D, D, d->out_dim, 32, false);
+  if (p - w != n_floats) return lb_fail(LB_ERR_ARG, "internal: blob walk mismatch");
+
+  lb_gns* g = new lb_gns();
+  g->desc = *d;
+  g->eng = e;
+  g->tap = nullptr;
+  g->kq_node = kpad / 8;
+  if (hipMalloc((void**)&g->blob, host.size() * sizeof(float)) != hipSuccess) {
+    delete g;
+    return lb_fail(LB_ERR_HIP, "hipMalloc(weights) failed");
+  }
+  if (hipMemcpy(g->blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(g->blob);
+    delete g;
+    return lb_fail(LB_ERR_HIP, "weight upload failed");
+  }
+  auto mk = [&](const Off& o) {
+    lb_mlp_w m{};
+    m.w0 = g->blob + o.w0;
+    m.b0 = g->blob + o.b0;
+    m.w1 = g->blob + o.w1;
+    m.b1 = g->blob + o.b1;
+    m.ln_s = o.ln ? g->blob + o.lns : nullptr;
+    m.ln_o = o.ln ? g->blob + o.lno : nullptr;
+    return m;
+  };
+  g->embed = has_emb ? g->blob + off_embed : nullptr;
+  g->enc_node = mk(o_enc_node);
+  g->enc_edge = mk(o_enc_edge);
+  g->dec = mk(o_dec);
+  for (int k = 0; k < L; ++k) {
+    g->proc_edge.push_back(mk(o_pe[k]));
+    g->proc_node.push_back(mk(o_pn[k]));
+    g->proj_w.push_back(g->blob + o_pw[k]);
+    g->proj_b.push_back(g->blob + o_pb[k]);
+  }
+  // node-sized network scratch
+  e->g.kpad = kpad;
+  const int64_t BN = e->BN;
+  for (void* b : {(void*)e->xnode, (void*)e->nlat, (void*)e->agg, (void*)e->psr})
+    if (b) (void)hipFree(b);
+  e->xnode = e->nlat = e->agg = e->psr = nullptr;
+  int rc = LB_OK;
+  if (!rc) rc = lb_alloc(&e->xnode, (size_t)BN * kpad);
+  if (!rc) rc = lb_alloc(&e->nlat, (size_t)BN * D);
+  if (!rc) rc = lb_alloc(&e->agg, (size_t)BN * D);
+  if (!rc) rc = lb_alloc(&e->psr, (size_t)BN * 2 * D);
+  if (rc) {
+    lb_gns_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return LB_OK;
+}
+
+extern "C" void lb_gns_destroy(lb_gns* g) {
+  if (!g) return;
+  if (g->blob) (void)hipFree(g->blob);
+  delete g;
+}
+
+extern "C" int lb_gns_set_tap(lb_gns* g, float* tap) {
+  if (!g) return lb_fail(LB_ERR_ARG, "null model");
+  g->tap = tap;
+  return LB_OK;
+}
+
+__global__ void k_acc_export(int64_t BN, int dim, const float* __restrict__ acc4,
+                             float* __restrict__ out) {
+  int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= BN) return;
+  for (int d = 0; d < dim; ++d) out[gi * dim + d] = acc4[gi * 4 + d];
+}
+
+extern "C" int lb_gns_forward(lb_engine* e, lb_gns* g, float* acc_out_dev) {
+  if (!e || !g) return lb_fail(LB_ERR_ARG, "null argument");
+  if (g->eng != e) return lb_fail(LB_ERR_ARG, "model was created for another engine");
+  if (e->e_cap <= 0) return lb_fail(LB_ERR_STATE, "lb_gns_forward before lb_nl_allocate");
+  if (e->g.force_kind == LB_FORCE_BUFFER && !e->force)
+    return lb_fail(LB_ERR_STATE, "LB_FORCE_BUFFER engine: call lb_set_force first");
+  LB_TRY(lbk_gns_forward(e, g));
+  if (acc_out_dev) {
+    const int nb = (int)((e->BN + 255) / 256);
+    hipLaunchKernelGGL(k_acc_export, dim3(nb), dim3(256), 0, e->stream, e->BN, e->g.dim, e->acc,
+                       acc_out_dev);
+    LB_HIP(hipGetLastError());
+  }
+  return LB_OK;
+}
+
+// --------------------------------------------------------------------- integrate / rollout
+extern "C" int lb_integrate(lb_engine* e, const float* acc_dev, const double* target_dev,
+                            double* pred_out_dev, int32_t pred_T) {
+  if (!e || !target_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  const float* acc = acc_dev ? acc_dev : e->acc;
+  const int stride = acc_dev ? e->g.dim : 4;
+  return lbk_integrate(e, acc, stride, target_dev, nullptr, 0, pred_out_dev, pred_T);
+}
+
+extern "C" int lb_case_integrate(lb_engine* e, int32_t mode, const float* pred_dev,
+                                 const double* pos_seq_dev, int32_t T, double* next_out_dev) {
+  if (!e || !pred_dev || !pos_seq_dev || !next_out_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  if (mode != 0 && mode != 1) return lb_fail(LB_ERR_ARG, "mode must be 0 (acc) or 1 (vel)");
+  if (T < 2 && mode == 0) return lb_fail(LB_ERR_ARG, "acc integration needs two frames");
+  return lbk_case_integrate(e, mode, pred_dev, pos_seq_dev, T, next_out_dev);
+}
+
+extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32_t T,
+                          int32_t n_steps, double* pred_out_dev, int32_t* n_realloc_out) {
+  if (!e || !g || !traj_dev || !pred_out_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  if (g->eng != e) return lb_fail(LB_ERR_ARG, "model was created for another engine");
+  if (T < e->g.isl) return lb_fail(LB_ERR_ARG, "trajectory shorter than input_seq_length");
+  if (e->g.force_kind == LB_FORCE_BUFFER)
+    return lb_fail(LB_ERR_UNSUPPORTED, "lb_rollout with LB_FORCE_BUFFER: drive the steps from the host");
+  int n_realloc = 0;
+  LB_TRY(lbk_load_window(e, traj_dev, T, 0, 0));
+  if (e->e_cap <= 0) LB_TRY(lb_nl_allocate(e, nullptr, nullptr, nullptr));
+  int step = 0;
+  while (step < n_steps) {
+    for (int s = step; s < n_steps; ++s) {
+      LB_TRY(lbk_nl_build(e, false));
+      LB_TRY(lbk_gns_forward(e, g));
+      LB_TRY(lbk_integrate(e, e->acc, 4, nullptr, traj_dev, T, pred_out_dev, n_steps));
+    }
+    LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, e->stream));
+    LB_HIP(hipStreamSynchronize(e->stream));
+    LB_TRY(lb_check_density(e));
+    if (e->ctrl_host->overflow_step < 0) break;
+    // (eval) Reallocate neighbors list at step k - rollout.py:139-151.  Every kernel after the
+    // overflowing build was a no-op, so window and step counter still describe step k.
+    step = e->ctrl_host->step;
+    ++n_realloc;
+    if (n_realloc > n_steps + 8) return lb_fail(LB_ERR_STATE, "neighbor list keeps overflowing");
+    LB_TRY(lb_nl_allocate(e, nullptr, nullptr, nullptr));
+  }
+  if (n_realloc_out) *n_realloc_out = n_realloc;
+  return LB_OK;
+}
+
+extern "C" int lb_metrics(lb_engine* e, const double* pred_dev, int32_t pred_T,
+                          const double* target_dev, int32_t target_T, int32_t n_steps, double* mse,
+                          double* mae) {
+  if (!e || !pred_dev || !target_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  if (n_steps > pred_T || n_steps > target_T) return lb_fail(LB_ERR_ARG, "n_steps exceeds pred_T/target_T");
+  return lbk_metrics(e, pred_dev, pred_T, target_dev, target_T, n_steps, mse, mae);
+}

@@ -1,0 +1,175 @@
+// lb_internal.h - engine object, device control block and kernel launchers shared by the
+// translation units of liblbhip.so.  gfx950 only (wave64, MFMA f32 32x32x2).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lbhip.h"
+
+#define LB_MAX_STENCIL_CAND 2048  // candidates staged in LDS per cell block (27*cap must fit)
+#define LB_MAX_ROW 256            // max degree of one receiver row
+#define LB_TILE 32                // rows (edges / nodes) per wave tile: the N of the 32x32x2 MFMA
+#define LB_D 128                  // latent width built so far
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident control block: everything a kernel needs to size itself without a host sync.
+struct lb_ctrl {
+  int32_t step;            // rollout step counter (ring head = step % isl)
+  int32_t overflow_step;   // first step whose neighbor list overflowed, -1 = none ("poison")
+  int32_t n_edges_total;   // real edges over all B trajectories, clamped to B*E_cap
+  int32_t n_edges_unclamped;
+  int32_t max_cell_occ;    // max particles in one cell (this build)
+  int32_t density_error;   // stencil/row exceeded the LDS tile bounds
+  int32_t pad0, pad1;
+};
+
+// Geometry + normalisation constants, passed by value to kernels.
+struct lb_geom {
+  int32_t dim, N, B, isl, periodic, has_bound, has_vel_mag, force_kind, force_axis;
+  int32_t use_cell_list;   // jax-md: cutoff < box/3 in every dim, else all-pairs candidates
+  int32_t ncell[3];        // cells per side (1 when !use_cell_list)
+  int32_t ncells;          // cells per trajectory
+  int32_t nstencil;        // 3^dim, or 1 when !use_cell_list
+  int32_t node_in;         // feature columns without embedding
+  int32_t kpad;            // node feature row stride (multiple of 32)
+  double cell_size[3];     // f32-rounded like jax-md, widened
+  double box[3], half_box[3];
+  double rc, rc2;
+  double vel_mean[3], vel_std[3], acc_mean[3], acc_std[3];
+  double bound_lo[3], bound_hi[3];
+  double force_split, force_lo[3], force_hi[3];
+};
+
+enum lb_timer_class {
+  LB_T_CELLS = 0,    // cell binning: count + scan + fill
+  LB_T_NEIGH,        // stencil search: count pass + row scan + fill pass (+edge features)
+  LB_T_NODEFEAT,     // node feature assembly
+  LB_T_ENC_NODE,     // encoder node MLP (+ first projection)
+  LB_T_ENC_EDGE,     // encoder edge MLP
+  LB_T_EDGE_MLP,     // processor edge MLP (gather + 2 GEMM + LN + residual)
+  LB_T_AGGREGATE,    // segment_sum over receivers
+  LB_T_NODE_MLP,     // processor node MLP (+ next projection)
+  LB_T_DECODER,      // decoder MLP
+  LB_T_INTEGRATE,    // integrator + kinematic select + window shift + prediction store
+  LB_T_MISC,
+  LB_T_COUNT
+};
+
+struct lb_timer_rec {
+  hipEvent_t a, b;
+  int cls;
+};
+
+struct lb_engine {
+  lb_case_desc desc;
+  lb_geom g;
+  hipStream_t stream;
+  int64_t BN;
+
+  // state
+  double* win;        // [isl][dim][B*N] SoA ring of positions
+  int32_t* ptype;     // [B*N]
+  double* force;      // [B*N*dim] (LB_FORCE_BUFFER) or null
+  lb_ctrl* ctrl;      // device
+  lb_ctrl* ctrl_host; // pinned mirror
+
+  // neighbor structures
+  int32_t cell_capacity, e_cap;      // frozen capacities (0 = not allocated)
+  int64_t e_alloc;                   // allocated edge slots (>= B*e_cap)
+  int32_t* cell_of;    // [BN] global cell id of each particle
+  int32_t* cell_count; // [B*ncells]
+  int32_t* cell_start; // [B*ncells+1]
+  int32_t* cell_fill;  // [B*ncells]
+  int32_t* cell_part;  // [BN] particle ids grouped by cell
+  int32_t* deg;        // [BN]
+  int32_t* row_ptr;    // [BN+1]
+  int32_t* senders;    // [e_alloc] global node ids
+  int32_t* receivers;  // [e_alloc]
+  float* efeat;        // [e_alloc][8]  rel_disp(dim), rel_dist, zero pad
+  double* efeat64;     // [e_alloc][4]  fp64 copy for the API (allocated on demand)
+  int32_t* overflow;   // [B] did_buffer_overflow
+  int32_t* nedges_b;   // [B]
+
+  // network scratch (allocated by lb_gns_create / regrown with e_alloc)
+  float* xnode;        // [BN][kpad]
+  float* nlat;         // [BN][D]
+  float* agg;          // [BN][D]
+  float* psr;          // [BN][2D]  projections of the node latents for the edge MLP
+  float* elat;         // [e_alloc][D]
+  float* msg;          // [e_alloc][D]
+  float* acc;          // [BN][4] decoder output (dim padded to 4)
+
+  // timers
+  bool timers_on;
+  std::vector<lb_timer_rec> trecs;
+  std::vector<hipEvent_t> epool;
+  double t_ms[LB_T_COUNT];
+  int64_t t_n[LB_T_COUNT];
+};
+
+struct lb_mlp_w {      // one packed 2-layer MLP on the device
+  const float* w0;     // packed fragments, K0pad x D
+  const float* b0;     // [D]
+  const float* w1;     // packed, D x Mpad
+  const float* b1;     // [Mpad]
+  const float* ln_s;   // [D] or null
+  const float* ln_o;
+};
+
+struct lb_gns {
+  lb_gns_desc desc;
+  lb_engine* eng;
+  float* blob;         // single device allocation holding everything below
+  const float* embed;  // [types][emb]
+  lb_mlp_w enc_node, enc_edge, dec;
+  std::vector<lb_mlp_w> proc_edge, proc_node;  // proc_edge[k].w0 packs only the edge-latent rows
+  std::vector<const float*> proj_w;            // packed [D x 2D]: sender | receiver rows of w0
+  std::vector<const float*> proj_b;            // [2D]: zeros | b0
+  int kq_node;         // node_in(+emb) padded to a multiple of 32, in units of 8
+  float* tap;
+};
+
+// ---------------------------------------------------------------------------------------------
+extern thread_local std::string g_lb_err;
+int lb_fail(int code, const char* fmt, ...);
+#define LB_HIP(call)                                                                   \
+  do {                                                                                 \
+    hipError_t _e = (call);                                                            \
+    if (_e != hipSuccess)                                                              \
+      return lb_fail(LB_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), \
+                     __FILE__, __LINE__);                                              \
+  } while (0)
+
+void lb_tic(lb_engine* e, int cls);
+void lb_toc(lb_engine* e);
+
+// lb_api.hip
+int lb_ensure_edges(lb_engine* e, int64_t need);
+
+// lb_neighbor.hip
+int lbk_nl_build(lb_engine* e, bool want_efeat64);
+int lbk_nl_export(lb_engine* e, int32_t* idx_out, int32_t* n_edges_out);
+int lbk_edge_features_export(lb_engine* e, double* rel_disp, double* rel_dist);
+
+// lb_state.hip
+int lbk_load_window(lb_engine* e, const double* traj, int T, int t0, int step);
+int lbk_read_window(lb_engine* e, double* out);
+int lbk_node_features(lb_engine* e, float* xnode, const float* embed, int emb, int ntypes,
+                      double* vel_hist, double* vel_mag, double* bound, double* force);
+int lbk_integrate(lb_engine* e, const float* acc, int acc_stride, const double* target,
+                  const double* traj, int T, double* pred, int pred_T);
+int lbk_case_integrate(lb_engine* e, int mode, const float* pred, const double* pos_seq, int T,
+                       double* out);
+int lbk_metrics(lb_engine* e, const double* pred, int pred_T, const double* target, int target_T,
+                int n_steps, double* mse, double* mae);
+
+// lb_gns.hip
+int lbk_gns_forward(lb_engine* e, lb_gns* g);
+int lbk_segment_sum(lb_engine* e, const float* msg, float* out, int D);
+void lb_pack_weight(const float* w, int K, int M, int Kpad, int Mpad, float* out);

@@ -1,0 +1,264 @@
+// lb_state.hip - position-window SoA ring, node features, integrator, rollout metrics.
+//
+// Reference functions replaced (paths relative to the reference repo):
+//   feature_transform, node part      lagrangebench/case_setup/features.py:47-107
+//   hk.Embed lookup + concat          lagrangebench/models/gns.py:164-169
+//   integrate_fn                      lagrangebench/case_setup/case.py:230-259
+//   _forward_eval (mask + shift)      lagrangebench/evaluate/rollout.py:61-73
+//   predictions.at[:, step].set       lagrangebench/evaluate/rollout.py:165-167
+//   MetricsComputer.mse / .mae        lagrangebench/evaluate/metrics.py:139-147
+//
+// HBM layout: win[slot][d][b*N+i] fp64 - structure-of-arrays so that every kernel reads positions
+// with unit stride across lanes; the window is a ring of isl slots (frame f of the window that
+// starts at step s lives in slot (s+f) % isl), so advancing the window writes ONE frame instead
+// of the reference's concatenate-and-copy of the whole (N, isl, dim) array.
+#include "lb_device.h"
+
+__global__ void k_load_window(lb_geom g, int64_t BN, const double* __restrict__ traj, int T, int t0,
+                              int step, double* __restrict__ win, lb_ctrl* __restrict__ ctrl) {
+  int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi == 0) ctrl->step = step;
+  if (gi >= BN) return;
+  for (int f = 0; f < g.isl; ++f) {
+    const int slot = (step + f) % g.isl;
+    for (int d = 0; d < g.dim; ++d)
+      win[((int64_t)slot * g.dim + d) * BN + gi] = traj[(gi * T + (t0 + f)) * g.dim + d];
+  }
+}
+
+int lbk_load_window(lb_engine* e, const double* traj, int T, int t0, int step) {
+  const int nb = (int)((e->BN + 255) / 256);
+  hipLaunchKernelGGL(k_load_window, dim3(nb), dim3(256), 0, e->stream, e->g, e->BN, traj, T, t0,
+                     step, e->win, e->ctrl);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
+__global__ void k_read_window(lb_geom g, int64_t BN, const double* __restrict__ win,
+                              const lb_ctrl* __restrict__ ctrl, double* __restrict__ out) {
+  int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= BN) return;
+  const int step = ctrl->step;
+  for (int f = 0; f < g.isl; ++f)
+    for (int d = 0; d < g.dim; ++d)
+      out[(gi * g.isl + f) * g.dim + d] = lb_pos(win, g, BN, step, f, d, gi);
+}
+
+int lbk_read_window(lb_engine* e, double* out) {
+  const int nb = (int)((e->BN + 255) / 256);
+  hipLaunchKernelGGL(k_read_window, dim3(nb), dim3(256), 0, e->stream, e->g, e->BN, e->win, e->ctrl,
+                     out);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
+// -------------------------------------------------------------------------- node features
+// One thread per particle.  Writes the fp32 network input row [vel_hist | vel_mag | bound | force |
+// embedding | 0-pad] (gns.py:135-169 column order) and, when asked, the fp64 feature arrays the
+// Python FeatureDict exposes.
+__global__ void k_node_features(lb_geom g, int64_t BN, const double* __restrict__ win,
+                                const lb_ctrl* __restrict__ ctrl, const int32_t* __restrict__ ptype,
+                                const double* __restrict__ force_buf, float* __restrict__ xnode,
+                                const float* __restrict__ embed, int emb, int ntypes,
+                                double* __restrict__ vel_hist, double* __restrict__ vel_mag,
+                                double* __restrict__ bound, double* __restrict__ force_out) {
+  if (xnode && ctrl->overflow_step >= 0) return;
+  int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= BN) return;
+  const int step = ctrl->step;
+  const int K = g.isl - 1, dim = g.dim;
+  float* x = xnode ? xnode + gi * g.kpad : nullptr;
+  int col = 0;
+  double pprev[3], pcur[3] = {0, 0, 0};
+  for (int d = 0; d < dim; ++d) pprev[d] = lb_pos(win, g, BN, step, 0, d, gi);
+  for (int t = 0; t < K; ++t) {
+    double s2 = 0.0;
+    for (int d = 0; d < dim; ++d) {
+      pcur[d] = lb_pos(win, g, BN, step, t + 1, d, gi);
+      const double v = lb_disp1(pcur[d], pprev[d], g.box[d], g.half_box[d], g.periodic);
+      const double nv = (v - g.vel_mean[d]) / g.vel_std[d];
+      if (x) x[t * dim + d] = (float)nv;
+      if (vel_hist) vel_hist[gi * (K * dim) + t * dim + d] = nv;
+      s2 = (d == 0) ? nv * nv : s2 + nv * nv;
+      pprev[d] = pcur[d];
+    }
+    if (g.has_vel_mag) {
+      const double m = sqrt(s2);
+      if (x) x[K * dim + t] = (float)m;
+      if (vel_mag) vel_mag[gi * K + t] = m;
+    }
+  }
+  col = K * dim + (g.has_vel_mag ? K : 0);
+  if (K == 0)
+    for (int d = 0; d < dim; ++d) pcur[d] = lb_pos(win, g, BN, step, 0, d, gi);
+  if (g.has_bound) {
+    for (int d = 0; d < dim; ++d) {
+      double lo = (pcur[d] - g.bound_lo[d]) / g.rc;
+      double hi = (g.bound_hi[d] - pcur[d]) / g.rc;
+      lo = fmin(fmax(lo, -1.0), 1.0);
+      hi = fmin(fmax(hi, -1.0), 1.0);
+      if (x) {
+        x[col + d] = (float)lo;
+        x[col + dim + d] = (float)hi;
+      }
+      if (bound) {
+        bound[gi * 2 * dim + d] = lo;
+        bound[gi * 2 * dim + dim + d] = hi;
+      }
+    }
+    col += 2 * dim;
+  }
+  if (g.force_kind != LB_FORCE_NONE) {
+    for (int d = 0; d < dim; ++d) {
+      double f;
+      if (g.force_kind == LB_FORCE_PIECEWISE)
+        f = (pcur[g.force_axis] > g.force_split) ? g.force_hi[d] : g.force_lo[d];
+      else
+        f = force_buf[gi * dim + d];
+      if (x) x[col + d] = (float)f;
+      if (force_out) force_out[gi * dim + d] = f;
+    }
+    col += dim;
+  }
+  if (x) {
+    if (ntypes > 1) {
+      int t = ptype[gi];
+      if (t < 0) t += ntypes;  // jnp negative index wraps (PAD_VALUE = -1 -> last row)
+      t = t < 0 ? 0 : (t >= ntypes ? ntypes - 1 : t);
+      for (int j = 0; j < emb; ++j) x[col + j] = embed[t * emb + j];
+      col += emb;
+    }
+    for (int j = col; j < g.kpad; ++j) x[j] = 0.f;
+  }
+}
+
+int lbk_node_features(lb_engine* e, float* xnode, const float* embed, int emb, int ntypes,
+                      double* vel_hist, double* vel_mag, double* bound, double* force) {
+  const int nb = (int)((e->BN + 255) / 256);
+  hipLaunchKernelGGL(k_node_features, dim3(nb), dim3(256), 0, e->stream, e->g, e->BN, e->win,
+                     e->ctrl, e->ptype, e->force, xnode, embed, emb, ntypes, vel_hist, vel_mag,
+                     bound, force);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
+// ------------------------------------------------------------------------------ integrator
+__global__ void k_integrate(lb_geom g, int64_t BN, double* __restrict__ win,
+                            const lb_ctrl* __restrict__ ctrl, const int32_t* __restrict__ ptype,
+                            const float* __restrict__ acc, int acc_stride,
+                            const double* __restrict__ target, const double* __restrict__ traj,
+                            int T, double* __restrict__ pred, int pred_T) {
+  if (ctrl->overflow_step >= 0) return;
+  int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= BN) return;
+  const int step = ctrl->step;
+  const int b = (int)(gi / g.N), i = (int)(gi % g.N);
+  const int pt = ptype[gi];
+  const bool kinematic = (pt == 1) || (pt == 2) || (pt == -1);  // utils.py:28-35
+  const int slot_new = (step + g.isl) % g.isl;
+  int tf = g.isl + step;
+  if (tf > T - 1) tf = T - 1;  // JAX clamps the out-of-range gather (rollout.py:159)
+  for (int d = 0; d < g.dim; ++d) {
+    double out;
+    if (kinematic) {
+      out = target ? target[gi * g.dim + d] : traj[(gi * T + tf) * g.dim + d];
+    } else {
+      const double p1 = lb_pos(win, g, BN, step, g.isl - 1, d, gi);
+      const double p0 = lb_pos(win, g, BN, step, g.isl - 2, d, gi);
+      const double a = g.acc_mean[d] + (double)acc[gi * acc_stride + d] * g.acc_std[d];
+      const double v = lb_disp1(p1, p0, g.box[d], g.half_box[d], g.periodic);
+      out = lb_shift1(p1, v + a, g.box[d], g.periodic);
+    }
+    win[((int64_t)slot_new * g.dim + d) * BN + gi] = out;
+    if (pred && step < pred_T) pred[(((int64_t)b * pred_T + step) * g.N + i) * g.dim + d] = out;
+  }
+}
+
+// case.integrate alone (stateless), case.py:230-259.
+__global__ void k_case_integrate(lb_geom g, int64_t BN, int mode, const float* __restrict__ pred,
+                                 const double* __restrict__ pos_seq, int T,
+                                 double* __restrict__ out) {
+  int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= BN) return;
+  for (int d = 0; d < g.dim; ++d) {
+    const double p1 = pos_seq[(gi * T + (T - 1)) * g.dim + d];
+    double nv;
+    if (mode == 1) {
+      nv = g.vel_mean[d] + (double)pred[gi * g.dim + d] * g.vel_std[d];
+    } else {
+      const double p0 = pos_seq[(gi * T + (T - 2)) * g.dim + d];
+      const double a = g.acc_mean[d] + (double)pred[gi * g.dim + d] * g.acc_std[d];
+      nv = lb_disp1(p1, p0, g.box[d], g.half_box[d], g.periodic) + a;
+    }
+    out[gi * g.dim + d] = lb_shift1(p1, nv, g.box[d], g.periodic);
+  }
+}
+
+int lbk_case_integrate(lb_engine* e, int mode, const float* pred, const double* pos_seq, int T,
+                       double* out) {
+  const int nb = (int)((e->BN + 255) / 256);
+  hipLaunchKernelGGL(k_case_integrate, dim3(nb), dim3(256), 0, e->stream, e->g, e->BN, mode, pred,
+                     pos_seq, T, out);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
+__global__ void k_advance(lb_ctrl* ctrl) {
+  if (ctrl->overflow_step >= 0) return;
+  ctrl->step += 1;
+}
+
+int lbk_integrate(lb_engine* e, const float* acc, int acc_stride, const double* target,
+                  const double* traj, int T, double* pred, int pred_T) {
+  const int nb = (int)((e->BN + 255) / 256);
+  lb_tic(e, LB_T_INTEGRATE);
+  hipLaunchKernelGGL(k_integrate, dim3(nb), dim3(256), 0, e->stream, e->g, e->BN, e->win, e->ctrl,
+                     e->ptype, acc, acc_stride, target, traj, T, pred, pred_T);
+  hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, e->stream, e->ctrl);
+  lb_toc(e);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
+// --------------------------------------------------------------------------------- metrics
+// One workgroup per (trajectory, step): fixed-order strided accumulation + LDS tree, fp64.
+__global__ void __launch_bounds__(256)
+    k_metrics(lb_geom g, const double* __restrict__ pred, int pred_T,
+              const double* __restrict__ target, int target_T, int n_steps,
+              double* __restrict__ mse, double* __restrict__ mae) {
+  __shared__ double s2[256], s1[256];
+  const int t = blockIdx.x, b = blockIdx.y;
+  double a2 = 0.0, a1 = 0.0;
+  const int n = g.N * g.dim;
+  for (int k = threadIdx.x; k < n; k += 256) {
+    const int i = k / g.dim, d = k % g.dim;
+    const double p = pred[(((int64_t)b * pred_T + t) * g.N + i) * g.dim + d];
+    const double q = target[(((int64_t)b * target_T + t) * g.N + i) * g.dim + d];
+    const double dd = lb_disp1(p, q, g.box[d], g.half_box[d], g.periodic);
+    a2 += dd * dd;
+    a1 += fabs(dd);
+  }
+  s2[threadIdx.x] = a2;
+  s1[threadIdx.x] = a1;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      s2[threadIdx.x] += s2[threadIdx.x + off];
+      s1[threadIdx.x] += s1[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (mse) mse[(int64_t)b * n_steps + t] = s2[0] / (double)n;
+    if (mae) mae[(int64_t)b * n_steps + t] = s1[0] / (double)n;
+  }
+}
+
+int lbk_metrics(lb_engine* e, const double* pred, int pred_T, const double* target, int target_T,
+                int n_steps, double* mse, double* mae) {
+  if (n_steps <= 0) return LB_OK;
+  hipLaunchKernelGGL(k_metrics, dim3(n_steps, e->g.B), dim3(256), 0, e->stream, e->g, pred, pred_T,
+                     target, target_T, n_steps, mse, mae);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}

@@ -1,0 +1,338 @@
+"""RolloutEngine: thin Python handle over liblbhip.so (include/lbhip.h).
+
+PyTorch is only plumbing here: tensors own the device memory that is handed to the C ABI as
+raw pointers, and ``torch.cuda.current_stream()`` supplies the hipStream_t.  All arithmetic of
+the hot path happens inside the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CaseDesc, GnsDesc, LbHipError, check, ptr
+
+
+def _d3(v, fill=0.0):
+    a = [fill, fill, fill]
+    for i, x in enumerate(list(v)[:3]):
+        a[i] = float(x)
+    return _lib.D3(*a)
+
+
+def _dev(t: torch.Tensor, dtype, device) -> torch.Tensor:
+    return t.to(device=device, dtype=dtype).contiguous()
+
+
+class ForceSpec:
+    """How external_force_fn(position) (features.py:105-107) is evaluated on the device.
+
+    * ``ForceSpec.piecewise(axis, split, f_lo, f_hi)``: f = pos[axis] > split ? f_hi : f_lo -
+      covers the RPF body force (``where(r[1] > 1.0, -1, 1) * g``) and constant gravity (DAM).
+    * ``ForceSpec.callable(fn)``: arbitrary ``fn(pos (n,dim) tensor) -> (n,dim)`` evaluated with
+      torch on the device each step and handed to the engine as a buffer.
+    """
+
+    def __init__(self, kind: int, axis=0, split=0.0, f_lo=(0, 0, 0), f_hi=(0, 0, 0), fn=None):
+        self.kind, self.axis, self.split, self.f_lo, self.f_hi, self.fn = kind, axis, split, f_lo, f_hi, fn
+
+    @staticmethod
+    def piecewise(axis: int, split: float, f_lo: Sequence[float], f_hi: Sequence[float]):
+        return ForceSpec(_lib.LB_FORCE_PIECEWISE, axis, split, tuple(f_lo), tuple(f_hi))
+
+    @staticmethod
+    def constant(f: Sequence[float]):
+        return ForceSpec(_lib.LB_FORCE_PIECEWISE, 0, 0.0, tuple(f), tuple(f))
+
+    @staticmethod
+    def callable(fn):
+        return ForceSpec(_lib.LB_FORCE_BUFFER, fn=fn)
+
+
+class RolloutEngine:
+    """One engine = one (case, batch size B, device)."""
+
+    def __init__(
+        self,
+        *,
+        dim: int,
+        n_particles: int,
+        batch: int,
+        isl: int,
+        box: Sequence[float],
+        periodic: bool,
+        r_cutoff: float,
+        multiplier: float,
+        vel_mean, vel_std, acc_mean, acc_std,
+        bounds=None,
+        has_bound: bool = False,
+        has_vel_mag: bool = False,
+        force: Optional[ForceSpec] = None,
+        device: Optional[torch.device] = None,
+    ):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise LbHipError("RolloutEngine needs a HIP device (torch.cuda.is_available() is False); "
+                             "there is no CPU fallback")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.dim, self.N, self.B, self.isl = dim, n_particles, batch, isl
+        self.force = force
+        d = CaseDesc()
+        d.dim, d.n_particles, d.batch, d.isl = dim, n_particles, batch, isl
+        d.periodic = int(bool(periodic))
+        d.has_bound = int(bool(has_bound))
+        d.has_vel_mag = int(bool(has_vel_mag))
+        d.force_kind = force.kind if force is not None else _lib.LB_FORCE_NONE
+        d.force_axis = force.axis if force is not None else 0
+        d.box = _d3(box, 1.0)
+        d.r_cutoff = float(r_cutoff)
+        d.capacity_multiplier = float(multiplier)
+        d.vel_mean, d.vel_std = _d3(vel_mean), _d3(vel_std, 1.0)
+        d.acc_mean, d.acc_std = _d3(acc_mean), _d3(acc_std, 1.0)
+        if bounds is not None:
+            b = np.asarray(bounds, dtype=np.float64)
+            d.bound_lo, d.bound_hi = _d3(b[:, 0]), _d3(b[:, 1])
+        if force is not None and force.kind == _lib.LB_FORCE_PIECEWISE:
+            d.force_split = float(force.split)
+            d.force_lo, d.force_hi = _d3(force.f_lo), _d3(force.f_hi)
+        self.desc = d
+        self.K = isl - 1
+        self.node_in = (self.K * dim + (self.K if has_vel_mag else 0) + (2 * dim if has_bound else 0)
+                        + (dim if d.force_kind != _lib.LB_FORCE_NONE else 0))
+        self.has_bound, self.has_vel_mag = bool(has_bound), bool(has_vel_mag)
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.current_stream(self.device)
+            h = C.c_void_p()
+            check(self.lib.lb_engine_create(C.byref(d), C.c_void_p(self.stream.cuda_stream), C.byref(h)),
+                  "lb_engine_create")
+        self._h = h
+        self._keep: List[torch.Tensor] = []  # tensors the library may still read asynchronously
+        self.cell_capacity = 0
+        self.e_cap = 0
+        self.version = 0  # bumped whenever window / list change: ties FeatureDicts to a state
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            torch.cuda.synchronize(self.device)
+            self.lib.lb_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _t(self, t: Optional[torch.Tensor], dtype) -> Optional[torch.Tensor]:
+        if t is None:
+            return None
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t))
+        t = _dev(t, dtype, self.device)
+        self._keep.append(t)
+        if len(self._keep) > 64:
+            self._keep = self._keep[-32:]
+        return t
+
+    # ------------------------------------------------------------------ state
+    def set_particle_type(self, ptype) -> None:
+        t = self._t(ptype, torch.int32).reshape(self.B, self.N)
+        check(self.lib.lb_set_particle_type(self._h, ptr(t)), "lb_set_particle_type")
+
+    def prepare_traj(self, pos) -> torch.Tensor:
+        """(B,N,T,dim) or (N,T,dim) positions -> fp64 contiguous device tensor."""
+        t = pos if isinstance(pos, torch.Tensor) else torch.as_tensor(np.asarray(pos))
+        if t.dim() == 3:
+            t = t[None]
+        if t.shape[0] != self.B or t.shape[1] != self.N or t.shape[3] != self.dim:
+            raise ValueError(f"trajectory shape {tuple(t.shape)} does not match engine "
+                             f"(B={self.B}, N={self.N}, dim={self.dim})")
+        return _dev(t, torch.float64, self.device)
+
+    def load_window(self, traj: torch.Tensor, t0: int = 0, step: int = 0) -> None:
+        traj = self.prepare_traj(traj)
+        self._keep.append(traj)
+        check(self.lib.lb_load_window(self._h, ptr(traj), traj.shape[2], t0, step), "lb_load_window")
+        self.version += 1
+        self._refresh_force()
+
+    def read_window(self) -> torch.Tensor:
+        out = torch.empty((self.B, self.N, self.isl, self.dim), dtype=torch.float64, device=self.device)
+        check(self.lib.lb_read_window(self._h, ptr(out)), "lb_read_window")
+        return out
+
+    def _refresh_force(self) -> None:
+        if self.force is not None and self.force.kind == _lib.LB_FORCE_BUFFER:
+            newest = self.read_window()[:, :, -1].reshape(self.B * self.N, self.dim)
+            f = self.force.fn(newest)
+            f = self._t(f, torch.float64).reshape(self.B, self.N, self.dim)
+            check(self.lib.lb_set_force(self._h, ptr(f)), "lb_set_force")
+
+    # ------------------------------------------------------------------ neighbor list
+    def nl_allocate(self) -> Tuple[int, int, List[int]]:
+        cc, ec = C.c_int32(), C.c_int32()
+        occ = (C.c_int32 * self.B)()
+        check(self.lib.lb_nl_allocate(self._h, C.byref(cc), C.byref(ec), occ), "lb_nl_allocate")
+        self.cell_capacity, self.e_cap = cc.value, ec.value
+        self.version += 1
+        return cc.value, ec.value, list(occ)
+
+    def nl_set_capacity(self, cell_capacity: int, e_cap: int) -> None:
+        check(self.lib.lb_nl_set_capacity(self._h, int(cell_capacity), int(e_cap)), "lb_nl_set_capacity")
+        self.cell_capacity, self.e_cap = int(cell_capacity), int(e_cap)
+
+    def nl_update(self) -> None:
+        check(self.lib.lb_nl_update(self._h), "lb_nl_update")
+        self.version += 1
+
+    def nl_flags(self) -> torch.Tensor:
+        out = torch.empty((self.B,), dtype=torch.int32, device=self.device)
+        check(self.lib.lb_nl_read_flags(self._h, ptr(out)), "lb_nl_read_flags")
+        return out
+
+    def nl_idx(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        idx = torch.empty((self.B, 2, self.e_cap), dtype=torch.int32, device=self.device)
+        ne = torch.empty((self.B,), dtype=torch.int32, device=self.device)
+        check(self.lib.lb_nl_read_idx(self._h, ptr(idx), ptr(ne)), "lb_nl_read_idx")
+        return idx, ne
+
+    def stats(self) -> Dict[str, int]:
+        n, ec, cc = C.c_int64(), C.c_int32(), C.c_int32()
+        check(self.lib.lb_stats(self._h, C.byref(n), C.byref(ec), C.byref(cc)), "lb_stats")
+        return {"n_edges_total": n.value, "e_cap": ec.value, "cell_capacity": cc.value}
+
+    # ------------------------------------------------------------------ features
+    def node_features(self) -> Dict[str, torch.Tensor]:
+        f64 = dict(dtype=torch.float64, device=self.device)
+        out = {"vel_hist": torch.empty((self.B, self.N, self.K * self.dim), **f64)}
+        vm = bd = fo = None
+        if self.has_vel_mag:
+            vm = out["vel_mag"] = torch.empty((self.B, self.N, self.K), **f64)
+        if self.has_bound:
+            bd = out["bound"] = torch.empty((self.B, self.N, 2 * self.dim), **f64)
+        if self.desc.force_kind != _lib.LB_FORCE_NONE:
+            fo = out["force"] = torch.empty((self.B, self.N, self.dim), **f64)
+        check(self.lib.lb_node_features(self._h, ptr(out["vel_hist"]), ptr(vm), ptr(bd), ptr(fo)),
+              "lb_node_features")
+        return out
+
+    def edge_features(self) -> Dict[str, torch.Tensor]:
+        f64 = dict(dtype=torch.float64, device=self.device)
+        rd = torch.empty((self.B, self.e_cap, self.dim), **f64)
+        rr = torch.empty((self.B, self.e_cap, 1), **f64)
+        check(self.lib.lb_edge_features(self._h, ptr(rd), ptr(rr)), "lb_edge_features")
+        return {"rel_disp": rd, "rel_dist": rr}
+
+    # ------------------------------------------------------------------ model
+    def gns_create(self, desc: GnsDesc, blob: np.ndarray) -> "GnsHandle":
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        h = C.c_void_p()
+        check(self.lib.lb_gns_create(self._h, C.byref(desc), blob.ctypes.data_as(C.c_void_p),
+                                     C.c_int64(blob.size), C.byref(h)), "lb_gns_create")
+        return GnsHandle(self, h, desc)
+
+    def gns_forward(self, gns: "GnsHandle", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty((self.B, self.N, self.dim), dtype=torch.float32, device=self.device)
+        check(self.lib.lb_gns_forward(self._h, gns._h, ptr(out)), "lb_gns_forward")
+        return out
+
+    # ------------------------------------------------------------------ integrate / rollout
+    def integrate(self, acc: Optional[torch.Tensor], target: torch.Tensor,
+                  pred: Optional[torch.Tensor] = None) -> None:
+        acc_t = self._t(acc, torch.float32) if acc is not None else None
+        tgt = self._t(target, torch.float64)
+        pred_T = pred.shape[1] if pred is not None else 0
+        check(self.lib.lb_integrate(self._h, ptr(acc_t), ptr(tgt), ptr(pred), pred_T), "lb_integrate")
+        self.version += 1
+        self._refresh_force()
+
+    def case_integrate(self, mode: int, pred: torch.Tensor, pos_seq: torch.Tensor) -> torch.Tensor:
+        p = self._t(pred, torch.float32)
+        ps = self.prepare_traj(pos_seq)
+        out = torch.empty((self.B, self.N, self.dim), dtype=torch.float64, device=self.device)
+        check(self.lib.lb_case_integrate(self._h, mode, ptr(p), ptr(ps), ps.shape[2], ptr(out)),
+              "lb_case_integrate")
+        return out
+
+    def rollout(self, gns: "GnsHandle", traj: torch.Tensor, n_steps: int) -> Tuple[torch.Tensor, int]:
+        traj = self.prepare_traj(traj)
+        pred = torch.zeros((self.B, n_steps, self.N, self.dim), dtype=torch.float64, device=self.device)
+        nre = C.c_int32(0)
+        check(self.lib.lb_rollout(self._h, gns._h, ptr(traj), traj.shape[2], n_steps, ptr(pred),
+                                  C.byref(nre)), "lb_rollout")
+        self.version += 1
+        st = self.stats()
+        self.e_cap, self.cell_capacity = st["e_cap"], st["cell_capacity"]
+        return pred, nre.value
+
+    def metrics(self, pred: torch.Tensor, target: torch.Tensor, n_steps: int,
+                want=("mse",)) -> Dict[str, torch.Tensor]:
+        """pred, target: (B,T,N,dim) (or (T,N,dim) when B == 1)."""
+        pred = _dev(pred if pred.dim() == 4 else pred[None], torch.float64, self.device)
+        target = _dev(target if target.dim() == 4 else target[None], torch.float64, self.device)
+        mse = torch.empty((self.B, n_steps), dtype=torch.float64, device=self.device) if "mse" in want else None
+        mae = torch.empty((self.B, n_steps), dtype=torch.float64, device=self.device) if "mae" in want else None
+        check(self.lib.lb_metrics(self._h, ptr(pred), pred.shape[1], ptr(target), target.shape[1], n_steps,
+                                  ptr(mse), ptr(mae)), "lb_metrics")
+        out = {}
+        if mse is not None:
+            out["mse"] = mse
+        if mae is not None:
+            out["mae"] = mae
+        return out
+
+    def segment_sum(self, msg: torch.Tensor) -> torch.Tensor:
+        msg = _dev(msg, torch.float32, self.device)
+        out = torch.empty((self.B * self.N, msg.shape[1]), dtype=torch.float32, device=self.device)
+        check(self.lib.lb_segment_sum(self._h, ptr(msg), ptr(out), msg.shape[1]), "lb_segment_sum")
+        return out
+
+    # ------------------------------------------------------------------ timers
+    def timers_enable(self, on: bool = True) -> None:
+        check(self.lib.lb_timers_enable(self._h, int(on)))
+
+    def timers_reset(self) -> None:
+        check(self.lib.lb_timers_reset(self._h))
+
+    def timers(self) -> Dict[str, Tuple[float, int]]:
+        out = {}
+        for c in range(self.lib.lb_timer_count()):
+            ms, n = C.c_double(), C.c_int64()
+            check(self.lib.lb_timer_get(self._h, c, C.byref(ms), C.byref(n)))
+            out[self.lib.lb_timer_name(c).decode()] = (ms.value, n.value)
+        return out
+
+
+class GnsHandle:
+    def __init__(self, engine: RolloutEngine, h, desc: GnsDesc):
+        self.engine, self._h, self.desc = engine, h, desc
+        self._tap = None
+
+    def set_tap(self, on: bool = True) -> Optional[torch.Tensor]:
+        e = self.engine
+        if on:
+            self._tap = torch.zeros((self.desc.num_mp_steps + 1, e.B * e.N, self.desc.latent_size),
+                                    dtype=torch.float32, device=e.device)
+            check(e.lib.lb_gns_set_tap(self._h, ptr(self._tap)))
+        else:
+            self._tap = None
+            check(e.lib.lb_gns_set_tap(self._h, None))
+        return self._tap
+
+    def close(self):
+        if self._h:
+            if self.engine._h:
+                torch.cuda.synchronize(self.engine.device)
+            self.engine.lib.lb_gns_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

