@@ -308,8 +308,18 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   if (!frozen) {
     // allocate path (host-synchronous by contract): size the edge buffers before the fill pass
     LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> occ(g.B);
+    LB_HIP(hipMemcpyAsync(occ.data(), e->nedges_b, sizeof(int32_t) * g.B, hipMemcpyDeviceToHost, s));
     LB_HIP(hipStreamSynchronize(s));
-    int rc = lb_ensure_edges(e, (int64_t)e->ctrl_host->n_edges_unclamped);
+    // room for this list AND for the capacity lb_nl_allocate is about to freeze
+    // (B * int(max_b occupancy * multiplier)): growing later would drop the list just built
+    int32_t occ_max = 0;
+    for (int b = 0; b < g.B; ++b) occ_max = occ[b] > occ_max ? occ[b] : occ_max;
+    const double mult = e->desc.capacity_multiplier > 0 ? e->desc.capacity_multiplier : 1.25;
+    int64_t need = (int64_t)e->ctrl_host->n_edges_unclamped;
+    const int64_t frozen_need = (int64_t)(occ_max * mult) * g.B;
+    if (frozen_need > need) need = frozen_need;
+    int rc = lb_ensure_edges(e, need);
     if (rc) return rc;
     // the scan clamped n_edges_total against the old allocation: refresh it
     e->ctrl_host->n_edges_total = e->ctrl_host->n_edges_unclamped;

@@ -1,0 +1,88 @@
+"""Multi-GPU: independent trajectories shard embarrassingly (the reference's only batching is a
+vmap over trajectories on one device, evaluate/rollout.py:226-230).  One process per GPU; there
+is NO data-path collective - torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo"
+in CPU tests) is used only to gather the per-trajectory metric vectors and to agree on the
+slowest rank's wall time.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (1 process = 1 GPU)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_trajectories(n_trajs: int, rank: int, world: int) -> List[int]:
+    """Trajectory i -> rank i % world."""
+    return [i for i in range(n_trajs) if i % world == rank]
+
+
+def barrier(device: Optional[torch.device] = None) -> None:
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if dist.is_initialized():
+        dist.barrier()
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_metrics(local: Dict[int, torch.Tensor], n_trajs: int, n_steps: int,
+                   device: Optional[torch.device] = None) -> Dict[int, torch.Tensor]:
+    """All-gather {trajectory index -> (n_steps,) metric vector} from every rank.  Each rank
+    contributes a dense (ceil(n_trajs/world), 1 + n_steps) block [index, values...]; slots a rank
+    does not own carry index -1.  Message size: 8*(1+n_steps) bytes per trajectory."""
+    if not dist.is_initialized():
+        return dict(local)
+    world = dist.get_world_size()
+    per = (n_trajs + world - 1) // world
+    dev = device if device is not None else torch.device("cpu")
+    block = torch.full((per, 1 + n_steps), -1.0, dtype=torch.float64, device=dev)
+    for slot, (idx, v) in enumerate(sorted(local.items())):
+        block[slot, 0] = float(idx)
+        block[slot, 1:] = v.to(dev, torch.float64)
+    out = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(out, block)
+    merged: Dict[int, torch.Tensor] = {}
+    for blk in out:
+        for row in blk.cpu():
+            if row[0] >= 0:
+                merged[int(row[0])] = row[1:].clone()
+    return merged
+
+
+def sharded_eval(run_trajs: Callable[[Sequence[int]], Dict[int, torch.Tensor]], n_trajs: int, n_steps: int,
+                 device: Optional[torch.device] = None) -> Dict[int, torch.Tensor]:
+    """Run ``run_trajs(my trajectory indices) -> {index: (n_steps,) metric}`` on every rank and
+    return the merged dictionary on all ranks."""
+    rank, _, world = env_world()
+    mine = shard_trajectories(n_trajs, rank, world)
+    local = run_trajs(mine) if mine else {}
+    return gather_metrics(local, n_trajs, n_steps, device)
