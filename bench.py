@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py - rollout throughput of the MI355X engine on BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W [--workload tgv3d] [--batch B]
+
+A "step" is ONE rollout step (neighbor-list rebuild -> features -> GNS-10-128 -> integrator ->
+prediction store) over one batch of B synthetic trajectories per GPU.  Inputs are resident in
+HBM before the timed region.  Rank 0 prints ONE JSON line:
+
+  metric/value : rollout particle-steps/s, whole job = n_gpus * B * N_particles * K / max-rank time
+  roofline     : dominant kernel (processor edge MLP, fp32 MFMA bound), timed with HIP events on
+                 the engine stream inside this run; + roofline_aggregate for the segment_sum kernel
+                 (HBM bound) that BASELINE.json's north_star singles out
+  cpu_baseline : the NumPy oracle (reference-shaped: padded E_cap rows, unfused ops) timed on this
+                 host's cores on a bounded sample (rank 0, N=1 only)
+
+Multi-GPU: launched by torch.distributed.run, one rank per GPU; trajectories are independent, so
+there is no data-path collective - RCCL only gathers the per-trajectory MSE vectors and the max
+wall time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = 157.3 TFLOP/s dense
+D = 128
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="tgv3d", choices=["tgv2d", "rpf2d", "tgv3d", "ldc3d", "dam2d"])
+    ap.add_argument("--batch", type=int, default=8, help="trajectories advanced together per GPU")
+    ap.add_argument("--mp-steps", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    from lagrangebench_amd import dist as lbdist
+    rank, local_rank, world = lbdist.init()
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    from tests._common import hip_case, make_params
+
+    B, K, W, L = args.batch, args.steps, args.warmup, args.mp_steps
+    ds = make_case(args.workload, n_trajs=world * B, extra_seq_length=max(K, W, 1))
+    dim = len(ds.box)
+    params = make_params(ds, num_mp_steps=L, random_affine=False)  # haiku-default init, decoder x0.01
+    model = GNS(dim, D, 2, L, 16)
+    case = hip_case(ds)
+    mine = [rank * B + i for i in range(B)]  # weak scaling: B trajectories per GPU
+    pos = np.stack([ds[i][0] for i in mine])
+    pt = np.stack([ds[i][1] for i in mine])
+    N = pos.shape[1]
+    eng = case.engine(B)
+    eng.set_particle_type(pt)
+    traj = eng.prepare_traj(pos)  # fp64, resident in HBM
+    handle = model.handle(eng, params)
+
+    # warm-up: allocates the neighbor list, touches every kernel
+    eng.rollout(handle, traj, max(W, 1))
+    lbdist.barrier(device)
+    t0 = time.perf_counter()
+    pred, n_realloc = eng.rollout(handle, traj, K)  # host-synchronous at the end
+    lbdist.barrier(device)
+    dt = time.perf_counter() - t0
+    dt = lbdist.max_over_ranks(dt, device)
+    st = eng.stats()
+    E_tot = st["n_edges_total"]
+
+    # gather the per-trajectory MSE vectors over RCCL (the only collective of the job)
+    tgt = traj[:, :, ds.input_seq_length:ds.input_seq_length + K].permute(0, 2, 1, 3).contiguous()
+    mse = eng.metrics(pred, tgt, K, want=("mse",))["mse"]
+    merged = lbdist.gather_metrics({mine[i]: mse[i] for i in range(B)}, world * B, K, device)
+
+    # second pass with per-kernel-class HIP events (same K steps) for the roofline objects
+    eng.timers_enable(True)
+    eng.timers_reset()
+    eng.rollout(handle, traj, K)
+    tm = eng.timers()
+    eng.timers_enable(False)
+
+    if rank != 0:
+        return
+    value = world * B * N * K / dt
+    ms_edge, n_edge = tm["edge_mlp"]
+    ms_agg, n_agg = tm["aggregate"]
+    us_edge = 1e3 * ms_edge / max(n_edge, 1)
+    us_agg = 1e3 * ms_agg / max(n_agg, 1)
+    # processor edge MLP, one launch = E_tot edges of one MP layer.
+    #   executed on MFMA: 2 GEMMs of (E x 128 x 128): 2*2*D*D flop/edge (the sender/receiver part of
+    #   W0 is projected per node); algorithmic (reference formulation): 2*4*D*D flop/edge.
+    flop_exec = E_tot * 2 * 2 * D * D
+    flop_algo = E_tot * 2 * 4 * D * D
+    tf_exec = flop_exec / (us_edge * 1e-6) / 1e12
+    agg_bytes = E_tot * (D * 4 + 4) + B * N * D * 4  # E*516 + N*512
+    gbs_agg = agg_bytes / (us_agg * 1e-6) / 1e9
+    breakdown = {k: round(v[0] / K, 4) for k, v in tm.items() if v[1] > 0}
+
+    out = {
+        "metric": "rollout particle-steps/sec",
+        "value": value,
+        "unit": "particle-steps/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": 1e3 * dt / K,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload} GNS-{L}-{D} inference rollout, neighbor list rebuilt every step",
+            "n_particles": int(N), "batch_per_gpu": B, "edges_per_traj": int(E_tot // B),
+            "input_seq_length": ds.input_seq_length, "geometry_dtype": "f64", "network_dtype": "f32",
+            "weights": "haiku-default init (seed 1234), decoder x0.01", "n_realloc": int(n_realloc),
+        },
+        "steps_per_s_per_traj": K / dt,
+        "mse20_mean": float(np.mean([float(v.mean()) for v in merged.values()])),
+        "roofline": {
+            "kernel": "k_edge_mlp<PROC>", "bound": "mfma", "achieved": tf_exec, "peak": MFMA_F32_PEAK_TF,
+            "unit": "TFLOP/s", "frac": tf_exec / MFMA_F32_PEAK_TF, "traffic": None,
+            "us_per_launch": us_edge, "launches": int(n_edge), "flop_per_launch_executed": flop_exec,
+            "flop_per_launch_algorithmic": flop_algo,
+            "achieved_algorithmic": flop_algo / (us_edge * 1e-6) / 1e12,
+        },
+        "roofline_aggregate": {
+            "kernel": "k_segment_sum", "bound": "hbm", "achieved": gbs_agg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs_agg / HBM_PEAK_GBS, "traffic": None, "us_per_launch": us_agg, "launches": int(n_agg),
+            "bytes_per_launch": agg_bytes,
+        },
+        "breakdown_ms_per_step": breakdown,
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(ds, params, L, args.cpu_steps)
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(ds, params, L, n_steps):
+    """The NumPy oracle in the reference's algorithmic shape (dense candidate matrix -> mask ->
+    compaction; MLPs over all E_cap padded rows; unfused gather/GEMM/LayerNorm/scatter-add; fp64
+    geometry, fp32 network; batch 1) on all host cores (BLAS threads)."""
+    from oracle import lb_oracle as O
+    from tests._common import oracle_case
+    cores = os.cpu_count() or 1
+    ocase = oracle_case(ds)
+    isl = ds.input_seq_length
+    pos, pt = ds[0]
+    pos = pos.astype(np.float64)
+
+    def apply(p, s, sample):
+        return O.gns_apply(p, sample[0], sample[1], num_mp_steps=L, skip_padding=False), s
+
+    _, nbrs = ocase.allocate_eval((pos[:, :isl], pt))
+    # 1 untimed step, then n_steps timed
+    O.eval_batched_rollout(apply, ocase, params, {}, (pos[None, :, :isl + 1], pt[None]), nbrs, 1, isl)
+    t0 = time.perf_counter()
+    O.eval_batched_rollout(apply, ocase, params, {}, (pos[None, :, :isl + n_steps], pt[None]), nbrs, n_steps, isl)
+    dt = time.perf_counter() - t0
+    return {
+        "value": len(pt) * n_steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+        "sample": f"{n_steps} rollout steps of 1 {ds.name} trajectory (N={len(pt)}) after 1 warm-up step, "
+                  f"NumPy/BLAS oracle in the reference's padded/unfused shape, {1e3 * dt / n_steps:.0f} ms/step",
+        "note": "JAX is not installable here: this is the reference-shaped CPU restatement, not JAX-CPU",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -219,6 +219,17 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
     lb_engine_destroy(e);
     return lb_fail(LB_ERR_HIP, "hipHostMalloc failed");
   }
+  if (hipHostMalloc((void**)&e->host_flag, sizeof(int32_t) * 4, hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&e->host_flag_dev, e->host_flag, 0) != hipSuccess) {
+    lb_engine_destroy(e);
+    return lb_fail(LB_ERR_HIP, "hipHostMalloc(mapped flag) failed");
+  }
+  e->host_flag[0] = -1;
+  for (int i = 0; i < 4; ++i)
+    if (hipEventCreateWithFlags(&e->step_ev[i], hipEventDisableTiming) != hipSuccess) {
+      lb_engine_destroy(e);
+      return lb_fail(LB_ERR_HIP, "hipEventCreate failed");
+    }
   lb_ctrl c0;
   memset(&c0, 0, sizeof(c0));
   c0.overflow_step = -1;
@@ -243,6 +254,9 @@ extern "C" void lb_engine_destroy(lb_engine* e) {
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->ctrl_host) (void)hipHostFree(e->ctrl_host);
+  if (e->host_flag) (void)hipHostFree(e->host_flag);
+  for (int i = 0; i < 4; ++i)
+    if (e->step_ev[i]) (void)hipEventDestroy(e->step_ev[i]);
   delete e;
 }
 
@@ -317,6 +331,7 @@ extern "C" int lb_nl_allocate(lb_engine* e, int32_t* cell_capacity_out, int32_t*
   LB_HIP(hipStreamSynchronize(e->stream));
   h->overflow_step = -1;
   h->density_error = 0;
+  e->host_flag[0] = -1;
   LB_HIP(hipMemcpyAsync(e->ctrl, h, sizeof(lb_ctrl), hipMemcpyHostToDevice, e->stream));
   e->cell_capacity = 0;
   e->e_cap = 0;
@@ -626,11 +641,19 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
   LB_TRY(lbk_load_window(e, traj_dev, T, 0, 0));
   if (e->e_cap <= 0) LB_TRY(lb_nl_allocate(e, nullptr, nullptr, nullptr));
   int step = 0;
+  const int RA = 3;  // steps the host may run ahead of the device
   while (step < n_steps) {
     for (int s = step; s < n_steps; ++s) {
+      if (s - step >= RA) {
+        // throttle: wait for step s-RA to retire, then look at the device-written host flag, so an
+        // overflow costs at most RA steps of no-op launches instead of the rest of the rollout
+        LB_HIP(hipEventSynchronize(e->step_ev[(s - RA) & 3]));
+        if (*(volatile int32_t*)e->host_flag >= 0) break;
+      }
       LB_TRY(lbk_nl_build(e, false));
       LB_TRY(lbk_gns_forward(e, g));
       LB_TRY(lbk_integrate(e, e->acc, 4, nullptr, traj_dev, T, pred_out_dev, n_steps));
+      LB_HIP(hipEventRecord(e->step_ev[s & 3], e->stream));
     }
     LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, e->stream));
     LB_HIP(hipStreamSynchronize(e->stream));

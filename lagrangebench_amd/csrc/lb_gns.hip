@@ -154,7 +154,9 @@ struct lb_edge_args {
 #define EDGE_THREADS 512
 #define EDGE_WAVES 8
 
-template <bool PROC>
+// ABL: ablation bits for tools/edge_bench.hip only (0 in the product): 1 no Ps/Pr gather, 2 no e
+// load, 4 no stores, 8 no LayerNorm, 16 no GEMM2, 32 no GEMM1.
+template <bool PROC, int ABL = 0>
 __global__ void __launch_bounds__(EDGE_THREADS, 2) k_edge_mlp(lb_edge_args a) {
   // PROC: [0,4096) = W0 edge part, [4096,8192) = W1.  ENC: [0,256) = W0 (K=8), [256,4352) = W1.
   constexpr int NW0 = PROC ? 4096 : 256;
@@ -191,18 +193,19 @@ __global__ void __launch_bounds__(EDGE_THREADS, 2) k_edge_mlp(lb_edge_args a) {
     if (PROC) {
       const int s = a.senders[rowc], r = a.receivers[rowc];
 #pragma unroll
-      for (int kq = 0; kq < 16; ++kq) ve[kq] = erow[2 * kq];
+      for (int kq = 0; kq < 16; ++kq) ve[kq] = (ABL & 2) ? f32x4{1.f, 2.f, 3.f, (float)lane} : erow[2 * kq];
       const f32x4* ps = reinterpret_cast<const f32x4*>(a.psr) + (int64_t)s * 64 + h;
       const f32x4* pr = reinterpret_cast<const f32x4*>(a.psr) + (int64_t)r * 64 + 32 + h;
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 t = ps[2 * (4 * mb + q)] + pr[2 * (4 * mb + q)];
+          const f32x4 t = (ABL & 1) ? f32x4{0.1f, 0.2f, (float)s, (float)r}
+                                    : ps[2 * (4 * mb + q)] + pr[2 * (4 * mb + q)];
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[mb][4 * q + j] = t[j];
         }
-      lb_gemm<16, 4>(ld0, ve, acc);
+      if constexpr (!(ABL & 32)) lb_gemm<16, 4>(ld0, ve, acc);
     } else {
       f32x4 vin[1];
       vin[0] = reinterpret_cast<const f32x4*>(a.efeat)[rowc * 2 + h];
@@ -213,10 +216,17 @@ __global__ void __launch_bounds__(EDGE_THREADS, 2) k_edge_mlp(lb_edge_args a) {
     lb_acc_to_v(acc, vh, true);
     f32x16 acc2[4];
     lb_acc_init(acc2, a.b1, h);
-    lb_gemm<16, 4>(ld1, vh, acc2);
+    if constexpr (!(ABL & 16)) lb_gemm<16, 4>(ld1, vh, acc2);
+    if constexpr ((ABL & 16) != 0) {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) acc2[mb] = acc2[mb] + acc[mb];
+    }
     f32x4 y[16];
-    lb_layernorm(acc2, y, a.ln_s, a.ln_o, h);
-    if (valid) {
+    if constexpr (ABL & 8)
+      lb_acc_to_v(acc2, y, false);
+    else
+      lb_layernorm(acc2, y, a.ln_s, a.ln_o, h);
+    if (valid && !((ABL & 4) && a.senders[0] != -12345)) {
       if (PROC) {
         f32x4* mrow = reinterpret_cast<f32x4*>(a.msg) + rowc * 32 + h;
 #pragma unroll

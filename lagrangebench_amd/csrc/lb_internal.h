@@ -78,6 +78,9 @@ struct lb_engine {
   double* force;      // [B*N*dim] (LB_FORCE_BUFFER) or null
   lb_ctrl* ctrl;      // device
   lb_ctrl* ctrl_host; // pinned mirror
+  int32_t* host_flag;     // pinned + device-mapped: first overflowing step (-1 = none), written by
+  int32_t* host_flag_dev; //   k_row_scan so lb_rollout can stop enqueuing without a stream sync
+  hipEvent_t step_ev[4];  // run-ahead throttle of lb_rollout
 
   // neighbor structures
   int32_t cell_capacity, e_cap;      // frozen capacities (0 = not allocated)

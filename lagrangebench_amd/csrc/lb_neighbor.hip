@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(1024)
     k_row_scan(lb_geom g, const int32_t* __restrict__ deg, int32_t* __restrict__ row_ptr, int n,
                lb_ctrl* __restrict__ ctrl, int32_t* __restrict__ overflow,
                int32_t* __restrict__ nedges_b, int32_t cell_capacity, int32_t e_cap,
-               int64_t e_alloc, int frozen) {
+               int64_t e_alloc, int frozen, int32_t* host_flag) {
   if (ctrl->overflow_step >= 0) return;
   const int total = lb_block_scan_excl(deg, row_ptr, n, nullptr);
   __syncthreads();
@@ -274,8 +274,10 @@ __global__ void __launch_bounds__(1024)
   if (threadIdx.x == 0) {
     ctrl->n_edges_unclamped = total;
     ctrl->n_edges_total = (int)min((int64_t)total, e_alloc);
-    if (frozen && (s_any || (int64_t)total > e_alloc) && ctrl->overflow_step < 0)
+    if (frozen && (s_any || (int64_t)total > e_alloc) && ctrl->overflow_step < 0) {
       ctrl->overflow_step = ctrl->step;
+      if (host_flag) *host_flag = ctrl->step;  // pinned host memory: visible once this kernel retires
+    }
   }
 }
 
@@ -304,7 +306,7 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
                      e->receivers, e->efeat, (double*)nullptr, e->e_alloc);
   hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, s, g, e->deg, e->row_ptr, (int)BN,
                      e->ctrl, e->overflow, e->nedges_b, e->cell_capacity, e->e_cap, e->e_alloc,
-                     frozen);
+                     frozen, e->host_flag_dev);
   if (!frozen) {
     // allocate path (host-synchronous by contract): size the edge buffers before the fill pass
     LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, s));
