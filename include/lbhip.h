@@ -153,6 +153,11 @@ void lb_gns_destroy(lb_gns* gns);
  * (rollout.py:59) on the engine's current window and neighbor list. */
 int lb_gns_forward(lb_engine* eng, lb_gns* gns, float* acc_out_dev);
 
+/* 1 (default): jraph.segment_sum is fused into the edge-MLP epilogue (segmented wavefront scan,
+ * no message round trip through HBM); 0: messages are written out and reduced by the stand-alone
+ * segment_sum kernel (lb_segment_sum's kernel).  Both are deterministic and atomic-free. */
+int lb_set_fused_aggregation(lb_engine* eng, int32_t on);
+
 /* Debug/parity taps: node latents after the encoder and after each MP step
  * ((num_mp_steps+1), B*N, latent) fp32, or NULL. */
 int lb_gns_set_tap(lb_gns* gns, float* node_latents_out_dev);

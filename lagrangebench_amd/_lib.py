@@ -62,6 +62,7 @@ _SIGS = {
     "lb_gns_create": (C.c_int, [_P, C.POINTER(GnsDesc), _P, C.c_int64, C.POINTER(_P)]),
     "lb_gns_destroy": (None, [_P]),
     "lb_gns_forward": (C.c_int, [_P, _P, _P]),
+    "lb_set_fused_aggregation": (C.c_int, [_P, C.c_int32]),
     "lb_gns_set_tap": (C.c_int, [_P, _P]),
     "lb_integrate": (C.c_int, [_P, _P, _P, _P, C.c_int32]),
     "lb_case_integrate": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P]),

@@ -2,6 +2,7 @@
 // packing, the device-resident rollout driver and the HIP-event timers used by bench.py.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -136,6 +137,10 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   e->BN = (int64_t)d->n_particles * d->batch;
   e->timers_on = false;
   for (int i = 0; i < LB_T_COUNT; ++i) e->t_ms[i] = 0, e->t_n[i] = 0;
+  {
+    const char* f = getenv("LB_FUSED_AGG");
+    e->fused_agg = (f && f[0] == '0') ? 0 : 1;
+  }
   lb_geom& g = e->g;
   memset(&g, 0, sizeof(g));
   g.dim = d->dim;
@@ -250,7 +255,7 @@ extern "C" void lb_engine_destroy(lb_engine* e) {
   void* bufs[] = {e->win, e->ptype, e->force, e->ctrl, e->cell_of, e->cell_count, e->cell_start,
                   e->cell_part, e->deg, e->row_ptr, e->senders, e->receivers, e->efeat, e->efeat64,
                   e->overflow, e->nedges_b, e->xnode, e->nlat, e->agg, e->psr, e->elat, e->msg,
-                  e->acc};
+                  e->part, e->acc};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->ctrl_host) (void)hipHostFree(e->ctrl_host);
@@ -265,13 +270,14 @@ int lb_ensure_edges(lb_engine* e, int64_t need) {
   if (need <= e->e_alloc && e->senders) return LB_OK;
   LB_HIP(hipStreamSynchronize(e->stream));
   int64_t n = std::max<int64_t>(need + need / 8 + 1024, 4096);
-  void* old[] = {e->senders, e->receivers, e->efeat, e->efeat64, e->elat, e->msg};
+  void* old[] = {e->senders, e->receivers, e->efeat, e->efeat64, e->elat, e->msg, e->part};
   for (void* b : old)
     if (b) (void)hipFree(b);
   e->senders = e->receivers = nullptr;
   e->efeat = nullptr;
   e->efeat64 = nullptr;
-  e->elat = e->msg = nullptr;
+  e->elat = e->msg = e->part = nullptr;
+  LB_TRY(lb_alloc(&e->part, (size_t)(n / LB_TILE + 2) * 2 * LB_D));
   LB_TRY(lb_alloc(&e->senders, (size_t)n));
   LB_TRY(lb_alloc(&e->receivers, (size_t)n));
   LB_TRY(lb_alloc(&e->efeat, (size_t)n * 8));
@@ -582,6 +588,12 @@ extern "C" void lb_gns_destroy(lb_gns* g) {
   if (!g) return;
   if (g->blob) (void)hipFree(g->blob);
   delete g;
+}
+
+extern "C" int lb_set_fused_aggregation(lb_engine* e, int32_t on) {
+  if (!e) return lb_fail(LB_ERR_ARG, "null engine");
+  e->fused_agg = on ? 1 : 0;
+  return LB_OK;
 }
 
 extern "C" int lb_gns_set_tap(lb_gns* g, float* tap) {

@@ -149,6 +149,11 @@ struct lb_edge_args {
   const float* b1;
   const float* ln_s;
   const float* ln_o;
+  // fused aggregation (PROC): receiver-sorted CSR + outputs
+  int fused;
+  const int32_t* row_ptr;
+  float* agg;   // [BN][128] rows complete inside one tile
+  float* part;  // [ntiles][2][128] segments cut by a tile boundary
 };
 
 #define EDGE_THREADS 512
@@ -228,18 +233,92 @@ __global__ void __launch_bounds__(EDGE_THREADS, 2) k_edge_mlp(lb_edge_args a) {
       lb_layernorm(acc2, y, a.ln_s, a.ln_o, h);
     if (valid && !((ABL & 4) && a.senders[0] != -12345)) {
       if (PROC) {
-        f32x4* mrow = reinterpret_cast<f32x4*>(a.msg) + rowc * 32 + h;
+        if (!a.fused) {
+          f32x4* mrow = reinterpret_cast<f32x4*>(a.msg) + rowc * 32 + h;
 #pragma unroll
-        for (int kq = 0; kq < 16; ++kq) {
-          mrow[2 * kq] = y[kq];  // e' : what segment_sum aggregates
-          // residual (gns.py:120-122); e is re-read (L2-resident, fetched a few us ago by this
-          // CU) instead of being kept in 64 VGPRs across both GEMMs
-          erow[2 * kq] = erow[2 * kq] + y[kq];
+          for (int kq = 0; kq < 16; ++kq) mrow[2 * kq] = y[kq];  // e' for the stand-alone segment_sum
         }
+        // residual (gns.py:120-122); e is re-read (L2-resident, fetched a few us ago by this CU)
+        // instead of being kept in 64 VGPRs across both GEMMs
+#pragma unroll
+        for (int kq = 0; kq < 16; ++kq) erow[2 * kq] = erow[2 * kq] + y[kq];
       } else {
 #pragma unroll
         for (int kq = 0; kq < 16; ++kq) erow[2 * kq] = y[kq];
       }
+    }
+    if (PROC && a.fused) {
+      // ---- fused jraph.segment_sum(e', receivers): the tile's 32 edges are consecutive rows of
+      // the receiver-sorted list, so every receiver is a contiguous lane range.  Segmented
+      // Hillis-Steele scan across the 32 lanes of each half-wave with DPP row shifts (offsets
+      // 1,2,4,8 inside a 16-lane row, row_bcast15 across rows); the last lane of a segment ends up
+      // with the receiver's sum for its 64 features.  Rows lying entirely inside the tile are
+      // written to agg[r]; the (at most two) segments cut by a tile boundary go to the tile's
+      // partial slots and are combined, in tile order, by the node kernel.  No atomics.
+      const int p = lane & 31;
+      const int rr = valid ? a.receivers[rowc] : (-1 - p);
+      const int r_prev = __shfl_up(rr, 1, 32);
+      const bool head = (p == 0) || (rr != r_prev);
+      const unsigned H = (unsigned)(__ballot(head) & 0xffffffffull);  // both halves: same pattern
+      const unsigned below = H & (p == 31 ? 0xffffffffu : ((2u << p) - 1u));
+      const int segstart = 31 - __clz(below);
+      const bool tail = (p == 31) || ((H >> (p + 1)) & 1u);
+      const int pr16 = p & 15;
+      const bool m1 = pr16 >= 1 && segstart <= p - 1, m2 = pr16 >= 2 && segstart <= p - 2;
+      const bool m4 = pr16 >= 4 && segstart <= p - 4, m8 = pr16 >= 8 && segstart <= p - 8;
+      const bool mb15 = p >= 16 && segstart <= 15;
+#pragma unroll
+      for (int kq = 0; kq < 16; ++kq)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x = y[kq][j];
+          float t;
+          t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xF, 0xF, true));
+          x += m1 ? t : 0.f;
+          t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xF, 0xF, true));
+          x += m2 ? t : 0.f;
+          t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xF, 0xF, true));
+          x += m4 ? t : 0.f;
+          t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xF, 0xF, true));
+          x += m8 ? t : 0.f;
+          t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xA, 0xF, false));
+          x += mb15 ? t : 0.f;
+          y[kq][j] = x;
+        }
+      if (tail && valid) {
+        const int k0 = a.row_ptr[rr], k1 = a.row_ptr[rr + 1];
+        const bool complete = (k0 >> 5) == ((k1 - 1) >> 5);
+        float* dst = complete ? a.agg + (int64_t)rr * 128
+                              : a.part + ((int64_t)tile * 2 + (k0 <= tile * LB_TILE ? 0 : 1)) * 128;
+        f32x4* d4 = reinterpret_cast<f32x4*>(dst) + h;
+#pragma unroll
+        for (int kq = 0; kq < 16; ++kq) d4[2 * kq] = y[kq];
+      }
+    }
+  }
+}
+
+// Gather a node's aggregated messages in the fused-aggregation scheme: one source when the
+// receiver's CSR row lies inside a single 32-edge tile (agg[g]), else the per-tile partial slots
+// in tile order.  Lane = node; v gets the lane's 64 features (half h).
+__device__ __forceinline__ void lb_load_agg_fused(const int32_t* __restrict__ row_ptr,
+                                                  const float* __restrict__ agg,
+                                                  const float* __restrict__ part, int64_t g, int h,
+                                                  f32x4 (&v)[16]) {
+  const int k0 = row_ptr[g], k1 = row_ptr[g + 1];
+  const int t0 = k0 >> 5, t1 = (k1 - 1) >> 5;
+  const bool single = t0 == t1;
+  const int nsrc = (k1 <= k0) ? 0 : (single ? 1 : t1 - t0 + 1);
+#pragma unroll
+  for (int kq = 0; kq < 16; ++kq) v[kq] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; __any(s < nsrc); ++s) {
+    if (s < nsrc) {
+      const int t = t0 + s;
+      const float* src = single ? agg + g * 128
+                                : part + ((int64_t)t * 2 + (k0 <= t * LB_TILE ? 0 : 1)) * 128;
+      const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + h;
+#pragma unroll
+      for (int kq = 0; kq < 16; ++kq) v[kq] = v[kq] + s4[2 * kq];
     }
   }
 }
@@ -260,6 +339,9 @@ struct lb_node_args {
   const float* wpp;   // packed 128 x 256 projection for the NEXT edge MLP, or null
   const float* bp;    // [256]
   float* psr;         // out [rows][256]
+  int fused;          // agg comes from the fused edge epilogue (agg + per-tile partial slots)
+  const int32_t* row_ptr;
+  const float* part;
 };
 
 template <int NKQ_A, int NKQ_B, bool RESID>
@@ -284,9 +366,13 @@ __global__ void __launch_bounds__(64) k_node_mlp(lb_node_args a) {
   }
   if constexpr (NKQ_B > 0) {
     f32x4 vb[NKQ_B];
-    const f32x4* gr = reinterpret_cast<const f32x4*>(a.agg) + rowc * (2 * NKQ_B) + h;
+    if (a.fused) {
+      lb_load_agg_fused(a.row_ptr, a.agg, a.part, rowc, h, vb);
+    } else {
+      const f32x4* gr = reinterpret_cast<const f32x4*>(a.agg) + rowc * (2 * NKQ_B) + h;
 #pragma unroll
-    for (int kq = 0; kq < NKQ_B; ++kq) vb[kq] = gr[2 * kq];
+      for (int kq = 0; kq < NKQ_B; ++kq) vb[kq] = gr[2 * kq];
+    }
     auto ld = [&](int kq, int mb) -> f32x4 { return w0[((NKQ_A + kq) * 4 + mb) * 64 + lane]; };
     lb_gemm<NKQ_B, 4>(ld, vb, acc);
   }
@@ -498,14 +584,20 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       a.b1 = g->proc_edge[k].b1;
       a.ln_s = g->proc_edge[k].ln_s;
       a.ln_o = g->proc_edge[k].ln_o;
+      a.fused = e->fused_agg;
+      a.row_ptr = e->row_ptr;
+      a.agg = e->agg;
+      a.part = e->part;
       lb_tic(e, LB_T_EDGE_MLP);
       hipLaunchKernelGGL((k_edge_mlp<true>), dim3(edge_blocks), dim3(EDGE_THREADS), 0, s, a);
       lb_toc(e);
     }
-    lb_tic(e, LB_T_AGGREGATE);
-    rc = lbk_segment_sum(e, e->msg, e->agg, LB_D);
-    lb_toc(e);
-    if (rc) return rc;
+    if (!e->fused_agg) {
+      lb_tic(e, LB_T_AGGREGATE);
+      rc = lbk_segment_sum(e, e->msg, e->agg, LB_D);
+      lb_toc(e);
+      if (rc) return rc;
+    }
     {
       lb_node_args a{};
       a.ctrl = e->ctrl;
@@ -522,6 +614,9 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       a.wpp = (k + 1 < L) ? g->proj_w[k + 1] : nullptr;
       a.bp = (k + 1 < L) ? g->proj_b[k + 1] : nullptr;
       a.psr = e->psr;
+      a.fused = e->fused_agg;
+      a.row_ptr = e->row_ptr;
+      a.part = e->part;
       lb_tic(e, LB_T_NODE_MLP);
       hipLaunchKernelGGL((k_node_mlp<16, 16, true>), dim3(ntile_n), dim3(64), 0, s, a);
       lb_toc(e);

@@ -105,7 +105,9 @@ struct lb_engine {
   float* agg;          // [BN][D]
   float* psr;          // [BN][2D]  projections of the node latents for the edge MLP
   float* elat;         // [e_alloc][D]
-  float* msg;          // [e_alloc][D]
+  float* msg;          // [e_alloc][D]   (stand-alone segment_sum path only)
+  float* part;         // [e_alloc/32+1][2][D] partial sums of receivers cut by a tile boundary
+  int fused_agg;       // 1: aggregation fused into the edge kernel (default), 0: msg + k_segment_sum
   float* acc;          // [BN][4] decoder output (dim padded to 4)
 
   // timers

@@ -241,6 +241,9 @@ class RolloutEngine:
         check(self.lib.lb_gns_forward(self._h, gns._h, ptr(out)), "lb_gns_forward")
         return out
 
+    def set_fused_aggregation(self, on: bool) -> None:
+        check(self.lib.lb_set_fused_aggregation(self._h, int(bool(on))), "lb_set_fused_aggregation")
+
     # ------------------------------------------------------------------ integrate / rollout
     def integrate(self, acc: Optional[torch.Tensor], target: torch.Tensor,
                   pred: Optional[torch.Tensor] = None) -> None:

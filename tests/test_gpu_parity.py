@@ -147,9 +147,10 @@ def test_nonperiodic_bound_feature_and_vel_mag():
 
 
 # ------------------------------------------------------------------ GNS forward
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_agg", "standalone_agg"])
 @pytest.mark.parametrize("name,scale,L", [("small2d", 1.0, 3), ("small3d", 1.0, 10), ("rpf2d", 0.5, 10),
-                                          ("ldc3d", 0.5, 4), ("tgv3d", 0.6, 10)])
-def test_gns_forward_parity(name, scale, L):
+                                          ("ldc3d", 0.5, 4), ("tgv3d", 0.6, 10), ("dam2d", 0.3, 3)])
+def test_gns_forward_parity(name, scale, L, fused):
     _need_gpu()
     from lagrangebench_amd.data import make_case
     from lagrangebench_amd.models import GNS
@@ -162,6 +163,7 @@ def test_gns_forward_parity(name, scale, L):
     pt = np.stack([ds[0][1], ds[1][1]])
     feats, nbrs = hcase.allocate_eval((pos[:, :, :isl], pt))
     eng = feats.engine
+    eng.set_fused_aggregation(fused)
     handle = model.handle(eng, params)
     tap = handle.set_tap(True)
     pred, _ = model.apply(params, {}, (feats, pt))
