@@ -140,6 +140,8 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   {
     const char* f = getenv("LB_FUSED_AGG");
     e->fused_agg = (f && f[0] == '0') ? 0 : 1;
+    const char* t = getenv("LB_EDGE_TILE");
+    e->edge_tile = (t && atoi(t) == 32) ? 32 : 16;
   }
   lb_geom& g = e->g;
   memset(&g, 0, sizeof(g));
@@ -277,7 +279,7 @@ int lb_ensure_edges(lb_engine* e, int64_t need) {
   e->efeat = nullptr;
   e->efeat64 = nullptr;
   e->elat = e->msg = e->part = nullptr;
-  LB_TRY(lb_alloc(&e->part, (size_t)(n / LB_TILE + 2) * 2 * LB_D));
+  LB_TRY(lb_alloc(&e->part, (size_t)(n / 16 + 2) * 2 * LB_D));  // sized for the 16-row tiles
   LB_TRY(lb_alloc(&e->senders, (size_t)n));
   LB_TRY(lb_alloc(&e->receivers, (size_t)n));
   LB_TRY(lb_alloc(&e->efeat, (size_t)n * 8));
@@ -464,6 +466,11 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     if (src) memcpy(host.data() + off, src, n * sizeof(float));
     return off;
   };
+  auto put_packed16 = [&](const float* src, int K, int M, int Kp) -> size_t {
+    std::vector<float> tmp((size_t)Kp * 128);
+    lb_pack_weight16(src, K, M, Kp, tmp.data());
+    return put(tmp.data(), tmp.size());
+  };
   auto put_packed = [&](const float* src, int K, int M, int Kp, int Mp) -> size_t {
     std::vector<float> tmp((size_t)Kp * Mp);
     lb_pack_weight(src, K, M, Kp, Mp, tmp.data());
@@ -496,7 +503,11 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     return o;
   };
   Off o_enc_node = read_mlp(nin, kpad, D, D, true);
+  const float* p_enc_edge = p;
   Off o_enc_edge = read_mlp(d->edge_in, 8, D, D, true);
+  const size_t o_ee_w0_16 = put_packed16(p_enc_edge, d->edge_in, D, 16);
+  const size_t o_ee_w1_16 = put_packed16(p_enc_edge + (size_t)d->edge_in * D + D, D, D, D);
+  std::vector<size_t> o_pe_w0_16(L), o_pe_w1_16(L);
   std::vector<Off> o_pe(L), o_pn(L);
   std::vector<size_t> o_pw(L), o_pb(L);
   for (int k = 0; k < L; ++k) {
@@ -518,8 +529,10 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     }
     Off o{};
     o.w0 = put_packed(w0 + (size_t)2 * D * D, D, D, D, D);  // edge rows only
+    o_pe_w0_16[k] = put_packed16(w0 + (size_t)2 * D * D, D, D, D);
     o.b0 = put(b0, D);
     p += (size_t)3 * D * D + D;
+    o_pe_w1_16[k] = put_packed16(p, D, D, D);
     o.w1 = put_packed(p, D, D, D, D); p += (size_t)D * D;
     o.b1 = put(p, D); p += D;
     o.ln = true;
@@ -564,7 +577,11 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     g->proc_node.push_back(mk(o_pn[k]));
     g->proj_w.push_back(g->blob + o_pw[k]);
     g->proj_b.push_back(g->blob + o_pb[k]);
+    g->proc_edge_w0_16.push_back(g->blob + o_pe_w0_16[k]);
+    g->proc_edge_w1_16.push_back(g->blob + o_pe_w1_16[k]);
   }
+  g->enc_edge_w0_16 = g->blob + o_ee_w0_16;
+  g->enc_edge_w1_16 = g->blob + o_ee_w1_16;
   // node-sized network scratch
   e->g.kpad = kpad;
   const int64_t BN = e->BN;

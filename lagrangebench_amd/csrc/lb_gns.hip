@@ -304,9 +304,9 @@ __global__ void __launch_bounds__(EDGE_THREADS, 2) k_edge_mlp(lb_edge_args a) {
 __device__ __forceinline__ void lb_load_agg_fused(const int32_t* __restrict__ row_ptr,
                                                   const float* __restrict__ agg,
                                                   const float* __restrict__ part, int64_t g, int h,
-                                                  f32x4 (&v)[16]) {
+                                                  int tile_shift, f32x4 (&v)[16]) {
   const int k0 = row_ptr[g], k1 = row_ptr[g + 1];
-  const int t0 = k0 >> 5, t1 = (k1 - 1) >> 5;
+  const int t0 = k0 >> tile_shift, t1 = (k1 - 1) >> tile_shift;
   const bool single = t0 == t1;
   const int nsrc = (k1 <= k0) ? 0 : (single ? 1 : t1 - t0 + 1);
 #pragma unroll
@@ -315,7 +315,7 @@ __device__ __forceinline__ void lb_load_agg_fused(const int32_t* __restrict__ ro
     if (s < nsrc) {
       const int t = t0 + s;
       const float* src = single ? agg + g * 128
-                                : part + ((int64_t)t * 2 + (k0 <= t * LB_TILE ? 0 : 1)) * 128;
+                                : part + ((int64_t)t * 2 + (k0 <= (t << tile_shift) ? 0 : 1)) * 128;
       const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + h;
 #pragma unroll
       for (int kq = 0; kq < 16; ++kq) v[kq] = v[kq] + s4[2 * kq];
@@ -340,6 +340,7 @@ struct lb_node_args {
   const float* bp;    // [256]
   float* psr;         // out [rows][256]
   int fused;          // agg comes from the fused edge epilogue (agg + per-tile partial slots)
+  int tile_shift;     // log2 of the edge kernel's tile (4 or 5)
   const int32_t* row_ptr;
   const float* part;
 };
@@ -367,7 +368,7 @@ __global__ void __launch_bounds__(64) k_node_mlp(lb_node_args a) {
   if constexpr (NKQ_B > 0) {
     f32x4 vb[NKQ_B];
     if (a.fused) {
-      lb_load_agg_fused(a.row_ptr, a.agg, a.part, rowc, h, vb);
+      lb_load_agg_fused(a.row_ptr, a.agg, a.part, rowc, h, a.tile_shift, vb);
     } else {
       const f32x4* gr = reinterpret_cast<const f32x4*>(a.agg) + rowc * (2 * NKQ_B) + h;
 #pragma unroll
@@ -565,7 +566,22 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
     a.ln_s = g->enc_edge.ln_s;
     a.ln_o = g->enc_edge.ln_o;
     lb_tic(e, LB_T_ENC_EDGE);
-    hipLaunchKernelGGL((k_edge_mlp<false>), dim3(edge_blocks), dim3(EDGE_THREADS), 0, s, a);
+    if (e->edge_tile == 16) {
+      lb_edge16_args b{};
+      b.ctrl = a.ctrl;
+      b.efeat = a.efeat;
+      b.elat = a.elat;
+      b.w0p = g->enc_edge_w0_16;
+      b.b0 = a.b0;
+      b.w1p = g->enc_edge_w1_16;
+      b.b1 = a.b1;
+      b.ln_s = a.ln_s;
+      b.ln_o = a.ln_o;
+      rc = lbk_edge16(e, b, false);
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL((k_edge_mlp<false>), dim3(edge_blocks), dim3(EDGE_THREADS), 0, s, a);
+    }
     lb_toc(e);
   }
   if (g->tap) LB_HIP(hipMemcpyAsync(g->tap, e->nlat, sizeof(float) * BN * LB_D, hipMemcpyDeviceToDevice, s));
@@ -589,7 +605,28 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       a.agg = e->agg;
       a.part = e->part;
       lb_tic(e, LB_T_EDGE_MLP);
-      hipLaunchKernelGGL((k_edge_mlp<true>), dim3(edge_blocks), dim3(EDGE_THREADS), 0, s, a);
+      if (e->edge_tile == 16) {
+        lb_edge16_args b{};
+        b.ctrl = a.ctrl;
+        b.senders = a.senders;
+        b.receivers = a.receivers;
+        b.elat = a.elat;
+        b.msg = a.msg;
+        b.psr = a.psr;
+        b.w0p = g->proc_edge_w0_16[k];
+        b.w1p = g->proc_edge_w1_16[k];
+        b.b1 = a.b1;
+        b.ln_s = a.ln_s;
+        b.ln_o = a.ln_o;
+        b.fused = a.fused;
+        b.row_ptr = a.row_ptr;
+        b.agg = a.agg;
+        b.part = a.part;
+        rc = lbk_edge16(e, b, true);
+        if (rc) return rc;
+      } else {
+        hipLaunchKernelGGL((k_edge_mlp<true>), dim3(edge_blocks), dim3(EDGE_THREADS), 0, s, a);
+      }
       lb_toc(e);
     }
     if (!e->fused_agg) {
@@ -615,6 +652,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       a.bp = (k + 1 < L) ? g->proj_b[k + 1] : nullptr;
       a.psr = e->psr;
       a.fused = e->fused_agg;
+      a.tile_shift = e->edge_tile == 16 ? 4 : 5;
       a.row_ptr = e->row_ptr;
       a.part = e->part;
       lb_tic(e, LB_T_NODE_MLP);

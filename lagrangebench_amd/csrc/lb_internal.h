@@ -108,6 +108,7 @@ struct lb_engine {
   float* msg;          // [e_alloc][D]   (stand-alone segment_sum path only)
   float* part;         // [e_alloc/32+1][2][D] partial sums of receivers cut by a tile boundary
   int fused_agg;       // 1: aggregation fused into the edge kernel (default), 0: msg + k_segment_sum
+  int edge_tile;       // 16: k_edge16 (16x16x4 MFMA, software-pipelined, default); 32: k_edge_mlp
   float* acc;          // [BN][4] decoder output (dim padded to 4)
 
   // timers
@@ -127,6 +128,26 @@ struct lb_mlp_w {      // one packed 2-layer MLP on the device
   const float* ln_o;
 };
 
+struct lb_edge16_args {  // lb_edge16.hip
+  const lb_ctrl* ctrl;
+  const int32_t* senders;
+  const int32_t* receivers;
+  const float* efeat;  // ENC input [E][8]
+  float* elat;         // [E][128] in/out
+  float* msg;          // [E][128] out (PROC, !fused)
+  const float* psr;    // [BN][256]
+  const float* w0p;    // 16-packed: PROC 128x128 (edge rows of W0), ENC 16x128
+  const float* b0;     // ENC only
+  const float* w1p;    // 16-packed 128x128
+  const float* b1;
+  const float* ln_s;
+  const float* ln_o;
+  int fused;
+  const int32_t* row_ptr;
+  float* agg;
+  float* part;         // [ceil(E/16)][2][128]
+};
+
 struct lb_gns {
   lb_gns_desc desc;
   lb_engine* eng;
@@ -136,6 +157,9 @@ struct lb_gns {
   std::vector<lb_mlp_w> proc_edge, proc_node;  // proc_edge[k].w0 packs only the edge-latent rows
   std::vector<const float*> proj_w;            // packed [D x 2D]: sender | receiver rows of w0
   std::vector<const float*> proj_b;            // [2D]: zeros | b0
+  const float* enc_edge_w0_16;                 // 16-row-tile packings of the edge MLP matrices
+  const float* enc_edge_w1_16;
+  std::vector<const float*> proc_edge_w0_16, proc_edge_w1_16;
   int kq_node;         // node_in(+emb) padded to a multiple of 32, in units of 8
   float* tap;
 };
@@ -178,3 +202,7 @@ int lbk_metrics(lb_engine* e, const double* pred, int pred_T, const double* targ
 int lbk_gns_forward(lb_engine* e, lb_gns* g);
 int lbk_segment_sum(lb_engine* e, const float* msg, float* out, int D);
 void lb_pack_weight(const float* w, int K, int M, int Kpad, int Mpad, float* out);
+
+// lb_edge16.hip
+void lb_pack_weight16(const float* w, int K, int M, int Kpad, float* out);
+int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc);
