@@ -42,30 +42,32 @@ void lb_pack_weight(const float* w, int K, int M, int Kpad, int Mpad, float* out
 }
 
 // acc[mb] += W^T(:, 8*NKQ k's) * B, weights fetched through `ld(kq, mb)`.
-// The weight fragments of step kq+1 are fetched before the 4*NMB MFMAs of step kq are issued
-// (software prefetch, 2*NMB vector registers); sched_barrier keeps hipcc from hoisting every
-// fetch of the fully unrolled loop to the top (which spills at the 256-VGPR budget).
-template <int NKQ, int NMB, typename LD>
+// The weight fragments of step kq+PF are fetched before the 4*NMB MFMAs of step kq are issued
+// (software prefetch ring of PF+1 fragment sets; PF = 1 suffices for LDS-resident weights, the node
+// kernels stream weights from L2 and use a deeper ring); sched_barrier keeps hipcc from hoisting
+// every fetch of the fully unrolled loop to the top (which spills at the VGPR budget).
+template <int NKQ, int NMB, int PF = 1, typename LD>
 __device__ __forceinline__ void lb_gemm(LD ld, const f32x4 (&v)[NKQ], f32x16 (&acc)[NMB]) {
-  f32x4 a_cur[NMB], a_nxt[NMB];
+  f32x4 ring[PF + 1][NMB];
 #pragma unroll
-  for (int mb = 0; mb < NMB; ++mb) a_cur[mb] = ld(0, mb);
+  for (int p = 0; p < PF; ++p)
+    if (p < NKQ) {
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) ring[p][mb] = ld(p, mb);
+    }
 #pragma unroll
   for (int kq = 0; kq < NKQ; ++kq) {
-    if (kq + 1 < NKQ) {
+    if (kq + PF < NKQ) {
 #pragma unroll
-      for (int mb = 0; mb < NMB; ++mb) a_nxt[mb] = ld(kq + 1, mb);
+      for (int mb = 0; mb < NMB; ++mb) ring[(kq + PF) % (PF + 1)][mb] = ld(kq + PF, mb);
     }
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
-      acc[mb] = MFMA(a_cur[mb][0], v[kq][0], acc[mb]);
-      acc[mb] = MFMA(a_cur[mb][1], v[kq][1], acc[mb]);
-      acc[mb] = MFMA(a_cur[mb][2], v[kq][2], acc[mb]);
-      acc[mb] = MFMA(a_cur[mb][3], v[kq][3], acc[mb]);
-    }
-    if (kq + 1 < NKQ) {
-#pragma unroll
-      for (int mb = 0; mb < NMB; ++mb) a_cur[mb] = a_nxt[mb];
+      const f32x4 a = ring[kq % (PF + 1)][mb];
+      acc[mb] = MFMA(a[0], v[kq][0], acc[mb]);
+      acc[mb] = MFMA(a[1], v[kq][1], acc[mb]);
+      acc[mb] = MFMA(a[2], v[kq][2], acc[mb]);
+      acc[mb] = MFMA(a[3], v[kq][3], acc[mb]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -345,6 +347,8 @@ struct lb_node_args {
   const float* part;
 };
 
+#define NODE_PF 3  // weight fragments in flight ahead of the MFMAs (L2 latency ~ 1-2 groups of 16 MFMAs)
+
 template <int NKQ_A, int NKQ_B, bool RESID>
 __global__ void __launch_bounds__(64) k_node_mlp(lb_node_args a) {
   if (a.ctrl->overflow_step >= 0) return;
@@ -363,7 +367,7 @@ __global__ void __launch_bounds__(64) k_node_mlp(lb_node_args a) {
 #pragma unroll
     for (int kq = 0; kq < NKQ_A; ++kq) va[kq] = xr[2 * kq];
     auto ld = [&](int kq, int mb) -> f32x4 { return w0[(kq * 4 + mb) * 64 + lane]; };
-    lb_gemm<NKQ_A, 4>(ld, va, acc);
+    lb_gemm<NKQ_A, 4, NODE_PF>(ld, va, acc);
   }
   if constexpr (NKQ_B > 0) {
     f32x4 vb[NKQ_B];
@@ -375,7 +379,7 @@ __global__ void __launch_bounds__(64) k_node_mlp(lb_node_args a) {
       for (int kq = 0; kq < NKQ_B; ++kq) vb[kq] = gr[2 * kq];
     }
     auto ld = [&](int kq, int mb) -> f32x4 { return w0[((NKQ_A + kq) * 4 + mb) * 64 + lane]; };
-    lb_gemm<NKQ_B, 4>(ld, vb, acc);
+    lb_gemm<NKQ_B, 4, NODE_PF>(ld, vb, acc);
   }
   f32x4 vh[16];
   lb_acc_to_v(acc, vh, true);
@@ -383,7 +387,7 @@ __global__ void __launch_bounds__(64) k_node_mlp(lb_node_args a) {
   lb_acc_init(acc2, a.b1, h);
   {
     auto ld = [&](int kq, int mb) -> f32x4 { return w1[(kq * 4 + mb) * 64 + lane]; };
-    lb_gemm<16, 4>(ld, vh, acc2);
+    lb_gemm<16, 4, NODE_PF>(ld, vh, acc2);
   }
   f32x4 y[16];
   lb_layernorm(acc2, y, a.ln_s, a.ln_o, h);
@@ -404,7 +408,7 @@ __global__ void __launch_bounds__(64) k_node_mlp(lb_node_args a) {
       f32x16 accp[4];
       lb_acc_init(accp, a.bp + 128 * half, h);
       auto ld = [&](int kq, int mb) -> f32x4 { return wp[(kq * 8 + half * 4 + mb) * 64 + lane]; };
-      lb_gemm<16, 4>(ld, y, accp);
+      lb_gemm<16, 4, NODE_PF>(ld, y, accp);
       if (valid) {
         f32x4* pr = reinterpret_cast<f32x4*>(a.psr) + rowc * 64 + half * 32 + h;
 #pragma unroll
