@@ -217,6 +217,7 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   A(lb_alloc(&e->cell_part, (size_t)BN));
   A(lb_alloc(&e->deg, (size_t)BN));
   A(lb_alloc(&e->row_ptr, (size_t)BN + 1));
+  A(lb_alloc(&e->scan_part, (size_t)((BN > (int64_t)nc ? BN : (int64_t)nc) / 2048 + 2)));
   A(lb_alloc(&e->overflow, (size_t)g.B));
   A(lb_alloc(&e->nedges_b, (size_t)g.B));
   A(lb_alloc(&e->acc, (size_t)BN * 4));
@@ -255,7 +256,7 @@ extern "C" void lb_engine_destroy(lb_engine* e) {
   lb_timers_collect(e);
   for (auto ev : e->epool) (void)hipEventDestroy(ev);
   void* bufs[] = {e->win, e->ptype, e->force, e->ctrl, e->cell_of, e->cell_count, e->cell_start,
-                  e->cell_part, e->deg, e->row_ptr, e->senders, e->receivers, e->efeat, e->efeat64,
+                  e->cell_part, e->deg, e->row_ptr, e->scan_part, e->senders, e->receivers, e->efeat, e->efeat64,
                   e->overflow, e->nedges_b, e->xnode, e->nlat, e->agg, e->psr, e->elat, e->msg,
                   e->part, e->acc};
   for (void* b : bufs)

@@ -92,6 +92,7 @@ struct lb_engine {
   int32_t* cell_part;  // [BN] particle ids grouped by cell
   int32_t* deg;        // [BN]
   int32_t* row_ptr;    // [BN+1]
+  int32_t* scan_part;  // partial sums of the two-level scans
   int32_t* senders;    // [e_alloc] global node ids
   int32_t* receivers;  // [e_alloc]
   float* efeat;        // [e_alloc][8]  rel_disp(dim), rel_dist, zero pad

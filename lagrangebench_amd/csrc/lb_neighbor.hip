@@ -5,8 +5,11 @@
 // feature_transform (lagrangebench/case_setup/features.py:110-124).
 //
 // Design (not a translation of jax-md's dense (N, 3^dim*cap) candidate matrix):
-//   1. k_cell_count / k_scan / k_cell_fill : counting sort of particles into cells (int atomics).
-//   2. k_nl<COUNT>  : one 256-thread workgroup per cell stages the particles of its 3^dim stencil
+//   1. k_cell_count / multi-block scan / k_cell_fill : counting sort of particles into cells (int
+//                     atomics); scans are two-level (per-2048-chunk partial sums, then every block
+//                     rebuilds its base from the partials) - no single-block bottleneck.
+//   2. k_nl<COUNT>  : one workgroup per cell (one wave when the frozen cell capacity bounds the
+//                     stencil to <= 512 candidates, else 256 threads) stages the particles of its 3^dim stencil
 //                     (ids + fp64 positions) in LDS once; each wave then owns receivers of the
 //                     cell and sweeps the staged tile 64 candidates at a time; the cutoff
 //                     predicate is evaluated in fp64 exactly as the reference does
@@ -22,8 +25,9 @@
 // atomic-free segmented aggregation.
 #include "lb_device.h"
 
-#define NL_THREADS 256
-#define NL_WAVES (NL_THREADS / 64)
+#define SCAN_THREADS 256
+#define SCAN_CHUNK (SCAN_THREADS * 8)
+#define NL_SMALL_MAXC 512
 
 // ------------------------------------------------------------------------------------ cells
 __global__ void k_cell_count(lb_geom g, int64_t BN, const double* __restrict__ win,
@@ -47,52 +51,77 @@ __global__ void k_cell_count(lb_geom g, int64_t BN, const double* __restrict__ w
   atomicAdd(&cell_count[gc], 1);
 }
 
-// Block-wide exclusive scan of n ints with 1024 threads (each thread owns a contiguous chunk).
-// Returns the total in every thread; *maxv (optional) receives the max element.
-__device__ int lb_block_scan_excl(const int32_t* __restrict__ in, int32_t* __restrict__ out, int n,
-                                  int* maxv) {
-  __shared__ int s_part[1024];
-  __shared__ int s_max[1024];
+// Two-level exclusive scan.  Pass 1: one partial sum (and max) per SCAN_CHUNK elements.
+__global__ void __launch_bounds__(SCAN_THREADS)
+    k_scan_partials(const int32_t* __restrict__ in, int n, int32_t* __restrict__ partial,
+                    const lb_ctrl* __restrict__ ctrl, int32_t* __restrict__ max_out) {
+  __shared__ int s_sum[SCAN_THREADS], s_mx[SCAN_THREADS];
+  if (ctrl->overflow_step >= 0) return;
   const int t = threadIdx.x;
-  const int chunk = (n + 1023) / 1024;
-  const int lo = t * chunk, hi = min(n, lo + chunk);
+  const int lo = blockIdx.x * SCAN_CHUNK + t * 8;
   int sum = 0, mx = 0;
-  for (int i = lo; i < hi; ++i) {
-    int v = in[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int v = (lo + i < n) ? in[lo + i] : 0;
     sum += v;
     mx = max(mx, v);
   }
-  s_part[t] = sum;
-  s_max[t] = mx;
+  s_sum[t] = sum;
+  s_mx[t] = mx;
   __syncthreads();
-  // Hillis-Steele inclusive scan over the 1024 partials
-  for (int off = 1; off < 1024; off <<= 1) {
-    int v = (t >= off) ? s_part[t - off] : 0;
-    int m = (t >= off) ? s_max[t - off] : 0;
-    __syncthreads();
-    s_part[t] += v;
-    s_max[t] = max(s_max[t], m);
+  for (int off = SCAN_THREADS / 2; off > 0; off >>= 1) {
+    if (t < off) {
+      s_sum[t] += s_sum[t + off];
+      s_mx[t] = max(s_mx[t], s_mx[t + off]);
+    }
     __syncthreads();
   }
-  int run = s_part[t] - sum;  // exclusive prefix of this chunk
-  for (int i = lo; i < hi; ++i) {
-    int v = in[i];
-    out[i] = run;
-    run += v;
+  if (t == 0) {
+    partial[blockIdx.x] = s_sum[0];
+    if (max_out) atomicMax(max_out, s_mx[0]);
   }
-  const int total = s_part[1023];
-  if (t == 0) out[n] = total;
-  if (maxv) *maxv = s_max[1023];
-  return total;
 }
 
-__global__ void __launch_bounds__(1024) k_cell_scan(const int32_t* __restrict__ cell_count,
-                                                   int32_t* __restrict__ cell_start, int n,
-                                                   lb_ctrl* __restrict__ ctrl) {
+// Pass 2: every block sums the partials before it (its base) and scans its own chunk.
+// out has n+1 entries; out[n] = total.
+__global__ void __launch_bounds__(SCAN_THREADS)
+    k_scan_apply(const int32_t* __restrict__ in, int32_t* __restrict__ out, int n,
+                 const int32_t* __restrict__ partial, const lb_ctrl* __restrict__ ctrl) {
+  __shared__ int s_a[SCAN_THREADS];
   if (ctrl->overflow_step >= 0) return;
-  int mx;
-  lb_block_scan_excl(cell_count, cell_start, n, &mx);
-  if (threadIdx.x == 0) ctrl->max_cell_occ = mx;
+  const int t = threadIdx.x, b = blockIdx.x;
+  int base = 0;
+  for (int i = t; i < b; i += SCAN_THREADS) base += partial[i];
+  s_a[t] = base;
+  __syncthreads();
+  for (int off = SCAN_THREADS / 2; off > 0; off >>= 1) {
+    if (t < off) s_a[t] += s_a[t + off];
+    __syncthreads();
+  }
+  base = s_a[0];
+  __syncthreads();
+  const int lo = b * SCAN_CHUNK + t * 8;
+  int v[8], sum = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = (lo + i < n) ? in[lo + i] : 0;
+    sum += v[i];
+  }
+  s_a[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < SCAN_THREADS; off <<= 1) {  // Hillis-Steele inclusive
+    const int add = (t >= off) ? s_a[t - off] : 0;
+    __syncthreads();
+    s_a[t] += add;
+    __syncthreads();
+  }
+  int run = base + s_a[t] - sum;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (lo + i < n) out[lo + i] = run;
+    run += v[i];
+  }
+  if (b == gridDim.x - 1 && t == SCAN_THREADS - 1) out[n] = base + s_a[t];
 }
 
 __global__ void k_cell_fill(int64_t BN, const lb_ctrl* __restrict__ ctrl,
@@ -108,15 +137,16 @@ __global__ void k_cell_fill(int64_t BN, const lb_ctrl* __restrict__ ctrl,
 }
 
 // -------------------------------------------------------------------------- stencil search
-template <bool FILL>
+template <bool FILL, int NL_THREADS, int MAXC>
 __global__ void __launch_bounds__(NL_THREADS)
     k_nl(lb_geom g, int64_t BN, const double* __restrict__ win, lb_ctrl* __restrict__ ctrl,
          const int32_t* __restrict__ cell_start, const int32_t* __restrict__ cell_part,
          int32_t* __restrict__ deg, const int32_t* __restrict__ row_ptr,
          int32_t* __restrict__ senders, int32_t* __restrict__ receivers, float* __restrict__ efeat,
          double* __restrict__ efeat64, int64_t e_alloc) {
-  __shared__ int s_id[LB_MAX_STENCIL_CAND];
-  __shared__ double s_p[3][LB_MAX_STENCIL_CAND];
+  constexpr int NL_WAVES = NL_THREADS / 64;
+  __shared__ int s_id[MAXC];
+  __shared__ double s_p[3][MAXC];
   __shared__ int s_row[NL_WAVES][LB_MAX_ROW];
   __shared__ int s_cstart[28], s_ccnt[28], s_coff[28];
 
@@ -158,9 +188,9 @@ __global__ void __launch_bounds__(NL_THREADS)
   }
   __syncthreads();
   int M = s_coff[g.nstencil];
-  if (M > LB_MAX_STENCIL_CAND) {
+  if (M > MAXC) {
     if (tid == 0) atomicExch(&ctrl->density_error, 1);
-    M = LB_MAX_STENCIL_CAND;
+    M = MAXC;
   }
   // stage the stencil's particles: ids + fp64 positions of the newest frame
   for (int j = tid; j < M; j += NL_THREADS) {
@@ -174,10 +204,16 @@ __global__ void __launch_bounds__(NL_THREADS)
 
   const int wave = tid >> 6, lane = tid & 63;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // the cell's own particles are the centre entry of the staged stencil: read the receivers from
+  // LDS instead of paying two dependent global round trips per receiver
+  const int centre = g.use_cell_list ? (g.dim == 2 ? 4 : 13) : 0;
+  const int own_off = s_coff[centre];
   for (int k = wave; k < own_cnt; k += NL_WAVES) {
-    const int gr = cell_part[own_start + k];
+    const bool in_lds = own_off + k < M;
+    const int gr = in_lds ? s_id[own_off + k] : cell_part[own_start + k];
     double pr[3] = {0, 0, 0};
-    for (int d = 0; d < g.dim; ++d) pr[d] = lb_pos(win, g, BN, step, g.isl - 1, d, gr);
+    for (int d = 0; d < g.dim; ++d)
+      pr[d] = in_lds ? s_p[d][own_off + k] : lb_pos(win, g, BN, step, g.isl - 1, d, gr);
     int count = 0;
     for (int c0 = 0; c0 < M; c0 += 64) {
       const int j = c0 + lane;
@@ -250,14 +286,14 @@ __global__ void __launch_bounds__(NL_THREADS)
 }
 
 // ------------------------------------------------------------------------------- row scan
-__global__ void __launch_bounds__(1024)
-    k_row_scan(lb_geom g, const int32_t* __restrict__ deg, int32_t* __restrict__ row_ptr, int n,
-               lb_ctrl* __restrict__ ctrl, int32_t* __restrict__ overflow,
-               int32_t* __restrict__ nedges_b, int32_t cell_capacity, int32_t e_cap,
-               int64_t e_alloc, int frozen, int32_t* host_flag) {
+// After the two-level scan of the degrees: per-trajectory edge counts, did_buffer_overflow flags
+// and the control block, all on the device (no host sync).
+__global__ void __launch_bounds__(256)
+    k_row_finish(lb_geom g, const int32_t* __restrict__ row_ptr, int n, lb_ctrl* __restrict__ ctrl,
+                 int32_t* __restrict__ overflow, int32_t* __restrict__ nedges_b,
+                 int32_t cell_capacity, int32_t e_cap, int64_t e_alloc, int frozen,
+                 int32_t* host_flag) {
   if (ctrl->overflow_step >= 0) return;
-  const int total = lb_block_scan_excl(deg, row_ptr, n, nullptr);
-  __syncthreads();
   __shared__ int s_any;
   if (threadIdx.x == 0) s_any = 0;
   __syncthreads();
@@ -272,6 +308,7 @@ __global__ void __launch_bounds__(1024)
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    const int total = row_ptr[n];
     ctrl->n_edges_unclamped = total;
     ctrl->n_edges_total = (int)min((int64_t)total, e_alloc);
     if (frozen && (s_any || (int64_t)total > e_alloc) && ctrl->overflow_step < 0) {
@@ -294,19 +331,36 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   const int nb = (int)((BN + 255) / 256);
   hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, s, g, BN, e->win, e->ctrl, e->cell_of,
                      e->cell_count);
-  hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, s, e->cell_count, e->cell_start,
-                     ncell_tot, e->ctrl);
+  LB_HIP(hipMemsetAsync(&e->ctrl->max_cell_occ, 0, sizeof(int32_t), s));
+  const int nsb_c = (ncell_tot + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  hipLaunchKernelGGL(k_scan_partials, dim3(nsb_c), dim3(SCAN_THREADS), 0, s, e->cell_count, ncell_tot,
+                     e->scan_part, e->ctrl, &e->ctrl->max_cell_occ);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nsb_c), dim3(SCAN_THREADS), 0, s, e->cell_count,
+                     e->cell_start, ncell_tot, e->scan_part, e->ctrl);
   hipLaunchKernelGGL(k_cell_fill, dim3(nb), dim3(256), 0, s, BN, e->ctrl, e->cell_of,
                      e->cell_start, e->cell_fill, e->cell_part);
   lb_toc(e);
 
   lb_tic(e, LB_T_NEIGH);
-  hipLaunchKernelGGL((k_nl<false>), dim3(ncell_tot), dim3(NL_THREADS), 0, s, g, BN, e->win,
-                     e->ctrl, e->cell_start, e->cell_part, e->deg, e->row_ptr, e->senders,
-                     e->receivers, e->efeat, (double*)nullptr, e->e_alloc);
-  hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, s, g, e->deg, e->row_ptr, (int)BN,
-                     e->ctrl, e->overflow, e->nedges_b, e->cell_capacity, e->e_cap, e->e_alloc,
-                     frozen, e->host_flag_dev);
+  // one wave per cell when the frozen cell capacity bounds the stencil (a cell holding more than
+  // cell_capacity particles flags overflow anyway); the 256-thread / 2048-candidate variant otherwise
+  const bool small = frozen && g.use_cell_list && (int64_t)e->cell_capacity * g.nstencil <= NL_SMALL_MAXC;
+  if (small)
+    hipLaunchKernelGGL((k_nl<false, 64, NL_SMALL_MAXC>), dim3(ncell_tot), dim3(64), 0, s, g, BN, e->win,
+                       e->ctrl, e->cell_start, e->cell_part, e->deg, e->row_ptr, e->senders,
+                       e->receivers, e->efeat, (double*)nullptr, e->e_alloc);
+  else
+    hipLaunchKernelGGL((k_nl<false, 256, LB_MAX_STENCIL_CAND>), dim3(ncell_tot), dim3(256), 0, s, g, BN,
+                       e->win, e->ctrl, e->cell_start, e->cell_part, e->deg, e->row_ptr, e->senders,
+                       e->receivers, e->efeat, (double*)nullptr, e->e_alloc);
+  const int nsb_r = (int)((BN + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  hipLaunchKernelGGL(k_scan_partials, dim3(nsb_r), dim3(SCAN_THREADS), 0, s, e->deg, (int)BN,
+                     e->scan_part, e->ctrl, (int32_t*)nullptr);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nsb_r), dim3(SCAN_THREADS), 0, s, e->deg, e->row_ptr, (int)BN,
+                     e->scan_part, e->ctrl);
+  hipLaunchKernelGGL(k_row_finish, dim3(1), dim3(256), 0, s, g, e->row_ptr, (int)BN, e->ctrl,
+                     e->overflow, e->nedges_b, e->cell_capacity, e->e_cap, e->e_alloc, frozen,
+                     e->host_flag_dev);
   if (!frozen) {
     // allocate path (host-synchronous by contract): size the edge buffers before the fill pass
     LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, s));
@@ -329,9 +383,14 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
                           hipMemcpyHostToDevice, s));
   }
   double* e64 = want_efeat64 ? e->efeat64 : nullptr;
-  hipLaunchKernelGGL((k_nl<true>), dim3(ncell_tot), dim3(NL_THREADS), 0, s, g, BN, e->win, e->ctrl,
-                     e->cell_start, e->cell_part, e->deg, e->row_ptr, e->senders, e->receivers,
-                     e->efeat, e64, e->e_alloc);
+  if (small)
+    hipLaunchKernelGGL((k_nl<true, 64, NL_SMALL_MAXC>), dim3(ncell_tot), dim3(64), 0, s, g, BN, e->win,
+                       e->ctrl, e->cell_start, e->cell_part, e->deg, e->row_ptr, e->senders,
+                       e->receivers, e->efeat, e64, e->e_alloc);
+  else
+    hipLaunchKernelGGL((k_nl<true, 256, LB_MAX_STENCIL_CAND>), dim3(ncell_tot), dim3(256), 0, s, g, BN,
+                       e->win, e->ctrl, e->cell_start, e->cell_part, e->deg, e->row_ptr, e->senders,
+                       e->receivers, e->efeat, e64, e->e_alloc);
   lb_toc(e);
   LB_HIP(hipGetLastError());
   return LB_OK;
