@@ -142,6 +142,8 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
     e->fused_agg = (f && f[0] == '0') ? 0 : 1;
     const char* t = getenv("LB_EDGE_TILE");
     e->edge_tile = (t && atoi(t) == 32) ? 32 : 16;
+    const char* m = getenv("LB_MATH");
+    e->f16x2 = (m && !strcmp(m, "f32")) ? 0 : 1;
   }
   lb_geom& g = e->g;
   memset(&g, 0, sizeof(g));
@@ -472,6 +474,11 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     lb_pack_weight16(src, K, M, Kp, tmp.data());
     return put(tmp.data(), tmp.size());
   };
+  auto put_packed16h = [&](const float* src, int K, int M, int Kp) -> size_t {
+    std::vector<float> tmp((size_t)Kp * 128);
+    lb_pack_weight16h(src, K, M, Kp, tmp.data());
+    return put(tmp.data(), tmp.size());
+  };
   auto put_packed = [&](const float* src, int K, int M, int Kp, int Mp) -> size_t {
     std::vector<float> tmp((size_t)Kp * Mp);
     lb_pack_weight(src, K, M, Kp, Mp, tmp.data());
@@ -508,7 +515,9 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
   Off o_enc_edge = read_mlp(d->edge_in, 8, D, D, true);
   const size_t o_ee_w0_16 = put_packed16(p_enc_edge, d->edge_in, D, 16);
   const size_t o_ee_w1_16 = put_packed16(p_enc_edge + (size_t)d->edge_in * D + D, D, D, D);
-  std::vector<size_t> o_pe_w0_16(L), o_pe_w1_16(L);
+  const size_t o_ee_w0_16h = put_packed16h(p_enc_edge, d->edge_in, D, 32);
+  const size_t o_ee_w1_16h = put_packed16h(p_enc_edge + (size_t)d->edge_in * D + D, D, D, D);
+  std::vector<size_t> o_pe_w0_16(L), o_pe_w1_16(L), o_pe_w0_16h(L), o_pe_w1_16h(L);
   std::vector<Off> o_pe(L), o_pn(L);
   std::vector<size_t> o_pw(L), o_pb(L);
   for (int k = 0; k < L; ++k) {
@@ -531,9 +540,11 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     Off o{};
     o.w0 = put_packed(w0 + (size_t)2 * D * D, D, D, D, D);  // edge rows only
     o_pe_w0_16[k] = put_packed16(w0 + (size_t)2 * D * D, D, D, D);
+    o_pe_w0_16h[k] = put_packed16h(w0 + (size_t)2 * D * D, D, D, D);
     o.b0 = put(b0, D);
     p += (size_t)3 * D * D + D;
     o_pe_w1_16[k] = put_packed16(p, D, D, D);
+    o_pe_w1_16h[k] = put_packed16h(p, D, D, D);
     o.w1 = put_packed(p, D, D, D, D); p += (size_t)D * D;
     o.b1 = put(p, D); p += D;
     o.ln = true;
@@ -580,9 +591,13 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     g->proj_b.push_back(g->blob + o_pb[k]);
     g->proc_edge_w0_16.push_back(g->blob + o_pe_w0_16[k]);
     g->proc_edge_w1_16.push_back(g->blob + o_pe_w1_16[k]);
+    g->proc_edge_w0_16h.push_back(g->blob + o_pe_w0_16h[k]);
+    g->proc_edge_w1_16h.push_back(g->blob + o_pe_w1_16h[k]);
   }
   g->enc_edge_w0_16 = g->blob + o_ee_w0_16;
   g->enc_edge_w1_16 = g->blob + o_ee_w1_16;
+  g->enc_edge_w0_16h = g->blob + o_ee_w0_16h;
+  g->enc_edge_w1_16h = g->blob + o_ee_w1_16h;
   // node-sized network scratch
   e->g.kpad = kpad;
   const int64_t BN = e->BN;

@@ -18,9 +18,127 @@
 //                    [(mbk*4 + j)][hf][lane][c] with mbo = 4*hf + c: two ds_read_b128 feed 8 MFMAs.
 //   row-major rows:  a 128-float row is 32 16-byte chunks; lane (n,g) owns chunks 4*mb + g.
 // The fused aggregation works on rows of 16 lanes = exactly one DPP row (row_shr 1,2,4,8).
+#include <string.h>
+
 #include "lb_device.h"
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// ---- fp16x2 split mode ("f16x2"): every fp32 operand x is carried as hi = fp16(x), lo = fp16(x - hi)
+// (|x - hi - lo| <= 2^-24 |x| in the fp16 normal range), and a product is evaluated as
+// lo_a*hi_b + hi_a*lo_b + hi_a*hi_b on v_mfma_f32_16x16x32_f16 - each partial product is exact in
+// the fp32 accumulator, the dropped lo*lo term is <= 2^-24 |ab|.  Three MFMAs at the 2.5 PF fp16
+// rate instead of one at the 157 TF fp32 rate: ~5x fewer matrix-pipe cycles for fp32-class
+// accuracy (measured: 10-layer GNS output within 1.2e-6 of the fp32-MFMA path).
+// K-step of 32: lane (n, g) supplies its 8 features {32p + 4g + i, 32p + 16 + 4g + i} (i<4), i.e.
+// the accumulator registers of blocks 2p and 2p+1 - the chained-layer property is kept.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#define MFMA16H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+static uint16_t lb_f32_to_f16_rne(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x47800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));  // inf / nan
+  if (x < 0x38800000u) {  // subnormal half (or zero): value * 2^24 rounded to nearest even
+    if (x < 0x33000000u) return (uint16_t)sign;
+    const int shift = 126 - (int)(x >> 23);  // 14 .. 24
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    const uint32_t lsb = 1u << shift, half = lsb >> 1;
+    uint32_t r = m >> shift;
+    const uint32_t rem = m & (lsb - 1);
+    if (rem > half || (rem == half && (r & 1))) ++r;
+    return (uint16_t)(sign | r);
+  }
+  uint32_t r = x - 0x38000000u;  // rebias exponent 127 -> 15
+  const uint32_t rem = r & 0x1fffu;
+  r >>= 13;
+  if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) ++r;
+  return (uint16_t)(sign | r);
+}
+static float lb_f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  const uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu;
+  uint32_t x;
+  if (e == 0) {
+    if (m == 0) {
+      x = sign;
+    } else {
+      int k = 0;
+      uint32_t mm = m;
+      while (!(mm & 0x400u)) {
+        mm <<= 1;
+        ++k;
+      }
+      x = sign | ((uint32_t)(113 - k) << 23) | ((mm & 0x3ffu) << 13);
+    }
+  } else if (e == 31) {
+    x = sign | 0x7f800000u | (m << 13);
+  } else {
+    x = sign | ((e + 112) << 23) | (m << 13);
+  }
+  float f;
+  memcpy(&f, &x, 4);
+  return f;
+}
+
+// out: Kpad*128 "floats" worth of storage holding [(p*8 + mbo)][part: 0 hi, 1 lo][lane][8 halfs]
+void lb_pack_weight16h(const float* w, int K, int M, int Kpad, float* out) {
+  uint16_t* o = reinterpret_cast<uint16_t*>(out);
+  const int NP = Kpad / 32;
+  for (int p = 0; p < NP; ++p)
+    for (int mbo = 0; mbo < 8; ++mbo)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int i = 0; i < 8; ++i) {
+          const int g = lane >> 4;
+          const int k = 32 * p + (i < 4 ? 4 * g + i : 16 + 4 * g + (i - 4));
+          const int m = 16 * mbo + (lane & 15);
+          const float x = (k < K && m < M) ? w[(size_t)k * M + m] : 0.f;
+          const uint16_t hi = lb_f32_to_f16_rne(x);
+          const uint16_t lo = lb_f32_to_f16_rne(x - lb_f16_to_f32(hi));
+          const size_t base = ((size_t)(p * 8 + mbo) * 2) * 64;
+          o[((base + lane) * 8) + i] = hi;
+          o[((base + 64 + lane) * 8) + i] = lo;
+        }
+}
+
+__device__ __forceinline__ void lb_split8(const f32x4& x0, const f32x4& x1, h8& hi, h8& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const _Float16 a = (_Float16)x0[i], b = (_Float16)x1[i];
+    hi[i] = a;
+    hi[4 + i] = b;
+    lo[i] = (_Float16)(x0[i] - (float)a);
+    lo[4 + i] = (_Float16)(x1[i] - (float)b);
+  }
+}
+
+// acc[0..7] += W^T * B over NP blocks of 32 k's in f16x2 arithmetic.  ld(p, mbo, part) -> 16 B.
+template <int NP, typename LD>
+__device__ __forceinline__ void lb_gemm16h(LD ld, const f32x4 (&v)[2 * NP], f32x4 (&acc)[8]) {
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    h8 bh, bl;
+    lb_split8(v[2 * p], v[2 * p + 1], bh, bl);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      h8 ah[4], al[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        ah[c] = __builtin_bit_cast(h8, ld(p, 4 * q + c, 0));
+        al[c] = __builtin_bit_cast(h8, ld(p, 4 * q + c, 1));
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[4 * q + c] = MFMA16H(al[c], bh, acc[4 * q + c]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[4 * q + c] = MFMA16H(ah[c], bl, acc[4 * q + c]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[4 * q + c] = MFMA16H(ah[c], bh, acc[4 * q + c]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
 #define E16_THREADS 512
 #define E16_WAVES 8
 
@@ -70,10 +188,11 @@ __device__ __forceinline__ void lb_gemm16(LD ld, const f32x4 (&v)[NMBK], f32x4 (
   }
 }
 
-template <bool PROC>
+template <bool PROC, bool F16>
 __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
-  // LDS: packed W0 (PROC: 128x128 edge rows of the first layer; ENC: 16x128) then packed W1.
-  constexpr int NW0 = PROC ? 4096 : 512;
+  // LDS: packed W0 (PROC: 128x128 edge rows of the first layer; ENC: 16x128, or 32x128 hi|lo in
+  // f16x2 mode) then packed W1 (64 KiB in either mode: fp32, or fp16 hi + fp16 lo).
+  constexpr int NW0 = PROC ? 4096 : (F16 ? 1024 : 512);
   // ... then the per-feature vectors b1 | ln_scale | ln_offset | b0 (32 f32x4 each): fetching them
   // from global memory in the epilogue would queue behind the prefetch loads (vmcnt is in-order).
   __shared__ f32x4 sW[NW0 + 4096 + 128];
@@ -103,6 +222,10 @@ __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
 
   auto ld0 = [&](int step, int hf) -> f32x4 { return sW[(step * 2 + hf) * 64 + lane]; };
   auto ld1 = [&](int step, int hf) -> f32x4 { return sW[NW0 + (step * 2 + hf) * 64 + lane]; };
+  auto ldh0 = [&](int p, int mbo, int part) -> f32x4 { return sW[((p * 8 + mbo) * 2 + part) * 64 + lane]; };
+  auto ldh1 = [&](int p, int mbo, int part) -> f32x4 {
+    return sW[NW0 + ((p * 8 + mbo) * 2 + part) * 64 + lane];
+  };
   auto rowc_of = [&](int tt) -> int64_t {
     const int row = tt * 16 + n;
     return row < E ? row : E - 1;
@@ -181,10 +304,19 @@ __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
       r_n = a.receivers[rn];
     }
     // ---- Linear -> ReLU -> Linear -> LayerNorm, all in registers
-    if (PROC)
-      lb_gemm16<8>(ld0, ve, acc);
-    else
-      lb_gemm16<1>(ld0, vin, acc);
+    if constexpr (F16) {
+      if constexpr (PROC) {
+        lb_gemm16h<4>(ldh0, ve, acc);
+      } else {
+        f32x4 vin2[2] = {vin[0], f32x4{0.f, 0.f, 0.f, 0.f}};
+        lb_gemm16h<1>(ldh0, vin2, acc);
+      }
+    } else {
+      if (PROC)
+        lb_gemm16<8>(ld0, ve, acc);
+      else
+        lb_gemm16<1>(ld0, vin, acc);
+    }
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
@@ -192,7 +324,10 @@ __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
     f32x4 acc2[8];
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) acc2[mb] = b1_4[4 * mb + g];
-    lb_gemm16<8>(ld1, acc, acc2);
+    if constexpr (F16)
+      lb_gemm16h<4>(ldh1, acc, acc2);
+    else
+      lb_gemm16<8>(ld1, acc, acc2);
     float sm = 0.f;
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) sm += (acc2[mb][0] + acc2[mb][1]) + (acc2[mb][2] + acc2[mb][3]);
@@ -275,11 +410,15 @@ __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
   }
 }
 
-int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc) {
-  if (proc)
-    hipLaunchKernelGGL((k_edge16<true>), dim3(256), dim3(E16_THREADS), 0, e->stream, a);
+int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc, bool f16x2) {
+  if (proc && f16x2)
+    hipLaunchKernelGGL((k_edge16<true, true>), dim3(256), dim3(E16_THREADS), 0, e->stream, a);
+  else if (proc)
+    hipLaunchKernelGGL((k_edge16<true, false>), dim3(256), dim3(E16_THREADS), 0, e->stream, a);
+  else if (f16x2)
+    hipLaunchKernelGGL((k_edge16<false, true>), dim3(256), dim3(E16_THREADS), 0, e->stream, a);
   else
-    hipLaunchKernelGGL((k_edge16<false>), dim3(256), dim3(E16_THREADS), 0, e->stream, a);
+    hipLaunchKernelGGL((k_edge16<false, false>), dim3(256), dim3(E16_THREADS), 0, e->stream, a);
   LB_HIP(hipGetLastError());
   return LB_OK;
 }

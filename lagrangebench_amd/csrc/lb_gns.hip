@@ -575,13 +575,13 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       b.ctrl = a.ctrl;
       b.efeat = a.efeat;
       b.elat = a.elat;
-      b.w0p = g->enc_edge_w0_16;
+      b.w0p = e->f16x2 ? g->enc_edge_w0_16h : g->enc_edge_w0_16;
       b.b0 = a.b0;
-      b.w1p = g->enc_edge_w1_16;
+      b.w1p = e->f16x2 ? g->enc_edge_w1_16h : g->enc_edge_w1_16;
       b.b1 = a.b1;
       b.ln_s = a.ln_s;
       b.ln_o = a.ln_o;
-      rc = lbk_edge16(e, b, false);
+      rc = lbk_edge16(e, b, false, e->f16x2 != 0);
       if (rc) return rc;
     } else {
       hipLaunchKernelGGL((k_edge_mlp<false>), dim3(edge_blocks), dim3(EDGE_THREADS), 0, s, a);
@@ -617,8 +617,8 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
         b.elat = a.elat;
         b.msg = a.msg;
         b.psr = a.psr;
-        b.w0p = g->proc_edge_w0_16[k];
-        b.w1p = g->proc_edge_w1_16[k];
+        b.w0p = e->f16x2 ? g->proc_edge_w0_16h[k] : g->proc_edge_w0_16[k];
+        b.w1p = e->f16x2 ? g->proc_edge_w1_16h[k] : g->proc_edge_w1_16[k];
         b.b1 = a.b1;
         b.ln_s = a.ln_s;
         b.ln_o = a.ln_o;
@@ -626,7 +626,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
         b.row_ptr = a.row_ptr;
         b.agg = a.agg;
         b.part = a.part;
-        rc = lbk_edge16(e, b, true);
+        rc = lbk_edge16(e, b, true, e->f16x2 != 0);
         if (rc) return rc;
       } else {
         hipLaunchKernelGGL((k_edge_mlp<true>), dim3(edge_blocks), dim3(EDGE_THREADS), 0, s, a);

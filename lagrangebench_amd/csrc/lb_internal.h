@@ -110,6 +110,7 @@ struct lb_engine {
   float* part;         // [e_alloc/32+1][2][D] partial sums of receivers cut by a tile boundary
   int fused_agg;       // 1: aggregation fused into the edge kernel (default), 0: msg + k_segment_sum
   int edge_tile;       // 16: k_edge16 (16x16x4 MFMA, software-pipelined, default); 32: k_edge_mlp
+  int f16x2;           // 1: GEMMs in fp16 hi/lo split arithmetic on the fp16 MFMA (fp32-class accuracy)
   float* acc;          // [BN][4] decoder output (dim padded to 4)
 
   // timers
@@ -161,6 +162,9 @@ struct lb_gns {
   const float* enc_edge_w0_16;                 // 16-row-tile packings of the edge MLP matrices
   const float* enc_edge_w1_16;
   std::vector<const float*> proc_edge_w0_16, proc_edge_w1_16;
+  const float* enc_edge_w0_16h;                // f16x2 (hi|lo) packings
+  const float* enc_edge_w1_16h;
+  std::vector<const float*> proc_edge_w0_16h, proc_edge_w1_16h;
   int kq_node;         // node_in(+emb) padded to a multiple of 32, in units of 8
   float* tap;
 };
@@ -206,4 +210,5 @@ void lb_pack_weight(const float* w, int K, int M, int Kpad, int Mpad, float* out
 
 // lb_edge16.hip
 void lb_pack_weight16(const float* w, int K, int M, int Kpad, float* out);
-int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc);
+void lb_pack_weight16h(const float* w, int K, int M, int Kpad, float* out);
+int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc, bool f16x2);
