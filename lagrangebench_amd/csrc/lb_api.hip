@@ -474,9 +474,9 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     lb_pack_weight16(src, K, M, Kp, tmp.data());
     return put(tmp.data(), tmp.size());
   };
-  auto put_packed16h = [&](const float* src, int K, int M, int Kp) -> size_t {
-    std::vector<float> tmp((size_t)Kp * 128);
-    lb_pack_weight16h(src, K, M, Kp, tmp.data());
+  auto put_packed16h = [&](const float* src, int K, int M, int Kp, int Mp = 128) -> size_t {
+    std::vector<float> tmp((size_t)Kp * Mp);
+    lb_pack_weight16h(src, K, M, Kp, tmp.data(), Mp);
     return put(tmp.data(), tmp.size());
   };
   auto put_packed = [&](const float* src, int K, int M, int Kp, int Mp) -> size_t {
@@ -510,6 +510,9 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     }
     return o;
   };
+  const size_t o_en_w0_h = put_packed16h(p, nin, D, kpad);
+  const size_t o_en_w1_h = put_packed16h(p + (size_t)nin * D + D, D, D, D);
+  std::vector<size_t> o_pn_w0_h(L), o_pn_w1_h(L), o_pw_h(L);
   Off o_enc_node = read_mlp(nin, kpad, D, D, true);
   const float* p_enc_edge = p;
   Off o_enc_edge = read_mlp(d->edge_in, 8, D, D, true);
@@ -533,6 +536,7 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
           wsr[(size_t)kk * 2 * D + D + m] = w0[(size_t)(D + kk) * D + m];
         }
       o_pw[k] = put_packed(wsr.data(), D, 2 * D, D, 2 * D);
+      o_pw_h[k] = put_packed16h(wsr.data(), D, 2 * D, D, 2 * D);
       std::vector<float> bb(2 * D, 0.f);
       memcpy(bb.data() + D, b0, sizeof(float) * D);
       o_pb[k] = put(bb.data(), 2 * D);
@@ -551,6 +555,8 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     o.lns = put(p, D); p += D;
     o.lno = put(p, D); p += D;
     o_pe[k] = o;
+    o_pn_w0_h[k] = put_packed16h(p, 2 * D, D, 2 * D);
+    o_pn_w1_h[k] = put_packed16h(p + (size_t)2 * D * D + D, D, D, D);
     o_pn[k] = read_mlp(2 * D, 2 * D, D, D, true);
   }
   Off o_dec = read_mlp(D, D, d->out_dim, 32, false);
@@ -591,11 +597,16 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     g->proj_b.push_back(g->blob + o_pb[k]);
     g->proc_edge_w0_16.push_back(g->blob + o_pe_w0_16[k]);
     g->proc_edge_w1_16.push_back(g->blob + o_pe_w1_16[k]);
+    g->proc_node_w0_h.push_back(g->blob + o_pn_w0_h[k]);
+    g->proc_node_w1_h.push_back(g->blob + o_pn_w1_h[k]);
+    g->proj_w_h.push_back(g->blob + o_pw_h[k]);
     g->proc_edge_w0_16h.push_back(g->blob + o_pe_w0_16h[k]);
     g->proc_edge_w1_16h.push_back(g->blob + o_pe_w1_16h[k]);
   }
   g->enc_edge_w0_16 = g->blob + o_ee_w0_16;
   g->enc_edge_w1_16 = g->blob + o_ee_w1_16;
+  g->enc_node_w0_h = g->blob + o_en_w0_h;
+  g->enc_node_w1_h = g->blob + o_en_w1_h;
   g->enc_edge_w0_16h = g->blob + o_ee_w0_16h;
   g->enc_edge_w1_16h = g->blob + o_ee_w1_16h;
   // node-sized network scratch

@@ -83,12 +83,12 @@ static float lb_f16_to_f32(uint16_t h) {
   return f;
 }
 
-// out: Kpad*128 "floats" worth of storage holding [(p*8 + mbo)][part: 0 hi, 1 lo][lane][8 halfs]
-void lb_pack_weight16h(const float* w, int K, int M, int Kpad, float* out) {
+// out: Kpad*Mpad "floats" worth of storage holding [(p*NMBO + mbo)][part: 0 hi, 1 lo][lane][8 halfs]
+void lb_pack_weight16h(const float* w, int K, int M, int Kpad, float* out, int Mpad) {
   uint16_t* o = reinterpret_cast<uint16_t*>(out);
-  const int NP = Kpad / 32;
+  const int NP = Kpad / 32, NMBO = Mpad / 16;
   for (int p = 0; p < NP; ++p)
-    for (int mbo = 0; mbo < 8; ++mbo)
+    for (int mbo = 0; mbo < NMBO; ++mbo)
       for (int lane = 0; lane < 64; ++lane)
         for (int i = 0; i < 8; ++i) {
           const int g = lane >> 4;
@@ -97,7 +97,7 @@ void lb_pack_weight16h(const float* w, int K, int M, int Kpad, float* out) {
           const float x = (k < K && m < M) ? w[(size_t)k * M + m] : 0.f;
           const uint16_t hi = lb_f32_to_f16_rne(x);
           const uint16_t lo = lb_f32_to_f16_rne(x - lb_f16_to_f32(hi));
-          const size_t base = ((size_t)(p * 8 + mbo) * 2) * 64;
+          const size_t base = ((size_t)(p * NMBO + mbo) * 2) * 64;
           o[((base + lane) * 8) + i] = hi;
           o[((base + 64 + lane) * 8) + i] = lo;
         }

@@ -326,26 +326,6 @@ __device__ __forceinline__ void lb_load_agg_fused(const int32_t* __restrict__ ro
 }
 
 // ============================================================================ node kernels
-struct lb_node_args {
-  const lb_ctrl* ctrl;
-  int64_t n_rows;
-  const float* xin;   // ENC: [rows][8*NKQ_A]; PROC: nlat [rows][128]
-  const float* agg;   // PROC: [rows][128]
-  float* nlat;        // out [rows][128]
-  const float* w0p;   // packed (8*(NKQ_A+NKQ_B)) x 128
-  const float* b0;
-  const float* w1p;
-  const float* b1;
-  const float* ln_s;
-  const float* ln_o;
-  const float* wpp;   // packed 128 x 256 projection for the NEXT edge MLP, or null
-  const float* bp;    // [256]
-  float* psr;         // out [rows][256]
-  int fused;          // agg comes from the fused edge epilogue (agg + per-tile partial slots)
-  int tile_shift;     // log2 of the edge kernel's tile (4 or 5)
-  const int32_t* row_ptr;
-  const float* part;
-};
 
 #define NODE_PF 3  // weight fragments in flight ahead of the MFMAs (L2 latency ~ 1-2 groups of 16 MFMAs)
 
@@ -552,7 +532,11 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
     a.bp = L > 0 ? g->proj_b[0] : nullptr;
     a.psr = e->psr;
     lb_tic(e, LB_T_ENC_NODE);
-    if (g->kq_node == 4)
+    if (e->f16x2) {
+      rc = lbk_node16h(e, a, g->enc_node_w0_h, g->enc_node_w1_h, L > 0 ? g->proj_w_h[0] : nullptr,
+                       g->kq_node / 4, 0, false);
+      if (rc) return rc;
+    } else if (g->kq_node == 4)
       hipLaunchKernelGGL((k_node_mlp<4, 0, false>), dim3(ntile_n), dim3(64), 0, s, a);
     else
       hipLaunchKernelGGL((k_node_mlp<8, 0, false>), dim3(ntile_n), dim3(64), 0, s, a);
@@ -660,7 +644,13 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       a.row_ptr = e->row_ptr;
       a.part = e->part;
       lb_tic(e, LB_T_NODE_MLP);
-      hipLaunchKernelGGL((k_node_mlp<16, 16, true>), dim3(ntile_n), dim3(64), 0, s, a);
+      if (e->f16x2) {
+        rc = lbk_node16h(e, a, g->proc_node_w0_h[k], g->proc_node_w1_h[k],
+                         (k + 1 < L) ? g->proj_w_h[k + 1] : nullptr, 4, 4, true);
+        if (rc) return rc;
+      } else {
+        hipLaunchKernelGGL((k_node_mlp<16, 16, true>), dim3(ntile_n), dim3(64), 0, s, a);
+      }
       lb_toc(e);
     }
     if (g->tap)

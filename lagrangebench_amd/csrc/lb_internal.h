@@ -150,6 +150,27 @@ struct lb_edge16_args {  // lb_edge16.hip
   float* part;         // [ceil(E/16)][2][128]
 };
 
+struct lb_node_args {
+  const lb_ctrl* ctrl;
+  int64_t n_rows;
+  const float* xin;   // ENC: [rows][8*NKQ_A]; PROC: nlat [rows][128]
+  const float* agg;   // PROC: [rows][128]
+  float* nlat;        // out [rows][128]
+  const float* w0p;   // packed (8*(NKQ_A+NKQ_B)) x 128
+  const float* b0;
+  const float* w1p;
+  const float* b1;
+  const float* ln_s;
+  const float* ln_o;
+  const float* wpp;   // packed 128 x 256 projection for the NEXT edge MLP, or null
+  const float* bp;    // [256]
+  float* psr;         // out [rows][256]
+  int fused;          // agg comes from the fused edge epilogue (agg + per-tile partial slots)
+  int tile_shift;     // log2 of the edge kernel's tile (4 or 5)
+  const int32_t* row_ptr;
+  const float* part;
+};
+
 struct lb_gns {
   lb_gns_desc desc;
   lb_engine* eng;
@@ -165,6 +186,10 @@ struct lb_gns {
   const float* enc_edge_w0_16h;                // f16x2 (hi|lo) packings
   const float* enc_edge_w1_16h;
   std::vector<const float*> proc_edge_w0_16h, proc_edge_w1_16h;
+  // f16x2 node-MLP packings: w0 (Kpad x 128), w1 (128 x 128), projection (128 x 256)
+  const float* enc_node_w0_h;
+  const float* enc_node_w1_h;
+  std::vector<const float*> proc_node_w0_h, proc_node_w1_h, proj_w_h;
   int kq_node;         // node_in(+emb) padded to a multiple of 32, in units of 8
   float* tap;
 };
@@ -210,5 +235,9 @@ void lb_pack_weight(const float* w, int K, int M, int Kpad, int Mpad, float* out
 
 // lb_edge16.hip
 void lb_pack_weight16(const float* w, int K, int M, int Kpad, float* out);
-void lb_pack_weight16h(const float* w, int K, int M, int Kpad, float* out);
+void lb_pack_weight16h(const float* w, int K, int M, int Kpad, float* out, int Mpad = 128);
+
+// lb_node16h.hip
+int lbk_node16h(lb_engine* e, const lb_node_args& a, const float* w0h, const float* w1h,
+                const float* wph, int npa, int npb, bool resid);
 int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc, bool f16x2);

@@ -1,0 +1,271 @@
+// lb_node16h.hip - node MLP (+ residual + next-layer sender/receiver projection) in f16x2
+// arithmetic, weights streamed through LDS.
+//
+// Reference: GNS._encoder node branch (models/gns.py:65-72) and the processor's
+// update_node_features + residual (gns.py:103-113,120-122), plus the per-node half of the next
+// edge MLP's first Linear (W0[:2D] split, see lb_gns.hip header).
+//
+// Why a different structure from the edge kernel: one node tile needs THREE weight matrices
+// (W0 256x128, W1 128x128, projection 128x256 = 320 KiB as fp16 hi|lo), which do not fit the
+// 160 KiB LDS, and in f16x2 arithmetic the matrix pipe consumes weight fragments far faster than
+// L2 can deliver them to a single wave.  So a 512-thread workgroup (8 waves = 8 tiles of 16 nodes)
+// walks the weights in 32 KiB chunks that are double-buffered in LDS: chunk c+1 is in flight
+// (global loads into 16 staging VGPRs) while all 8 waves run their MFMAs on chunk c; one barrier
+// per chunk.  Each weight byte is fetched from L2 once per 128 nodes instead of once per 32.
+// Inside a wave the layers are chained in registers exactly as in lb_edge16.hip (16x16x32 fp16
+// MFMA, C-layout lane (n = l&15, g = l>>4) holds features 16*mb + 4*g + j).
+#include "lb_device.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#define MFMA16H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define N16_THREADS 512
+#define CHUNK_VEC 2048  // f32x4 per chunk (32 KiB)
+
+__device__ __forceinline__ void lb_split8n(const f32x4& x0, const f32x4& x1, h8& hi, h8& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const _Float16 a = (_Float16)x0[i], b = (_Float16)x1[i];
+    hi[i] = a;
+    hi[4 + i] = b;
+    lo[i] = (_Float16)(x0[i] - (float)a);
+    lo[4 + i] = (_Float16)(x1[i] - (float)b);
+  }
+}
+
+// 4 output blocks (mbo0..mbo0+3) of one k-step p from the LDS chunk: frag index inside the chunk
+// is ((pp*NMBO + mbo)*2 + part)*64 + lane.
+template <int NMBO>
+__device__ __forceinline__ void lb_mfma_quad(const f32x4* __restrict__ buf, int pp, int mbo0, int lane,
+                                             const h8& bh, const h8& bl, f32x4* acc) {
+  h8 ah[4], al[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    ah[c] = __builtin_bit_cast(h8, buf[((pp * NMBO + mbo0 + c) * 2 + 0) * 64 + lane]);
+    al[c] = __builtin_bit_cast(h8, buf[((pp * NMBO + mbo0 + c) * 2 + 1) * 64 + lane]);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = MFMA16H(al[c], bh, acc[c]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = MFMA16H(ah[c], bl, acc[c]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = MFMA16H(ah[c], bh, acc[c]);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// node's aggregated messages, 16-row layout (lane (n,g) owns chunks 4*mb + g of the 128-float row)
+__device__ __forceinline__ void lb_load_agg16(const lb_node_args& a, int64_t gnode, int g, f32x4 (&v)[8]) {
+  if (!a.fused) {
+    const f32x4* gr = reinterpret_cast<const f32x4*>(a.agg) + gnode * 32 + g;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) v[mb] = gr[4 * mb];
+    return;
+  }
+  const int k0 = a.row_ptr[gnode], k1 = a.row_ptr[gnode + 1];
+  const int t0 = k0 >> a.tile_shift, t1 = (k1 - 1) >> a.tile_shift;
+  const bool single = t0 == t1;
+  const int nsrc = (k1 <= k0) ? 0 : (single ? 1 : t1 - t0 + 1);
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) v[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; __any(s < nsrc); ++s) {
+    if (s < nsrc) {
+      const int t = t0 + s;
+      const float* src = single ? a.agg + gnode * 128
+                                : a.part + ((int64_t)t * 2 + (k0 <= (t << a.tile_shift) ? 0 : 1)) * 128;
+      const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + g;
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) v[mb] = v[mb] + s4[4 * mb];
+    }
+  }
+}
+
+// NPA: k-steps (of 32) of input A (encoder features or node latents); NPB: 4 when the aggregated
+// messages are a second input (processor), else 0.
+template <int NPA, int NPB, bool RESID>
+__global__ void __launch_bounds__(N16_THREADS, 2)
+    k_node16h(lb_node_args a, const f32x4* __restrict__ w0h, const f32x4* __restrict__ w1h,
+              const f32x4* __restrict__ wph) {
+  __shared__ f32x4 sB[2][CHUNK_VEC];
+  __shared__ f32x4 sP[192];  // per-feature vectors, see below
+  if (a.ctrl->overflow_step >= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  constexpr int NP0 = NPA + NPB;
+  constexpr int NCH0 = (NP0 + 1) / 2;  // chunks of W0 (2 k-steps x 8 blocks x hi|lo = 2048 vec)
+  const bool has_proj = wph != nullptr;
+  const int n_chunks = NCH0 + 2 + (has_proj ? 4 : 0);
+
+  // per-feature vectors into LDS: [0,32) b0, [32,64) b1, [64,96) ln_s, [96,128) ln_o, [128,192) bp
+  if (tid < 128) {
+    const float* src = tid < 32 ? a.b0 : (tid < 64 ? a.b1 : (tid < 96 ? a.ln_s : a.ln_o));
+    sP[tid] = reinterpret_cast<const f32x4*>(src)[tid & 31];
+  } else if (tid < 192) {
+    sP[tid] = (has_proj && a.bp) ? reinterpret_cast<const f32x4*>(a.bp)[tid - 128] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // chunk c -> (source, number of f32x4)
+  auto chunk_src = [&](int c, const f32x4*& src, int& nvec) {
+    if (c < NCH0) {
+      src = w0h + (size_t)c * CHUNK_VEC;
+      nvec = (2 * c + 2 <= NP0) ? CHUNK_VEC : CHUNK_VEC / 2;
+    } else if (c < NCH0 + 2) {
+      src = w1h + (size_t)(c - NCH0) * CHUNK_VEC;
+      nvec = CHUNK_VEC;
+    } else {
+      src = wph + (size_t)(c - NCH0 - 2) * CHUNK_VEC;
+      nvec = CHUNK_VEC;
+    }
+  };
+  f32x4 stg[4];
+  auto stage_issue = [&](int c) {
+    const f32x4* src;
+    int nvec;
+    chunk_src(c, src, nvec);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * N16_THREADS;
+      stg[i] = src[idx < nvec ? idx : 0];
+    }
+  };
+  auto stage_commit = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sB[c & 1][tid + i * N16_THREADS] = stg[i];
+  };
+
+  // ---- this wave's 16 rows
+  const int64_t row = ((int64_t)blockIdx.x * 8 + wave) * 16 + n;
+  const bool valid = row < a.n_rows;
+  const int64_t rowc = valid ? row : a.n_rows - 1;
+
+  stage_issue(0);
+  f32x4 va[2 * NPA];
+  {
+    const f32x4* xr = reinterpret_cast<const f32x4*>(a.xin) + rowc * (8 * NPA) + g;
+#pragma unroll
+    for (int mb = 0; mb < 2 * NPA; ++mb) va[mb] = xr[4 * mb];
+  }
+  f32x4 vb[NPB > 0 ? 8 : 1];
+  if constexpr (NPB > 0) lb_load_agg16(a, rowc, g, vb);
+  stage_commit(0);
+  __syncthreads();
+
+  int c = 0;
+  f32x4 acc[8];
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) acc[mb] = sP[4 * mb + g];
+  // ---- GEMM1 over [input A | aggregated messages]
+#pragma unroll
+  for (int ch = 0; ch < NCH0; ++ch, ++c) {
+    if (c + 1 < n_chunks) stage_issue(c + 1);
+    const f32x4* buf = sB[c & 1];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const int p = 2 * ch + pp;
+      if (p < NP0) {
+        h8 bh, bl;
+        if (p < NPA)
+          lb_split8n(va[2 * (p < NPA ? p : 0)], va[2 * (p < NPA ? p : 0) + 1], bh, bl);
+        else
+          lb_split8n(vb[NPB > 0 ? 2 * (p - NPA) : 0], vb[NPB > 0 ? 2 * (p - NPA) + 1 : 0], bh, bl);
+        lb_mfma_quad<8>(buf, pp, 0, lane, bh, bl, &acc[0]);
+        lb_mfma_quad<8>(buf, pp, 4, lane, bh, bl, &acc[4]);
+      }
+    }
+    if (c + 1 < n_chunks) stage_commit(c + 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[mb][j] = fmaxf(acc[mb][j], 0.f);
+  // ---- GEMM2
+  f32x4 acc2[8];
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) acc2[mb] = sP[32 + 4 * mb + g];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch, ++c) {
+    if (c + 1 < n_chunks) stage_issue(c + 1);
+    const f32x4* buf = sB[c & 1];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const int p = 2 * ch + pp;
+      h8 bh, bl;
+      lb_split8n(acc[2 * p], acc[2 * p + 1], bh, bl);
+      lb_mfma_quad<8>(buf, pp, 0, lane, bh, bl, &acc2[0]);
+      lb_mfma_quad<8>(buf, pp, 4, lane, bh, bl, &acc2[4]);
+    }
+    if (c + 1 < n_chunks) stage_commit(c + 1);
+    __syncthreads();
+  }
+  // ---- LayerNorm (+ residual)
+  float sm = 0.f;
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) sm += (acc2[mb][0] + acc2[mb][1]) + (acc2[mb][2] + acc2[mb][3]);
+  sm += __shfl_xor(sm, 16);
+  sm += __shfl_xor(sm, 32);
+  const float mean = sm * (1.0f / 128.0f);
+  float vs = 0.f;
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = acc2[mb][j] - mean;
+      vs += d * d;
+    }
+  vs += __shfl_xor(vs, 16);
+  vs += __shfl_xor(vs, 32);
+  const float rs = 1.0f / sqrtf(vs * (1.0f / 128.0f) + 1e-5f);
+  f32x4 y[8];
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const f32x4 sc = sP[64 + 4 * mb + g], of = sP[96 + 4 * mb + g];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[mb][j] = (sc[j] * rs) * (acc2[mb][j] - mean) + of[j];
+    if constexpr (RESID) y[mb] = va[mb < 2 * NPA ? mb : 0] + y[mb];
+  }
+  if (valid) {
+    f32x4* nr = reinterpret_cast<f32x4*>(a.nlat) + row * 32 + g;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) nr[4 * mb] = y[mb];
+  }
+  // ---- projection for the next edge MLP: psr = y @ [Ws | Wr] + [0 | b0_next], 16 output blocks
+  if (has_proj) {
+    f32x4 accp[16];
+#pragma unroll
+    for (int mb = 0; mb < 16; ++mb) accp[mb] = sP[128 + 4 * mb + g];
+#pragma unroll
+    for (int p = 0; p < 4; ++p, ++c) {
+      if (c + 1 < n_chunks) stage_issue(c + 1);
+      const f32x4* buf = sB[c & 1];
+      h8 bh, bl;
+      lb_split8n(y[2 * p], y[2 * p + 1], bh, bl);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) lb_mfma_quad<16>(buf, 0, 4 * q, lane, bh, bl, &accp[4 * q]);
+      if (c + 1 < n_chunks) stage_commit(c + 1);
+      __syncthreads();
+    }
+    if (valid) {
+      f32x4* pr = reinterpret_cast<f32x4*>(a.psr) + row * 64 + g;
+#pragma unroll
+      for (int mb = 0; mb < 16; ++mb) pr[4 * mb] = accp[mb];
+    }
+  }
+}
+
+int lbk_node16h(lb_engine* e, const lb_node_args& a, const float* w0h, const float* w1h,
+                const float* wph, int npa, int npb, bool resid) {
+  const int nblk = (int)((a.n_rows + 127) / 128);
+  const f32x4* w0 = reinterpret_cast<const f32x4*>(w0h);
+  const f32x4* w1 = reinterpret_cast<const f32x4*>(w1h);
+  const f32x4* wp = reinterpret_cast<const f32x4*>(wph);
+  dim3 grid(nblk), block(N16_THREADS);
+  if (npa == 4 && npb == 4 && resid)
+    hipLaunchKernelGGL((k_node16h<4, 4, true>), grid, block, 0, e->stream, a, w0, w1, wp);
+  else if (npa == 1 && npb == 0 && !resid)
+    hipLaunchKernelGGL((k_node16h<1, 0, false>), grid, block, 0, e->stream, a, w0, w1, wp);
+  else if (npa == 2 && npb == 0 && !resid)
+    hipLaunchKernelGGL((k_node16h<2, 0, false>), grid, block, 0, e->stream, a, w0, w1, wp);
+  else
+    return lb_fail(LB_ERR_UNSUPPORTED, "k_node16h<%d,%d,%d> not instantiated", npa, npb, (int)resid);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
