@@ -17,6 +17,10 @@
 //   A operand:       lane (m = l&15, g) supplies W[16*mbk + 4*g + j][16*mbo + m]; packed on the host as
 //                    [(mbk*4 + j)][hf][lane][c] with mbo = 4*hf + c: two ds_read_b128 feed 8 MFMAs.
 //   row-major rows:  a 128-float row is 32 16-byte chunks; lane (n,g) owns chunks 4*mb + g.
+//   edge latents:    `elat` is private to the edge kernels, so it is stored TILE-BLOCKED,
+//                    elat4[(tile*8 + mb)*64 + lane] = features 16*mb + 4*g .. +3 of edge 16*tile + n:
+//                    every wave-level load/store of the latents is one contiguous 1 KiB (8 full
+//                    128-B lines) instead of 16 half-used lines of 16 different rows.
 // The fused aggregation works on rows of 16 lanes = exactly one DPP row (row_shr 1,2,4,8).
 #include <string.h>
 
@@ -188,7 +192,9 @@ __device__ __forceinline__ void lb_gemm16(LD ld, const f32x4 (&v)[NMBK], f32x4 (
   }
 }
 
-template <bool PROC, bool F16>
+// ABL (tools/edge_bench.hip only, 0 in the product): 1 no Ps/Pr gather, 2 no e load, 4 no stores,
+// 8 no LayerNorm, 16 no GEMM2, 32 no GEMM1, 64 no segmented scan.
+template <bool PROC, bool F16, int ABL = 0>
 __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
   // LDS: packed W0 (PROC: 128x128 edge rows of the first layer; ENC: 16x128, or 32x128 hi|lo in
   // f16x2 mode) then packed W1 (64 KiB in either mode: fp32, or fp16 hi + fp16 lo).
@@ -249,14 +255,14 @@ __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
   auto issue = [&](int tt, int s, int r) {
     const int64_t rc = rowc_of(tt);
     if (PROC) {
-      const f32x4* er = reinterpret_cast<const f32x4*>(a.elat) + rc * 32 + g;
+      const f32x4* er = reinterpret_cast<const f32x4*>(a.elat) + (int64_t)tt * 512 + lane;
       const f32x4* ps = psr4 + (int64_t)s * 64 + g;
       const f32x4* pr = psr4 + (int64_t)r * 64 + 32 + g;
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb) {
-        ve_n[mb] = er[4 * mb];
-        ps_n[mb] = ps[4 * mb];
-        pr_n[mb] = pr[4 * mb];
+        ve_n[mb] = (ABL & 2) ? f32x4{1.f, 2.f, (float)rc, (float)mb} : er[64 * mb];
+        ps_n[mb] = (ABL & 1) ? f32x4{.1f, .2f, (float)s, (float)mb} : ps[4 * mb];
+        pr_n[mb] = (ABL & 1) ? f32x4{.3f, .1f, (float)r, (float)mb} : pr[4 * mb];
       }
     } else {
       vin_n = reinterpret_cast<const f32x4*>(a.efeat)[rc * 2 + (g & 1)];
@@ -304,7 +310,8 @@ __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
       r_n = a.receivers[rn];
     }
     // ---- Linear -> ReLU -> Linear -> LayerNorm, all in registers
-    if constexpr (F16) {
+    if constexpr (ABL & 32) {
+    } else if constexpr (F16) {
       if constexpr (PROC) {
         lb_gemm16h<4>(ldh0, ve, acc);
       } else {
@@ -324,7 +331,10 @@ __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
     f32x4 acc2[8];
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) acc2[mb] = b1_4[4 * mb + g];
-    if constexpr (F16)
+    if constexpr (ABL & 16) {
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) acc2[mb] = acc2[mb] + acc[mb];
+    } else if constexpr (F16)
       lb_gemm16h<4>(ldh1, acc, acc2);
     else
       lb_gemm16<8>(ld1, acc, acc2);
@@ -350,27 +360,29 @@ __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
     for (int mb = 0; mb < 8; ++mb) {
       const f32x4 sc = lns4[4 * mb + g], of = lno4[4 * mb + g];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) y[mb][j] = (sc[j] * rs) * (acc2[mb][j] - mean) + of[j];
+      for (int j = 0; j < 4; ++j)
+        y[mb][j] = (ABL & 8) ? acc2[mb][j] : (sc[j] * rs) * (acc2[mb][j] - mean) + of[j];
     }
     // ---- stores
     const int row = t * 16 + n;
     const bool valid = row < E;
-    if (valid) {
-      f32x4* er = reinterpret_cast<f32x4*>(a.elat) + (int64_t)row * 32 + g;
+    const bool do_store = !((ABL & 4) && a.row_ptr[0] != -12345);
+    if (do_store) {  // whole tile (rows past E are padding inside the blocked allocation)
+      f32x4* er = reinterpret_cast<f32x4*>(a.elat) + (int64_t)t * 512 + lane;
       if (PROC) {
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb) er[4 * mb] = ve[mb] + y[mb];  // residual, gns.py:120-122
-        if (!a.fused) {
+        for (int mb = 0; mb < 8; ++mb) er[64 * mb] = ve[mb] + y[mb];  // residual, gns.py:120-122
+        if (!a.fused && valid) {
           f32x4* mr = reinterpret_cast<f32x4*>(a.msg) + (int64_t)row * 32 + g;
 #pragma unroll
           for (int mb = 0; mb < 8; ++mb) mr[4 * mb] = y[mb];
         }
       } else {
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb) er[4 * mb] = y[mb];
+        for (int mb = 0; mb < 8; ++mb) er[64 * mb] = y[mb];
       }
     }
-    if (PROC && a.fused) {
+    if (PROC && a.fused && !(ABL & 64)) {
       // fused jraph.segment_sum: segmented Hillis-Steele scan inside each 16-lane DPP row
       const int rr = valid ? r_cur : (-1 - n);
       const int r_prev = __builtin_amdgcn_update_dpp(-2, rr, 0x111, 0xF, 0xF, false);
@@ -379,25 +391,22 @@ __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
       const unsigned below = H & ((2u << n) - 1u);
       const int segstart = 31 - __clz(below);
       const bool tail = (n == 15) || ((H >> (n + 1)) & 1u);
-      const bool m1 = n >= 1 && segstart <= n - 1, m2 = n >= 2 && segstart <= n - 2;
-      const bool m4 = n >= 4 && segstart <= n - 4, m8 = n >= 8 && segstart <= n - 8;
+      // masks as 0/1 floats: x += shifted * m is ONE v_fmac_f32 with a DPP source per register and
+      // step (a select would be three instructions); lanes past E contribute exact zeros
+      const float m1 = (n >= 1 && segstart <= n - 1) ? 1.f : 0.f, m2 = (n >= 2 && segstart <= n - 2) ? 1.f : 0.f;
+      const float m4 = (n >= 4 && segstart <= n - 4) ? 1.f : 0.f, m8 = (n >= 8 && segstart <= n - 8) ? 1.f : 0.f;
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float x = y[mb][j];
-          float q;
-          q = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xF, 0xF, true));
-          x += m1 ? q : 0.f;
-          q = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xF, 0xF, true));
-          x += m2 ? q : 0.f;
-          q = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xF, 0xF, true));
-          x += m4 ? q : 0.f;
-          q = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xF, 0xF, true));
-          x += m8 ? q : 0.f;
+          float x = valid ? y[mb][j] : 0.f;
+          x = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xF, 0xF, true)), m1, x);
+          x = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xF, 0xF, true)), m2, x);
+          x = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xF, 0xF, true)), m4, x);
+          x = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xF, 0xF, true)), m8, x);
           y[mb][j] = x;
         }
-      if (tail && valid) {
+      if (tail && valid && do_store) {
         const int k0 = a.row_ptr[rr], k1 = a.row_ptr[rr + 1];
         const bool complete = (k0 >> 4) == ((k1 - 1) >> 4);
         float* dst = complete ? a.agg + (int64_t)rr * 128
