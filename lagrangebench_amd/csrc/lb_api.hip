@@ -220,6 +220,7 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   A(lb_alloc(&e->deg, (size_t)BN));
   A(lb_alloc(&e->row_ptr, (size_t)BN + 1));
   A(lb_alloc(&e->scan_part, (size_t)((BN > (int64_t)nc ? BN : (int64_t)nc) / 2048 + 2)));
+  A(lb_alloc(&e->cpos, (size_t)d->dim * BN));
   A(lb_alloc(&e->overflow, (size_t)g.B));
   A(lb_alloc(&e->nedges_b, (size_t)g.B));
   A(lb_alloc(&e->acc, (size_t)BN * 4));
@@ -258,7 +259,8 @@ extern "C" void lb_engine_destroy(lb_engine* e) {
   lb_timers_collect(e);
   for (auto ev : e->epool) (void)hipEventDestroy(ev);
   void* bufs[] = {e->win, e->ptype, e->force, e->ctrl, e->cell_of, e->cell_count, e->cell_start,
-                  e->cell_part, e->deg, e->row_ptr, e->scan_part, e->senders, e->receivers, e->efeat, e->efeat64,
+                  e->cell_part, e->deg, e->row_ptr, e->scan_part, e->cpos, e->tmp_send, e->tmp_feat, e->tmp_feat64,
+                  e->senders, e->receivers, e->efeat, e->efeat64,
                   e->overflow, e->nedges_b, e->xnode, e->nlat, e->agg, e->psr, e->elat, e->msg,
                   e->part, e->acc};
   for (void* b : bufs)
@@ -367,6 +369,23 @@ extern "C" int lb_nl_allocate(lb_engine* e, int32_t* cell_capacity_out, int32_t*
   if (ecap * e->g.B > (int64_t)1 << 30) return lb_fail(LB_ERR_ARG, "B*E_cap exceeds int32 range");
   e->e_cap = (int32_t)std::max<int64_t>(ecap, 1);
   LB_TRY(lb_ensure_edges(e, (int64_t)e->e_cap * e->g.B));
+  // per-node slots of the single-sweep update path: twice the current max degree
+  {
+    int32_t want = std::max(16, ((2 * h->max_deg + 7) / 8) * 8);
+    want = std::min<int32_t>(want, LB_MAX_ROW);
+    if (want > e->maxd || !e->tmp_send) {
+      LB_HIP(hipStreamSynchronize(e->stream));
+      for (void* b : {(void*)e->tmp_send, (void*)e->tmp_feat, (void*)e->tmp_feat64})
+        if (b) (void)hipFree(b);
+      e->tmp_send = nullptr;
+      e->tmp_feat = nullptr;
+      e->tmp_feat64 = nullptr;
+      e->maxd = want;
+      LB_TRY(lb_alloc(&e->tmp_send, (size_t)e->BN * want));
+      LB_TRY(lb_alloc(&e->tmp_feat, (size_t)e->BN * want * 4));
+      LB_TRY(lb_alloc(&e->tmp_feat64, (size_t)e->BN * want * 4));
+    }
+  }
   if (cell_capacity_out) *cell_capacity_out = e->cell_capacity;
   if (e_cap_out) *e_cap_out = e->e_cap;
   if (occupancy_out) memcpy(occupancy_out, occ.data(), sizeof(int32_t) * e->g.B);

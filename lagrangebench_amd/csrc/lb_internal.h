@@ -26,7 +26,8 @@ struct lb_ctrl {
   int32_t n_edges_unclamped;
   int32_t max_cell_occ;    // max particles in one cell (this build)
   int32_t density_error;   // stencil/row exceeded the LDS tile bounds
-  int32_t pad0, pad1;
+  int32_t max_deg;         // max receiver degree (this build)
+  int32_t row_overflow;    // a row outgrew the per-node slots of the single-sweep update path
 };
 
 // Geometry + normalisation constants, passed by value to kernels.
@@ -93,6 +94,11 @@ struct lb_engine {
   int32_t* deg;        // [BN]
   int32_t* row_ptr;    // [BN+1]
   int32_t* scan_part;  // partial sums of the two-level scans
+  double* cpos;        // [dim][BN] newest-frame positions in cell-sorted order
+  int32_t maxd;        // per-node slot count of the single-sweep update path (0 = not sized)
+  int32_t* tmp_send;   // [BN][maxd] sorted sender rows before compaction
+  float* tmp_feat;     // [BN][maxd][4]
+  double* tmp_feat64;  // [BN][maxd][4]
   int32_t* senders;    // [e_alloc] global node ids
   int32_t* receivers;  // [e_alloc]
   float* efeat;        // [e_alloc][8]  rel_disp(dim), rel_dist, zero pad

@@ -5,21 +5,21 @@
 // feature_transform (lagrangebench/case_setup/features.py:110-124).
 //
 // Design (not a translation of jax-md's dense (N, 3^dim*cap) candidate matrix):
-//   1. k_cell_count / multi-block scan / k_cell_fill : counting sort of particles into cells (int
-//                     atomics); scans are two-level (per-2048-chunk partial sums, then every block
-//                     rebuilds its base from the partials) - no single-block bottleneck.
-//   2. k_nl<COUNT>  : one workgroup per cell (one wave when the frozen cell capacity bounds the
-//                     stencil to <= 512 candidates, else 256 threads) stages the particles of its 3^dim stencil
-//                     (ids + fp64 positions) in LDS once; each wave then owns receivers of the
-//                     cell and sweeps the staged tile 64 candidates at a time; the cutoff
-//                     predicate is evaluated in fp64 exactly as the reference does
-//                     (metric(pos[sender], pos[receiver]) < r_c^2) and reduced with a wavefront
-//                     ballot + popcount.
-//   3. k_row_scan   : exclusive scan of the degrees -> CSR row_ptr, per-trajectory edge counts,
-//                     did_buffer_overflow flags, all on the device (no host sync).
-//   4. k_nl<FILL>   : same sweep; ballot/prefix compaction into a per-wave LDS row, rank-sort of
-//                     the row by sender id, write senders/receivers at row_ptr[r]+rank together
-//                     with the edge features (rel_disp, rel_dist).
+//   1. k_cell_count / two-level scan / k_cell_fill : counting sort of the particles into cells
+//      (int atomics); k_cell_fill also writes the cell-sorted fp64 positions so that a cell's
+//      particles are one contiguous HBM range.
+//   2. k_nl : one workgroup per cell (one wave when the frozen cell capacity bounds the stencil to
+//      <= 512 candidates, else 256 threads) stages the particles of its 3^dim stencil (ids + fp64
+//      positions) in LDS once; each wave owns receivers of the cell and sweeps the staged tile 64
+//      candidates at a time.  The cutoff predicate is evaluated in fp64 exactly as the reference
+//      does (metric(pos[sender], pos[receiver]) < r_c^2), reduced with a wavefront ballot +
+//      popcount prefix; the row is compacted into LDS and rank-sorted by sender id.
+//        update path (capacities frozen): ONE sweep writes each receiver's sorted row + its edge
+//          features into fixed-stride per-node slots, then a two-level scan of the degrees gives the
+//          CSR offsets and k_nl_compact moves the rows into place (pure streaming copy);
+//        allocate path (sizes unknown): count sweep -> scan -> host sizes the buffers -> fill sweep.
+//   3. k_row_finish : per-trajectory edge counts, did_buffer_overflow flags and the control block,
+//      all on the device (no host sync).
 // Output: CSR by receiver over the B*N nodes of the batch, senders ascending inside a row, i.e.
 // the edge list sorted by (receiver, sender) - deterministic, and directly consumable by the
 // atomic-free segmented aggregation.
@@ -28,6 +28,8 @@
 #define SCAN_THREADS 256
 #define SCAN_CHUNK (SCAN_THREADS * 8)
 #define NL_SMALL_MAXC 512
+
+enum { NL_COUNT = 0, NL_FILL = 1, NL_ROWS = 2 };
 
 // ------------------------------------------------------------------------------------ cells
 __global__ void k_cell_count(lb_geom g, int64_t BN, const double* __restrict__ win,
@@ -124,67 +126,82 @@ __global__ void __launch_bounds__(SCAN_THREADS)
   if (b == gridDim.x - 1 && t == SCAN_THREADS - 1) out[n] = base + s_a[t];
 }
 
-__global__ void k_cell_fill(int64_t BN, const lb_ctrl* __restrict__ ctrl,
-                            const int32_t* __restrict__ cell_of,
+__global__ void k_cell_fill(lb_geom g, int64_t BN, const double* __restrict__ win,
+                            const lb_ctrl* __restrict__ ctrl, const int32_t* __restrict__ cell_of,
                             const int32_t* __restrict__ cell_start, int32_t* __restrict__ cell_fill,
-                            int32_t* __restrict__ cell_part) {
+                            int32_t* __restrict__ cell_part, double* __restrict__ cpos) {
   if (ctrl->overflow_step >= 0) return;
   int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gi >= BN) return;
+  const int step = ctrl->step;
   const int gc = cell_of[gi];
-  const int slot = atomicAdd(&cell_fill[gc], 1);
-  cell_part[cell_start[gc] + slot] = (int32_t)gi;
+  const int slot = cell_start[gc] + atomicAdd(&cell_fill[gc], 1);
+  cell_part[slot] = (int32_t)gi;
+  for (int d = 0; d < g.dim; ++d) cpos[(int64_t)d * BN + slot] = lb_pos(win, g, BN, step, g.isl - 1, d, gi);
 }
 
 // -------------------------------------------------------------------------- stencil search
-template <bool FILL, int NL_THREADS, int MAXC>
+struct lb_nl_args {
+  const int32_t* cell_start;
+  const int32_t* cell_part;
+  const double* cpos;       // [dim][BN] positions in cell-sorted order
+  int32_t* deg;             // [BN]
+  const int32_t* row_ptr;   // NL_FILL
+  int32_t* senders;         // NL_FILL: CSR arrays; NL_ROWS: per-node slots [BN][maxd]
+  int32_t* receivers;       // NL_FILL
+  float* efeat;             // NL_FILL: [E][8]; NL_ROWS: [BN][maxd][4]
+  double* efeat64;          // optional fp64 copy, same indexing with 4 doubles per edge
+  int64_t e_alloc;
+  int32_t maxd;
+};
+
+template <int MODE, int NL_THREADS, int MAXC>
 __global__ void __launch_bounds__(NL_THREADS)
-    k_nl(lb_geom g, int64_t BN, const double* __restrict__ win, lb_ctrl* __restrict__ ctrl,
-         const int32_t* __restrict__ cell_start, const int32_t* __restrict__ cell_part,
-         int32_t* __restrict__ deg, const int32_t* __restrict__ row_ptr,
-         int32_t* __restrict__ senders, int32_t* __restrict__ receivers, float* __restrict__ efeat,
-         double* __restrict__ efeat64, int64_t e_alloc) {
+    k_nl(lb_geom g, int64_t BN, lb_ctrl* __restrict__ ctrl, lb_nl_args a) {
   constexpr int NL_WAVES = NL_THREADS / 64;
   __shared__ int s_id[MAXC];
   __shared__ double s_p[3][MAXC];
   __shared__ int s_row[NL_WAVES][LB_MAX_ROW];
-  __shared__ int s_cstart[28], s_ccnt[28], s_coff[28];
+  __shared__ int s_cstart[28], s_coff[29];
 
   if (ctrl->overflow_step >= 0) return;
   const int tid = threadIdx.x;
   const int gc = blockIdx.x;
   const int b = gc / g.ncells, h = gc % g.ncells;
-  const int own_start = cell_start[gc];
-  const int own_cnt = cell_start[gc + 1] - own_start;
+  const int own_start = a.cell_start[gc];
+  const int own_cnt = a.cell_start[gc + 1] - own_start;
   if (own_cnt == 0) return;
-  const int step = ctrl->step;
 
-  if (tid < g.nstencil) {
-    int nh = h;
-    if (g.use_cell_list) {
-      int c[3] = {h % g.ncell[0], (h / g.ncell[0]) % g.ncell[1], h / (g.ncell[0] * g.ncell[1])};
-      int o[3] = {tid % 3 - 1, (tid / 3) % 3 - 1, tid / 9 - 1};
-      nh = 0;
-      int mult = 1;
-      for (int d = 0; d < g.dim; ++d) {
-        int cc = c[d] + o[d];  // jax-md rolls the cell buffer: the stencil always wraps
-        cc = cc < 0 ? cc + g.ncell[d] : (cc >= g.ncell[d] ? cc - g.ncell[d] : cc);
-        nh += cc * mult;
-        mult *= g.ncell[d];
+  // stencil cells: start + count, exclusive prefix of the counts with a wave scan
+  if (tid < 64) {
+    int cnt = 0;
+    if (tid < g.nstencil) {
+      int nh = h;
+      if (g.use_cell_list) {
+        int c[3] = {h % g.ncell[0], (h / g.ncell[0]) % g.ncell[1], h / (g.ncell[0] * g.ncell[1])};
+        int o[3] = {tid % 3 - 1, (tid / 3) % 3 - 1, tid / 9 - 1};
+        nh = 0;
+        int mult = 1;
+        for (int d = 0; d < g.dim; ++d) {
+          int cc = c[d] + o[d];  // jax-md rolls the cell buffer: the stencil always wraps
+          cc = cc < 0 ? cc + g.ncell[d] : (cc >= g.ncell[d] ? cc - g.ncell[d] : cc);
+          nh += cc * mult;
+          mult *= g.ncell[d];
+        }
       }
+      const int ngc = b * g.ncells + nh;
+      const int st = a.cell_start[ngc];
+      s_cstart[tid] = st;
+      cnt = a.cell_start[ngc + 1] - st;
     }
-    const int ngc = b * g.ncells + nh;
-    s_cstart[tid] = cell_start[ngc];
-    s_ccnt[tid] = cell_start[ngc + 1] - cell_start[ngc];
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int off = 0;
-    for (int k = 0; k < g.nstencil; ++k) {
-      s_coff[k] = off;
-      off += s_ccnt[k];
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const int v = __shfl_up(incl, off);
+      if (tid >= off) incl += v;
     }
-    s_coff[g.nstencil] = off;
+    if (tid < g.nstencil) s_coff[tid] = incl - cnt;
+    if (tid == g.nstencil - 1) s_coff[g.nstencil] = incl;
   }
   __syncthreads();
   int M = s_coff[g.nstencil];
@@ -192,28 +209,29 @@ __global__ void __launch_bounds__(NL_THREADS)
     if (tid == 0) atomicExch(&ctrl->density_error, 1);
     M = MAXC;
   }
-  // stage the stencil's particles: ids + fp64 positions of the newest frame
+  // stage the stencil's particles (ids + fp64 positions, contiguous per cell in the sorted arrays)
   for (int j = tid; j < M; j += NL_THREADS) {
-    int k = 0;
-    while (k + 1 < g.nstencil && j >= s_coff[k + 1]) ++k;
-    const int gp = cell_part[s_cstart[k] + (j - s_coff[k])];
-    s_id[j] = gp;
-    for (int d = 0; d < g.dim; ++d) s_p[d][j] = lb_pos(win, g, BN, step, g.isl - 1, d, gp);
+    int lo = 0, hi = g.nstencil;  // largest k with s_coff[k] <= j
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_coff[mid] <= j) lo = mid; else hi = mid;
+    }
+    const int src = s_cstart[lo] + (j - s_coff[lo]);
+    s_id[j] = a.cell_part[src];
+    for (int d = 0; d < g.dim; ++d) s_p[d][j] = a.cpos[(int64_t)d * BN + src];
   }
   __syncthreads();
 
   const int wave = tid >> 6, lane = tid & 63;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  // the cell's own particles are the centre entry of the staged stencil: read the receivers from
-  // LDS instead of paying two dependent global round trips per receiver
+  // the cell's own particles are the centre entry of the staged stencil
   const int centre = g.use_cell_list ? (g.dim == 2 ? 4 : 13) : 0;
   const int own_off = s_coff[centre];
   for (int k = wave; k < own_cnt; k += NL_WAVES) {
-    const bool in_lds = own_off + k < M;
-    const int gr = in_lds ? s_id[own_off + k] : cell_part[own_start + k];
+    if (own_off + k >= M) break;  // truncated stencil (density error already flagged)
+    const int gr = s_id[own_off + k];
     double pr[3] = {0, 0, 0};
-    for (int d = 0; d < g.dim; ++d)
-      pr[d] = in_lds ? s_p[d][own_off + k] : lb_pos(win, g, BN, step, g.isl - 1, d, gr);
+    for (int d = 0; d < g.dim; ++d) pr[d] = s_p[d][own_off + k];
     int count = 0;
     for (int c0 = 0; c0 < M; c0 += 64) {
       const int j = c0 + lane;
@@ -230,58 +248,90 @@ __global__ void __launch_bounds__(NL_THREADS)
         ok = d2 < g.rc2;  // strict <
       }
       const unsigned long long mask = __ballot(ok);
-      if (FILL && ok) {
+      if (MODE != NL_COUNT && ok) {
         const int pos = count + __popcll(mask & lt_mask);
         if (pos < LB_MAX_ROW) s_row[wave][pos] = j;
       }
       count += __popcll(mask);
     }
-    if (!FILL) {
-      if (lane == 0) deg[gr] = count;
-    } else {
-      if (count > LB_MAX_ROW) {
-        if (lane == 0) atomicExch(&ctrl->density_error, 2);
-        count = LB_MAX_ROW;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      const int base = row_ptr[gr];
-      for (int t = lane; t < count; t += 64) {
-        const int j = s_row[wave][t];
-        const int my = s_id[j];
-        int rank = 0;
-        for (int u = 0; u < count; ++u) rank += (s_id[s_row[wave][u]] < my) ? 1 : 0;
-        const int64_t slot = (int64_t)base + rank;
-        if (slot < e_alloc) {
-          senders[slot] = my;
-          receivers[slot] = gr;
-          // features.py:115-124: disp(pos[receiver], pos[sender]) / r_c and its norm
-          double rd[3] = {0, 0, 0};
-          double s2 = 0.0;
-          for (int d = 0; d < g.dim; ++d) {
-            rd[d] = lb_disp1(pr[d], s_p[d][j], g.box[d], g.half_box[d], g.periodic) / g.rc;
-            s2 = (d == 0) ? rd[d] * rd[d] : s2 + rd[d] * rd[d];
-          }
-          const double dist = s2 > 0.0 ? sqrt(s2) : 0.0;
-          f32x4 lo = {0.f, 0.f, 0.f, 0.f};
-          if (g.dim == 2) {
-            lo = f32x4{(float)rd[0], (float)rd[1], (float)dist, 0.f};
-          } else {
-            lo = f32x4{(float)rd[0], (float)rd[1], (float)rd[2], (float)dist};
-          }
-          f32x4* ef = reinterpret_cast<f32x4*>(efeat + slot * 8);
+    if (MODE != NL_FILL && lane == 0) {
+      a.deg[gr] = count;
+      // one hot word: 64k same-address atomics would serialise (~12 ns each); almost every row is
+      // filtered out by the plain (monotonic, possibly stale) read
+      if (count > *(volatile int32_t*)&ctrl->max_deg) atomicMax(&ctrl->max_deg, count);
+    }
+    if (MODE == NL_COUNT) continue;
+    if (count > LB_MAX_ROW) {
+      if (lane == 0) atomicExch(&ctrl->density_error, 2);
+      count = LB_MAX_ROW;
+    }
+    if (MODE == NL_ROWS && count > a.maxd) {
+      if (lane == 0) atomicExch(&ctrl->row_overflow, 1);  // per-node slots too small: re-allocate
+      count = a.maxd;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const int64_t base = (MODE == NL_ROWS) ? (int64_t)gr * a.maxd : (int64_t)a.row_ptr[gr];
+    for (int t = lane; t < count; t += 64) {
+      const int j = s_row[wave][t];
+      const int my = s_id[j];
+      int rank = 0;
+      for (int u = 0; u < count; ++u) rank += (s_id[s_row[wave][u]] < my) ? 1 : 0;
+      const int64_t slot = base + rank;
+      if (MODE == NL_ROWS || slot < a.e_alloc) {
+        a.senders[slot] = my;
+        // features.py:115-124: disp(pos[receiver], pos[sender]) / r_c and its norm
+        double rd[3] = {0, 0, 0};
+        double s2 = 0.0;
+        for (int d = 0; d < g.dim; ++d) {
+          rd[d] = lb_disp1(pr[d], s_p[d][j], g.box[d], g.half_box[d], g.periodic) / g.rc;
+          s2 = (d == 0) ? rd[d] * rd[d] : s2 + rd[d] * rd[d];
+        }
+        const double dist = s2 > 0.0 ? sqrt(s2) : 0.0;
+        const f32x4 lo = (g.dim == 2) ? f32x4{(float)rd[0], (float)rd[1], (float)dist, 0.f}
+                                      : f32x4{(float)rd[0], (float)rd[1], (float)rd[2], (float)dist};
+        if (MODE == NL_ROWS) {
+          reinterpret_cast<f32x4*>(a.efeat)[slot] = lo;
+        } else {
+          a.receivers[slot] = gr;
+          f32x4* ef = reinterpret_cast<f32x4*>(a.efeat + slot * 8);
           ef[0] = lo;
           ef[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (efeat64) {
-            double* e64 = efeat64 + slot * 4;
-            e64[0] = rd[0];
-            e64[1] = rd[1];
-            e64[2] = rd[2];
-            e64[3] = dist;
-          }
+        }
+        if (a.efeat64) {
+          double* e64 = a.efeat64 + slot * 4;
+          e64[0] = rd[0];
+          e64[1] = rd[1];
+          e64[2] = rd[2];
+          e64[3] = dist;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+}
+
+// NL_ROWS -> CSR: one 16-lane group per node copies its sorted row into place.
+__global__ void __launch_bounds__(256)
+    k_nl_compact(int64_t BN, const lb_ctrl* __restrict__ ctrl, const int32_t* __restrict__ deg,
+                 const int32_t* __restrict__ row_ptr, int32_t maxd, const int32_t* __restrict__ tsend,
+                 const float* __restrict__ tfeat, const double* __restrict__ tfeat64,
+                 int32_t* __restrict__ senders, int32_t* __restrict__ receivers,
+                 float* __restrict__ efeat, double* __restrict__ efeat64, int64_t e_alloc) {
+  if (ctrl->overflow_step >= 0) return;
+  const int64_t gnode = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (gnode >= BN) return;
+  const int d = min(deg[gnode], maxd);
+  const int64_t base = row_ptr[gnode];
+  for (int k = threadIdx.x & 15; k < d; k += 16) {
+    const int64_t src = gnode * maxd + k, dst = base + k;
+    if (dst >= e_alloc) break;
+    senders[dst] = tsend[src];
+    receivers[dst] = (int32_t)gnode;
+    f32x4* ef = reinterpret_cast<f32x4*>(efeat + dst * 8);
+    ef[0] = reinterpret_cast<const f32x4*>(tfeat)[src];
+    ef[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (efeat64 && tfeat64)
+      for (int c = 0; c < 4; ++c) efeat64[dst * 4 + c] = tfeat64[src * 4 + c];
   }
 }
 
@@ -300,9 +350,11 @@ __global__ void __launch_bounds__(256)
   for (int b = threadIdx.x; b < g.B; b += blockDim.x) {
     const int eb = row_ptr[(b + 1) * g.N] - row_ptr[b * g.N];
     nedges_b[b] = eb;
-    // did_buffer_overflow = cell list overflow | occupancy > max_occupancy (jax-md)
+    // did_buffer_overflow = cell list overflow | occupancy > max_occupancy (jax-md); a row that
+    // outgrew the engine's per-node slots is reported the same way (the driver re-allocates)
     int ov = 0;
-    if (frozen) ov = (eb > e_cap) || (g.use_cell_list && ctrl->max_cell_occ > cell_capacity);
+    if (frozen)
+      ov = (eb > e_cap) || (g.use_cell_list && ctrl->max_cell_occ > cell_capacity) || ctrl->row_overflow;
     overflow[b] = ov;
     if (ov) atomicExch(&s_any, 1);
   }
@@ -319,6 +371,17 @@ __global__ void __launch_bounds__(256)
 }
 
 // ----------------------------------------------------------------------------------- host
+template <int MODE>
+static void lb_launch_nl(lb_engine* e, bool small, const lb_nl_args& a) {
+  const int ncell_tot = e->g.B * e->g.ncells;
+  if (small)
+    hipLaunchKernelGGL((k_nl<MODE, 64, NL_SMALL_MAXC>), dim3(ncell_tot), dim3(64), 0, e->stream, e->g,
+                       e->BN, e->ctrl, a);
+  else
+    hipLaunchKernelGGL((k_nl<MODE, 256, LB_MAX_STENCIL_CAND>), dim3(ncell_tot), dim3(256), 0, e->stream,
+                       e->g, e->BN, e->ctrl, a);
+}
+
 int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   const lb_geom& g = e->g;
   const int64_t BN = e->BN;
@@ -328,31 +391,42 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
 
   lb_tic(e, LB_T_CELLS);
   LB_HIP(hipMemsetAsync(e->cell_count, 0, sizeof(int32_t) * 2 * (size_t)ncell_tot, s));
+  // max_cell_occ, max_deg, row_overflow are rebuilt every pass (adjacent ints in lb_ctrl)
+  LB_HIP(hipMemsetAsync(&e->ctrl->max_cell_occ, 0, sizeof(int32_t), s));
+  LB_HIP(hipMemsetAsync(&e->ctrl->max_deg, 0, 2 * sizeof(int32_t), s));
   const int nb = (int)((BN + 255) / 256);
   hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, s, g, BN, e->win, e->ctrl, e->cell_of,
                      e->cell_count);
-  LB_HIP(hipMemsetAsync(&e->ctrl->max_cell_occ, 0, sizeof(int32_t), s));
   const int nsb_c = (ncell_tot + SCAN_CHUNK - 1) / SCAN_CHUNK;
   hipLaunchKernelGGL(k_scan_partials, dim3(nsb_c), dim3(SCAN_THREADS), 0, s, e->cell_count, ncell_tot,
                      e->scan_part, e->ctrl, &e->ctrl->max_cell_occ);
   hipLaunchKernelGGL(k_scan_apply, dim3(nsb_c), dim3(SCAN_THREADS), 0, s, e->cell_count,
                      e->cell_start, ncell_tot, e->scan_part, e->ctrl);
-  hipLaunchKernelGGL(k_cell_fill, dim3(nb), dim3(256), 0, s, BN, e->ctrl, e->cell_of,
-                     e->cell_start, e->cell_fill, e->cell_part);
+  hipLaunchKernelGGL(k_cell_fill, dim3(nb), dim3(256), 0, s, g, BN, e->win, e->ctrl, e->cell_of,
+                     e->cell_start, e->cell_fill, e->cell_part, e->cpos);
   lb_toc(e);
 
   lb_tic(e, LB_T_NEIGH);
   // one wave per cell when the frozen cell capacity bounds the stencil (a cell holding more than
   // cell_capacity particles flags overflow anyway); the 256-thread / 2048-candidate variant otherwise
   const bool small = frozen && g.use_cell_list && (int64_t)e->cell_capacity * g.nstencil <= NL_SMALL_MAXC;
-  if (small)
-    hipLaunchKernelGGL((k_nl<false, 64, NL_SMALL_MAXC>), dim3(ncell_tot), dim3(64), 0, s, g, BN, e->win,
-                       e->ctrl, e->cell_start, e->cell_part, e->deg, e->row_ptr, e->senders,
-                       e->receivers, e->efeat, (double*)nullptr, e->e_alloc);
-  else
-    hipLaunchKernelGGL((k_nl<false, 256, LB_MAX_STENCIL_CAND>), dim3(ncell_tot), dim3(256), 0, s, g, BN,
-                       e->win, e->ctrl, e->cell_start, e->cell_part, e->deg, e->row_ptr, e->senders,
-                       e->receivers, e->efeat, (double*)nullptr, e->e_alloc);
+  const bool rows = frozen && e->maxd > 0 && e->tmp_send && (!want_efeat64 || e->tmp_feat64);
+  lb_nl_args a{};
+  a.cell_start = e->cell_start;
+  a.cell_part = e->cell_part;
+  a.cpos = e->cpos;
+  a.deg = e->deg;
+  a.row_ptr = e->row_ptr;
+  a.e_alloc = e->e_alloc;
+  a.maxd = e->maxd;
+  if (rows) {
+    a.senders = e->tmp_send;
+    a.efeat = e->tmp_feat;
+    a.efeat64 = want_efeat64 ? e->tmp_feat64 : nullptr;
+    lb_launch_nl<NL_ROWS>(e, small, a);
+  } else {
+    lb_launch_nl<NL_COUNT>(e, small, a);
+  }
   const int nsb_r = (int)((BN + SCAN_CHUNK - 1) / SCAN_CHUNK);
   hipLaunchKernelGGL(k_scan_partials, dim3(nsb_r), dim3(SCAN_THREADS), 0, s, e->deg, (int)BN,
                      e->scan_part, e->ctrl, (int32_t*)nullptr);
@@ -361,6 +435,15 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   hipLaunchKernelGGL(k_row_finish, dim3(1), dim3(256), 0, s, g, e->row_ptr, (int)BN, e->ctrl,
                      e->overflow, e->nedges_b, e->cell_capacity, e->e_cap, e->e_alloc, frozen,
                      e->host_flag_dev);
+  if (rows) {
+    hipLaunchKernelGGL(k_nl_compact, dim3((int)((BN + 15) / 16)), dim3(256), 0, s, BN, e->ctrl, e->deg,
+                       e->row_ptr, e->maxd, e->tmp_send, e->tmp_feat,
+                       want_efeat64 ? e->tmp_feat64 : (const double*)nullptr, e->senders, e->receivers,
+                       e->efeat, want_efeat64 ? e->efeat64 : (double*)nullptr, e->e_alloc);
+    lb_toc(e);
+    LB_HIP(hipGetLastError());
+    return LB_OK;
+  }
   if (!frozen) {
     // allocate path (host-synchronous by contract): size the edge buffers before the fill pass
     LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, s));
@@ -381,16 +464,13 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
     e->ctrl_host->n_edges_total = e->ctrl_host->n_edges_unclamped;
     LB_HIP(hipMemcpyAsync(&e->ctrl->n_edges_total, &e->ctrl_host->n_edges_total, sizeof(int32_t),
                           hipMemcpyHostToDevice, s));
+    a.e_alloc = e->e_alloc;
   }
-  double* e64 = want_efeat64 ? e->efeat64 : nullptr;
-  if (small)
-    hipLaunchKernelGGL((k_nl<true, 64, NL_SMALL_MAXC>), dim3(ncell_tot), dim3(64), 0, s, g, BN, e->win,
-                       e->ctrl, e->cell_start, e->cell_part, e->deg, e->row_ptr, e->senders,
-                       e->receivers, e->efeat, e64, e->e_alloc);
-  else
-    hipLaunchKernelGGL((k_nl<true, 256, LB_MAX_STENCIL_CAND>), dim3(ncell_tot), dim3(256), 0, s, g, BN,
-                       e->win, e->ctrl, e->cell_start, e->cell_part, e->deg, e->row_ptr, e->senders,
-                       e->receivers, e->efeat, e64, e->e_alloc);
+  a.senders = e->senders;
+  a.receivers = e->receivers;
+  a.efeat = e->efeat;
+  a.efeat64 = want_efeat64 ? e->efeat64 : nullptr;
+  lb_launch_nl<NL_FILL>(e, small, a);
   lb_toc(e);
   LB_HIP(hipGetLastError());
   return LB_OK;
