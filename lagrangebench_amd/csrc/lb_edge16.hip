@@ -107,15 +107,22 @@ void lb_pack_weight16h(const float* w, int K, int M, int Kpad, float* out, int M
         }
 }
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+// x -> hi = fp16(x) (RNE), lo = fp16(x - hi): written on 2-vectors so that hipcc emits the packed
+// v_cvt_pk_f16_f32 / v_pk_add_f32 forms (5 VALU per two elements instead of ~10).
 __device__ __forceinline__ void lb_split8(const f32x4& x0, const f32x4& x1, h8& hi, h8& lo) {
+  const f32x2_t a[4] = {{x0[0], x0[1]}, {x0[2], x0[3]}, {x1[0], x1[1]}, {x1[2], x1[3]}};
+  h2_t hh[4], ll[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const _Float16 a = (_Float16)x0[i], b = (_Float16)x1[i];
-    hi[i] = a;
-    hi[4 + i] = b;
-    lo[i] = (_Float16)(x0[i] - (float)a);
-    lo[4 + i] = (_Float16)(x1[i] - (float)b);
+    hh[i] = __builtin_convertvector(a[i], h2_t);
+    const f32x2_t back = __builtin_convertvector(hh[i], f32x2_t);
+    ll[i] = __builtin_convertvector(a[i] - back, h2_t);
   }
+  hi = h8{hh[0][0], hh[0][1], hh[1][0], hh[1][1], hh[2][0], hh[2][1], hh[3][0], hh[3][1]};
+  lo = h8{ll[0][0], ll[0][1], ll[1][0], ll[1][1], ll[2][0], ll[2][1], ll[3][0], ll[3][1]};
 }
 
 // acc[0..7] += W^T * B over NP blocks of 32 k's in f16x2 arithmetic.  ld(p, mbo, part) -> 16 B.

@@ -9,7 +9,7 @@
 //      (int atomics); k_cell_fill also writes the cell-sorted fp64 positions so that a cell's
 //      particles are one contiguous HBM range.
 //   2. k_nl : one workgroup per cell (one wave when the frozen cell capacity bounds the stencil to
-//      <= 512 candidates, else 256 threads) stages the particles of its 3^dim stencil (ids + fp64
+//      <= 1024 candidates, else 256 threads) stages the particles of its 3^dim stencil (ids + fp64
 //      positions) in LDS once; each wave owns receivers of the cell and sweeps the staged tile 64
 //      candidates at a time.  The cutoff predicate is evaluated in fp64 exactly as the reference
 //      does (metric(pos[sender], pos[receiver]) < r_c^2), reduced with a wavefront ballot +
@@ -27,7 +27,7 @@
 
 #define SCAN_THREADS 256
 #define SCAN_CHUNK (SCAN_THREADS * 8)
-#define NL_SMALL_MAXC 512
+#define NL_SMALL_MAXC 1024
 
 enum { NL_COUNT = 0, NL_FILL = 1, NL_ROWS = 2 };
 
