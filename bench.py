@@ -8,9 +8,12 @@ prediction store) over one batch of B synthetic trajectories per GPU.  Inputs ar
 HBM before the timed region.  Rank 0 prints ONE JSON line:
 
   metric/value : rollout particle-steps/s, whole job = n_gpus * B * N_particles * K / max-rank time
-  roofline     : dominant kernel (processor edge MLP, fp32 MFMA bound), timed with HIP events on
-                 the engine stream inside this run; + roofline_aggregate for the segment_sum kernel
-                 (HBM bound) that BASELINE.json's north_star singles out
+  roofline     : the dominant kernel (processor edge MLP with the fused aggregation), timed with HIP
+                 events on the engine stream inside this run.  In the default f16x2 arithmetic the
+                 kernel's binding ceiling is HBM (edge latents stream once in, once out per layer);
+                 its MFMA-side utilisation is reported next to it.  With LB_MATH=f32 the kernel is
+                 bound by the fp32 MFMA pipe and the object says so.
+  roofline_aggregate : the stand-alone jraph.segment_sum kernel (HBM bound) north_star singles out
   cpu_baseline : the NumPy oracle (reference-shaped: padded E_cap rows, unfused ops) timed on this
                  host's cores on a bounded sample (rank 0, N=1 only)
 
@@ -34,12 +37,30 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = 157.3 TFLOP/s dense
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA, dense
+MFMA_F16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: bf16/fp16 MFMA, dense (2:1-sparse figure is 2x)
 D = 128
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def pmc_traffic(kernel_substr: str, workload: str, batch: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this command;
+    FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  None if not measured."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            tab = json.load(f)
+        ent = tab.get(f"{workload}_b{batch}", {})
+        for k, v in ent.items():
+            if kernel_substr in k:
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -51,7 +72,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="trajectories advanced together per GPU")
     ap.add_argument("--mp-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     args = ap.parse_args()
 
     from lagrangebench_amd import dist as lbdist
@@ -67,6 +88,7 @@ def main():
     from tests._common import hip_case, make_params
 
     B, K, W, L = args.batch, args.steps, args.warmup, args.mp_steps
+    math_mode = "f32" if os.environ.get("LB_MATH") == "f32" else "f16x2"
     ds = make_case(args.workload, n_trajs=world * B, extra_seq_length=max(K, W, 1))
     dim = len(ds.box)
     params = make_params(ds, num_mp_steps=L, random_affine=False)  # haiku-default init, decoder x0.01
@@ -81,7 +103,9 @@ def main():
     traj = eng.prepare_traj(pos)  # fp64, resident in HBM
     handle = model.handle(eng, params)
 
-    # warm-up: allocates the neighbor list, touches every kernel
+    # warm-up: W steps of the same rollout (allocates the neighbor list, touches every kernel; with
+    # W >= K the capacities have grown to what the timed rollout needs, as they have in the steady
+    # state of eval_rollout's loop over trajectory batches)
     eng.rollout(handle, traj, max(W, 1))
     lbdist.barrier(device)
     t0 = time.perf_counter()
@@ -122,13 +146,38 @@ def main():
     ms_agg, n_agg = tm["aggregate"]
     us_edge = 1e3 * ms_edge / max(n_edge, 1)
     us_agg = 1e3 * ms_agg / max(n_agg, 1)
-    # processor edge MLP, one launch = E_tot edges of one MP layer.
-    #   executed on MFMA: 2 GEMMs of (E x 128 x 128): 2*2*D*D flop/edge (the sender/receiver part of
-    #   W0 is projected per node); algorithmic (reference formulation): 2*4*D*D flop/edge.
-    flop_exec = E_tot * 2 * 2 * D * D
+    BN = B * N
+    # ---- dominant kernel: processor edge MLP (+ fused aggregation), one launch = one MP layer.
+    # Algorithmic HBM bytes (SURVEY 8d "edge latents round-trip HBM" + node-side rows):
+    #   read e (E*512) + write e (E*512) + sender/receiver ids (E*8) + projections read once (N*1024)
+    #   + aggregated messages written once (N*512)
+    edge_bytes = E_tot * (2 * D * 4 + 8) + BN * (2 * D * 4 + D * 4)
+    gbs_edge = edge_bytes / (us_edge * 1e-6) / 1e9
+    # flops: algorithmic (reference formulation) 2*4*D*D per edge; executed products
+    # 2*2*D*D per edge (sender/receiver part projected per node), x3 MFMA passes in f16x2
     flop_algo = E_tot * 2 * 4 * D * D
-    tf_exec = flop_exec / (us_edge * 1e-6) / 1e12
-    agg_bytes = E_tot * (D * 4 + 4) + B * N * D * 4  # E*516 + N*512
+    flop_prod = E_tot * 2 * 2 * D * D
+    if math_mode == "f16x2":
+        mfma = {"dtype": "f16 (x3 split passes)", "achieved": 3 * flop_prod / (us_edge * 1e-6) / 1e12,
+                "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s"}
+    else:
+        mfma = {"dtype": "f32", "achieved": flop_prod / (us_edge * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF,
+                "unit": "TFLOP/s"}
+    mfma["frac"] = mfma["achieved"] / mfma["peak"]
+    mfma["fp32_equivalent_algorithmic_tflops"] = flop_algo / (us_edge * 1e-6) / 1e12
+    kern = "k_edge16<PROC," + ("f16x2>" if math_mode == "f16x2" else "f32>")
+    if math_mode == "f16x2":
+        roof = {"kernel": kern, "bound": "hbm", "achieved": gbs_edge, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs_edge / HBM_PEAK_GBS,
+                "traffic": pmc_traffic("k_edge16<true, true", args.workload, B),
+                "us_per_launch": us_edge, "launches": int(n_edge), "bytes_per_launch": edge_bytes, "mfma": mfma}
+    else:
+        roof = {"kernel": kern, "bound": "mfma", "achieved": mfma["achieved"], "peak": mfma["peak"],
+                "unit": "TFLOP/s", "frac": mfma["frac"],
+                "traffic": pmc_traffic("k_edge16<true, false", args.workload, B),
+                "us_per_launch": us_edge, "launches": int(n_edge), "flop_per_launch_executed": flop_prod,
+                "hbm": {"achieved": gbs_edge, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_edge / HBM_PEAK_GBS}}
+    agg_bytes = E_tot * (D * 4 + 4) + BN * D * 4  # E*516 + N*512
     gbs_agg = agg_bytes / (us_agg * 1e-6) / 1e9
     breakdown = {k: round(v[0] / K, 4) for k, v in tm.items() if v[1] > 0 and not (fused and k == "aggregate")}
 
@@ -143,27 +192,22 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if math_mode == "f32" else "f32 (GEMMs as fp16 hi/lo split products, fp32 accumulate)",
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload} GNS-{L}-{D} inference rollout, neighbor list rebuilt every step",
             "n_particles": int(N), "batch_per_gpu": B, "edges_per_traj": int(E_tot // B),
-            "input_seq_length": ds.input_seq_length, "geometry_dtype": "f64", "network_dtype": "f32",
+            "input_seq_length": ds.input_seq_length, "geometry_dtype": "f64", "network_math": math_mode,
             "weights": "haiku-default init (seed 1234), decoder x0.01", "n_realloc": int(n_realloc),
         },
         "steps_per_s_per_traj": K / dt,
         "mse20_mean": float(np.mean([float(v.mean()) for v in merged.values()])),
-        "roofline": {
-            "kernel": "k_edge_mlp<PROC>", "bound": "mfma", "achieved": tf_exec, "peak": MFMA_F32_PEAK_TF,
-            "unit": "TFLOP/s", "frac": tf_exec / MFMA_F32_PEAK_TF, "traffic": None,
-            "us_per_launch": us_edge, "launches": int(n_edge), "flop_per_launch_executed": flop_exec,
-            "flop_per_launch_algorithmic": flop_algo,
-            "achieved_algorithmic": flop_algo / (us_edge * 1e-6) / 1e12,
-        },
+        "roofline": roof,
         "roofline_aggregate": {
             "kernel": "k_segment_sum", "bound": "hbm", "achieved": gbs_agg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gbs_agg / HBM_PEAK_GBS, "traffic": None, "us_per_launch": us_agg, "launches": int(n_agg),
-            "bytes_per_launch": agg_bytes, "on_hot_path": not fused,
+            "frac": gbs_agg / HBM_PEAK_GBS, "traffic": pmc_traffic("k_segment_sum", args.workload, B),
+            "us_per_launch": us_agg, "launches": int(n_agg), "bytes_per_launch": agg_bytes,
+            "on_hot_path": not fused,
             "note": ("stand-alone jraph.segment_sum kernel timed on the same receiver-sorted list; the hot path "
                      "fuses the aggregation into the edge-MLP epilogue (no message round trip)") if fused else "",
         },
@@ -176,19 +220,26 @@ def main():
 
 
 def cpu_baseline(ds, params, L, n_steps):
-    """The NumPy oracle in the reference's algorithmic shape (dense candidate matrix -> mask ->
+    """The CPU restatement in the reference's algorithmic shape (dense candidate matrix -> mask ->
     compaction; MLPs over all E_cap padded rows; unfused gather/GEMM/LayerNorm/scatter-add; fp64
-    geometry, fp32 network; batch 1) on all host cores (BLAS threads)."""
+    geometry, fp32 network; batch 1) on all host cores: torch-CPU for the network
+    (oracle/lb_oracle_torch.py), NumPy for the neighbor list / features / integrator."""
     from oracle import lb_oracle as O
+    from oracle import lb_oracle_torch as OT
     from tests._common import oracle_case
-    cores = os.cpu_count() or 1
+    # threads: torch-CPU on the MI355X host (256 hardware threads) is fastest at 32 threads and
+    # collapses when oversubscribed (measured with tools/cpu_threads_probe.py: 4/8/16/32/64/256
+    # threads -> 2.6/2.0/1.8/1.6/2.5/47 s per forward); "cores" reports the threads actually used
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
     ocase = oracle_case(ds)
     isl = ds.input_seq_length
     pos, pt = ds[0]
     pos = pos.astype(np.float64)
+    pt_params = OT.params_to_torch(params)
 
     def apply(p, s, sample):
-        return O.gns_apply(p, sample[0], sample[1], num_mp_steps=L, skip_padding=False), s
+        return OT.gns_apply(pt_params, sample[0], sample[1], num_mp_steps=L), s
 
     _, nbrs = ocase.allocate_eval((pos[:, :isl], pt))
     # 1 untimed step, then n_steps timed
@@ -198,8 +249,9 @@ def cpu_baseline(ds, params, L, n_steps):
     dt = time.perf_counter() - t0
     return {
         "value": len(pt) * n_steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-        "sample": f"{n_steps} rollout steps of 1 {ds.name} trajectory (N={len(pt)}) after 1 warm-up step, "
-                  f"NumPy/BLAS oracle in the reference's padded/unfused shape, {1e3 * dt / n_steps:.0f} ms/step",
+        "sample": f"{n_steps} rollout steps of 1 {ds.name} trajectory (N={len(pt)}) after 1 warm-up step; "
+                  f"torch-CPU network + NumPy neighbor list in the reference's padded/unfused shape, "
+                  f"{1e3 * dt / n_steps:.0f} ms/step",
         "note": "JAX is not installable here: this is the reference-shaped CPU restatement, not JAX-CPU",
     }
 

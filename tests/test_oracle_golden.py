@@ -165,3 +165,19 @@ def test_gns_shapes_and_padding_invariance():
     b = O.gns_apply(params, feats, pt, num_mp_steps=3, skip_padding=True)["acc"]
     assert a.shape == (n, dim) and a.dtype == np.float32
     assert np.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_torch_cpu_baseline_matches_numpy_oracle():
+    """oracle/lb_oracle_torch.py (bench.py's cpu_baseline network) == the NumPy oracle."""
+    import torch
+    from oracle import lb_oracle_torch as OT
+    from lagrangebench_amd.data import make_case
+    from tests._common import make_params, oracle_case
+    ds = make_case("small3d", n_trajs=1, extra_seq_length=2)
+    case = oracle_case(ds)
+    params = make_params(ds, num_mp_steps=4)
+    pos, pt = ds[0]
+    feats, _ = case.allocate_eval((pos[:, :6].astype(np.float64), pt))
+    a = O.gns_apply(params, feats, pt, num_mp_steps=4)["acc"]
+    b = OT.gns_apply(OT.params_to_torch(params), feats, pt, num_mp_steps=4)["acc"]
+    assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max()

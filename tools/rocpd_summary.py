@@ -37,10 +37,15 @@ def main():
             ev2k[ev] = names.get(kid, str(kid))
         tot = sum(sum(v) for v in stat.values()) or 1
         print(f"== {db}")
-        print(f"{'kernel':70s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'%':>6s}")
+        print("(avg_real_us / real: launches of at least 20 % of the kernel's median duration, i.e. without the "
+              "no-op launches that follow a neighbor-list overflow during warm-up)")
+        print(f"{'kernel':70s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'%':>6s} "
+              f"{'real':>6s} {'avg_real_us':>11s}")
         for k, v in sorted(stat.items(), key=lambda kv: -sum(kv[1])):
+            med = sorted(v)[len(v) // 2]
+            real = [x for x in v if x >= 0.2 * med]
             print(f"{k[:70]:70s} {len(v):7d} {sum(v)/1e6:10.3f} {sum(v)/len(v)/1e3:10.2f} {min(v)/1e3:9.2f} "
-                  f"{max(v)/1e3:9.2f} {100*sum(v)/tot:6.2f}")
+                  f"{max(v)/1e3:9.2f} {100*sum(v)/tot:6.2f} {len(real):6d} {sum(real)/len(real)/1e3:11.2f}")
         pmc_names = {r[0]: r[1] for r in c.execute(f"select id, name from {t['rocpd_info_pmc']}")}
         if pmc_names:
             acc = defaultdict(lambda: defaultdict(float))
