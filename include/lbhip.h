@@ -195,6 +195,12 @@ int lb_rollout(lb_engine* eng, lb_gns* gns, const double* traj_dev, int32_t T, i
 int lb_metrics(lb_engine* eng, const double* pred_dev, int32_t pred_T, const double* target_dev,
                int32_t target_T, int32_t n_steps, double* mse_out_dev, double* mae_out_dev);
 
+/* MetricsComputer "e_kin" - evaluate/metrics.py:98-125,157-160: kinetic energy of strided frames of
+ * one rollout (B,T,N,dim) fp64: out[b][k] = dx^dim * sum((disp(x[1+k*stride], x[k*stride]) / dt)^2),
+ * k < n_out = ceil((T-1)/stride) (= len(x[1::stride])).  out (B,n_out) fp64. */
+int lb_ekin(lb_engine* eng, const double* rollout_dev, int32_t T, int32_t stride, double dt, double dx,
+            double* out_dev, int32_t n_out);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------ */
 
 /* Enable per-kernel-class HIP-event timing on the engine stream.  Classes: see lb_timer_name. */

@@ -176,7 +176,7 @@ class CaseSetupFn:
         return out if batched else out[0]
 
 
-def _force_spec(external_force_fn) -> Optional[ForceSpec]:
+def _force_spec(external_force_fn, bounds=None) -> Optional[ForceSpec]:
     if external_force_fn is None:
         return None
     if isinstance(external_force_fn, ForceSpec):
@@ -185,6 +185,14 @@ def _force_spec(external_force_fn) -> Optional[ForceSpec]:
         return ForceSpec.piecewise(external_force_fn["axis"], external_force_fn["split"],
                                    external_force_fn["f_lo"], external_force_fn["f_hi"])
     if callable(external_force_fn):
+        # the reference's convention: fn(single position (dim,)) -> (dim,) (features.py:105-107 vmaps
+        # it).  The published force.py files are piecewise constant: compile to a device ForceSpec.
+        if bounds is not None:
+            from ..data.data import force_spec_from_callable
+            try:
+                return force_spec_from_callable(external_force_fn, bounds)
+            except Exception:
+                pass
         return ForceSpec.callable(external_force_fn)
     raise TypeError("external_force_fn must be None, a ForceSpec, a dict or a callable")
 
@@ -218,4 +226,4 @@ def case_builder(
                                   "data, matscipy) is not built")
     return CaseSetupFn(box=box, metadata=metadata, input_seq_length=input_seq_length,
                        cfg_neighbors=cfg_neighbors, cfg_model=cfg_model, noise_std=noise_std,
-                       force=_force_spec(external_force_fn), dtype=dtype, device=device)
+                       force=_force_spec(external_force_fn, metadata.get("bounds")), dtype=dtype, device=device)

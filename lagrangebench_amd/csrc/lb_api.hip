@@ -745,6 +745,15 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
   return LB_OK;
 }
 
+extern "C" int lb_ekin(lb_engine* e, const double* rollout_dev, int32_t T, int32_t stride, double dt,
+                       double dx, double* out_dev, int32_t n_out) {
+  if (!e || !rollout_dev || !out_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  if (stride < 1 || T < 2) return lb_fail(LB_ERR_ARG, "need stride >= 1 and T >= 2");
+  const int expect = (T - 1 + stride - 1) / stride;  // len(x[1::stride]) == len(x[0:-1:stride])
+  if (n_out != expect) return lb_fail(LB_ERR_ARG, "n_out must be ceil((T-1)/stride) = %d", expect);
+  return lbk_ekin(e, rollout_dev, T, stride, n_out, dt, dx, out_dev);
+}
+
 extern "C" int lb_metrics(lb_engine* e, const double* pred_dev, int32_t pred_T,
                           const double* target_dev, int32_t target_T, int32_t n_steps, double* mse,
                           double* mae) {

@@ -229,6 +229,8 @@ int lbk_node_features(lb_engine* e, float* xnode, const float* embed, int emb, i
                       double* vel_hist, double* vel_mag, double* bound, double* force);
 int lbk_integrate(lb_engine* e, const float* acc, int acc_stride, const double* target,
                   const double* traj, int T, double* pred, int pred_T);
+int lbk_ekin(lb_engine* e, const double* roll, int T, int stride, int n_out, double dt, double dx,
+             double* out);
 int lbk_case_integrate(lb_engine* e, int mode, const float* pred, const double* pos_seq, int T,
                        double* out);
 int lbk_metrics(lb_engine* e, const double* pred, int pred_T, const double* target, int target_T,

@@ -254,6 +254,43 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// MetricsComputer "e_kin" (evaluate/metrics.py:98-125,157-160): kinetic energy of strided frames,
+// E[k] = dx^dim * sum_{i,d} (disp(x[1 + k*stride], x[k*stride]) / dt)^2, one workgroup per (traj, k).
+__global__ void __launch_bounds__(256)
+    k_ekin(lb_geom g, const double* __restrict__ roll, int T, int stride, int n_out, double inv_dt,
+           double vol, double* __restrict__ out) {
+  __shared__ double s2[256];
+  const int k = blockIdx.x, b = blockIdx.y;
+  const int t0 = k * stride, t1 = 1 + k * stride;
+  double a2 = 0.0;
+  const int n = g.N * g.dim;
+  for (int q = threadIdx.x; q < n; q += 256) {
+    const int i = q / g.dim, d = q % g.dim;
+    const double p1 = roll[(((int64_t)b * T + t1) * g.N + i) * g.dim + d];
+    const double p0 = roll[(((int64_t)b * T + t0) * g.N + i) * g.dim + d];
+    const double v = lb_disp1(p1, p0, g.box[d], g.half_box[d], g.periodic) * inv_dt;
+    a2 += v * v;
+  }
+  s2[threadIdx.x] = a2;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s2[threadIdx.x] += s2[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[(int64_t)b * n_out + k] = s2[0] * vol;
+}
+
+int lbk_ekin(lb_engine* e, const double* roll, int T, int stride, int n_out, double dt, double dx,
+             double* out) {
+  if (n_out <= 0) return LB_OK;
+  double vol = 1.0;
+  for (int d = 0; d < e->g.dim; ++d) vol *= dx;
+  hipLaunchKernelGGL(k_ekin, dim3(n_out, e->g.B), dim3(256), 0, e->stream, e->g, roll, T, stride, n_out,
+                     1.0 / dt, vol, out);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
 int lbk_metrics(lb_engine* e, const double* pred, int pred_T, const double* target, int target_T,
                 int n_steps, double* mse, double* mae) {
   if (n_steps <= 0) return LB_OK;

@@ -289,6 +289,15 @@ class RolloutEngine:
             out["mae"] = mae
         return out
 
+    def ekin(self, rollout: torch.Tensor, stride: int, dt: float, dx: float) -> torch.Tensor:
+        """Kinetic energy of strided frames of (B,T,N,dim) (or (T,N,dim)) positions -> (B, n_out)."""
+        r = _dev(rollout if rollout.dim() == 4 else rollout[None], torch.float64, self.device)
+        T = r.shape[1]
+        n_out = (T - 1 + stride - 1) // stride
+        out = torch.empty((self.B, n_out), dtype=torch.float64, device=self.device)
+        check(self.lib.lb_ekin(self._h, ptr(r), T, int(stride), float(dt), float(dx), ptr(out), n_out), "lb_ekin")
+        return out
+
     def segment_sum(self, msg: torch.Tensor) -> torch.Tensor:
         msg = _dev(msg, torch.float32, self.device)
         out = torch.empty((self.B * self.N, msg.shape[1]), dtype=torch.float32, device=self.device)

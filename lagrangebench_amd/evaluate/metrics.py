@@ -1,7 +1,9 @@
 """Rollout metrics - mirror of lagrangebench/evaluate/metrics.py.
 
-Built: ``mse`` and ``mae`` (metrics.py:86-96,139-147), computed on the device by lb_metrics.
-Not built yet: ``e_kin`` and ``sinkhorn`` raise NotImplementedError.
+Built: ``mse`` and ``mae`` (metrics.py:86-96,139-147) and ``e_kin`` (metrics.py:98-125,157-160),
+computed on the device by lb_metrics / lb_ekin.
+Not built yet: ``sinkhorn`` (OTT / POT optimal transport) raises
+NotImplementedError.
 """
 from __future__ import annotations
 
@@ -26,8 +28,8 @@ class MetricsComputer:
             active_metrics = []
         assert all(m in self.METRICS for m in active_metrics)
         for m in active_metrics:
-            if m in ("sinkhorn", "e_kin"):
-                raise NotImplementedError(f"metric {m!r} is not built yet (mse/mae only)")
+            if m == "sinkhorn":
+                raise NotImplementedError("metric 'sinkhorn' is not built yet (mse / mae / e_kin are)")
         self._active_metrics = list(active_metrics)
         self._dist_fn = dist_fn
         self._loss_ranges = loss_ranges if loss_ranges is not None else [1, 5, 10, 20, 50, 100]
@@ -51,6 +53,17 @@ class MetricsComputer:
         want = [m for m in self._active_metrics if m in ("mse", "mae")]
         res = eng.metrics(pred, tgt[:, :T], T, want=want) if want else {}
         out: Dict[str, torch.Tensor] = {}
+        if "e_kin" in self._active_metrics:
+            # metrics.py:98-125: strided velocities -> kinetic energy, predicted vs target, and its MSE
+            dt = self._metadata["dt"] * self._metadata["write_every"]
+            dx = self._metadata["dx"]
+            ek_p = eng.ekin(pred, self._stride, dt, dx)
+            ek_t = eng.ekin(tgt[:, :T], self._stride, dt, dx)
+            mse_e = ((ek_p - ek_t) ** 2).mean(dim=1)
+            if batched:
+                out["e_kin"] = {"predicted": ek_p, "target": ek_t, "mse": mse_e}
+            else:
+                out["e_kin"] = {"predicted": ek_p[0], "target": ek_t[0], "mse": mse_e[0]}
         for name in want:
             v = res[name] if batched else res[name][0]
             out[name] = v

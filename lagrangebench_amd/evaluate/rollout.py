@@ -148,7 +148,7 @@ def eval_rollout(model_apply: Callable, case, params, state, loader_eval: Iterab
         current_batch_size = len(traj_batch_i[0])
         for j in range(current_batch_size):
             ind = i * batch_size + j
-            eval_metrics[f"rollout_{ind}"] = {k: v[j] for k, v in metrics_batch.items()}
+            eval_metrics[f"rollout_{ind}"] = broadcast_from_batch(metrics_batch, j)
         if rollout_dir is not None and out_type == "pkl":
             pos_np = np.asarray(traj_batch_i[0])
             for j in range(current_batch_size):
@@ -163,7 +163,9 @@ def eval_rollout(model_apply: Callable, case, params, state, loader_eval: Iterab
 
     if rollout_dir is not None:
         t = time.strftime("%Y_%m_%d_%H_%M_%S", time.localtime())
-        cpu = {k: {kk: vv.cpu().numpy() for kk, vv in v.items()} for k, v in eval_metrics.items()}
+        def _cpu(x):
+            return {k: _cpu(v) for k, v in x.items()} if isinstance(x, dict) else x.cpu().numpy()
+        cpu = _cpu(eval_metrics)
         with open(f"{rollout_dir}/metrics{t}.pkl", "wb") as f:
             pickle.dump(cpu, f)
     return eval_metrics
@@ -193,8 +195,11 @@ def infer(model, case, data_test, params=None, state=None, load_ckp: Optional[st
     if n_trajs == -1:
         n_trajs = data_test.num_samples
     if params is None:
-        raise NotImplementedError("load_ckp (haiku checkpoint import, utils.py:99-128) is the next "
-                                  "scope row (SURVEY.md 8f N2); pass params=")
+        # rollout.py:359 load_haiku(load_ckp); a Haiku-named GNS tree is mapped onto the engine's layout
+        from ..utils import gns_params_from_haiku, load_haiku
+        params, state, _, _ = load_haiku(load_ckp)
+        if isinstance(model, GNS) and "enc_node/linear_0" not in params:
+            params = gns_params_from_haiku(params, model._mp_steps, model._blocks_per_step)
     if state is None:
         state = {}
     loader_test = _Loader(data_test, cfg.batch_size)

@@ -647,6 +647,12 @@ def mae(displacement_fn, pred, target):
     return float(np.abs(displacement_fn(pred, target)).mean())
 
 
+def e_kin(displacement_fn, rollout, stride, dt, dx, dim):
+    """metrics.py:98-125,157-160 for one rollout (T, N, dim): dx^dim * sum((v/dt)^2) per strided frame."""
+    v = displacement_fn(rollout[1::stride], rollout[0:-1:stride])
+    return ((v / dt) ** 2).sum(axis=(1, 2)) * dx**dim
+
+
 def metrics_mse_mae(displacement_fn, pred_rollout, target_rollout, active=("mse",),
                     loss_ranges=(1, 5, 10, 20, 50, 100)):
     """metrics.py:69-96: per-step metric and the shorter-horizon slices."""

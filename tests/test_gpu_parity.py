@@ -357,3 +357,64 @@ def test_metrics_match_oracle():
     ref = O.metrics_mse_mae(disp, pred, tgt, active=("mse", "mae"))
     assert np.allclose(_np(m["mse"])[0], ref["mse"], rtol=1e-12)
     assert np.allclose(_np(m["mae"])[0], ref["mae"], rtol=1e-12)
+
+
+def test_ekin_metric_matches_oracle():
+    """MetricsComputer e_kin (metrics.py:98-125) through lb_ekin."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.evaluate.metrics import MetricsComputer
+    ds = make_case("small2d", n_trajs=1, extra_seq_length=23)
+    ds.metadata["dt"], ds.metadata["write_every"] = 0.002, 5
+    hcase = hip_case(ds)
+    pos, pt = ds[0]
+    rng = np.random.default_rng(5)
+    tgt = np.transpose(pos[:, 6:], (1, 0, 2)).astype(np.float64)
+    pred = np.mod(tgt + rng.normal(0, 1e-3, tgt.shape), ds.box)
+    disp, _ = O.space_periodic(ds.box)
+    for stride in (1, 10):
+        mc = MetricsComputer(["mse", "e_kin"], hcase.displacement, ds.metadata, 6, stride=stride, case=hcase)
+        m = mc(torch.from_numpy(pred), torch.from_numpy(tgt))
+        dt, dx = 0.01, ds.metadata["dx"]
+        ref_p = O.e_kin(disp, pred, stride, dt, dx, 2)
+        ref_t = O.e_kin(disp, tgt, stride, dt, dx, 2)
+        assert m["e_kin"]["predicted"].shape == ref_p.shape
+        assert np.allclose(_np(m["e_kin"]["predicted"]), ref_p, rtol=1e-12)
+        assert np.allclose(_np(m["e_kin"]["target"]), ref_t, rtol=1e-12)
+        assert np.isclose(float(m["e_kin"]["mse"]), ((ref_p - ref_t) ** 2).mean(), rtol=1e-9)
+        assert m["mse"].shape == (23,)
+
+
+def test_infer_from_h5_dataset_and_haiku_checkpoint(tmp_path):
+    """runner.py's inference route on real files: H5Dataset (ctypes HDF5 reader) + load_ckp (Haiku
+    checkpoint format) -> infer, against the oracle on the same trajectories.  N = 3 particles,
+    box 5, r_c 3: the all-pairs branch, tiles almost empty."""
+    _need_gpu()
+    from lagrangebench_amd.case_setup import case_builder
+    from lagrangebench_amd.data import H5Dataset
+    from lagrangebench_amd.evaluate import infer
+    from lagrangebench_amd.models import GNS
+    from lagrangebench_amd.utils import gns_params_to_haiku, save_haiku
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "3D_LJ_3_1214every1")
+    isl, n_steps, L = 6, 20, 2
+    ds = H5Dataset("valid", root, name="lj3d", input_seq_length=isl, extra_seq_length=n_steps)
+    assert ds.num_samples == 405 // 26
+    md = ds.metadata
+    bounds = np.array(md["bounds"])
+    box = bounds[:, 1] - bounds[:, 0]
+    model = GNS(3, 128, 2, L, 16)
+    params = model.init_params(11, node_in=(isl - 1) * 3, edge_in=4, decoder_scale=0.1)
+    ckp = str(tmp_path / "ckp")
+    save_haiku(ckp, gns_params_to_haiku(params, L), {}, None, {"step": 1, "loss": 1.0})
+    case = case_builder(box, md, isl, noise_std=3e-4)
+    out = infer(model, case, ds, load_ckp=ckp, cfg_eval_infer={"batch_size": 2, "n_trajs": 3, "metrics": ["mse"]},
+                n_rollout_steps=n_steps)
+    assert sorted(out) == ["rollout_0", "rollout_1", "rollout_2"]
+    ocase = O.case_builder(box, md, isl, noise_std=3e-4)
+    for i in range(3):
+        pos, pt = ds[i]
+        _, nb = ocase.allocate_eval((pos[:, :isl].astype(np.float64), pt))
+        _, m, _ = O.eval_batched_rollout(oracle_model_apply(L), ocase, params, {}, (pos[None].astype(np.float64), pt[None]),
+                                         nb, n_rollout_steps=n_steps, t_window=isl)
+        mh = _np(out[f"rollout_{i}"]["mse"])
+        assert np.abs(mh - m[0]["mse"]).max() <= 1e-5 and np.allclose(mh, m[0]["mse"], rtol=1e-3, atol=1e-12)
