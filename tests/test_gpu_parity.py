@@ -418,3 +418,61 @@ def test_infer_from_h5_dataset_and_haiku_checkpoint(tmp_path):
                                          nb, n_rollout_steps=n_steps, t_window=isl)
         mh = _np(out[f"rollout_{i}"]["mse"])
         assert np.abs(mh - m[0]["mse"]).max() <= 1e-5 and np.allclose(mh, m[0]["mse"], rtol=1e-3, atol=1e-12)
+
+
+# ------------------------------------------------------------------ full-size properties
+def test_full_size_tgv3d_properties():
+    """BASELINE.json's target size (TGV3D, 8000 particles, GNS-10-128): size-independent properties
+    instead of an oracle run - sortedness and symmetry of the edge list, self edges, batch
+    consistency (B=2 of the same trajectory vs B=1), run-to-run determinism, and an
+    analytic check of the integrator through a network whose output is pinned to its decoder bias."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    n_steps, L = 4, 10
+    ds = make_case("tgv3d", n_trajs=1, extra_seq_length=n_steps)
+    hcase = hip_case(ds)
+    isl = ds.input_seq_length
+    pos, pt = ds[0]
+    N = len(pt)
+    feats, nbrs = hcase.allocate_eval((pos[:, :isl], pt))
+    idx = _np(nbrs.idx)
+    ne = int(_np(nbrs.n_edges))
+    r, s = idx[0, :ne].astype(np.int64), idx[1, :ne].astype(np.int64)
+    key = r * N + s
+    assert (np.diff(key) > 0).all()                      # sorted by (receiver, sender), no duplicates
+    assert np.array_equal(np.sort(s * N + r), key)        # symmetric
+    assert np.isin(np.arange(N) * (N + 1), key).all()     # every particle has its self edge
+    assert (idx[:, ne:] == N).all() and 10 < ne / N < 20
+
+    params = make_params(ds, num_mp_steps=L)
+    model = GNS(3, 128, 2, L, 16)
+    e1 = hcase.engine(1)
+    e1.set_particle_type(pt[None])
+    p1, _ = e1.rollout(model.handle(e1, params), pos[None].astype(np.float64), n_steps)
+    p1b, _ = e1.rollout(model.handle(e1, params), pos[None].astype(np.float64), n_steps)
+    assert np.array_equal(_np(p1), _np(p1b))             # deterministic
+    e2 = hcase.engine(2)
+    e2.set_particle_type(np.stack([pt, pt]))
+    p2, _ = e2.rollout(model.handle(e2, params), np.stack([pos, pos]).astype(np.float64), n_steps)
+    # slot 0 sees the same 16-edge tiles as the B=1 run: bit-identical.  Slot 1's edges start at an
+    # arbitrary offset of the concatenated list, so its receivers are cut by different tile boundaries
+    # and the fp32 partial sums associate differently: equal to fp32 round-off, not bitwise.
+    assert np.array_equal(_np(p2[0]), _np(p1[0]))
+    assert np.abs(_np(p2[1]) - _np(p1[0])).max() < 1e-7 * float(ds.metadata["dx"])
+
+    # decoder weights zero, bias b: acc == b for every particle, so the rollout is the closed form
+    # x_{t+1} = shift(x_t, disp(x_t, x_{t-1}) + acc_mean + b * acc_std)  (case.py:230-259)
+    pz = {k: {kk: vv.copy() for kk, vv in v.items()} for k, v in params.items()}
+    pz["decoder/linear_1"]["w"][:] = 0
+    b = np.array([0.3, -0.2, 0.1], np.float32)
+    pz["decoder/linear_1"]["b"][:] = b
+    pr, _ = e1.rollout(model.handle(e1, pz), pos[None].astype(np.float64), n_steps)
+    stats = O.get_dataset_stats(ds.metadata, ds.isotropic_norm, ds.noise_std)
+    disp, shift = O.space_periodic(ds.box)
+    a = stats["acceleration"]["mean"] + b.astype(np.float64) * stats["acceleration"]["std"]
+    x0, x1 = pos[:, isl - 2].astype(np.float64), pos[:, isl - 1].astype(np.float64)
+    for t in range(n_steps):
+        x2 = shift(x1, disp(x1, x0) + a)
+        assert np.array_equal(_np(pr[0, t]), x2), t
+        x0, x1 = x1, x2
