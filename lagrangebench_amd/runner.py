@@ -1,0 +1,97 @@
+"""Runner: mirror of lagrangebench/runner.py for the inference route (`mode: infer`).
+
+``train_or_infer(cfg)`` (runner.py:25-143), ``setup_data`` (:146-189) and ``setup_model`` (:192-292)
+keep their signatures.  ``cfg`` is a nested mapping with the reference's keys (a dict or anything
+dict-like such as an OmegaConf DictConfig); missing keys fall back to ``defaults``.  Training
+(`mode: train | all`) is out of scope and raises.
+"""
+from __future__ import annotations
+
+import os
+import os.path as osp
+from typing import Callable, Dict, Optional, Tuple, Type
+
+import numpy as np
+
+from . import models
+from .case_setup import case_builder
+from .data import H5Dataset
+from .defaults import defaults, merge
+from .evaluate import averaged_metrics, infer
+from .utils import NodeType
+
+_RUN_DEFAULTS = {
+    "mode": "infer", "load_ckp": None, "dtype": "float64", "seed": 0,
+    "dataset": {"src": None, "name": None},
+    "model": dict(defaults.model),
+    "train": {"noise_std": 3e-4, "pushforward": {"unrolls": [0]}},
+    "eval": {"test": False, "n_rollout_steps": 20, "rollout_dir": None,
+             "infer": dict(defaults.eval.infer), "train": dict(defaults.eval.train)},
+    "logging": {"ckp_dir": None},
+    "neighbors": dict(defaults.neighbors),
+}
+
+
+def setup_data(cfg) -> Tuple[H5Dataset, H5Dataset, H5Dataset]:
+    """runner.py:146-189."""
+    cfg = merge(_RUN_DEFAULTS, cfg)
+    dataset_path = cfg.dataset.src
+    if not osp.isabs(dataset_path):
+        dataset_path = osp.join(os.getcwd(), dataset_path)
+    if cfg.logging.ckp_dir is not None:
+        os.makedirs(cfg.logging.ckp_dir, exist_ok=True)
+    if cfg.eval.rollout_dir is not None:
+        os.makedirs(cfg.eval.rollout_dir, exist_ok=True)
+    kw = dict(dataset_path=dataset_path, name=cfg.dataset.name, input_seq_length=cfg.model.input_seq_length,
+              nl_backend=cfg.neighbors.backend)
+    data_train = H5Dataset("train", extra_seq_length=cfg.train.pushforward.unrolls[-1], **kw)
+    data_valid = H5Dataset("valid", extra_seq_length=cfg.eval.n_rollout_steps, **kw)
+    data_test = H5Dataset("test", extra_seq_length=cfg.eval.n_rollout_steps, **kw)
+    return data_train, data_valid, data_test
+
+
+def setup_model(cfg, metadata: Dict, homogeneous_particles: bool = False, has_external_force: bool = False,
+                normalization_stats: Optional[Dict] = None) -> Tuple[Callable, Type]:
+    """runner.py:192-292.  Returns (model, MODEL class); the model already exposes .init/.apply
+    (no hk.transform_with_state step)."""
+    cfg = merge(_RUN_DEFAULTS, cfg)
+    name = str(cfg.model.name).lower()
+    if name == "gns":
+        model = models.GNS(
+            particle_dimension=metadata["dim"], latent_size=cfg.model.latent_dim,
+            blocks_per_step=cfg.model.num_mlp_layers, num_mp_steps=cfg.model.num_mp_steps,
+            num_particle_types=NodeType.SIZE, particle_type_embedding_size=16)
+        return model, models.GNS
+    raise NotImplementedError(f"model {cfg.model.name!r}: only 'gns' is built (segnn/egnn/painn/linear are not)")
+
+
+def train_or_infer(cfg):
+    """runner.py:25-143, inference route."""
+    cfg = merge(_RUN_DEFAULTS, cfg)
+    if cfg.mode != "infer":
+        raise NotImplementedError("mode must be 'infer': training is out of scope for this engine")
+    if cfg.dtype != "float64":
+        raise NotImplementedError("only dtype=float64 is built")
+    data_train, data_valid, data_test = setup_data(cfg)
+    metadata = data_train.metadata
+    bounds = np.array(metadata["bounds"])
+    box = bounds[:, 1] - bounds[:, 0]
+    case = case_builder(box=box, metadata=metadata, input_seq_length=cfg.model.input_seq_length,
+                        cfg_neighbors=cfg.neighbors, cfg_model=cfg.model, noise_std=cfg.train.noise_std,
+                        external_force_fn=data_train.external_force_fn, dtype=cfg.dtype)
+    _, particle_type = data_train[0]
+    model, _ = setup_model(cfg, metadata=metadata,
+                           homogeneous_particles=particle_type.max() == particle_type.min(),
+                           has_external_force=data_train.external_force_fn is not None,
+                           normalization_stats=case.normalization_stats)
+    print("Start inference...")
+    model_dir = cfg.load_ckp
+    assert model_dir, "model_dir must be specified for inference."
+    is_test = cfg.eval.test
+    metrics = infer(model, case, data_test if is_test else data_valid, load_ckp=model_dir,
+                    cfg_eval_infer=cfg.eval.infer, rollout_dir=cfg.eval.rollout_dir,
+                    n_rollout_steps=cfg.eval.n_rollout_steps, seed=cfg.seed)
+    split = "test" if is_test else "valid"
+    print(f"Metrics of {model_dir} on {split} split:")
+    print(averaged_metrics(metrics))
+    return 0

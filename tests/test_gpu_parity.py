@@ -476,3 +476,37 @@ def test_full_size_tgv3d_properties():
         x2 = shift(x1, disp(x1, x0) + a)
         assert np.array_equal(_np(pr[0, t]), x2), t
         x0, x1 = x1, x2
+
+
+def test_runner_infer_end_to_end(tmp_path):
+    """tests/runner_test.py of the reference runs train_or_infer end to end on the LJ dataset and
+    expects 0; the same for the inference route here (dataset on disk + checkpoint on disk)."""
+    _need_gpu()
+    from lagrangebench_amd.models import GNS
+    from lagrangebench_amd.runner import train_or_infer
+    from lagrangebench_amd.utils import gns_params_to_haiku, save_haiku
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "3D_LJ_3_1214every1")
+    L = 2
+    params = GNS(3, 128, 2, L, 16).init_params(5, node_in=15, edge_in=4, decoder_scale=0.1)
+    ckp = str(tmp_path / "ckp")
+    save_haiku(ckp, gns_params_to_haiku(params, L), {}, None, {"step": 0, "loss": 1.0})
+    cfg = {"mode": "infer", "load_ckp": ckp, "dataset": {"src": root, "name": "lj3d"},
+           "model": {"name": "gns", "num_mp_steps": L, "input_seq_length": 6},
+           "eval": {"n_rollout_steps": 10, "rollout_dir": str(tmp_path / "rollout"),
+                    "infer": {"n_trajs": 2, "batch_size": 2, "metrics": ["mse", "e_kin"], "out_type": "pkl"}}}
+    cfg["eval"]["infer"]["metrics_stride"] = 5
+    # e_kin needs dt * write_every and dx in the metadata (present in the LJ metadata except write_every)
+    import json, shutil
+    ds_dir = tmp_path / "3D_LJ_3_1214every1"
+    shutil.copytree(root, ds_dir)
+    md = json.load(open(ds_dir / "metadata.json"))
+    md.setdefault("write_every", 1)
+    json.dump(md, open(ds_dir / "metadata.json", "w"))
+    cfg["dataset"]["src"] = str(ds_dir)
+    assert train_or_infer(cfg) == 0
+    files = sorted(os.listdir(tmp_path / "rollout"))
+    assert "rollout_0.pkl" in files and "rollout_1.pkl" in files and any(f.startswith("metrics") for f in files)
+    import pickle
+    r0 = pickle.load(open(tmp_path / "rollout" / "rollout_0.pkl", "rb"))
+    assert r0["predicted_rollout"].shape == (16, 3, 3) and r0["ground_truth_rollout"].shape == (16, 3, 3)
+    assert np.array_equal(r0["predicted_rollout"][:6], r0["ground_truth_rollout"][:6].astype(np.float64))
