@@ -9,9 +9,11 @@
 // (W0 256x128, W1 128x128, projection 128x256 = 320 KiB as fp16 hi|lo), which do not fit the
 // 160 KiB LDS, and in f16x2 arithmetic the matrix pipe consumes weight fragments far faster than
 // L2 can deliver them to a single wave.  So a 512-thread workgroup (8 waves = 8 tiles of 16 nodes)
-// walks the weights in 32 KiB chunks that are double-buffered in LDS: chunk c+1 is in flight
-// (global loads into 16 staging VGPRs) while all 8 waves run their MFMAs on chunk c; one barrier
-// per chunk.  Each weight byte is fetched from L2 once per 128 nodes instead of once per 32.
+// walks the weights in 32 KiB chunks through a ring of three LDS buffers: chunks c+1 and c+2 are in
+// flight (global loads into 2 x 16 staging VGPRs, committed to LDS one chunk ahead of use) while
+// all 8 waves run their MFMAs on chunk c; one barrier per chunk.  Each weight byte is fetched from
+// L2 once per 128 nodes instead of once per 32, and the L2 latency (~2 us) is covered by two chunks
+// of MFMA work instead of one.
 // Inside a wave the layers are chained in registers exactly as in lb_edge16.hip (16x16x32 fp16
 // MFMA, C-layout lane (n = l&15, g = l>>4) holds features 16*mb + 4*g + j).
 #include "lb_device.h"
@@ -87,19 +89,19 @@ __device__ __forceinline__ void lb_load_agg16(const lb_node_args& a, int64_t gno
 
 // NPA: k-steps (of 32) of input A (encoder features or node latents); NPB: 4 when the aggregated
 // messages are a second input (processor), else 0.
-template <int NPA, int NPB, bool RESID>
+template <int NPA, int NPB, bool RESID, bool PROJ>
 __global__ void __launch_bounds__(N16_THREADS, 2)
     k_node16h(lb_node_args a, const f32x4* __restrict__ w0h, const f32x4* __restrict__ w1h,
               const f32x4* __restrict__ wph) {
-  __shared__ f32x4 sB[2][CHUNK_VEC];
+  __shared__ f32x4 sB[3][CHUNK_VEC];
   __shared__ f32x4 sP[192];  // per-feature vectors, see below
   if (a.ctrl->overflow_step >= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
   constexpr int NP0 = NPA + NPB;
   constexpr int NCH0 = (NP0 + 1) / 2;  // chunks of W0 (2 k-steps x 8 blocks x hi|lo = 2048 vec)
-  const bool has_proj = wph != nullptr;
-  const int n_chunks = NCH0 + 2 + (has_proj ? 4 : 0);
+  constexpr bool has_proj = PROJ;
+  constexpr int n_chunks = NCH0 + 2 + (PROJ ? 4 : 0);
 
   // per-feature vectors into LDS: [0,32) b0, [32,64) b1, [64,96) ln_s, [96,128) ln_o, [128,192) bp
   if (tid < 128) {
@@ -122,20 +124,20 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
       nvec = CHUNK_VEC;
     }
   };
-  f32x4 stg[4];
-  auto stage_issue = [&](int c) {
+  f32x4 stg[2][4];
+  auto stage_issue = [&](int c) {  // chunk c -> staging set c & 1
     const f32x4* src;
     int nvec;
     chunk_src(c, src, nvec);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * N16_THREADS;
-      stg[i] = src[idx < nvec ? idx : 0];
+      stg[c & 1][i] = src[idx < nvec ? idx : 0];
     }
   };
-  auto stage_commit = [&](int c) {
+  auto stage_commit = [&](int c) {  // staging set c & 1 -> LDS ring slot c % 3
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sB[c & 1][tid + i * N16_THREADS] = stg[i];
+    for (int i = 0; i < 4; ++i) sB[c % 3][tid + i * N16_THREADS] = stg[c & 1][i];
   };
 
   // ---- this wave's 16 rows
@@ -144,6 +146,7 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
   const int64_t rowc = valid ? row : a.n_rows - 1;
 
   stage_issue(0);
+  if (n_chunks > 1) stage_issue(1);
   f32x4 va[2 * NPA];
   {
     const f32x4* xr = reinterpret_cast<const f32x4*>(a.xin) + rowc * (8 * NPA) + g;
@@ -162,8 +165,8 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
   // ---- GEMM1 over [input A | aggregated messages]
 #pragma unroll
   for (int ch = 0; ch < NCH0; ++ch, ++c) {
-    if (c + 1 < n_chunks) stage_issue(c + 1);
-    const f32x4* buf = sB[c & 1];
+    if (c + 2 < n_chunks) stage_issue(c + 2);
+    const f32x4* buf = sB[c % 3];
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
       const int p = 2 * ch + pp;
@@ -190,8 +193,8 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
   for (int mb = 0; mb < 8; ++mb) acc2[mb] = sP[32 + 4 * mb + g];
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch, ++c) {
-    if (c + 1 < n_chunks) stage_issue(c + 1);
-    const f32x4* buf = sB[c & 1];
+    if (c + 2 < n_chunks) stage_issue(c + 2);
+    const f32x4* buf = sB[c % 3];
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
       const int p = 2 * ch + pp;
@@ -241,8 +244,8 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
     for (int mb = 0; mb < 16; ++mb) accp[mb] = sP[128 + 4 * mb + g];
 #pragma unroll
     for (int p = 0; p < 4; ++p, ++c) {
-      if (c + 1 < n_chunks) stage_issue(c + 1);
-      const f32x4* buf = sB[c & 1];
+      if (c + 2 < n_chunks) stage_issue(c + 2);
+      const f32x4* buf = sB[c % 3];
       h8 bh, bl;
       lb_split8n(y[2 * p], y[2 * p + 1], bh, bl);
 #pragma unroll
@@ -265,12 +268,20 @@ int lbk_node16h(lb_engine* e, const lb_node_args& a, const float* w0h, const flo
   const f32x4* w1 = reinterpret_cast<const f32x4*>(w1h);
   const f32x4* wp = reinterpret_cast<const f32x4*>(wph);
   dim3 grid(nblk), block(N16_THREADS);
+  const bool proj = wph != nullptr;
+#define LB_N16(A, B, R)                                                                          \
+  do {                                                                                           \
+    if (proj)                                                                                    \
+      hipLaunchKernelGGL((k_node16h<A, B, R, true>), grid, block, 0, e->stream, a, w0, w1, wp);  \
+    else                                                                                         \
+      hipLaunchKernelGGL((k_node16h<A, B, R, false>), grid, block, 0, e->stream, a, w0, w1, wp); \
+  } while (0)
   if (npa == 4 && npb == 4 && resid)
-    hipLaunchKernelGGL((k_node16h<4, 4, true>), grid, block, 0, e->stream, a, w0, w1, wp);
+    LB_N16(4, 4, true);
   else if (npa == 1 && npb == 0 && !resid)
-    hipLaunchKernelGGL((k_node16h<1, 0, false>), grid, block, 0, e->stream, a, w0, w1, wp);
+    LB_N16(1, 0, false);
   else if (npa == 2 && npb == 0 && !resid)
-    hipLaunchKernelGGL((k_node16h<2, 0, false>), grid, block, 0, e->stream, a, w0, w1, wp);
+    LB_N16(2, 0, false);
   else
     return lb_fail(LB_ERR_UNSUPPORTED, "k_node16h<%d,%d,%d> not instantiated", npa, npb, (int)resid);
   LB_HIP(hipGetLastError());
