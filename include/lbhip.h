@@ -188,6 +188,42 @@ int lb_case_integrate(lb_engine* eng, int32_t mode, const float* pred_dev, const
 int lb_rollout(lb_engine* eng, lb_gns* gns, const double* traj_dev, int32_t T, int32_t n_steps,
                double* pred_out_dev, int32_t* n_realloc_out);
 
+/* ---- SEGNN (models/segnn.py:403-610), lmax_hidden = lmax_attributes = 1 --------------------- */
+
+typedef struct lb_segnn lb_segnn;
+
+/* SEGNN hyper-parameters (runner.py:217-237; configs: scalar_units 64 -> hidden irreps
+ * 32x0e+32x1o through weight_balanced_irreps, segnn.py:365-400). */
+typedef struct lb_segnn_desc {
+  int32_t hidden;           /* multiplicity of 0e and of 1o in the hidden irreps; only 32 is built */
+  int32_t blocks_per_step;  /* num_mlp_layers (2) */
+  int32_t num_mp_steps;
+  int32_t homogeneous;      /* homogeneous_particles: 1 = no one-hot particle-type scalars */
+  int32_t n_vels;           /* input_seq_length - 1 */
+  int32_t velocity_avg;     /* velocity_aggregate: 1 "avg", 0 "last" */
+} lb_segnn_desc;
+
+/* SEGNN(...) + params.  weights_host: one (ws, wv, b) triple per O3TensorProduct in call order
+ * (embedding_nodes; per layer message tp_0.. then update tp_0..; readout_0..; output):
+ *   ws (K, Ms) weights of the 0e outputs (gated blocks: Ms = 2*hidden, activated scalars first,
+ *   then the gates), wv (K, Mv) weights of the 1o outputs, b (Ms).  K indexes the tensor-product
+ *   channels operand by operand, scalar-derived channels first, then vector-derived
+ *   (oracle/segnn_oracle.py:tp_inputs); the 1/sqrt(K) of e3nn's Linear is applied here. */
+int lb_segnn_create(lb_engine* eng, const lb_segnn_desc* desc, const float* weights_host,
+                    int64_t n_floats, lb_segnn** out);
+void lb_segnn_destroy(lb_segnn* segnn);
+
+/* SEGNN.__call__ -> {"acc": (B,N,dim) fp32} (segnn.py:595-610) on the current window + list. */
+int lb_segnn_forward(lb_engine* eng, lb_segnn* segnn, float* acc_out_dev);
+
+/* Debug/parity tap: hidden node state after the embedding and after each layer,
+ * ((num_mp_steps+1), B*N, 128) fp32 rows [s(32) | vx(32) | vy(32) | vz(32)], or NULL. */
+int lb_segnn_set_tap(lb_segnn* segnn, float* hidden_out_dev);
+
+/* lb_rollout with SEGNN as the model. */
+int lb_segnn_rollout(lb_engine* eng, lb_segnn* segnn, const double* traj_dev, int32_t T,
+                     int32_t n_steps, double* pred_out_dev, int32_t* n_realloc_out);
+
 /* MetricsComputer.mse / .mae per step - evaluate/metrics.py:139-147: mean over (N,dim) of
  * disp(pred,target)^2 (|.|) with the case's displacement.  Both rollouts are (B,T,N,dim) fp64,
  * the layout metrics_computer receives (rollout.py:171-176).  Outputs (B,n_steps) fp64,

@@ -39,6 +39,15 @@ class GnsDesc(C.Structure):
     ]
 
 
+class SegnnDesc(C.Structure):
+    """lb_segnn_desc (include/lbhip.h)."""
+
+    _fields_ = [
+        ("hidden", C.c_int32), ("blocks_per_step", C.c_int32), ("num_mp_steps", C.c_int32),
+        ("homogeneous", C.c_int32), ("n_vels", C.c_int32), ("velocity_avg", C.c_int32),
+    ]
+
+
 # name -> (restype, argtypes).  Every symbol include/lbhip.h declares must be listed here;
 # tests/test_abi.py checks the two against each other.
 _P = C.c_void_p
@@ -76,6 +85,11 @@ _SIGS = {
     "lb_timer_get": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "lb_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lb_segment_sum": (C.c_int, [_P, _P, _P, C.c_int32]),
+    "lb_segnn_create": (C.c_int, [_P, C.POINTER(SegnnDesc), _P, C.c_int64, C.POINTER(_P)]),
+    "lb_segnn_destroy": (None, [_P]),
+    "lb_segnn_forward": (C.c_int, [_P, _P, _P]),
+    "lb_segnn_set_tap": (C.c_int, [_P, _P]),
+    "lb_segnn_rollout": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_int32)]),
 }
 
 _lib: Optional[C.CDLL] = None

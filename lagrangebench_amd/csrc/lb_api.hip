@@ -705,10 +705,18 @@ extern "C" int lb_case_integrate(lb_engine* e, int32_t mode, const float* pred_d
   return lbk_case_integrate(e, mode, pred_dev, pos_seq_dev, T, next_out_dev);
 }
 
+static int gns_forward_thunk(lb_engine* e, void* model) { return lbk_gns_forward(e, (lb_gns*)model); }
+
 extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32_t T,
                           int32_t n_steps, double* pred_out_dev, int32_t* n_realloc_out) {
   if (!e || !g || !traj_dev || !pred_out_dev) return lb_fail(LB_ERR_ARG, "null argument");
   if (g->eng != e) return lb_fail(LB_ERR_ARG, "model was created for another engine");
+  return lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, n_realloc_out);
+}
+
+int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* model,
+                       const double* traj_dev, int32_t T, int32_t n_steps, double* pred_out_dev,
+                       int32_t* n_realloc_out) {
   if (T < e->g.isl) return lb_fail(LB_ERR_ARG, "trajectory shorter than input_seq_length");
   if (e->g.force_kind == LB_FORCE_BUFFER)
     return lb_fail(LB_ERR_UNSUPPORTED, "lb_rollout with LB_FORCE_BUFFER: drive the steps from the host");
@@ -726,7 +734,7 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
         if (*(volatile int32_t*)e->host_flag >= 0) break;
       }
       LB_TRY(lbk_nl_build(e, false));
-      LB_TRY(lbk_gns_forward(e, g));
+      LB_TRY(forward(e, model));
       LB_TRY(lbk_integrate(e, e->acc, 4, nullptr, traj_dev, T, pred_out_dev, n_steps));
       LB_HIP(hipEventRecord(e->step_ev[s & 3], e->stream));
     }

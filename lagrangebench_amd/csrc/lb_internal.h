@@ -236,6 +236,17 @@ int lbk_case_integrate(lb_engine* e, int mode, const float* pred, const double* 
 int lbk_metrics(lb_engine* e, const double* pred, int pred_T, const double* target, int target_T,
                 int n_steps, double* mse, double* mae);
 
+int lbk_node_features_raw(lb_engine* e, float* xnode, int kpad);
+
+// lb_api.hip: the device-resident step loop shared by the models
+int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* model,
+                       const double* traj_dev, int32_t T, int32_t n_steps, double* pred_out_dev,
+                       int32_t* n_realloc_out);
+
+// lb_segnn.hip
+struct lb_segnn;
+int lbk_segnn_forward(lb_engine* e, lb_segnn* m);
+
 // lb_gns.hip
 int lbk_gns_forward(lb_engine* e, lb_gns* g);
 int lbk_segment_sum(lb_engine* e, const float* msg, float* out, int D);

@@ -142,6 +142,17 @@ int lbk_node_features(lb_engine* e, float* xnode, const float* embed, int emb, i
   return LB_OK;
 }
 
+// Same feature row without embedding columns, at a caller-chosen row stride (SEGNN input).
+int lbk_node_features_raw(lb_engine* e, float* xnode, int kpad) {
+  lb_geom g = e->g;
+  g.kpad = kpad;
+  const int nb = (int)((e->BN + 255) / 256);
+  hipLaunchKernelGGL(k_node_features, dim3(nb), dim3(256), 0, e->stream, g, e->BN, e->win, e->ctrl,
+                     e->ptype, e->force, xnode, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
 // ------------------------------------------------------------------------------ integrator
 __global__ void k_integrate(lb_geom g, int64_t BN, double* __restrict__ win,
                             const lb_ctrl* __restrict__ ctrl, const int32_t* __restrict__ ptype,

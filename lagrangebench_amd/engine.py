@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CaseDesc, GnsDesc, LbHipError, check, ptr
+from ._lib import CaseDesc, GnsDesc, LbHipError, SegnnDesc, check, ptr
 
 
 def _d3(v, fill=0.0):
@@ -241,6 +241,19 @@ class RolloutEngine:
         check(self.lib.lb_gns_forward(self._h, gns._h, ptr(out)), "lb_gns_forward")
         return out
 
+    def segnn_create(self, desc: SegnnDesc, blob: np.ndarray) -> "SegnnHandle":
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        h = C.c_void_p()
+        check(self.lib.lb_segnn_create(self._h, C.byref(desc), blob.ctypes.data_as(C.c_void_p),
+                                       C.c_int64(blob.size), C.byref(h)), "lb_segnn_create")
+        return SegnnHandle(self, h, desc)
+
+    def segnn_forward(self, segnn: "SegnnHandle", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty((self.B, self.N, self.dim), dtype=torch.float32, device=self.device)
+        check(self.lib.lb_segnn_forward(self._h, segnn._h, ptr(out)), "lb_segnn_forward")
+        return out
+
     def set_fused_aggregation(self, on: bool) -> None:
         check(self.lib.lb_set_fused_aggregation(self._h, int(bool(on))), "lb_set_fused_aggregation")
 
@@ -262,12 +275,14 @@ class RolloutEngine:
               "lb_case_integrate")
         return out
 
-    def rollout(self, gns: "GnsHandle", traj: torch.Tensor, n_steps: int) -> Tuple[torch.Tensor, int]:
+    def rollout(self, model, traj: torch.Tensor, n_steps: int) -> Tuple[torch.Tensor, int]:
+        """model: a GnsHandle (lb_rollout) or a SegnnHandle (lb_segnn_rollout)."""
         traj = self.prepare_traj(traj)
         pred = torch.zeros((self.B, n_steps, self.N, self.dim), dtype=torch.float64, device=self.device)
         nre = C.c_int32(0)
-        check(self.lib.lb_rollout(self._h, gns._h, ptr(traj), traj.shape[2], n_steps, ptr(pred),
-                                  C.byref(nre)), "lb_rollout")
+        fn, name = ((self.lib.lb_segnn_rollout, "lb_segnn_rollout") if isinstance(model, SegnnHandle)
+                    else (self.lib.lb_rollout, "lb_rollout"))
+        check(fn(self._h, model._h, ptr(traj), traj.shape[2], n_steps, ptr(pred), C.byref(nre)), name)
         self.version += 1
         st = self.stats()
         self.e_cap, self.cell_capacity = st["e_cap"], st["cell_capacity"]
@@ -341,6 +356,36 @@ class GnsHandle:
             if self.engine._h:
                 torch.cuda.synchronize(self.engine.device)
             self.engine.lib.lb_gns_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SegnnHandle:
+    def __init__(self, engine: RolloutEngine, h, desc: SegnnDesc):
+        self.engine, self._h, self.desc = engine, h, desc
+        self._tap = None
+
+    def set_tap(self, on: bool = True) -> Optional[torch.Tensor]:
+        e = self.engine
+        if on:
+            self._tap = torch.zeros((self.desc.num_mp_steps + 1, e.B * e.N, 128), dtype=torch.float32,
+                                    device=e.device)
+            check(e.lib.lb_segnn_set_tap(self._h, ptr(self._tap)))
+        else:
+            self._tap = None
+            check(e.lib.lb_segnn_set_tap(self._h, None))
+        return self._tap
+
+    def close(self):
+        if self._h:
+            if self.engine._h:
+                torch.cuda.synchronize(self.engine.device)
+            self.engine.lib.lb_segnn_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -26,6 +26,7 @@ import torch
 from ..case_setup.features import FeatureDict, NeighborList
 from ..defaults import defaults, merge
 from ..models.gns import GNS
+from ..models.segnn import SEGNN
 from ..utils import broadcast_from_batch, broadcast_to_batch, get_kinematic_mask
 from .metrics import MetricsComputer, MetricsDict
 
@@ -50,7 +51,7 @@ def _gns_of(model_apply) -> Optional[GNS]:
     while isinstance(fn, partial):
         fn = fn.func
     owner = getattr(fn, "__self__", None)
-    return owner if isinstance(owner, GNS) else None
+    return owner if isinstance(owner, (GNS, SEGNN)) else None
 
 
 def _eval_batched_rollout(forward_eval_vmap: Callable, preprocess_eval_vmap: Callable, case, params, state,

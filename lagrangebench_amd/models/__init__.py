@@ -1,4 +1,5 @@
 from .base import BaseModel
 from .gns import GNS
+from .segnn import SEGNN, node_irreps
 
-__all__ = ["BaseModel", "GNS"]
+__all__ = ["BaseModel", "GNS", "SEGNN", "node_irreps"]

@@ -1,0 +1,162 @@
+"""SEGNN behind the reference's model API - lagrangebench/models/segnn.py:403-610.
+
+Construction arguments are the reference's (segnn.py:444-459); irreps are given as e3nn-style
+strings ("5x1o+9x0e").  Built: the configuration every published SEGNN config uses -
+``lmax_hidden = lmax_attributes = 1``, ``scalar_units = 64`` (hidden irreps 32x0e+32x1o through
+weight_balanced_irreps, segnn.py:365-400), ``norm=None``, ``embed_msg_features=False``, output
+"1x1o".  The forward pass runs in lagrangebench_amd/csrc/lb_segnn.hip.
+
+Parameters are a dict ``{block: {"ws": (K, Ms), "wv": (K, Mv), "b": (Ms,)}}`` with blocks
+``embedding_nodes``, ``layer_{k}/message_{i}``, ``layer_{k}/update_{i}``, ``readout_{i}``,
+``output``; K indexes the tensor-product channels operand by operand, scalar-derived first
+(oracle/segnn_oracle.py documents the e3nn conventions this assumes; parity with e3nn-jax itself
+is unpinned - it cannot be installed here).
+"""
+from __future__ import annotations
+
+import re
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from .._lib import SegnnDesc
+from .base import BaseModel
+
+
+def parse_irreps(irreps) -> Tuple[int, int]:
+    """"5x1o + 1x1o + 9x0e" -> (n_scalars 0e, n_vectors 1o); anything else is not built."""
+    ns = nv = 0
+    for term in str(irreps).replace(" ", "").split("+"):
+        if not term:
+            continue
+        m = re.fullmatch(r"(?:(\d+)x)?(\d+)([eo])", term)
+        if m is None:
+            raise ValueError(f"cannot parse irreps term {term!r}")
+        mul, l, p = int(m.group(1) or 1), int(m.group(2)), m.group(3)
+        if (l, p) == (0, "e"):
+            ns += mul
+        elif (l, p) == (1, "o"):
+            nv += mul
+        else:
+            raise NotImplementedError(f"irrep {l}{p} is not built (0e and 1o only)")
+    return ns, nv
+
+
+def node_irreps(metadata, input_seq_length: int, has_external_force: bool, has_magnitudes: bool,
+                has_homogeneous_particles: bool) -> str:
+    """models/utils.py:75-97 - irreps of the node features for a dataset."""
+    irreps = [f"{input_seq_length - 1}x1o"]
+    if not any(metadata["periodic_boundary_conditions"]):
+        irreps.append("2x1o")
+    if has_external_force:
+        irreps.append("1x1o")
+    if has_magnitudes:
+        irreps.append(f"{input_seq_length - 1}x0e")
+    if not has_homogeneous_particles:
+        irreps.append("9x0e")
+    return "+".join(irreps)
+
+
+def weight_balanced_hidden(scalar_units: int) -> int:
+    """weight_balanced_irreps for lmax 1 (segnn.py:365-400): smallest n with 4 n^2 >= units^2."""
+    n = 0
+    while 4 * n * n < scalar_units**2:
+        n += 1
+    return n
+
+
+class SEGNN(BaseModel):
+    def __init__(self, node_features_irreps, edge_features_irreps, scalar_units: int, lmax_hidden: int,
+                 lmax_attributes: int, output_irreps, num_mp_steps: int, n_vels: int,
+                 velocity_aggregate: str = "avg", homogeneous_particles: bool = True, norm=None,
+                 blocks_per_step: int = 2, embed_msg_features: bool = False):
+        assert velocity_aggregate in ["avg", "last"], \
+            "Invalid velocity aggregate. Must be one of 'avg', 'sum' or 'last'."
+        if lmax_hidden != 1 or lmax_attributes != 1:
+            raise NotImplementedError("SEGNN: only lmax_hidden = lmax_attributes = 1 is built")
+        if norm not in (None, "none"):
+            raise NotImplementedError("SEGNN: instance/batch norm (segnn.py:336-352) is not built")
+        if embed_msg_features:
+            raise NotImplementedError("SEGNN: embed_msg_features is not built")
+        if parse_irreps(output_irreps) != (0, 1):
+            raise NotImplementedError("SEGNN: only output_irreps='1x1o' is built")
+        if parse_irreps(edge_features_irreps) != (1, 1):
+            raise NotImplementedError("SEGNN: edge_features_irreps must be '1x1o+1x0e'")
+        self._node_ns, self._node_nv = parse_irreps(node_features_irreps)
+        self._hidden = weight_balanced_hidden(scalar_units)
+        self._num_mp_steps = num_mp_steps
+        self._blocks_per_step = blocks_per_step
+        self._n_vels = n_vels
+        self._velocity_aggregate = velocity_aggregate
+        self._homogeneous_particles = homogeneous_particles
+        self._handles: Dict[Tuple[int, int], Tuple[object, object]] = {}
+
+    # ------------------------------------------------------------------ parameters
+    def block_shapes(self) -> List[Tuple[str, int, int, int]]:
+        """(name, K, Ms, Mv) of every O3TensorProduct in call order (= lb_segnn_create's order)."""
+        C, B = self._hidden, self._blocks_per_step
+        out = [("embedding_nodes", self._node_ns + self._node_nv, C, C)]
+        for k in range(self._num_mp_steps):
+            for i in range(B):
+                out.append((f"layer_{k}/message_{i}", 4 * C + 2 if i == 0 else 2 * C, 2 * C, C))
+            for i in range(B):
+                out.append((f"layer_{k}/update_{i}", 4 * C if i == 0 else 2 * C, C if i == B - 1 else 2 * C, C))
+        for i in range(B):
+            out.append((f"readout_{i}", 2 * C, 2 * C, C))
+        out.append(("output", 2 * C, 0, 1))
+        return out
+
+    def init_params(self, seed) -> Dict:
+        """uniform_init with weight_std 1 (segnn.py:30-41 under e3nn's "element" normalisation),
+        zero biases."""
+        rng = np.random.default_rng(seed)
+        p = {}
+        for name, K, ms, mv in self.block_shapes():
+            p[name] = {"ws": rng.uniform(-1, 1, size=(K, ms)).astype(np.float32),
+                       "wv": rng.uniform(-1, 1, size=(K, mv)).astype(np.float32),
+                       "b": np.zeros((ms,), np.float32)}
+        return p
+
+    def init(self, key, sample):
+        seed = int(np.asarray(key).ravel()[-1]) if key is not None else 0
+        return self.init_params(seed), {}
+
+    def flatten(self, params) -> np.ndarray:
+        out = []
+        for name, K, ms, mv in self.block_shapes():
+            blk = params[name]
+            ws, wv, b = (np.asarray(blk[k], np.float32) for k in ("ws", "wv", "b"))
+            if ws.shape != (K, ms) or wv.shape != (K, mv) or b.shape != (ms,):
+                raise ValueError(f"SEGNN params[{name!r}]: expected ws {(K, ms)}, wv {(K, mv)}, b {(ms,)}; "
+                                 f"got {ws.shape}, {wv.shape}, {b.shape}")
+            out += [ws.ravel(), wv.ravel(), b.ravel()]
+        return np.concatenate(out)
+
+    # ------------------------------------------------------------------ engine binding
+    def handle(self, engine, params):
+        key = (id(engine), id(params))
+        hit = self._handles.get(key)
+        if hit is not None and hit[1] is params:
+            return hit[0]
+        d = SegnnDesc()
+        d.hidden, d.blocks_per_step, d.num_mp_steps = self._hidden, self._blocks_per_step, self._num_mp_steps
+        d.homogeneous = int(bool(self._homogeneous_particles))
+        d.n_vels = self._n_vels
+        d.velocity_avg = int(self._velocity_aggregate == "avg")
+        h = engine.segnn_create(d, self.flatten(params))
+        self._handles[key] = (h, params)
+        return h
+
+    def apply(self, params, state, sample):
+        features, particle_type = sample
+        engine = getattr(features, "engine", None)
+        if engine is None:
+            raise TypeError("SEGNN.apply needs the FeatureDict returned by case.preprocess_eval/"
+                            "allocate_eval (it names the engine state to run on)")
+        if features.version != engine.version:
+            raise RuntimeError("features are stale: the engine state changed since they were produced")
+        acc = engine.segnn_forward(self.handle(engine, params))
+        return {"acc": acc if features.batched else acc[0]}, state
+
+    def __call__(self, params, state, sample):
+        return self.apply(params, state, sample)

@@ -1,0 +1,170 @@
+"""SEGNN (lmax 1): the oracle's O(3)-equivariance (the reference's own SEGNN test,
+tests/models_test.py:70-87) on CPU; HIP forward / rollout against the oracle on the GPU.
+
+Parity with e3nn-jax itself is unpinned (oracle/segnn_oracle.py header): tolerance 1e-5 relative
+to the largest output, HIP fp32 MFMA vs NumPy fp32."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lb_oracle as O
+from oracle import segnn_oracle as S
+from tests._common import hip_case, oracle_case, rel_err
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+# ------------------------------------------------------------------------------- CPU
+def _random_graph_features(R, n=40, K=5, E=200):
+    r = np.random.default_rng(1)
+    vh = r.standard_normal((n, K, 3))
+    force = r.standard_normal((n, 3))
+    bound = r.standard_normal((n, 2, 3))
+    s = np.concatenate([r.integers(0, n, E), np.arange(n)])
+    rc = np.concatenate([r.integers(0, n, E), np.arange(n)])
+    rd = r.standard_normal((E + n, 3))
+    rd[E:] = 0  # self edges
+    vh, force, bound, rd = vh @ R.T, force @ R.T, bound @ R.T, rd @ R.T
+    return {"vel_hist": vh.reshape(n, -1), "vel_mag": np.linalg.norm(vh, axis=-1), "force": force,
+            "bound": np.concatenate([bound[:, 0], bound[:, 1]], -1), "rel_disp": rd,
+            "rel_dist": np.linalg.norm(rd, axis=-1, keepdims=True), "senders": s, "receivers": rc}
+
+
+def test_oracle_is_o3_equivariant():
+    from scipy.stats import ortho_group
+    n, K = 40, 5
+    pt = np.random.default_rng(2).integers(0, 3, n)
+    p = S.segnn_init(np.random.default_rng(0), node_ns=K + 9, node_nv=K + 3, num_mp_steps=3, random_bias=True)
+    out0 = S.segnn_apply(p, _random_graph_features(np.eye(3)), pt, K, False)["acc"]
+    assert np.abs(out0).max() > 1e-3
+    dets = []
+    for seed in range(4):
+        R = ortho_group.rvs(3, random_state=seed)
+        dets.append(np.sign(np.linalg.det(R)))
+        out1 = S.segnn_apply(p, _random_graph_features(R), pt, K, False)["acc"]
+        assert np.abs(out1 - out0 @ R.T).max() < 2e-6 * max(1.0, np.abs(out0).max())
+    assert -1 in dets and 1 in dets  # reflections and rotations both covered
+
+
+def test_gate_normalisation_constants():
+    from scipy.integrate import quad
+    g = lambda z: np.exp(-0.5 * z * z) / np.sqrt(2 * np.pi)
+    m_silu = quad(lambda z: (z / (1 + np.exp(-z))) ** 2 * g(z), -12, 12)[0]
+    m_sig = quad(lambda z: (1 / (1 + np.exp(-z))) ** 2 * g(z), -12, 12)[0]
+    # the oracle follows e3nn's 1e6-point quantile grid, which clips the tails: ~2e-5 off the integral
+    assert abs(S.C_SILU - m_silu ** -0.5) < 1e-4
+    assert abs(S.C_SIGMOID - m_sig ** -0.5) < 1e-4
+
+
+def test_spherical_harmonics_l1():
+    v = np.array([[0.0, 0.0, 0.0], [3.0, 0.0, 4.0]])
+    y = S.spherical_harmonics(v)
+    assert np.allclose(y[0], [0.5 / np.sqrt(np.pi), 0, 0, 0])
+    assert np.allclose(y[1, 1:], np.sqrt(3 / (4 * np.pi)) * np.array([0.6, 0.0, 0.8]), atol=1e-7)
+    # "integral" normalisation: sum_m Y_1m^2 = 3 / (4 pi)
+    assert np.isclose((y[1, 1:] ** 2).sum(), 3 / (4 * np.pi), atol=1e-7)
+
+
+def test_model_shapes_match_oracle():
+    from lagrangebench_amd.models import SEGNN, node_irreps
+    from lagrangebench_amd.models.segnn import parse_irreps
+    md = {"periodic_boundary_conditions": [False, False]}
+    irr = node_irreps(md, 6, True, True, False)
+    assert irr == "5x1o+2x1o+1x1o+5x0e+9x0e"
+    assert parse_irreps(irr) == (14, 8)
+    m = SEGNN(irr, "1x1o+1x0e", 64, 1, 1, "1x1o", num_mp_steps=3, n_vels=5, homogeneous_particles=False)
+    p = S.segnn_init(np.random.default_rng(0), node_ns=14, node_nv=8, num_mp_steps=3)
+    for name, K, ms, mv in m.block_shapes():
+        assert p[name]["ws"].shape == (K, ms) and p[name]["wv"].shape == (K, mv), name
+    assert m.flatten(p).size == sum(v["ws"].size + v["wv"].size + v["b"].size
+                                    for v in p.values() if isinstance(v, dict))
+    with pytest.raises(NotImplementedError):
+        SEGNN(irr, "1x1o+1x0e", 64, 2, 1, "1x1o", 3, 5)
+    with pytest.raises(NotImplementedError):
+        SEGNN(irr, "1x1o+1x0e", 64, 1, 1, "1x1o", 3, 5, norm="instance")
+
+
+# ------------------------------------------------------------------------------- GPU
+def _setup(name, scale, L, magnitudes=True, seed=7, out_scale=1.0):
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import SEGNN, node_irreps
+    ds = make_case(name, n_trajs=2, extra_seq_length=6, scale=scale)
+    ds.magnitude_features = magnitudes
+    isl = ds.input_seq_length
+    homog = bool(np.all(ds[0][1] == 0))
+    irr = node_irreps(ds.metadata, isl, ds.external_force_fn is not None, magnitudes, homog)
+    model = SEGNN(irr, "1x1o+1x0e", 64, 1, 1, "1x1o", num_mp_steps=L, n_vels=isl - 1,
+                  homogeneous_particles=homog)
+    params = S.segnn_init(np.random.default_rng(seed), node_ns=model._node_ns, node_nv=model._node_nv,
+                          num_mp_steps=L, random_bias=True)
+    params["output"]["wv"] = (params["output"]["wv"] * out_scale).astype(np.float32)
+    return ds, model, params, homog
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,scale,L,mag", [("small2d", 1.0, 2, True), ("small3d", 1.0, 3, True),
+                                              ("dam2d", 0.3, 3, True), ("rpf2d", 0.5, 10, False),
+                                              ("ldc3d", 0.5, 2, True)])
+def test_segnn_forward_parity(name, scale, L, mag):
+    _need_gpu()
+    ds, model, params, homog = _setup(name, scale, L, mag)
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    isl = ds.input_seq_length
+    pos = np.stack([ds[0][0], ds[1][0]])
+    pt = np.stack([ds[0][1], ds[1][1]])
+    feats, nbrs = hcase.allocate_eval((pos[:, :, :isl], pt))
+    eng = feats.engine
+    handle = model.handle(eng, params)
+    tap = handle.set_tap(True)
+    pred, _ = model.apply(params, {}, (feats, pt))
+    acc, tap = _np(pred["acc"]), _np(tap)
+    N = pos.shape[1]
+    for b in range(2):
+        of, _ = ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))
+        ref, lat = S.segnn_apply(params, of, pt[b], isl - 1, homog, return_latents=True)
+        for k, f in enumerate(lat):
+            got = tap[k][b * N:(b + 1) * N]
+            want = np.concatenate([f.s, f.v[:, :, 0], f.v[:, :, 1], f.v[:, :, 2]], axis=1)
+            assert rel_err(got, want) < 1e-5, f"hidden state {k}"
+        assert rel_err(acc[b], ref["acc"]) < 1e-5
+    handle.set_tap(False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,scale", [("small2d", 1.0), ("dam2d", 0.3)])
+def test_segnn_rollout_parity(name, scale):
+    """lb_segnn_rollout (device step loop) against the oracle's eval loop, 5 steps."""
+    _need_gpu()
+    from lagrangebench_amd.evaluate.rollout import _eval_batched_rollout, _forward_eval
+    from functools import partial
+    ds, model, params, homog = _setup(name, scale, 2, True, out_scale=0.02)
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    isl = ds.input_seq_length
+    n_steps = 5
+    pos = np.stack([ds[0][0], ds[1][0]])
+    pt = np.stack([ds[0][1], ds[1][1]])
+    feats, nbrs = hcase.allocate_eval((pos[:, :, :isl], pt))
+    fwd = partial(_forward_eval, model_apply=model.apply, case_integrate=hcase.integrate)
+    fwd._lb_gns = model
+    metrics = lambda pred, target: {}
+    pred, _, _ = _eval_batched_rollout(fwd, hcase.preprocess_eval, hcase, params, {}, (pos, pt), nbrs,
+                                       metrics, n_steps, isl)
+    pred = _np(pred)
+
+    def oracle_apply(p, state, sample):
+        f, ptype = sample
+        return S.segnn_apply(p, f, ptype, isl - 1, homog), state
+
+    for b in range(2):
+        _, onbrs = ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))
+        ref, _, _ = O.eval_batched_rollout(oracle_apply, ocase, params, {}, (pos[b:b + 1], pt[b:b + 1]), onbrs,
+                                           n_steps, isl)
+        dx = float(ds.metadata["dx"]) if "dx" in ds.metadata else 1.0 / 16
+        assert np.abs(pred[b] - np.asarray(ref)[0]).max() < 1e-6 * dx
