@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--workload", default="tgv3d", choices=["tgv2d", "rpf2d", "tgv3d", "ldc3d", "dam2d"])
     ap.add_argument("--batch", type=int, default=8, help="trajectories advanced together per GPU")
     ap.add_argument("--mp-steps", type=int, default=10)
+    ap.add_argument("--model", default="gns", choices=["gns", "segnn"],
+                    help="gns: BASELINE.json's headline config; segnn: configs[4] (SEGNN-10-64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
     args = ap.parse_args()
@@ -82,6 +84,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+
+    if args.model == "segnn":
+        return run_segnn(args, rank, world, device)
 
     from lagrangebench_amd.data import make_case
     from lagrangebench_amd.models import GNS
@@ -216,6 +221,74 @@ def main():
 
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ds, params, L, args.cpu_steps)
+    print(json.dumps(out), flush=True)
+
+
+def run_segnn(args, rank, world, device):
+    """configs[4]: SEGNN-10-64 (lmax 1) rollout.  Same step definition and timing contract as the
+    GNS line; the dominant kernel is the message tensor-product block pair (fp32 MFMA bound)."""
+    from lagrangebench_amd import dist as lbdist
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import SEGNN, node_irreps
+    from oracle import segnn_oracle as S  # weights only (same init as the parity tests)
+    from tests._common import hip_case
+
+    B, K, W, L = args.batch, args.steps, args.warmup, args.mp_steps
+    ds = make_case(args.workload, n_trajs=world * B, extra_seq_length=max(K, W, 1))
+    ds.magnitude_features = True  # configs/*/segnn.yaml
+    isl = ds.input_seq_length
+    homog = bool(np.all(ds[0][1] == 0))
+    irr = node_irreps(ds.metadata, isl, ds.external_force_fn is not None, True, homog)
+    model = SEGNN(irr, "1x1o+1x0e", 64, 1, 1, "1x1o", num_mp_steps=L, n_vels=isl - 1, homogeneous_particles=homog)
+    params = S.segnn_init(np.random.default_rng(1234), node_ns=model._node_ns, node_nv=model._node_nv,
+                          num_mp_steps=L)
+    params["output"]["wv"] = (params["output"]["wv"] * 0.01).astype(np.float32)
+    case = hip_case(ds)
+    mine = [rank * B + i for i in range(B)]
+    pos = np.stack([ds[i][0] for i in mine])
+    pt = np.stack([ds[i][1] for i in mine])
+    N = pos.shape[1]
+    eng = case.engine(B)
+    eng.set_particle_type(pt)
+    traj = eng.prepare_traj(pos)
+    handle = model.handle(eng, params)
+    eng.rollout(handle, traj, max(W, 1))
+    lbdist.barrier(device)
+    t0 = time.perf_counter()
+    pred, n_realloc = eng.rollout(handle, traj, K)
+    lbdist.barrier(device)
+    dt = lbdist.max_over_ranks(time.perf_counter() - t0, device)
+    E_tot = eng.stats()["n_edges_total"]
+    eng.timers_enable(True)
+    eng.timers_reset()
+    eng.rollout(handle, traj, K)
+    tm = eng.timers()
+    eng.timers_enable(False)
+    if rank != 0:
+        return
+    ms_msg, n_msg = tm["edge_mlp"]  # one record per layer = the two gated message blocks
+    us_msg = 1e3 * ms_msg / max(n_msg, 1)
+    C = 32
+    flop_exec = E_tot * 2 * (136 + 64) * (2 * C + 3 * C)    # K padded to 136 / 64, 64 scalar + 3x32 vector outputs
+    flop_algo = E_tot * 2 * (130 + 64) * (2 * C + 3 * C)
+    tf = flop_exec / (us_msg * 1e-6) / 1e12
+    msg_bytes = E_tot * (2 * 512 + 512 + 512 + 512 + 16 + 64 + 8)  # gathers f_s, f_r; write/read block 0; write block 1
+    out = {
+        "metric": "rollout particle-steps/sec", "value": world * B * N * K / dt, "unit": "particle-steps/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload} SEGNN-{L}-64 (lmax 1) inference rollout, neighbor list rebuilt every step",
+                   "n_particles": int(N), "batch_per_gpu": B, "edges_per_traj": int(E_tot // B),
+                   "input_seq_length": isl, "geometry_dtype": "f64", "network_math": "f32",
+                   "weights": "U(-1,1) e3nn-style init (seed 1234), output x0.01", "n_realloc": int(n_realloc)},
+        "steps_per_s_per_traj": K / dt,
+        "roofline": {"kernel": "k_sg_tp<GATE> x2 (message blocks of one layer)", "bound": "mfma", "achieved": tf,
+                     "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,
+                     "us_per_launch": us_msg, "launches": int(n_msg), "flop_per_launch_executed": flop_exec,
+                     "flop_per_launch_algorithmic": flop_algo,
+                     "hbm": {"achieved": msg_bytes / (us_msg * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}},
+        "breakdown_ms_per_step": {k: round(v[0] / K, 4) for k, v in tm.items() if v[1] > 0},
+    }
     print(json.dumps(out), flush=True)
 
 

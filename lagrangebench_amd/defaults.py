@@ -26,6 +26,7 @@ defaults = _wrap({
     "model": {
         "name": None, "input_seq_length": 6, "num_mp_steps": 10, "num_mlp_layers": 2,
         "latent_dim": 128, "isotropic_norm": False, "magnitude_features": False,
+        "lmax_attributes": 1, "lmax_hidden": 1, "segnn_norm": "none", "velocity_aggregate": "avg",
     },                                        # defaults.py:38-63
     "train": {"noise_std": 3e-4},             # defaults.py:75
     "eval": {

@@ -62,7 +62,20 @@ def setup_model(cfg, metadata: Dict, homogeneous_particles: bool = False, has_ex
             blocks_per_step=cfg.model.num_mlp_layers, num_mp_steps=cfg.model.num_mp_steps,
             num_particle_types=NodeType.SIZE, particle_type_embedding_size=16)
         return model, models.GNS
-    raise NotImplementedError(f"model {cfg.model.name!r}: only 'gns' is built (segnn/egnn/painn/linear are not)")
+    if name == "segnn":
+        # runner.py:217-245: Hx1o vel, [2x1o boundary], [1x1o force], [Hx0e |vel|], [9x0e type]
+        isl = cfg.model.input_seq_length
+        irreps = models.node_irreps(metadata, isl, has_external_force, cfg.model.magnitude_features,
+                                    homogeneous_particles)
+        model = models.SEGNN(
+            node_features_irreps=irreps, edge_features_irreps="1x1o+1x0e",
+            scalar_units=cfg.model.latent_dim, lmax_hidden=cfg.model.lmax_hidden,
+            lmax_attributes=cfg.model.lmax_attributes, output_irreps="1x1o",
+            num_mp_steps=cfg.model.num_mp_steps, n_vels=isl - 1,
+            velocity_aggregate=cfg.model.velocity_aggregate, homogeneous_particles=homogeneous_particles,
+            blocks_per_step=cfg.model.num_mlp_layers, norm=cfg.model.segnn_norm)
+        return model, models.SEGNN
+    raise NotImplementedError(f"model {cfg.model.name!r}: 'gns' and 'segnn' are built (egnn/painn/linear are not)")
 
 
 def train_or_infer(cfg):
