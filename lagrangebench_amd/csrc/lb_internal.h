@@ -247,6 +247,12 @@ int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* mo
 struct lb_segnn;
 int lbk_segnn_forward(lb_engine* e, lb_segnn* m);
 
+// lb_segnn_msg.hip
+void lb_sg_msg_image(const float* ws0, const float* wv0, const float* b0, const float* ws1,
+                     const float* wv1, const float* b1, float* out);
+int lb_sg_msg_image_floats(void);
+int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg);
+
 // lb_gns.hip
 int lbk_gns_forward(lb_engine* e, lb_gns* g);
 int lbk_segment_sum(lb_engine* e, const float* msg, float* out, int D);

@@ -24,6 +24,7 @@
 // (lane, register) position of the accumulator, so one 4 KiB LDS hand-off does it.  Residual
 // add, gating and the [s|vx|vy|vz] store are fused into the epilogue.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 
@@ -93,6 +94,8 @@ struct lb_segnn {
   float* eattr;    // [e_alloc][4]
   float* msgsv;    // [e_alloc][16]
   float* tap;
+  std::vector<const float*> msg_image;  // per layer: LDS image of the fused message kernel
+  bool fused_msg;  // gather + both message blocks + segment_sum in one kernel (blocks_per_step == 2)
 };
 
 template <typename T>
@@ -381,7 +384,7 @@ extern "C" int lb_segnn_create(lb_engine* e, const lb_segnn_desc* d, const float
     if (src) memcpy(host.data() + off, src, n * sizeof(float));
     return off;
   };
-  struct Pending { lb_sg_block b; size_t ws, wv, bias; };
+  struct Pending { lb_sg_block b; size_t ws, wv, bias; const float *raw_ws, *raw_wv, *raw_b; };
   std::vector<Pending> pend;
   const float* p = w;
   const float* pend_end = w + n_floats;
@@ -418,10 +421,13 @@ extern "C" int lb_segnn_create(lb_engine* e, const lb_segnn_desc* d, const float
       if (M > 0) lb_pack_weight(padded.data(), Kpad, M, Kpad, Mpad, tmp.data());
       return put(tmp.data(), tmp.size());
     };
+    pd.raw_ws = p;
     pd.ws = pack(p, Ms, 32 * (b.ms_blocks > 0 ? b.ms_blocks : 1));
     p += (size_t)ktrue * Ms;
+    pd.raw_wv = p;
     pd.wv = pack(p, Mv, 32);
     p += (size_t)ktrue * Mv;
+    pd.raw_b = p;
     std::vector<float> bb(64, 0.f);
     memcpy(bb.data(), p, sizeof(float) * Ms);
     pd.bias = put(bb.data(), 64);
@@ -447,6 +453,17 @@ extern "C" int lb_segnn_create(lb_engine* e, const lb_segnn_desc* d, const float
     return lb_fail(LB_ERR_ARG, "segnn weight blob has %lld floats, expected %lld", (long long)n_floats,
                    (long long)(p - w));
   }
+  // fused message kernel (lb_segnn_msg.hip): one LDS image per layer; pend[1 + k*2B + {0,1}]
+  std::vector<size_t> image_off;
+  if (B == 2) {
+    std::vector<float> img((size_t)lb_sg_msg_image_floats());
+    for (int k = 0; k < L; ++k) {
+      const Pending& m0 = pend[1 + (size_t)k * 2 * B];
+      const Pending& m1 = pend[2 + (size_t)k * 2 * B];
+      lb_sg_msg_image(m0.raw_ws, m0.raw_wv, m0.raw_b, m1.raw_ws, m1.raw_wv, m1.raw_b, img.data());
+      image_off.push_back(put(img.data(), img.size()));
+    }
+  }
   int rc = sg_alloc(&m->blob, host.size());
   if (!rc && hipMemcpy(m->blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
     rc = lb_fail(LB_ERR_HIP, "weight upload failed");
@@ -465,6 +482,11 @@ extern "C" int lb_segnn_create(lb_engine* e, const lb_segnn_desc* d, const float
   }
   for (int i = 0; i < B; ++i) m->readout.push_back(take());
   m->output = take();
+  for (size_t off : image_off) m->msg_image.push_back(m->blob + off);
+  {
+    const char* f = getenv("LB_SEGNN_FUSED");
+    m->fused_msg = (B == 2) && !(f && f[0] == '0');
+  }
   const int64_t BN = e->BN;
   if (!rc) rc = sg_alloc(&m->xnode, (size_t)BN * 32);
   if (!rc) rc = sg_alloc(&m->nodesv, (size_t)BN * m->node_stride);
@@ -525,6 +547,12 @@ int lbk_segnn_forward(lb_engine* e, lb_segnn* m) {
   float* eb[2] = {e->elat, e->msg};
   for (int k = 0; k < L; ++k) {
     // message: [f_sender | f_receiver | (rel_disp, rel_dist)] -> gated blocks (segnn.py:280-304)
+    if (m->fused_msg) {
+      lb_tic(e, LB_T_EDGE_MLP);
+      int rc = lbk_sg_message(e, m->f, m->msg_image[k], m->agg);
+      lb_toc(e);
+      if (rc) return rc;
+    } else {
     lb_tic(e, LB_T_EDGE_MLP);
     const float* cur = nullptr;
     for (int i = 0; i < B; ++i) {
@@ -545,6 +573,7 @@ int lbk_segnn_forward(lb_engine* e, lb_segnn* m) {
     lb_tic(e, LB_T_AGGREGATE);
     LB_TRY(lbk_segment_sum(e, cur, m->agg, 128));
     lb_toc(e);
+    }
     // update: [f | agg] -> gated blocks -> linear block -> residual (segnn.py:306-334)
     lb_tic(e, LB_T_NODE_MLP);
     const float* ncur = nullptr;
