@@ -95,6 +95,7 @@ struct lb_segnn {
   float* msgsv;    // [e_alloc][16]
   float* tap;
   std::vector<const float*> msg_image;  // per layer: LDS image of the fused message kernel
+  std::vector<const float*> upd_image;  // per layer: LDS image of the fused update kernel
   bool fused_msg;  // gather + both message blocks + segment_sum in one kernel (blocks_per_step == 2)
 };
 
@@ -454,7 +455,7 @@ extern "C" int lb_segnn_create(lb_engine* e, const lb_segnn_desc* d, const float
                    (long long)(p - w));
   }
   // fused message kernel (lb_segnn_msg.hip): one LDS image per layer; pend[1 + k*2B + {0,1}]
-  std::vector<size_t> image_off;
+  std::vector<size_t> image_off, upd_image_off;
   if (B == 2) {
     std::vector<float> img((size_t)lb_sg_msg_image_floats());
     for (int k = 0; k < L; ++k) {
@@ -462,6 +463,13 @@ extern "C" int lb_segnn_create(lb_engine* e, const lb_segnn_desc* d, const float
       const Pending& m1 = pend[2 + (size_t)k * 2 * B];
       lb_sg_msg_image(m0.raw_ws, m0.raw_wv, m0.raw_b, m1.raw_ws, m1.raw_wv, m1.raw_b, img.data());
       image_off.push_back(put(img.data(), img.size()));
+    }
+    std::vector<float> uimg((size_t)lb_sg_upd_image_floats());
+    for (int k = 0; k < L; ++k) {
+      const Pending& u0 = pend[3 + (size_t)k * 2 * B];
+      const Pending& u1 = pend[4 + (size_t)k * 2 * B];
+      lb_sg_upd_image(u0.raw_ws, u0.raw_wv, u0.raw_b, u1.raw_ws, u1.raw_wv, u1.raw_b, uimg.data());
+      upd_image_off.push_back(put(uimg.data(), uimg.size()));
     }
   }
   int rc = sg_alloc(&m->blob, host.size());
@@ -483,6 +491,7 @@ extern "C" int lb_segnn_create(lb_engine* e, const lb_segnn_desc* d, const float
   for (int i = 0; i < B; ++i) m->readout.push_back(take());
   m->output = take();
   for (size_t off : image_off) m->msg_image.push_back(m->blob + off);
+  for (size_t off : upd_image_off) m->upd_image.push_back(m->blob + off);
   {
     const char* f = getenv("LB_SEGNN_FUSED");
     m->fused_msg = (B == 2) && !(f && f[0] == '0');
@@ -576,6 +585,13 @@ int lbk_segnn_forward(lb_engine* e, lb_segnn* m) {
     }
     // update: [f | agg] -> gated blocks -> linear block -> residual (segnn.py:306-334)
     lb_tic(e, LB_T_NODE_MLP);
+    if (m->fused_msg) {
+      int rc = lbk_sg_update(e, m->f, m->agg, m->nattr, m->upd_image[k]);
+      lb_toc(e);
+      if (rc) return rc;
+      LB_TRY(tap(k + 1));
+      continue;
+    }
     const float* ncur = nullptr;
     for (int i = 0; i < B; ++i) {
       const bool last = i == B - 1;

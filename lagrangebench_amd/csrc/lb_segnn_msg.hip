@@ -402,6 +402,98 @@ __global__ void __launch_bounds__(256) k_sg_agg_finish(const lb_ctrl* __restrict
   *out = s;
 }
 
+// ------------------------------------------------------------------------------ node update
+// SEGNNLayer._update (segnn.py:306-334) for blocks_per_step == 2 as one kernel:
+//   [f | agg] -> O3TensorProductGate -> O3TensorProduct -> f += .   Node attribute a0 == 1.
+// Same register-chained f16x2 scheme as k_sg_msg, on tiles of 16 consecutive nodes.
+#define SGU_WS0 0      // K=128 x M=64
+#define SGU_WT0 2048   // K=64 x M=32
+#define SGU_WV0 2560
+#define SGU_WS1 3072   // K=64 x M=64 (columns 32..63 zero: the last block has no gates)
+#define SGU_WT1 4096
+#define SGU_WV1 4352
+#define SGU_VEC 4608   // b0 (16 f32x4), b1 (16, upper half zero)
+#define SGU_IMAGE 4640
+
+struct lb_sg_upd_args {
+  const lb_ctrl* ctrl;
+  int64_t n_rows;
+  float* f;             // [rows][128] in/out
+  const float* agg;     // [rows][128]
+  const float* nattr;   // [rows][4]
+  const float* image;
+};
+
+__global__ void __launch_bounds__(SGM_THREADS, 2) k_sg_upd(lb_sg_upd_args a) {
+  __shared__ f32x4 sW[SGU_IMAGE];
+  if (a.ctrl->overflow_step >= 0) return;
+  const int tid = threadIdx.x;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.image);
+    for (int i = tid; i < SGU_IMAGE; i += SGM_THREADS) sW[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int ntiles = (int)((a.n_rows + 15) >> 4);
+  const f32x4* vec = &sW[SGU_VEC];
+  for (int t = blockIdx.x * SGM_WAVES + wave; t < ntiles; t += gridDim.x * SGM_WAVES) {
+    const int64_t row = (int64_t)t * 16 + n;
+    const bool valid = row < a.n_rows;
+    const int64_t rl = valid ? row : a.n_rows - 1;
+    f32x4* frow = reinterpret_cast<f32x4*>(a.f) + rl * 32 + g;
+    const f32x4* arow = reinterpret_cast<const f32x4*>(a.agg) + rl * 32 + g;
+    f32x4 X0[8], X1[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      X0[mb] = frow[4 * mb];
+      X1[mb] = arow[4 * mb];
+    }
+    const f32x4 na = reinterpret_cast<const f32x4*>(a.nattr)[rl];
+    const float at[3] = {na[1], na[2], na[3]};
+    f32x4 S[4], T[2], V[3][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) S[m] = vec[4 * m + g];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      T[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) V[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    sg_operand(&sW[SGU_WS0], &sW[SGU_WT0], &sW[SGU_WV0], 0, 0, lane, X0, at, S, T, V);
+    sg_operand(&sW[SGU_WS0], &sW[SGU_WT0], &sW[SGU_WV0], 2, 1, lane, X1, at, S, T, V);
+    f32x4 H[8];
+    {
+      const f32x4 g0 = sg_sigmoid4(S[2]), g1 = sg_sigmoid4(S[3]);
+      H[0] = sg_silu4(S[0]);
+      H[1] = sg_silu4(S[1]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        H[2 + 2 * c] = (V[c][0] + T[0] * at[c]) * g0;
+        H[3 + 2 * c] = (V[c][1] + T[1] * at[c]) * g1;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) S[m] = vec[16 + 4 * m + g];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      T[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) V[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    sg_operand(&sW[SGU_WS1], &sW[SGU_WT1], &sW[SGU_WV1], 0, 0, lane, H, at, S, T, V);
+    if (valid) {  // residual, segnn.py:331
+      frow[0] = X0[0] + S[0];
+      frow[4] = X0[1] + S[1];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        frow[4 * (2 + 2 * c)] = X0[2 + 2 * c] + (V[c][0] + T[0] * at[c]);
+        frow[4 * (3 + 2 * c)] = X0[3 + 2 * c] + (V[c][1] + T[1] * at[c]);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ host side
 // LDS image of one layer from the raw block weights (oracle channel order):
 //   ws0 (130 x 64), wv0 (130 x 32), b0 (64); ws1 (64 x 64), wv1 (64 x 32), b1 (64).
@@ -482,6 +574,64 @@ int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg)
   const int nb = (int)((e->BN + 7) / 8);
   hipLaunchKernelGGL(k_sg_agg_finish, dim3(nb), dim3(256), 0, e->stream, e->ctrl, e->BN, e->row_ptr,
                      e->part, agg);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
+// LDS image of one layer's update from the raw block weights (oracle channel order):
+//   ws0 (128 x 64), wv0 (128 x 32), b0 (64); ws1 (64 x 32), wv1 (64 x 32), b1 (32).
+void lb_sg_upd_image(const float* ws0, const float* wv0, const float* b0, const float* ws1,
+                     const float* wv1, const float* b1, float* out /* SGU_IMAGE*4 floats */) {
+  const float sc0 = 1.0f / sqrtf(128.f), sc1 = 1.0f / sqrtf(64.f), is3 = 0.5773502691896258f;
+  memset(out, 0, sizeof(float) * SGU_IMAGE * 4);
+  std::vector<float> m;
+  auto pack = [&](int K, int M, int off) { lb_pack_weight16h(m.data(), K, M, K, out + (size_t)off * 4, M); };
+  m.assign(128 * 64, 0.f);
+  for (int k = 0; k < 128; ++k) {
+    const float f = ((k >> 5) & 1) ? is3 * sc0 : sc0;  // node attribute a0 == 1
+    for (int j = 0; j < 64; ++j) m[k * 64 + j] = ws0[k * 64 + j] * f;
+  }
+  pack(128, 64, SGU_WS0);
+  m.assign(64 * 32, 0.f);
+  for (int o = 0; o < 2; ++o)
+    for (int k = 0; k < 32; ++k)
+      for (int j = 0; j < 32; ++j) m[(o * 32 + k) * 32 + j] = wv0[(o * 64 + k) * 32 + j] * sc0;
+  pack(64, 32, SGU_WT0);
+  for (int o = 0; o < 2; ++o)
+    for (int k = 0; k < 32; ++k)
+      for (int j = 0; j < 32; ++j) m[(o * 32 + k) * 32 + j] = wv0[(o * 64 + 32 + k) * 32 + j] * sc0;
+  pack(64, 32, SGU_WV0);
+  m.assign(64 * 64, 0.f);
+  for (int k = 0; k < 64; ++k) {
+    const float f = (k >= 32) ? is3 * sc1 : sc1;
+    for (int j = 0; j < 32; ++j) m[k * 64 + j] = ws1[k * 32 + j] * f;
+  }
+  pack(64, 64, SGU_WS1);
+  m.assign(32 * 32, 0.f);
+  for (int k = 0; k < 32; ++k)
+    for (int j = 0; j < 32; ++j) m[k * 32 + j] = wv1[k * 32 + j] * sc1;
+  pack(32, 32, SGU_WT1);
+  for (int k = 0; k < 32; ++k)
+    for (int j = 0; j < 32; ++j) m[k * 32 + j] = wv1[(32 + k) * 32 + j] * sc1;
+  pack(32, 32, SGU_WV1);
+  float* v = out + (size_t)SGU_VEC * 4;
+  for (int j = 0; j < 64; ++j) v[j] = b0[j];
+  for (int j = 0; j < 32; ++j) v[64 + j] = b1[j];
+}
+
+int lb_sg_upd_image_floats(void) { return SGU_IMAGE * 4; }
+
+int lbk_sg_update(lb_engine* e, float* f, const float* agg, const float* nattr, const float* image) {
+  lb_sg_upd_args a{};
+  a.ctrl = e->ctrl;
+  a.n_rows = e->BN;
+  a.f = f;
+  a.agg = agg;
+  a.nattr = nattr;
+  a.image = image;
+  const int ntiles = (int)((e->BN + 15) / 16);
+  const int nb = std::min(256, (ntiles + SGM_WAVES - 1) / SGM_WAVES);
+  hipLaunchKernelGGL(k_sg_upd, dim3(nb), dim3(SGM_THREADS), 0, e->stream, a);
   LB_HIP(hipGetLastError());
   return LB_OK;
 }
