@@ -72,6 +72,25 @@ def test_spherical_harmonics_l1():
     assert np.isclose((y[1, 1:] ** 2).sum(), 3 / (4 * np.pi), atol=1e-7)
 
 
+def test_tensor_product_component_normalisation():
+    """e3nn's irrep_normalization="component" (A3) is DEFINED by: unit-variance inputs give
+    unit-variance output components on every path.  Checks the 1/sqrt(3) of 1o x 1o -> 0e and the
+    unit factors of the other three paths; then the "element" Linear (A4) keeps that variance for
+    U(-1,1)*sqrt(3) (unit-variance) weights."""
+    rng = np.random.default_rng(0)
+    R, C = 20000, 8
+    x = S.SV(rng.standard_normal((R, C)), rng.standard_normal((R, C, 3)))
+    attr = rng.standard_normal((R, 4)).astype(np.float32)
+    xs, xv = S.tp_inputs([x], attr)
+    var_s = xs.var(axis=0)          # [s*a0 (C) | (v.a)/sqrt3 (C)]
+    var_v = xv.var(axis=(0, 2))     # [s*a_c (C) | v_c*a0 (C)]
+    assert np.allclose(var_s, 1.0, atol=0.08) and np.allclose(var_v, 1.0, atol=0.08)
+    p = {"ws": (rng.uniform(-1, 1, (2 * C, 64)) * np.sqrt(3)).astype(np.float32),
+         "wv": (rng.uniform(-1, 1, (2 * C, 64)) * np.sqrt(3)).astype(np.float32), "b": np.zeros(64, np.float32)}
+    out = S.o3_tensor_product(p, [x], attr)
+    assert abs(out.s.var() - 1.0) < 0.15 and abs(out.v.var() - 1.0) < 0.15
+
+
 def test_model_shapes_match_oracle():
     from lagrangebench_amd.models import SEGNN, node_irreps
     from lagrangebench_amd.models.segnn import parse_irreps
