@@ -28,6 +28,7 @@
 #define SCAN_THREADS 256
 #define SCAN_CHUNK (SCAN_THREADS * 8)
 #define NL_SMALL_MAXC 1024
+#define NL_TINY_MAXC 384   // 10.5 KiB of LDS per one-wave workgroup: ~15 cells in flight per CU
 
 enum { NL_COUNT = 0, NL_FILL = 1, NL_ROWS = 2 };
 
@@ -271,11 +272,20 @@ __global__ void __launch_bounds__(NL_THREADS)
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     const int64_t base = (MODE == NL_ROWS) ? (int64_t)gr * a.maxd : (int64_t)a.row_ptr[gr];
-    for (int t = lane; t < count; t += 64) {
-      const int j = s_row[wave][t];
-      const int my = s_id[j];
+    for (int t0 = 0; t0 < count; t0 += 64) {
+      const int t = t0 + lane;
+      const bool act = t < count;
+      const int j = act ? s_row[wave][t] : 0;
+      const int my = act ? s_id[j] : 0x7fffffff;
+      // rank of this sender id inside the row: rows of <= 64 neighbors (the normal case) compare
+      // against lane broadcasts (v_readlane, no LDS round trips), longer rows walk the LDS row
       int rank = 0;
-      for (int u = 0; u < count; ++u) rank += (s_id[s_row[wave][u]] < my) ? 1 : 0;
+      if (count <= 64) {
+        for (int u = 0; u < count; ++u) rank += (__builtin_amdgcn_readlane(my, u) < my) ? 1 : 0;
+      } else {
+        for (int u = 0; u < count; ++u) rank += (s_id[s_row[wave][u]] < my) ? 1 : 0;
+      }
+      if (!act) continue;
       const int64_t slot = base + rank;
       if (MODE == NL_ROWS || slot < a.e_alloc) {
         a.senders[slot] = my;
@@ -372,9 +382,12 @@ __global__ void __launch_bounds__(256)
 
 // ----------------------------------------------------------------------------------- host
 template <int MODE>
-static void lb_launch_nl(lb_engine* e, bool small, const lb_nl_args& a) {
+static void lb_launch_nl(lb_engine* e, int small, const lb_nl_args& a) {
   const int ncell_tot = e->g.B * e->g.ncells;
-  if (small)
+  if (small == 2)
+    hipLaunchKernelGGL((k_nl<MODE, 64, NL_TINY_MAXC>), dim3(ncell_tot), dim3(64), 0, e->stream, e->g,
+                       e->BN, e->ctrl, a);
+  else if (small == 1)
     hipLaunchKernelGGL((k_nl<MODE, 64, NL_SMALL_MAXC>), dim3(ncell_tot), dim3(64), 0, e->stream, e->g,
                        e->BN, e->ctrl, a);
   else
@@ -409,7 +422,9 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   lb_tic(e, LB_T_NEIGH);
   // one wave per cell when the frozen cell capacity bounds the stencil (a cell holding more than
   // cell_capacity particles flags overflow anyway); the 256-thread / 2048-candidate variant otherwise
-  const bool small = frozen && g.use_cell_list && (int64_t)e->cell_capacity * g.nstencil <= NL_SMALL_MAXC;
+  // (the LDS footprint of the staged stencil sets how many cells a CU keeps in flight)
+  const int64_t cand_cap = (int64_t)e->cell_capacity * g.nstencil;
+  const int small = !(frozen && g.use_cell_list) ? 0 : (cand_cap <= NL_TINY_MAXC ? 2 : (cand_cap <= NL_SMALL_MAXC ? 1 : 0));
   const bool rows = frozen && e->maxd > 0 && e->tmp_send && (!want_efeat64 || e->tmp_feat64);
   lb_nl_args a{};
   a.cell_start = e->cell_start;
