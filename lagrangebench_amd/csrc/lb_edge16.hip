@@ -377,8 +377,12 @@ __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
     if (do_store) {  // whole tile (rows past E are padding inside the blocked allocation)
       f32x4* er = reinterpret_cast<f32x4*>(a.elat) + (int64_t)t * 512 + lane;
       if (PROC) {
+        // residual, gns.py:120-122; the updated latents of the LAST layer are never read again
+        // (the decoder only takes the node latents, gns.py:125-133): their store is skipped
+        if (!a.skip_elat_store) {
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb) er[64 * mb] = ve[mb] + y[mb];  // residual, gns.py:120-122
+          for (int mb = 0; mb < 8; ++mb) er[64 * mb] = ve[mb] + y[mb];
+        }
         if (!a.fused && valid) {
           f32x4* mr = reinterpret_cast<f32x4*>(a.msg) + (int64_t)row * 32 + g;
 #pragma unroll

@@ -610,6 +610,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
         b.row_ptr = a.row_ptr;
         b.agg = a.agg;
         b.part = a.part;
+        b.skip_elat_store = (k == L - 1) && e->fused_agg && !g->tap;
         rc = lbk_edge16(e, b, true, e->f16x2 != 0);
         if (rc) return rc;
       } else {

@@ -154,6 +154,7 @@ struct lb_edge16_args {  // lb_edge16.hip
   const int32_t* row_ptr;
   float* agg;
   float* part;         // [ceil(E/16)][2][128]
+  int skip_elat_store; // last processor layer: the updated edge latents have no reader
 };
 
 struct lb_node_args {
