@@ -558,7 +558,7 @@ int lbk_segnn_forward(lb_engine* e, lb_segnn* m) {
     // message: [f_sender | f_receiver | (rel_disp, rel_dist)] -> gated blocks (segnn.py:280-304)
     if (m->fused_msg) {
       lb_tic(e, LB_T_EDGE_MLP);
-      int rc = lbk_sg_message(e, m->f, m->msg_image[k], m->agg);
+      int rc = lbk_sg_message(e, m->f, m->msg_image[k], m->agg, false);
       lb_toc(e);
       if (rc) return rc;
     } else {
@@ -586,7 +586,7 @@ int lbk_segnn_forward(lb_engine* e, lb_segnn* m) {
     // update: [f | agg] -> gated blocks -> linear block -> residual (segnn.py:306-334)
     lb_tic(e, LB_T_NODE_MLP);
     if (m->fused_msg) {
-      int rc = lbk_sg_update(e, m->f, m->agg, m->nattr, m->upd_image[k]);
+      int rc = lbk_sg_update(e, m->f, m->agg, m->nattr, m->upd_image[k], true);
       lb_toc(e);
       if (rc) return rc;
       LB_TRY(tap(k + 1));

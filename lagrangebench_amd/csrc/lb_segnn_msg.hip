@@ -422,6 +422,8 @@ struct lb_sg_upd_args {
   const float* agg;     // [rows][128]
   const float* nattr;   // [rows][4]
   const float* image;
+  const int32_t* row_ptr;  // with part != null: combine k_sg_msg's partial slots here
+  const float* part;
 };
 
 __global__ void __launch_bounds__(SGM_THREADS, 2) k_sg_upd(lb_sg_upd_args a) {
@@ -445,9 +447,32 @@ __global__ void __launch_bounds__(SGM_THREADS, 2) k_sg_upd(lb_sg_upd_args a) {
     const f32x4* arow = reinterpret_cast<const f32x4*>(a.agg) + rl * 32 + g;
     f32x4 X0[8], X1[8];
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-      X0[mb] = frow[4 * mb];
-      X1[mb] = arow[4 * mb];
+    for (int mb = 0; mb < 8; ++mb) X0[mb] = frow[4 * mb];
+    if (a.part == nullptr) {
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) X1[mb] = arow[4 * mb];
+    } else {
+      // aggregated messages straight from k_sg_msg: whole rows sit in agg, rows cut by a 16-edge
+      // tile boundary are the sum of their per-tile partial slots in tile order (deterministic)
+      const int E = a.ctrl->n_edges_total;
+      int k0 = a.row_ptr[rl], k1 = a.row_ptr[rl + 1];
+      k0 = k0 < E ? k0 : E;
+      k1 = k1 < E ? k1 : E;
+      const int t0 = k0 >> 4, t1 = (k1 - 1) >> 4;
+      const bool single = t0 == t1;
+      const int nsrc = (k1 <= k0) ? 0 : (single ? 1 : t1 - t0 + 1);
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) X1[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; __any(s < nsrc); ++s) {
+        if (s < nsrc) {
+          const int tt = t0 + s;
+          const float* src = single ? a.agg + rl * 128
+                                    : a.part + ((int64_t)tt * 2 + (k0 <= (tt << 4) ? 0 : 1)) * 128;
+          const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + g;
+#pragma unroll
+          for (int mb = 0; mb < 8; ++mb) X1[mb] = X1[mb] + s4[4 * mb];
+        }
+      }
     }
     const f32x4 na = reinterpret_cast<const f32x4*>(a.nattr)[rl];
     const float at[3] = {na[1], na[2], na[3]};
@@ -548,7 +573,7 @@ void lb_sg_msg_image(const float* ws0, const float* wv0, const float* b0, const 
 
 int lb_sg_msg_image_floats(void) { return SGM_IMAGE * 4; }
 
-int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg) {
+int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg, bool finish) {
   lb_sg_msg_args a{};
   a.ctrl = e->ctrl;
   a.senders = e->senders;
@@ -571,9 +596,11 @@ int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg)
     hipLaunchKernelGGL((k_sg_msg<1>), dim3(grid), dim3(SGM_THREADS), 0, e->stream, a);
   else
     hipLaunchKernelGGL((k_sg_msg<0>), dim3(grid), dim3(SGM_THREADS), 0, e->stream, a);
-  const int nb = (int)((e->BN + 7) / 8);
-  hipLaunchKernelGGL(k_sg_agg_finish, dim3(nb), dim3(256), 0, e->stream, e->ctrl, e->BN, e->row_ptr,
-                     e->part, agg);
+  if (finish) {  // consumers other than k_sg_upd want complete rows in agg
+    const int nb = (int)((e->BN + 7) / 8);
+    hipLaunchKernelGGL(k_sg_agg_finish, dim3(nb), dim3(256), 0, e->stream, e->ctrl, e->BN, e->row_ptr,
+                       e->part, agg);
+  }
   LB_HIP(hipGetLastError());
   return LB_OK;
 }
@@ -621,7 +648,8 @@ void lb_sg_upd_image(const float* ws0, const float* wv0, const float* b0, const 
 
 int lb_sg_upd_image_floats(void) { return SGU_IMAGE * 4; }
 
-int lbk_sg_update(lb_engine* e, float* f, const float* agg, const float* nattr, const float* image) {
+int lbk_sg_update(lb_engine* e, float* f, const float* agg, const float* nattr, const float* image,
+                  bool combine_partials) {
   lb_sg_upd_args a{};
   a.ctrl = e->ctrl;
   a.n_rows = e->BN;
@@ -629,6 +657,8 @@ int lbk_sg_update(lb_engine* e, float* f, const float* agg, const float* nattr, 
   a.agg = agg;
   a.nattr = nattr;
   a.image = image;
+  a.row_ptr = e->row_ptr;
+  a.part = combine_partials ? e->part : nullptr;
   const int ntiles = (int)((e->BN + 15) / 16);
   const int nb = std::min(256, (ntiles + SGM_WAVES - 1) / SGM_WAVES);
   hipLaunchKernelGGL(k_sg_upd, dim3(nb), dim3(SGM_THREADS), 0, e->stream, a);
