@@ -43,21 +43,67 @@ __device__ __forceinline__ void lb_split8n(const f32x4& x0, const f32x4& x1, h8&
 
 // 4 output blocks (mbo0..mbo0+3) of one k-step p from the LDS chunk: frag index inside the chunk
 // is ((pp*NMBO + mbo)*2 + part)*64 + lane.
-template <int NMBO>
-__device__ __forceinline__ void lb_mfma_quad(const f32x4* __restrict__ buf, int pp, int mbo0, int lane,
-                                             const h8& bh, const h8& bl, f32x4* acc) {
+struct lb_frag4 {
   h8 ah[4], al[4];
+};
+template <int NMBO>
+__device__ __forceinline__ void lb_quad_load(const f32x4* __restrict__ buf, int pp, int mbo0, int lane,
+                                             lb_frag4& f) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    ah[c] = __builtin_bit_cast(h8, buf[((pp * NMBO + mbo0 + c) * 2 + 0) * 64 + lane]);
-    al[c] = __builtin_bit_cast(h8, buf[((pp * NMBO + mbo0 + c) * 2 + 1) * 64 + lane]);
+    f.ah[c] = __builtin_bit_cast(h8, buf[((pp * NMBO + mbo0 + c) * 2 + 0) * 64 + lane]);
+    f.al[c] = __builtin_bit_cast(h8, buf[((pp * NMBO + mbo0 + c) * 2 + 1) * 64 + lane]);
   }
+}
+// three passes over 4 independent accumulators (the spacing the f16 MFMA accumulate chain needs)
+__device__ __forceinline__ void lb_quad_mfma(const lb_frag4& f, const h8& bh, const h8& bl, f32x4* acc) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c) acc[c] = MFMA16H(al[c], bh, acc[c]);
+  for (int c = 0; c < 4; ++c) acc[c] = MFMA16H(f.al[c], bh, acc[c]);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) acc[c] = MFMA16H(ah[c], bl, acc[c]);
+  for (int c = 0; c < 4; ++c) acc[c] = MFMA16H(f.ah[c], bl, acc[c]);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) acc[c] = MFMA16H(ah[c], bh, acc[c]);
+  for (int c = 0; c < 4; ++c) acc[c] = MFMA16H(f.ah[c], bh, acc[c]);
+}
+// One LDS chunk = 4 quads.  The fragments of quad i+1 are fetched (8 ds_read_b128) before the 12
+// MFMAs of quad i issue, so LDS latency hides behind the matrix pipe instead of adding to it.
+// GEMM chunk (NMBO = 8): quads (pp 0, blocks 0-3), (pp 0, 4-7), (pp 1, 0-3), (pp 1, 4-7), B operand
+// b0 for pp 0 and b1 for pp 1, n_pp = number of valid k-steps in the chunk.
+__device__ __forceinline__ void lb_chunk_gemm8(const f32x4* __restrict__ buf, int lane, int n_pp,
+                                               const h8& b0h, const h8& b0l, const h8& b1h,
+                                               const h8& b1l, f32x4* acc) {
+  lb_frag4 f0, f1;
+  lb_quad_load<8>(buf, 0, 0, lane, f0);
+  __builtin_amdgcn_sched_barrier(0);
+  lb_quad_load<8>(buf, 0, 4, lane, f1);
+  lb_quad_mfma(f0, b0h, b0l, &acc[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  if (n_pp > 1) lb_quad_load<8>(buf, 1, 0, lane, f0);
+  lb_quad_mfma(f1, b0h, b0l, &acc[4]);
+  __builtin_amdgcn_sched_barrier(0);
+  if (n_pp > 1) {
+    lb_quad_load<8>(buf, 1, 4, lane, f1);
+    lb_quad_mfma(f0, b1h, b1l, &acc[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    lb_quad_mfma(f1, b1h, b1l, &acc[4]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// projection chunk (NMBO = 16, one k-step): quads over blocks 0-3, 4-7, 8-11, 12-15
+__device__ __forceinline__ void lb_chunk_proj16(const f32x4* __restrict__ buf, int lane, const h8& bh,
+                                                const h8& bl, f32x4* acc) {
+  lb_frag4 f0, f1;
+  lb_quad_load<16>(buf, 0, 0, lane, f0);
+  __builtin_amdgcn_sched_barrier(0);
+  lb_quad_load<16>(buf, 0, 4, lane, f1);
+  lb_quad_mfma(f0, bh, bl, &acc[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  lb_quad_load<16>(buf, 0, 8, lane, f0);
+  lb_quad_mfma(f1, bh, bl, &acc[4]);
+  __builtin_amdgcn_sched_barrier(0);
+  lb_quad_load<16>(buf, 0, 12, lane, f1);
+  lb_quad_mfma(f0, bh, bl, &acc[8]);
+  __builtin_amdgcn_sched_barrier(0);
+  lb_quad_mfma(f1, bh, bl, &acc[12]);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -167,19 +213,21 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
   for (int ch = 0; ch < NCH0; ++ch, ++c) {
     if (c + 2 < n_chunks) stage_issue(c + 2);
     const f32x4* buf = sB[c % 3];
+    h8 bh[2], bl[2];
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
       const int p = 2 * ch + pp;
       if (p < NP0) {
-        h8 bh, bl;
         if (p < NPA)
-          lb_split8n(va[2 * (p < NPA ? p : 0)], va[2 * (p < NPA ? p : 0) + 1], bh, bl);
+          lb_split8n(va[2 * (p < NPA ? p : 0)], va[2 * (p < NPA ? p : 0) + 1], bh[pp], bl[pp]);
         else
-          lb_split8n(vb[NPB > 0 ? 2 * (p - NPA) : 0], vb[NPB > 0 ? 2 * (p - NPA) + 1 : 0], bh, bl);
-        lb_mfma_quad<8>(buf, pp, 0, lane, bh, bl, &acc[0]);
-        lb_mfma_quad<8>(buf, pp, 4, lane, bh, bl, &acc[4]);
+          lb_split8n(vb[NPB > 0 ? 2 * (p - NPA) : 0], vb[NPB > 0 ? 2 * (p - NPA) + 1 : 0], bh[pp], bl[pp]);
+      } else {
+        bh[pp] = bh[0];
+        bl[pp] = bl[0];
       }
     }
+    lb_chunk_gemm8(buf, lane, (2 * ch + 1 < NP0) ? 2 : 1, bh[0], bl[0], bh[1], bl[1], acc);
     if (c + 1 < n_chunks) stage_commit(c + 1);
     __syncthreads();
   }
@@ -195,14 +243,10 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
   for (int ch = 0; ch < 2; ++ch, ++c) {
     if (c + 2 < n_chunks) stage_issue(c + 2);
     const f32x4* buf = sB[c % 3];
+    h8 bh[2], bl[2];
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-      const int p = 2 * ch + pp;
-      h8 bh, bl;
-      lb_split8n(acc[2 * p], acc[2 * p + 1], bh, bl);
-      lb_mfma_quad<8>(buf, pp, 0, lane, bh, bl, &acc2[0]);
-      lb_mfma_quad<8>(buf, pp, 4, lane, bh, bl, &acc2[4]);
-    }
+    for (int pp = 0; pp < 2; ++pp) lb_split8n(acc[2 * (2 * ch + pp)], acc[2 * (2 * ch + pp) + 1], bh[pp], bl[pp]);
+    lb_chunk_gemm8(buf, lane, 2, bh[0], bl[0], bh[1], bl[1], acc2);
     if (c + 1 < n_chunks) stage_commit(c + 1);
     __syncthreads();
   }
@@ -248,8 +292,7 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
       const f32x4* buf = sB[c % 3];
       h8 bh, bl;
       lb_split8n(y[2 * p], y[2 * p + 1], bh, bl);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) lb_mfma_quad<16>(buf, 0, 4 * q, lane, bh, bl, &accp[4 * q]);
+      lb_chunk_proj16(buf, lane, bh, bl, accp);
       if (c + 1 < n_chunks) stage_commit(c + 1);
       __syncthreads();
     }
