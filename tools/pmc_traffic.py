@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """profiles/pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
 
-    python tools/pmc_traffic.py <key e.g. tgv3d_b8> <fetch results.db> <write results.db>
+    python tools/pmc_traffic.py <key e.g. tgv3d_b8> <fetch results.db> <write results.db> [out.json]
 
 Per kernel: average FETCH_SIZE / WRITE_SIZE per launch (KB, summed over the counter's instances,
 no-op launches - duration < 20 % of the kernel's median, i.e. the poisoned launches after a
@@ -42,6 +42,7 @@ def per_kernel(db, counter):
 
 def main():
     key, fdb, wdb = sys.argv[1:4]
+    out_path = sys.argv[4] if len(sys.argv) > 4 else None
     f, w = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     tab = json.load(open(path)) if os.path.exists(path) else {}
@@ -51,7 +52,7 @@ def main():
             ent[k[:80]] = {"fetch_kb": round(f[k], 1), "write_kb": round(w.get(k, 0.0), 1),
                            "hbm_bytes_per_launch": int((2 * f[k] + w.get(k, 0.0)) * 1024)}
     tab[key] = ent
-    json.dump(tab, open(path, "w"), indent=1, sort_keys=True)
+    json.dump(tab, open(out_path or path, "w"), indent=1, sort_keys=True)
     for k, v in sorted(ent.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:8]:
         print(f"{k[:60]:60s} fetch {v['fetch_kb']:12.1f} KB  write {v['write_kb']:12.1f} KB  hbm {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB")
 
