@@ -28,7 +28,6 @@
 #define SCAN_THREADS 256
 #define SCAN_CHUNK (SCAN_THREADS * 8)
 #define NL_SMALL_MAXC 1024
-#define NL_TINY_MAXC 384   // 10.5 KiB of LDS per one-wave workgroup: ~15 cells in flight per CU
 
 enum { NL_COUNT = 0, NL_FILL = 1, NL_ROWS = 2 };
 
@@ -381,18 +380,32 @@ __global__ void __launch_bounds__(256)
 }
 
 // ----------------------------------------------------------------------------------- host
+// `small` = staged-candidate capacity of the one-wave variant to use (a multiple of 128 up to
+// NL_SMALL_MAXC), or 0 for the 256-thread / 2048-candidate variant.  The LDS footprint of the
+// staged stencil (28 B per candidate) sets how many cells a CU keeps in flight - the search is
+// latency bound, so the smallest variant that holds cell_capacity * 3^dim candidates is used.
 template <int MODE>
 static void lb_launch_nl(lb_engine* e, int small, const lb_nl_args& a) {
   const int ncell_tot = e->g.B * e->g.ncells;
-  if (small == 2)
-    hipLaunchKernelGGL((k_nl<MODE, 64, NL_TINY_MAXC>), dim3(ncell_tot), dim3(64), 0, e->stream, e->g,
-                       e->BN, e->ctrl, a);
-  else if (small == 1)
-    hipLaunchKernelGGL((k_nl<MODE, 64, NL_SMALL_MAXC>), dim3(ncell_tot), dim3(64), 0, e->stream, e->g,
-                       e->BN, e->ctrl, a);
-  else
-    hipLaunchKernelGGL((k_nl<MODE, 256, LB_MAX_STENCIL_CAND>), dim3(ncell_tot), dim3(256), 0, e->stream,
-                       e->g, e->BN, e->ctrl, a);
+#define LB_NL_CASE(C)                                                                              \
+  case C:                                                                                          \
+    hipLaunchKernelGGL((k_nl<MODE, 64, C>), dim3(ncell_tot), dim3(64), 0, e->stream, e->g, e->BN,  \
+                       e->ctrl, a);                                                                \
+    break;
+  switch (small) {
+    LB_NL_CASE(128)
+    LB_NL_CASE(256)
+    LB_NL_CASE(384)
+    LB_NL_CASE(512)
+    LB_NL_CASE(640)
+    LB_NL_CASE(768)
+    LB_NL_CASE(896)
+    LB_NL_CASE(1024)
+    default:
+      hipLaunchKernelGGL((k_nl<MODE, 256, LB_MAX_STENCIL_CAND>), dim3(ncell_tot), dim3(256), 0,
+                         e->stream, e->g, e->BN, e->ctrl, a);
+  }
+#undef LB_NL_CASE
 }
 
 int lbk_nl_build(lb_engine* e, bool want_efeat64) {
@@ -424,7 +437,8 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   // cell_capacity particles flags overflow anyway); the 256-thread / 2048-candidate variant otherwise
   // (the LDS footprint of the staged stencil sets how many cells a CU keeps in flight)
   const int64_t cand_cap = (int64_t)e->cell_capacity * g.nstencil;
-  const int small = !(frozen && g.use_cell_list) ? 0 : (cand_cap <= NL_TINY_MAXC ? 2 : (cand_cap <= NL_SMALL_MAXC ? 1 : 0));
+  const int small = (frozen && g.use_cell_list && cand_cap <= NL_SMALL_MAXC)
+                        ? (int)std::max<int64_t>(128, (cand_cap + 127) / 128 * 128) : 0;
   const bool rows = frozen && e->maxd > 0 && e->tmp_send && (!want_efeat64 || e->tmp_feat64);
   lb_nl_args a{};
   a.cell_start = e->cell_start;
