@@ -8,12 +8,16 @@
 //   1. k_cell_count / two-level scan / k_cell_fill : counting sort of the particles into cells
 //      (int atomics); k_cell_fill also writes the cell-sorted fp64 positions so that a cell's
 //      particles are one contiguous HBM range.
-//   2. k_nl : one workgroup per cell (one wave when the frozen cell capacity bounds the stencil to
-//      <= 1024 candidates, else 256 threads) stages the particles of its 3^dim stencil (ids + fp64
-//      positions) in LDS once; each wave owns receivers of the cell and sweeps the staged tile 64
-//      candidates at a time.  The cutoff predicate is evaluated in fp64 exactly as the reference
-//      does (metric(pos[sender], pos[receiver]) < r_c^2), reduced with a wavefront ballot +
-//      popcount prefix; the row is compacted into LDS and rank-sorted by sender id.
+//   2. stencil search, two kernels with identical results:
+//      k_nlw (3^3-cell stencils): one WAVE per receiver walks the particles of its stencil cells -
+//        short contiguous runs of the cell-sorted arrays, L2 resident - 64 candidates per sweep
+//        straight from global memory; no staging, 1.3 KiB of LDS per wave, full occupancy;
+//      k_nl (3^2-cell stencils and the all-pairs case): one workgroup per cell stages the stencil's
+//        particles (ids + fp64 positions) in LDS once (in 128-candidate capacity steps: the LDS
+//        footprint sets the occupancy) and each wave sweeps the tile for the receivers of the cell.
+//      In both the cutoff predicate is evaluated in fp64 exactly as the reference does
+//      (metric(pos[sender], pos[receiver]) < r_c^2), reduced with a wavefront ballot + popcount
+//      prefix; the row is compacted into LDS and rank-sorted by sender id with lane broadcasts.
 //        update path (capacities frozen): ONE sweep writes each receiver's sorted row + its edge
 //          features into fixed-stride per-node slots, then a two-level scan of the degrees gives the
 //          CSR offsets and k_nl_compact moves the rows into place (pure streaming copy);
@@ -23,6 +27,8 @@
 // Output: CSR by receiver over the B*N nodes of the batch, senders ascending inside a row, i.e.
 // the edge list sorted by (receiver, sender) - deterministic, and directly consumable by the
 // atomic-free segmented aggregation.
+#include <cstdlib>
+
 #include "lb_device.h"
 
 #define SCAN_THREADS 256
@@ -142,6 +148,7 @@ __global__ void k_cell_fill(lb_geom g, int64_t BN, const double* __restrict__ wi
 
 // -------------------------------------------------------------------------- stencil search
 struct lb_nl_args {
+  const int32_t* cell_of;   // [BN] global cell id of each particle
   const int32_t* cell_start;
   const int32_t* cell_part;
   const double* cpos;       // [dim][BN] positions in cell-sorted order
@@ -319,6 +326,152 @@ __global__ void __launch_bounds__(NL_THREADS)
   }
 }
 
+// One WAVE per receiver, nothing staged: the receiver (slot r of the cell-sorted order) walks the
+// particles of its 3^dim stencil cells - 3^dim short contiguous runs of the cell-sorted arrays, L2
+// resident - 64 candidates per sweep, straight from global memory.  The only LDS is the wave's own
+// row buffer and its 3^dim-entry stencil table (1.3 KiB per wave), so a CU keeps its full
+// complement of waves in flight; the search is latency bound (three dependent memory round trips
+// per receiver), and with one workgroup per CELL the staged stencil (28 B x cell_capacity x 3^dim of
+// LDS) capped the occupancy at a handful of waves per CU.  Same predicate, same operand order.
+#define NLW_WAVES 4
+template <int MODE>
+__global__ void __launch_bounds__(64 * NLW_WAVES)
+    k_nlw(lb_geom g, int64_t BN, lb_ctrl* __restrict__ ctrl, lb_nl_args a) {
+  __shared__ int s_row[NLW_WAVES][LB_MAX_ROW];
+  __shared__ int s_cstart[NLW_WAVES][28], s_coff[NLW_WAVES][29];
+  if (ctrl->overflow_step >= 0) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * NLW_WAVES + wave;  // receiver slot in cell-sorted order
+  if (r >= BN) return;
+  const int gr = a.cell_part[r];
+  const int gc = a.cell_of[gr];
+  const int b = gc / g.ncells, h = gc % g.ncells;
+  {
+    int cnt = 0;
+    if (lane < g.nstencil) {
+      int nh = h;
+      if (g.use_cell_list) {
+        int c[3] = {h % g.ncell[0], (h / g.ncell[0]) % g.ncell[1], h / (g.ncell[0] * g.ncell[1])};
+        int o[3] = {lane % 3 - 1, (lane / 3) % 3 - 1, lane / 9 - 1};
+        nh = 0;
+        int mult = 1;
+        for (int d = 0; d < g.dim; ++d) {
+          int cc = c[d] + o[d];  // jax-md rolls the cell buffer: the stencil always wraps
+          cc = cc < 0 ? cc + g.ncell[d] : (cc >= g.ncell[d] ? cc - g.ncell[d] : cc);
+          nh += cc * mult;
+          mult *= g.ncell[d];
+        }
+      }
+      const int ngc = b * g.ncells + nh;
+      const int st = a.cell_start[ngc];
+      s_cstart[wave][lane] = st;
+      cnt = a.cell_start[ngc + 1] - st;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const int v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    if (lane < g.nstencil) s_coff[wave][lane] = incl - cnt;
+    if (lane == g.nstencil - 1) s_coff[wave][g.nstencil] = incl;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  const int M = s_coff[wave][g.nstencil];
+  double pr[3] = {0, 0, 0};
+  for (int d = 0; d < g.dim; ++d) pr[d] = a.cpos[(int64_t)d * BN + r];
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  auto slot_of = [&](int j) -> int {  // candidate j -> slot in the cell-sorted arrays
+    int lo = 0, hi = g.nstencil;      // largest k with s_coff[k] <= j
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_coff[wave][mid] <= j) lo = mid; else hi = mid;
+    }
+    return s_cstart[wave][lo] + (j - s_coff[wave][lo]);
+  };
+  int count = 0;
+  for (int c0 = 0; c0 < M; c0 += 64) {
+    const int j = c0 + lane;
+    bool ok = false;
+    int src = 0;
+    if (j < M) {
+      src = slot_of(j);
+      // metric_sq(position[sender], position[receiver]): sum of squares in x,y,z order, no FMA
+      double dd = lb_disp1(a.cpos[src], pr[0], g.box[0], g.half_box[0], g.periodic);
+      double d2 = dd * dd;
+      for (int d = 1; d < g.dim; ++d) {
+        dd = lb_disp1(a.cpos[(int64_t)d * BN + src], pr[d], g.box[d], g.half_box[d], g.periodic);
+        d2 = d2 + dd * dd;
+      }
+      ok = d2 < g.rc2;  // strict <
+    }
+    const unsigned long long mask = __ballot(ok);
+    if (MODE != NL_COUNT && ok) {
+      const int pos = count + __popcll(mask & lt_mask);
+      if (pos < LB_MAX_ROW) s_row[wave][pos] = src;
+    }
+    count += __popcll(mask);
+  }
+  if (MODE != NL_FILL && lane == 0) {
+    a.deg[gr] = count;
+    if (count > *(volatile int32_t*)&ctrl->max_deg) atomicMax(&ctrl->max_deg, count);
+  }
+  if (MODE == NL_COUNT) return;
+  if (count > LB_MAX_ROW) {
+    if (lane == 0) atomicExch(&ctrl->density_error, 2);
+    count = LB_MAX_ROW;
+  }
+  if (MODE == NL_ROWS && count > a.maxd) {
+    if (lane == 0) atomicExch(&ctrl->row_overflow, 1);  // per-node slots too small: re-allocate
+    count = a.maxd;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  const int64_t base = (MODE == NL_ROWS) ? (int64_t)gr * a.maxd : (int64_t)a.row_ptr[gr];
+  for (int t0 = 0; t0 < count; t0 += 64) {
+    const int t = t0 + lane;
+    const bool act = t < count;
+    const int src = act ? s_row[wave][t] : 0;
+    const int my = act ? a.cell_part[src] : 0x7fffffff;
+    // rank of this sender id inside the row (ids are unique): lane broadcasts for rows <= 64
+    int rank = 0;
+    if (count <= 64) {
+      for (int u = 0; u < count; ++u) rank += (__builtin_amdgcn_readlane(my, u) < my) ? 1 : 0;
+    } else {
+      for (int u = 0; u < count; ++u) rank += (a.cell_part[s_row[wave][u]] < my) ? 1 : 0;
+    }
+    if (!act) continue;
+    const int64_t slot = base + rank;
+    if (MODE == NL_ROWS || slot < a.e_alloc) {
+      a.senders[slot] = my;
+      // features.py:115-124: disp(pos[receiver], pos[sender]) / r_c and its norm
+      double rd[3] = {0, 0, 0};
+      double s2 = 0.0;
+      for (int d = 0; d < g.dim; ++d) {
+        rd[d] = lb_disp1(pr[d], a.cpos[(int64_t)d * BN + src], g.box[d], g.half_box[d], g.periodic) / g.rc;
+        s2 = (d == 0) ? rd[d] * rd[d] : s2 + rd[d] * rd[d];
+      }
+      const double dist = s2 > 0.0 ? sqrt(s2) : 0.0;
+      const f32x4 lo = (g.dim == 2) ? f32x4{(float)rd[0], (float)rd[1], (float)dist, 0.f}
+                                    : f32x4{(float)rd[0], (float)rd[1], (float)rd[2], (float)dist};
+      if (MODE == NL_ROWS) {
+        reinterpret_cast<f32x4*>(a.efeat)[slot] = lo;
+      } else {
+        a.receivers[slot] = gr;
+        f32x4* ef = reinterpret_cast<f32x4*>(a.efeat + slot * 8);
+        ef[0] = lo;
+        ef[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (a.efeat64) {
+        double* e64 = a.efeat64 + slot * 4;
+        e64[0] = rd[0];
+        e64[1] = rd[1];
+        e64[2] = rd[2];
+        e64[3] = dist;
+      }
+    }
+  }
+}
+
 // NL_ROWS -> CSR: one 16-lane group per node copies its sorted row into place.
 __global__ void __launch_bounds__(256)
     k_nl_compact(int64_t BN, const lb_ctrl* __restrict__ ctrl, const int32_t* __restrict__ deg,
@@ -386,6 +539,15 @@ __global__ void __launch_bounds__(256)
 // latency bound, so the smallest variant that holds cell_capacity * 3^dim candidates is used.
 template <int MODE>
 static void lb_launch_nl(lb_engine* e, int small, const lb_nl_args& a) {
+  // measured (MI355X, B = 8): 3^3-cell stencils favour the wave-per-receiver kernel (TGV3D 0.28 ->
+  // 0.18 ms per step), 3^2-cell stencils the staged per-cell kernel (DAM2D 0.11 vs 0.15 ms)
+  static const char* force = getenv("LB_NL_KERNEL");  // "cell" | "wave": ablation override
+  const bool per_wave = force ? force[0] == 'w' : e->g.nstencil == 27;
+  if (per_wave) {
+    const int nb = (int)((e->BN + NLW_WAVES - 1) / NLW_WAVES);
+    hipLaunchKernelGGL((k_nlw<MODE>), dim3(nb), dim3(64 * NLW_WAVES), 0, e->stream, e->g, e->BN, e->ctrl, a);
+    return;
+  }
   const int ncell_tot = e->g.B * e->g.ncells;
 #define LB_NL_CASE(C)                                                                              \
   case C:                                                                                          \
@@ -441,6 +603,7 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
                         ? (int)std::max<int64_t>(128, (cand_cap + 127) / 128 * 128) : 0;
   const bool rows = frozen && e->maxd > 0 && e->tmp_send && (!want_efeat64 || e->tmp_feat64);
   lb_nl_args a{};
+  a.cell_of = e->cell_of;
   a.cell_start = e->cell_start;
   a.cell_part = e->cell_part;
   a.cpos = e->cpos;
