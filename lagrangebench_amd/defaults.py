@@ -35,7 +35,7 @@ defaults = _wrap({
         "train": {"n_trajs": -1, "metrics_stride": 10, "batch_size": 1, "metrics": ["mse"],
                   "out_type": "none"},
         "infer": {"n_trajs": -1, "metrics_stride": 1, "batch_size": 2, "metrics": ["mse"],
-                  "out_type": "none", "n_extrap_steps": 0},   # defaults.py:136-148 (e_kin/sinkhorn: not built)
+                  "out_type": "none", "n_extrap_steps": 0},   # defaults.py:136-148 (reference default adds e_kin, sinkhorn; sinkhorn is not built)
     },
     "neighbors": {"backend": "jaxmd_vmap", "multiplier": 1.25},  # defaults.py:170-175
 })
