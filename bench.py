@@ -190,11 +190,13 @@ def main():
                 "unit": "TFLOP/s"}
     mfma["frac"] = mfma["achieved"] / mfma["peak"]
     mfma["fp32_equivalent_algorithmic_tflops"] = flop_algo / (us_edge * 1e-6) / 1e12
-    kern = "k_edge16<PROC," + ("f16x2>" if math_mode == "f16x2" else "f32>")
+    three = os.environ.get("LB_EDGE_WAVES", "3") == "3" and fused
+    kern = ("k_edge16n (PROC, f16x2, 3 waves/SIMD)" if (math_mode == "f16x2" and three)
+            else "k_edge16<PROC," + ("f16x2>" if math_mode == "f16x2" else "f32>"))
     if math_mode == "f16x2":
         roof = {"kernel": kern, "bound": "hbm", "achieved": gbs_edge, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs_edge / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("k_edge16<true, true", args.workload, B),
+                "traffic": pmc_traffic("k_edge16n" if three else "k_edge16<true, true", args.workload, B),
                 "us_per_launch": us_edge, "launches": int(n_edge), "bytes_per_launch": edge_bytes, "mfma": mfma}
     else:
         roof = {"kernel": kern, "bound": "mfma", "achieved": mfma["achieved"], "peak": mfma["peak"],
