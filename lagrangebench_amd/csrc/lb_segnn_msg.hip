@@ -197,22 +197,24 @@ struct lb_sg_msg_args {
   int32_t dim;
 };
 
-template <int DBG>
-__global__ void __launch_bounds__(SGM_THREADS, 2) k_sg_msg(lb_sg_msg_args a) {
+// NT = 512: two waves per SIMD with the software pipeline (DBG 0); NT = 768 with DBG 1: three
+// waves per SIMD, no register prefetch (the other two waves hide the latency) - see k_edge16n.
+template <int DBG, int NT>
+__global__ void __launch_bounds__(NT, NT / 256) k_sg_msg(lb_sg_msg_args a) {
   __shared__ f32x4 sW[SGM_IMAGE];
   if (a.ctrl->overflow_step >= 0) return;
   const int tid = threadIdx.x;
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.image);
-    for (int i = tid; i < SGM_IMAGE; i += SGM_THREADS) sW[i] = src[i];
+    for (int i = tid; i < SGM_IMAGE; i += NT) sW[i] = src[i];
   }
   __syncthreads();
   const int E = a.ctrl->n_edges_total;
   const int ntiles = (E + 15) >> 4;
   const int lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
-  const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * SGM_WAVES + wave;
-  const int stride = (gridDim.x >> 3) * SGM_WAVES;
+  const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * (NT / 64) + wave;
+  const int stride = (gridDim.x >> 3) * (NT / 64);
   const int t_lo = (int)(((int64_t)ntiles * xcd) >> 3), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) >> 3);
   int t = t_lo + slot;
   if (t >= t_hi) return;
@@ -588,14 +590,17 @@ int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg,
   static const int dbg = getenv("LB_SGM_DBG") ? atoi(getenv("LB_SGM_DBG")) : 0;
   static const int grid = getenv("LB_SGM_GRID") ? atoi(getenv("LB_SGM_GRID")) : 256;
   a.msg = e->msg;
+  static const int waves = getenv("LB_EDGE_WAVES") ? atoi(getenv("LB_EDGE_WAVES")) : 3;
   if (dbg & 2) {
-    hipLaunchKernelGGL((k_sg_msg<2>), dim3(grid), dim3(SGM_THREADS), 0, e->stream, a);
+    hipLaunchKernelGGL((k_sg_msg<2, 512>), dim3(grid), dim3(512), 0, e->stream, a);
     return lbk_segment_sum(e, e->msg, agg, 128);
   }
-  if (dbg & 1)
-    hipLaunchKernelGGL((k_sg_msg<1>), dim3(grid), dim3(SGM_THREADS), 0, e->stream, a);
+  if (waves == 3)
+    hipLaunchKernelGGL((k_sg_msg<1, 768>), dim3(grid), dim3(768), 0, e->stream, a);
+  else if (dbg & 1)
+    hipLaunchKernelGGL((k_sg_msg<1, 512>), dim3(grid), dim3(512), 0, e->stream, a);
   else
-    hipLaunchKernelGGL((k_sg_msg<0>), dim3(grid), dim3(SGM_THREADS), 0, e->stream, a);
+    hipLaunchKernelGGL((k_sg_msg<0, 512>), dim3(grid), dim3(512), 0, e->stream, a);
   if (finish) {  // consumers other than k_sg_upd want complete rows in agg
     const int nb = (int)((e->BN + 7) / 8);
     hipLaunchKernelGGL(k_sg_agg_finish, dim3(nb), dim3(256), 0, e->stream, e->ctrl, e->BN, e->row_ptr,
