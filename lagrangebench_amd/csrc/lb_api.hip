@@ -269,6 +269,7 @@ extern "C" void lb_engine_destroy(lb_engine* e) {
   if (e->host_flag) (void)hipHostFree(e->host_flag);
   for (int i = 0; i < 4; ++i)
     if (e->step_ev[i]) (void)hipEventDestroy(e->step_ev[i]);
+  if (e->gstream) (void)hipStreamDestroy(e->gstream);
   delete e;
 }
 
@@ -714,18 +715,51 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
   return lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, n_realloc_out);
 }
 
+// One rollout step (neighbor list -> model -> integrator) enqueued on e->stream.
+static int lb_enqueue_step(lb_engine* e, int (*forward)(lb_engine*, void*), void* model,
+                           const double* traj_dev, int32_t T, double* pred_out_dev, int32_t n_steps) {
+  LB_TRY(lbk_nl_build(e, false));
+  LB_TRY(forward(e, model));
+  return lbk_integrate(e, e->acc, 4, nullptr, traj_dev, T, pred_out_dev, n_steps);
+}
+
 int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* model,
                        const double* traj_dev, int32_t T, int32_t n_steps, double* pred_out_dev,
                        int32_t* n_realloc_out) {
   if (T < e->g.isl) return lb_fail(LB_ERR_ARG, "trajectory shorter than input_seq_length");
   if (e->g.force_kind == LB_FORCE_BUFFER)
     return lb_fail(LB_ERR_UNSUPPORTED, "lb_rollout with LB_FORCE_BUFFER: drive the steps from the host");
+  // LB_GRAPH=1: the step (about 50 launches whose arguments do not change between neighbor-list
+  // re-allocations - the step index lives in the device control block) is captured once into a
+  // hipGraph and replayed; pays off when the step is launch-bound (one small trajectory).
+  // Capture needs a non-default stream: the rollout then runs on an engine-owned stream that is
+  // ordered after the caller's stream on entry; lb_rollout is host-synchronous on exit anyway.
+  static const bool want_graph = getenv("LB_GRAPH") && getenv("LB_GRAPH")[0] == '1';
+  const bool use_graph = want_graph && !e->timers_on;
+  hipStream_t user_stream = e->stream;
+  hipGraphExec_t exec = nullptr;
+  struct Restore {
+    lb_engine* e;
+    hipStream_t s;
+    hipGraphExec_t* x;
+    ~Restore() {
+      if (*x) (void)hipGraphExecDestroy(*x);
+      e->stream = s;
+    }
+  } restore{e, user_stream, &exec};
+  if (use_graph) {
+    if (!e->gstream) LB_HIP(hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking));
+    LB_HIP(hipEventRecord(e->step_ev[0], user_stream));
+    LB_HIP(hipStreamWaitEvent(e->gstream, e->step_ev[0], 0));
+    e->stream = e->gstream;
+  }
   int n_realloc = 0;
   LB_TRY(lbk_load_window(e, traj_dev, T, 0, 0));
   if (e->e_cap <= 0) LB_TRY(lb_nl_allocate(e, nullptr, nullptr, nullptr));
   int step = 0;
   const int RA = 3;  // steps the host may run ahead of the device
   while (step < n_steps) {
+    bool warm = false;  // the first step after a (re-)allocation runs uncaptured: lazy buffer growth
     for (int s = step; s < n_steps; ++s) {
       if (s - step >= RA) {
         // throttle: wait for step s-RA to retire, then look at the device-written host flag, so an
@@ -733,9 +767,22 @@ int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* mo
         LB_HIP(hipEventSynchronize(e->step_ev[(s - RA) & 3]));
         if (*(volatile int32_t*)e->host_flag >= 0) break;
       }
-      LB_TRY(lbk_nl_build(e, false));
-      LB_TRY(forward(e, model));
-      LB_TRY(lbk_integrate(e, e->acc, 4, nullptr, traj_dev, T, pred_out_dev, n_steps));
+      if (use_graph && warm && !exec) {
+        hipGraph_t graph = nullptr;
+        LB_HIP(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = lb_enqueue_step(e, forward, model, traj_dev, T, pred_out_dev, n_steps);
+        const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
+        if (rc) return rc;
+        if (ce != hipSuccess) return lb_fail(LB_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) return lb_fail(LB_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+      }
+      if (exec)
+        LB_HIP(hipGraphLaunch(exec, e->stream));
+      else
+        LB_TRY(lb_enqueue_step(e, forward, model, traj_dev, T, pred_out_dev, n_steps));
+      warm = true;
       LB_HIP(hipEventRecord(e->step_ev[s & 3], e->stream));
     }
     LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, e->stream));
@@ -747,6 +794,10 @@ int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* mo
     step = e->ctrl_host->step;
     ++n_realloc;
     if (n_realloc > n_steps + 8) return lb_fail(LB_ERR_STATE, "neighbor list keeps overflowing");
+    if (exec) {  // capacities, buffers and kernel variants may change: capture again
+      (void)hipGraphExecDestroy(exec);
+      exec = nullptr;
+    }
     LB_TRY(lb_nl_allocate(e, nullptr, nullptr, nullptr));
   }
   if (n_realloc_out) *n_realloc_out = n_realloc;

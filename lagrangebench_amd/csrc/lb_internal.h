@@ -82,6 +82,7 @@ struct lb_engine {
   int32_t* host_flag;     // pinned + device-mapped: first overflowing step (-1 = none), written by
   int32_t* host_flag_dev; //   k_row_scan so lb_rollout can stop enqueuing without a stream sync
   hipEvent_t step_ev[4];  // run-ahead throttle of lb_rollout
+  hipStream_t gstream;    // engine-owned stream of the hipGraph rollout (LB_GRAPH=1), lazily created
 
   // neighbor structures
   int32_t cell_capacity, e_cap;      // frozen capacities (0 = not allocated)
