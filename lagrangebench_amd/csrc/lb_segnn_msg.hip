@@ -67,13 +67,7 @@ __device__ __forceinline__ void sg_split8(const f32x4& x0, const f32x4& x1, h8& 
 // an accumulate chain acc = mfma(a, b, acc) whose links are issued with fewer than ~4 independent
 // MFMAs in between intermittently loses a link's contribution (hipcc rotates the accumulator
 // registers, vDst != SrcC, and then under-spaces the dependent v_mfma_f32_16x16x32_f16).  Every
-// pass below therefore walks >= 6 independent accumulators before it touches one again, and the
-// operand registers are kept alive across the group so they are not recycled as destinations.
-#ifdef SGM_KEEPALIVE
-#define SGM_KEEP(x) asm volatile("" ::"v"(x))
-#else
-#define SGM_KEEP(x)
-#endif
+// pass below therefore walks >= 6 independent accumulators before it touches one again.
 
 // One tensor-product block on an operand row X (8 f32x4: s0 s1 x0 x1 y0 y1 z0 z1) with edge
 // attribute a[3]; ws/wt/wv: LDS matrices packed by lb_pack_weight16h (4 / 2 / 2 output blocks),
@@ -110,18 +104,6 @@ __device__ __forceinline__ void sg_operand(const f32x4* __restrict__ ws, const f
     for (int m = 0; m < 4; ++m) S[m] = MFMA16H(sh[m], bh, S[m]);
 #pragma unroll
     for (int m = 0; m < 2; ++m) T[m] = MFMA16H(th[m], bh, T[m]);
-    SGM_KEEP(bh);
-    SGM_KEEP(bl);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      SGM_KEEP(sh[m]);
-      SGM_KEEP(sl[m]);
-    }
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      SGM_KEEP(th[m]);
-      SGM_KEEP(tl[m]);
-    }
     __builtin_amdgcn_sched_barrier(0);
   }
   {
@@ -149,23 +131,6 @@ __device__ __forceinline__ void sg_operand(const f32x4* __restrict__ ws, const f
     SGM_PASS(sh, dl, wh, vl)
     SGM_PASS(sh, dh, wh, vh)
 #undef SGM_PASS
-    SGM_KEEP(dh);
-    SGM_KEEP(dl);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      SGM_KEEP(vh[c]);
-      SGM_KEEP(vl[c]);
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      SGM_KEEP(sh[m]);
-      SGM_KEEP(sl[m]);
-    }
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      SGM_KEEP(wh[m]);
-      SGM_KEEP(wl[m]);
-    }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -193,12 +158,14 @@ struct lb_sg_msg_args {
   const float* image;   // SGM_IMAGE f32x4 of this layer
   float* agg;           // [BN][128]
   float* part;          // [ceil(E/16)][2][128]
-  float* msg;           // debug (DBG & 2): [E][128]
+  float* msg;           // ablation (MODE & 2): [E][128]
   int32_t dim;
 };
 
-// NT = 512: two waves per SIMD with the software pipeline (DBG 0); NT = 768 with DBG 1: three
-// waves per SIMD, no register prefetch (the other two waves hide the latency) - see k_edge16n.
+// Schedules (MODE bit 0 = no register prefetch, bit 1 = ablation: write per-edge messages instead
+// of the fused aggregation):  <1, 768> (default) three waves per SIMD, each wave loads its own tile and
+// the other two hide the latency (see k_edge16n);  <0, 512> two waves per SIMD with a software
+// pipeline inside the wave (LB_EDGE_WAVES=2).
 template <int DBG, int NT>
 __global__ void __launch_bounds__(NT, NT / 256) k_sg_msg(lb_sg_msg_args a) {
   __shared__ f32x4 sW[SGM_IMAGE];
@@ -262,7 +229,7 @@ __global__ void __launch_bounds__(NT, NT / 256) k_sg_msg(lb_sg_msg_args a) {
     }
     f32x4 ef = ef_n;
     int r_cur = r_pref;
-    if (DBG & 1) {  // debug: no pipeline, load this tile synchronously
+    if (DBG & 1) {  // no register prefetch: load this tile now
       const int64_t rc = rowc_of(t);
       const int s0 = a.senders[rc], r0 = a.receivers[rc];
       issue(t, s0, r0);
@@ -337,7 +304,7 @@ __global__ void __launch_bounds__(NT, NT / 256) k_sg_msg(lb_sg_msg_args a) {
     // ---- fused segment_sum over the receiver-sorted list (same scheme as k_edge16's epilogue)
     const int row = t * 16 + n;
     const bool valid = row < E;
-    if (DBG & 2) {  // debug: plain per-edge message rows, reduced by k_segment_sum
+    if (DBG & 2) {  // ablation: plain per-edge message rows, reduced by k_segment_sum
       if (valid) {
         f32x4* mr = reinterpret_cast<f32x4*>(a.msg) + (int64_t)row * 32 + g;
 #pragma unroll
