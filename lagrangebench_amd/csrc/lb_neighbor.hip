@@ -39,10 +39,16 @@ enum { NL_COUNT = 0, NL_FILL = 1, NL_ROWS = 2 };
 
 // ------------------------------------------------------------------------------------ cells
 __global__ void k_cell_count(lb_geom g, int64_t BN, const double* __restrict__ win,
-                             const lb_ctrl* __restrict__ ctrl, int32_t* __restrict__ cell_of,
+                             lb_ctrl* __restrict__ ctrl, int32_t* __restrict__ cell_of,
                              int32_t* __restrict__ cell_count) {
   if (ctrl->overflow_step >= 0) return;
   int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi == 0) {
+    // per-build maxima: only kernels launched AFTER this one (scan, stencil search) write them
+    ctrl->max_cell_occ = 0;
+    ctrl->max_deg = 0;
+    ctrl->row_overflow = 0;
+  }
   if (gi >= BN) return;
   const int step = ctrl->step;
   const int b = (int)(gi / g.N);
@@ -579,9 +585,7 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
 
   lb_tic(e, LB_T_CELLS);
   LB_HIP(hipMemsetAsync(e->cell_count, 0, sizeof(int32_t) * 2 * (size_t)ncell_tot, s));
-  // max_cell_occ, max_deg, row_overflow are rebuilt every pass (adjacent ints in lb_ctrl)
-  LB_HIP(hipMemsetAsync(&e->ctrl->max_cell_occ, 0, sizeof(int32_t), s));
-  LB_HIP(hipMemsetAsync(&e->ctrl->max_deg, 0, 2 * sizeof(int32_t), s));
+  // (max_cell_occ, max_deg, row_overflow are reset by k_cell_count)
   const int nb = (int)((BN + 255) / 256);
   hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, s, g, BN, e->win, e->ctrl, e->cell_of,
                      e->cell_count);
