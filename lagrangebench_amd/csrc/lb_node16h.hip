@@ -20,7 +20,9 @@
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define MFMA16H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
-#define N16_THREADS 512
+#define N16_THREADS 256
+#define N16_WAVES (N16_THREADS / 64)
+#define N16_STG (2048 / N16_THREADS)  // f32x4 staged per thread and chunk
 #define CHUNK_VEC 2048  // f32x4 per chunk (32 KiB)
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -139,7 +141,7 @@ template <int NPA, int NPB, bool RESID, bool PROJ>
 __global__ void __launch_bounds__(N16_THREADS, 2)
     k_node16h(lb_node_args a, const f32x4* __restrict__ w0h, const f32x4* __restrict__ w1h,
               const f32x4* __restrict__ wph) {
-  __shared__ f32x4 sB[3][CHUNK_VEC];
+  __shared__ f32x4 sB[2][CHUNK_VEC];
   __shared__ f32x4 sP[192];  // per-feature vectors, see below
   if (a.ctrl->overflow_step >= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -170,29 +172,37 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
       nvec = CHUNK_VEC;
     }
   };
-  f32x4 stg[2][4];
-  auto stage_issue = [&](int c) {  // chunk c -> staging set c & 1
+  // Two-slot LDS ring, one staging register set: at step c the chunk c+1 (loaded during step c-1)
+  // is committed into the slot chunk c-1 has just released, then the loads of chunk c+2 are issued
+  // into the same registers, then chunk c is consumed; one barrier per step.  Two 4-wave workgroups
+  // share a CU (2 x 67 KiB of LDS), so the prologue / epilogue memory phases of one overlap the
+  // MFMA phase of the other.
+  f32x4 stg[N16_STG];
+  auto stage_issue = [&](int c) {
     const f32x4* src;
     int nvec;
     chunk_src(c, src, nvec);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < N16_STG; ++i) {
       const int idx = tid + i * N16_THREADS;
-      stg[c & 1][i] = src[idx < nvec ? idx : 0];
+      stg[i] = src[idx < nvec ? idx : 0];
     }
   };
-  auto stage_commit = [&](int c) {  // staging set c & 1 -> LDS ring slot c % 3
+  auto stage_commit = [&](int c) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sB[c % 3][tid + i * N16_THREADS] = stg[c & 1][i];
+    for (int i = 0; i < N16_STG; ++i) sB[c & 1][tid + i * N16_THREADS] = stg[i];
+  };
+  auto stage_step = [&](int c) {  // start of step c
+    if (c + 1 < n_chunks) stage_commit(c + 1);
+    if (c + 2 < n_chunks) stage_issue(c + 2);
   };
 
   // ---- this wave's 16 rows
-  const int64_t row = ((int64_t)blockIdx.x * 8 + wave) * 16 + n;
+  const int64_t row = ((int64_t)blockIdx.x * N16_WAVES + wave) * 16 + n;
   const bool valid = row < a.n_rows;
   const int64_t rowc = valid ? row : a.n_rows - 1;
 
   stage_issue(0);
-  if (n_chunks > 1) stage_issue(1);
   f32x4 va[2 * NPA];
   {
     const f32x4* xr = reinterpret_cast<const f32x4*>(a.xin) + rowc * (8 * NPA) + g;
@@ -202,6 +212,7 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
   f32x4 vb[NPB > 0 ? 8 : 1];
   if constexpr (NPB > 0) lb_load_agg16(a, rowc, g, vb);
   stage_commit(0);
+  if (n_chunks > 1) stage_issue(1);
   __syncthreads();
 
   int c = 0;
@@ -211,8 +222,8 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
   // ---- GEMM1 over [input A | aggregated messages]
 #pragma unroll
   for (int ch = 0; ch < NCH0; ++ch, ++c) {
-    if (c + 2 < n_chunks) stage_issue(c + 2);
-    const f32x4* buf = sB[c % 3];
+    stage_step(c);
+    const f32x4* buf = sB[c & 1];
     h8 bh[2], bl[2];
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
@@ -228,7 +239,6 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
       }
     }
     lb_chunk_gemm8(buf, lane, (2 * ch + 1 < NP0) ? 2 : 1, bh[0], bl[0], bh[1], bl[1], acc);
-    if (c + 1 < n_chunks) stage_commit(c + 1);
     __syncthreads();
   }
 #pragma unroll
@@ -241,13 +251,12 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
   for (int mb = 0; mb < 8; ++mb) acc2[mb] = sP[32 + 4 * mb + g];
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch, ++c) {
-    if (c + 2 < n_chunks) stage_issue(c + 2);
-    const f32x4* buf = sB[c % 3];
+    stage_step(c);
+    const f32x4* buf = sB[c & 1];
     h8 bh[2], bl[2];
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) lb_split8n(acc[2 * (2 * ch + pp)], acc[2 * (2 * ch + pp) + 1], bh[pp], bl[pp]);
     lb_chunk_gemm8(buf, lane, 2, bh[0], bl[0], bh[1], bl[1], acc2);
-    if (c + 1 < n_chunks) stage_commit(c + 1);
     __syncthreads();
   }
   // ---- LayerNorm (+ residual)
@@ -288,12 +297,11 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
     for (int mb = 0; mb < 16; ++mb) accp[mb] = sP[128 + 4 * mb + g];
 #pragma unroll
     for (int p = 0; p < 4; ++p, ++c) {
-      if (c + 2 < n_chunks) stage_issue(c + 2);
-      const f32x4* buf = sB[c % 3];
+      stage_step(c);
+      const f32x4* buf = sB[c & 1];
       h8 bh, bl;
       lb_split8n(y[2 * p], y[2 * p + 1], bh, bl);
       lb_chunk_proj16(buf, lane, bh, bl, accp);
-      if (c + 1 < n_chunks) stage_commit(c + 1);
       __syncthreads();
     }
     if (valid) {
@@ -306,7 +314,7 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
 
 int lbk_node16h(lb_engine* e, const lb_node_args& a, const float* w0h, const float* w1h,
                 const float* wph, int npa, int npb, bool resid) {
-  const int nblk = (int)((a.n_rows + 127) / 128);
+  const int nblk = (int)((a.n_rows + 16 * N16_WAVES - 1) / (16 * N16_WAVES));
   const f32x4* w0 = reinterpret_cast<const f32x4*>(w0h);
   const f32x4* w1 = reinterpret_cast<const f32x4*>(w1h);
   const f32x4* wp = reinterpret_cast<const f32x4*>(wph);
