@@ -214,7 +214,8 @@ def segnn_apply(p, features, particle_type, n_vels: int, homogeneous: bool, retu
     node, node_attr, edge_attr, msg, senders, receivers, dim = segnn_transform(
         features, particle_type, n_vels, homogeneous)
     n = node.s.shape[0]
-    B, L = p["blocks"], p["layers"]
+    B = p["blocks"] if "blocks" in p else sum(1 for k in p if k.startswith("readout_"))
+    L = p["layers"] if "layers" in p else sum(1 for k in p if k.endswith("/message_0"))
     f = o3_tensor_product(p["embedding_nodes"], [node], node_attr)
     lat = [f]
     for k in range(L):

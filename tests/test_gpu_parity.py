@@ -510,3 +510,55 @@ def test_runner_infer_end_to_end(tmp_path):
     r0 = pickle.load(open(tmp_path / "rollout" / "rollout_0.pkl", "rb"))
     assert r0["predicted_rollout"].shape == (16, 3, 3) and r0["ground_truth_rollout"].shape == (16, 3, 3)
     assert np.array_equal(r0["predicted_rollout"][:6], r0["ground_truth_rollout"][:6].astype(np.float64))
+
+
+# ------------------------------------------------------------------ odd shapes
+@pytest.mark.parametrize("name,scale,isl,B,L", [("small2d", 1.0, 2, 3, 1), ("small3d", 1.0, 3, 1, 2),
+                                               ("rpf2d", 0.37, 2, 3, 2), ("dam2d", 0.23, 4, 2, 1)])
+def test_odd_shapes_gns_and_segnn(name, scale, isl, B, L):
+    """input_seq_length 2..4 (a single velocity), batch sizes that are not powers of two, particle
+    counts that are not multiples of a tile, one message-passing layer: forward parity of both
+    models and a 3-step device rollout against the oracle."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS, SEGNN, node_irreps
+    from oracle import segnn_oracle as S
+    ds = make_case(name, n_trajs=B, extra_seq_length=4, input_seq_length=isl, scale=scale)
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    dim = len(ds.box)
+    pos = np.stack([ds[i][0] for i in range(B)])
+    pt = np.stack([ds[i][1] for i in range(B)])
+    feats, nbrs = hcase.allocate_eval((pos[:, :, :isl], pt))
+    # GNS
+    params = make_params(ds, num_mp_steps=L, decoder_scale=1.0)
+    gns = GNS(dim, 128, 2, L, 16)
+    acc = _np(gns.apply(params, {}, (feats, pt))[0]["acc"])
+    # SEGNN
+    homog = bool(np.all(pt == 0))
+    irr = node_irreps(ds.metadata, isl, ds.external_force_fn is not None, False, homog)
+    seg = SEGNN(irr, "1x1o+1x0e", 64, 1, 1, "1x1o", num_mp_steps=L, n_vels=isl - 1, homogeneous_particles=homog)
+    sp = seg.init_params(11)
+    sh = seg.handle(feats.engine, sp)
+    stap = sh.set_tap(True)
+    acc_s = _np(seg.apply(sp, {}, (feats, pt))[0]["acc"])
+    stap = _np(stap)
+    N = pos.shape[1]
+    for b in range(B):
+        of, on = ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))
+        ref = O.gns_apply(params, of, pt[b], num_mp_steps=L, skip_padding=True)["acc"]
+        assert rel_err(acc[b], ref) < 1e-5
+        ref_s, lat = S.segnn_apply(sp, of, pt[b], isl - 1, homog, return_latents=True)
+        for k, f in enumerate(lat):
+            want = np.concatenate([f.s, f.v[:, :, 0], f.v[:, :, 1], f.v[:, :, 2]], axis=1)
+            assert rel_err(stap[k][b * N:(b + 1) * N], want) < 1e-5
+        # with a single input velocity and default-init weights the output nearly cancels (1e-4 of the
+        # hidden magnitude): bound the error by the scale of what is being summed
+        hid = float(np.abs(lat[-1].s).max())
+        assert np.abs(acc_s[b] - ref_s["acc"]).max() < 1e-5 * max(hid, float(np.abs(ref_s["acc"]).max()))
+    # short rollout of the GNS through the device loop
+    from lagrangebench_amd.evaluate import infer
+    p2 = make_params(ds, num_mp_steps=L)
+    out = infer(gns, hcase, ds, params=p2, cfg_eval_infer={"batch_size": B, "metrics": ["mse"]}, n_rollout_steps=3)
+    preds_o, metrics_o = _oracle_rollout(ds, p2, L, 3, list(range(B)))
+    for b in range(B):
+        assert np.allclose(_np(out[f"rollout_{b}"]["mse"]), metrics_o[b]["mse"], rtol=1e-3, atol=1e-12)
