@@ -157,6 +157,30 @@ def test_segnn_forward_parity(name, scale, L, mag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("blocks", [1, 3])
+def test_segnn_other_block_depths(blocks):
+    """blocks_per_step != 2 (configs use 2) runs through the per-block kernel instead of the fused
+    message / update kernels."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import SEGNN, node_irreps
+    ds = make_case("small3d", n_trajs=1, extra_seq_length=2)
+    ds.magnitude_features = True
+    isl = ds.input_seq_length
+    irr = node_irreps(ds.metadata, isl, False, True, True)
+    model = SEGNN(irr, "1x1o+1x0e", 64, 1, 1, "1x1o", num_mp_steps=2, n_vels=isl - 1, blocks_per_step=blocks)
+    params = S.segnn_init(np.random.default_rng(3), node_ns=model._node_ns, node_nv=model._node_nv,
+                          num_mp_steps=2, blocks_per_step=blocks, random_bias=True)
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    pos, pt = ds[0]
+    feats, _ = hcase.allocate_eval((pos[:, :isl], pt))
+    acc = _np(model.apply(params, {}, (feats, pt))[0]["acc"])
+    of, _ = ocase.allocate_eval((pos[:, :isl].astype(np.float64), pt))
+    ref = S.segnn_apply(params, of, pt, isl - 1, True)["acc"]
+    assert rel_err(acc, ref) < 1e-5
+
+
+@pytest.mark.gpu
 def test_segnn_forward_is_bitwise_deterministic():
     """No atomics, fixed summation order: repeated forwards must agree bit for bit.  (Also the
     regression test for the MFMA accumulate-chain spacing issue described in DESIGN.md: it showed up
