@@ -29,6 +29,7 @@ from ..models.gns import GNS
 from ..models.segnn import SEGNN
 from ..utils import broadcast_from_batch, broadcast_to_batch, get_kinematic_mask
 from .metrics import MetricsComputer, MetricsDict
+from .utils import write_vtk
 
 
 def _forward_eval(params, state, sample, current_positions, target_positions, model_apply: Callable,
@@ -125,8 +126,6 @@ def eval_rollout(model_apply: Callable, case, params, state, loader_eval: Iterab
     eval_metrics = {}
     if rollout_dir is not None:
         os.makedirs(rollout_dir, exist_ok=True)
-    if out_type == "vtk":
-        raise NotImplementedError("out_type='vtk' (pyvista writer, evaluate/utils.py) is out of scope; use 'pkl'")
 
     forward_eval = partial(_forward_eval, model_apply=model_apply, case_integrate=case.integrate)
     gns = _gns_of(model_apply)
@@ -150,15 +149,22 @@ def eval_rollout(model_apply: Callable, case, params, state, loader_eval: Iterab
         for j in range(current_batch_size):
             ind = i * batch_size + j
             eval_metrics[f"rollout_{ind}"] = broadcast_from_batch(metrics_batch, j)
-        if rollout_dir is not None and out_type == "pkl":
+        if rollout_dir is not None and out_type in ("pkl", "vtk"):
             pos_np = np.asarray(traj_batch_i[0])
             for j in range(current_batch_size):
                 pos_input = np.transpose(pos_np[j], (1, 0, 2))
                 example_full = np.concatenate([pos_input[:t_window], example_rollout_batch[j].cpu().numpy()])
                 example = {"predicted_rollout": example_full, "ground_truth_rollout": pos_input,
                            "particle_type": np.asarray(traj_batch_i[1][j])}
-                with open(os.path.join(rollout_dir, f"rollout_{i * batch_size + j}.pkl"), "wb") as f:
-                    pickle.dump(example, f)
+                file_prefix = os.path.join(rollout_dir, f"rollout_{i * batch_size + j}")
+                if out_type == "vtk":  # one file per time step, rollout.py:278-292
+                    for k in range(example_full.shape[0]):
+                        write_vtk({"r": example_full[k], "tag": example["particle_type"]}, f"{file_prefix}_{k}.vtk")
+                    for k in range(pos_input.shape[0]):
+                        write_vtk({"r": pos_input[k], "tag": example["particle_type"]}, f"{file_prefix}_ref_{k}.vtk")
+                else:
+                    with open(f"{file_prefix}.pkl", "wb") as f:
+                        pickle.dump(example, f)
         if (i * batch_size + j + 1) >= n_trajs:
             break
 

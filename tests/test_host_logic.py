@@ -91,3 +91,22 @@ def test_pack_weight_layout():
     assert sorted(out.tolist()) == sorted(W.ravel().tolist())  # a permutation: nothing dropped
     # lane 37 (row 5, upper half), kq=1, mb=1, j=2 -> k = 8+4+2 = 14, m = 32+5
     assert out[((1 * NMB + 1) * 64 + 37) * 4 + 2] == W[14, 37]
+
+
+def test_write_vtk_and_pkl2vtk(tmp_path):
+    """evaluate/utils.py:9-77 - legacy VTK polydata per frame (ASCII fallback without pyvista)."""
+    import pickle
+    from lagrangebench_amd.evaluate import pkl2vtk, write_vtk
+    rng = np.random.default_rng(0)
+    r = rng.random((7, 2))
+    write_vtk({"r": r, "tag": np.arange(7, dtype=np.int32), "v": rng.random((7, 2))}, str(tmp_path / "a.vtk"))
+    txt = (tmp_path / "a.vtk").read_bytes()
+    assert txt.startswith(b"# vtk DataFile") and b"POINTS 7" in txt
+    roll = {"predicted_rollout": rng.random((3, 7, 3)), "ground_truth_rollout": rng.random((3, 7, 3)),
+            "particle_type": np.zeros(7, np.int32)}
+    with open(tmp_path / "rollout_0.pkl", "wb") as f:
+        pickle.dump(roll, f)
+    pkl2vtk(str(tmp_path / "rollout_0.pkl"), str(tmp_path / "vtk"))
+    names = sorted(p.name for p in (tmp_path / "vtk").iterdir())
+    assert names == ["rollout_0_0.vtk", "rollout_0_1.vtk", "rollout_0_2.vtk",
+                     "rollout_0_ref_0.vtk", "rollout_0_ref_1.vtk", "rollout_0_ref_2.vtk"]
