@@ -562,3 +562,30 @@ def test_odd_shapes_gns_and_segnn(name, scale, isl, B, L):
     preds_o, metrics_o = _oracle_rollout(ds, p2, L, 3, list(range(B)))
     for b in range(B):
         assert np.allclose(_np(out[f"rollout_{b}"]["mse"]), metrics_o[b]["mse"], rtol=1e-3, atol=1e-12)
+
+
+def test_rpf2d_400_step_rollout_properties():
+    """BASELINE.json configs[1] (RPF2D GNS-10-128, 400-step rollout) at full size: the rollout runs
+    through several neighbor-list re-allocations, stays finite and inside the periodic box, and a
+    repeat that STARTS from the capacities the first run ended with (a different re-allocation
+    history) gives bit-identical positions - results do not depend on the capacity history."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    ds = make_case("rpf2d", n_trajs=2, extra_seq_length=400)
+    model = GNS(2, 128, 2, 10, 16)
+    params = make_params(ds, num_mp_steps=10, random_affine=False)
+    hcase = hip_case(ds)
+    pos = np.stack([ds[0][0], ds[1][0]])
+    pt = np.stack([ds[0][1], ds[1][1]])
+    eng = hcase.engine(2)
+    eng.set_particle_type(pt)
+    traj = eng.prepare_traj(pos)
+    handle = model.handle(eng, params)
+    pred, n_realloc = eng.rollout(handle, traj, 400)
+    p = _np(pred)
+    assert p.shape == (2, 400, pos.shape[1], 2) and np.isfinite(p).all()
+    assert (p >= 0).all() and (p[..., 0] <= ds.box[0]).all() and (p[..., 1] <= ds.box[1]).all()
+    assert n_realloc >= 1
+    pred2, n2 = eng.rollout(handle, traj, 400)
+    assert n2 < n_realloc and np.array_equal(p, _np(pred2))
