@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--model", default="gns", choices=["gns", "segnn"],
                     help="gns: BASELINE.json's headline config; segnn: configs[4] (SEGNN-10-64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shuffle", action="store_true",
+                    help="randomly permute the particle ids (memory-locality ablation; default: lattice order)")
     ap.add_argument("--cpu-steps", type=int, default=5)
     args = ap.parse_args()
 
@@ -123,6 +125,9 @@ def main():
     pos = np.stack([ds[i][0] for i in mine])
     pt = np.stack([ds[i][1] for i in mine])
     N = pos.shape[1]
+    if args.shuffle:  # particle order of real SPH output is not lattice order: same physics, random ids
+        perm = np.random.default_rng(7).permutation(N)
+        pos, pt = pos[:, perm], pt[:, perm]
     eng = case.engine(B)
     eng.set_particle_type(pt)
     traj = eng.prepare_traj(pos)  # fp64, resident in HBM
