@@ -589,3 +589,42 @@ def test_rpf2d_400_step_rollout_properties():
     assert n_realloc >= 1
     pred2, n2 = eng.rollout(handle, traj, 400)
     assert n2 < n_realloc and np.array_equal(p, _np(pred2))
+
+
+def test_full_size_ldc3d_properties():
+    """BASELINE.json configs[3] (LDC3D, ~8.1k particles, wall + moving-lid particle types) at full size: edge-list invariants, determinism, batch consistency, and kinematic
+    particles (wall, lid) following the ground truth bit for bit during a device rollout."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    n_steps, L = 6, 10
+    ds = make_case("ldc3d", n_trajs=2, extra_seq_length=n_steps)
+    hcase = hip_case(ds)
+    isl = ds.input_seq_length
+    pos = np.stack([ds[0][0], ds[1][0]])
+    pt = np.stack([ds[0][1], ds[1][1]])
+    N = pos.shape[1]
+    feats, nbrs = hcase.allocate_eval((pos[:1, :, :isl], pt[:1]))
+    idx = _np(nbrs.idx)[0]
+    ne = int(_np(nbrs.n_edges).ravel()[0])
+    r, s = idx[0, :ne].astype(np.int64), idx[1, :ne].astype(np.int64)
+    key = r * N + s
+    assert (np.diff(key) > 0).all() and np.array_equal(np.sort(s * N + r), key)
+    assert np.isin(np.arange(N) * (N + 1), key).all() and (idx[:, ne:] == N).all()
+
+    params = make_params(ds, num_mp_steps=L)
+    model = GNS(3, 128, 2, L, 16)
+    e2 = hcase.engine(2)
+    e2.set_particle_type(pt)
+    a, _ = e2.rollout(model.handle(e2, params), pos.astype(np.float64), n_steps)
+    b, _ = e2.rollout(model.handle(e2, params), pos.astype(np.float64), n_steps)
+    a, b = _np(a), _np(b)
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+    e1 = hcase.engine(1)
+    e1.set_particle_type(pt[:1])
+    solo, _ = e1.rollout(model.handle(e1, params), pos[:1].astype(np.float64), n_steps)
+    assert np.array_equal(_np(solo)[0], a[0])
+    kin = (pt[0] == 1) | (pt[0] == 2)
+    assert kin.any() and (~kin).any()
+    truth = np.transpose(pos[0][:, isl:isl + n_steps], (1, 0, 2)).astype(np.float64)
+    assert np.array_equal(a[0][:, kin], truth[:, kin])
