@@ -187,13 +187,19 @@ def _force_spec(external_force_fn, bounds=None) -> Optional[ForceSpec]:
     if callable(external_force_fn):
         # the reference's convention: fn(single position (dim,)) -> (dim,) (features.py:105-107 vmaps
         # it).  The published force.py files are piecewise constant: compile to a device ForceSpec.
+        # Anything else is evaluated on the host per particle - never handed to the batched slot
+        # as is: a function like where(r[1] > 1, ...) would index ROW 1 of an (n, dim) tensor.
+        if getattr(external_force_fn, "_lb_batched", False):  # opt-in: fn((n, dim) tensor) -> (n, dim)
+            return ForceSpec.callable(external_force_fn)
         if bounds is not None:
             from ..data.data import force_spec_from_callable
             try:
                 return force_spec_from_callable(external_force_fn, bounds)
-            except Exception:
-                pass
-        return ForceSpec.callable(external_force_fn)
+            except Exception as exc:  # the probe itself failed: keep the reference semantics, slowly
+                warnings.warn(f"external_force_fn could not be compiled to a device ForceSpec ({exc!r}); "
+                              "evaluating it per particle on the host")
+        from ..data.data import per_particle_host_force
+        return ForceSpec.callable(per_particle_host_force(external_force_fn))
     raise TypeError("external_force_fn must be None, a ForceSpec, a dict or a callable")
 
 

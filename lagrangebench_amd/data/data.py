@@ -66,6 +66,17 @@ def _load_force_fn(path: str) -> Callable:
             sys.modules.pop(k, None)
 
 
+def per_particle_host_force(fn: Callable):
+    """vmap(external_force_fn) of features.py:105-107 for a reference-convention function
+    ``fn(position (dim,)) -> (dim,)``, evaluated row by row on the host."""
+    def host_fn(pos):  # (n, dim) torch tensor -> (n, dim)
+        import torch
+        p = pos.detach().cpu().numpy()
+        return torch.from_numpy(np.stack([np.asarray(fn(r), dtype=np.float64) for r in p]))
+    host_fn._lb_batched = True
+    return host_fn
+
+
 def force_spec_from_callable(fn: Callable, bounds, n_probe: int = 64):
     """Compile a single-position force function into a ForceSpec by probing it on a grid:
     constant -> ForceSpec.constant; one switch along one axis -> ForceSpec.piecewise; otherwise a
@@ -106,11 +117,7 @@ def force_spec_from_callable(fn: Callable, bounds, n_probe: int = 64):
     if split_axis is not None and split_axis >= 0:
         return ForceSpec.piecewise(split_axis, split_at, f_lo, f_hi)
 
-    def host_fn(pos):  # (n, dim) torch tensor -> (n, dim)
-        import torch
-        p = pos.detach().cpu().numpy()
-        return torch.from_numpy(np.stack([np.asarray(fn(r), dtype=np.float64) for r in p]))
-    return ForceSpec.callable(host_fn)
+    return ForceSpec.callable(per_particle_host_force(fn))
 
 
 class H5Dataset:
@@ -171,6 +178,18 @@ class H5Dataset:
         if self._db is None:
             self._db = h5.open_file(self.file_path)
         return self._db
+
+    def close(self):
+        """Release the HDF5 handles (the reference relies on h5py's garbage collection)."""
+        if self._db is not None:
+            self._db.close()
+            self._db = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def get_trajectory(self, idx: int):
         """data.py:199-225."""

@@ -156,7 +156,7 @@ class File:
         self._id = self._lib.H5Fopen(path.encode(), 0, 0)
         if self._id < 0:
             raise FileNotFoundError(path)
-        self._open: List[Dataset] = []
+        self._open: dict = {}  # path -> Dataset: one HDF5 dataset id per path for the file's lifetime
 
     def keys(self) -> List[str]:
         info = _GInfo()
@@ -171,14 +171,15 @@ class File:
         return out
 
     def __getitem__(self, path: str) -> Dataset:
-        d = Dataset(self, path)
-        self._open.append(d)
+        d = self._open.get(path)
+        if d is None:
+            d = self._open[path] = Dataset(self, path)
         return d
 
     def close(self):
-        for d in self._open:
+        for d in self._open.values():
             d.close()
-        self._open = []
+        self._open = {}
         if self._id >= 0:
             self._lib.H5Fclose(self._id)
             self._id = -1

@@ -74,15 +74,20 @@ class MetricsComputer:
 
 
 def averaged_metrics(eval_metrics: MetricsDict) -> Dict[str, float]:
-    """metrics.py:233-252: average over steps then trajectories; mse -> "val/loss"."""
-    small = defaultdict(lambda: 0.0)
+    """metrics.py:233-252: per rollout the mean of every metric is appended to a list per key
+    (``mse``/``mae`` both land in ``loss``, ``e_kin`` contributes its ``mse``); the result holds the
+    mean ``val/{k}`` and the standard deviation ``val/std{k}`` of each list."""
+    trajectory_averages = defaultdict(list)
     for rollout in eval_metrics.values():
-        for k, m in rollout.items():
-            if k in ["e_kin"]:
-                k = "e_kin"
-                m = m["mse"]
+        for k, v in rollout.items():
+            if k == "e_kin":
+                v = v["mse"]
             if k in ["mse", "mae"]:
                 k = "loss"
-            small[f"val/{k}"] += float(torch.as_tensor(m).double().mean())
-    n = max(len(eval_metrics), 1)
-    return {k: v / n for k, v in small.items()}
+            trajectory_averages[k].append(float(torch.as_tensor(v).double().mean()))
+    small_metrics = {}
+    for k, v in trajectory_averages.items():
+        small_metrics[f"val/{k}"] = float(np.mean(v))
+    for k, v in trajectory_averages.items():
+        small_metrics[f"val/std{k}"] = float(np.std(v))
+    return small_metrics

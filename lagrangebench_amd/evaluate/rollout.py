@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 from ..case_setup.features import FeatureDict, NeighborList
+from .._lib import LB_FORCE_BUFFER
 from ..defaults import defaults, merge
 from ..models.gns import GNS
 from ..models.segnn import SEGNN
@@ -77,6 +78,10 @@ def _eval_batched_rollout(forward_eval_vmap: Callable, preprocess_eval_vmap: Cal
     target_positions_batch = traj[:, :, t_window:t_window + traj_len]
 
     gns = getattr(forward_eval_vmap, "_lb_gns", None)
+    if gns is not None and eng.force is not None and eng.force.kind == LB_FORCE_BUFFER:
+        # a host-evaluated external_force_fn (features.py:105-107 with an arbitrary callable) has to
+        # be refreshed between steps: lb_rollout cannot call back into Python, drive the loop here
+        gns = None
     if gns is not None:
         # ---- fused path: lb_rollout ---------------------------------------------------
         eng.set_particle_type(ptype)

@@ -33,14 +33,20 @@ def _mlp(p, name, x, bps):
 
 
 @torch.no_grad()
-def gns_apply(params_t, features, particle_type, num_mp_steps=10, blocks_per_step=2):
+def gns_apply(params_t, features, particle_type, num_mp_steps=10, blocks_per_step=2,
+              skip_padding=False, return_intermediates=False):
     """GNS.__call__ in the reference's padded shape (padding id N gathers node N-1, is dropped by
-    the scatter-add)."""
+    the scatter-add).  ``skip_padding`` evaluates the real edges only (same node outputs);
+    ``return_intermediates`` also returns the node latents after the encoder and every layer
+    (same keys as lb_oracle.gns_apply), used by the full-size parity tests."""
     nodes, edges = O.gns_transform(features)
     nodes, edges = torch.from_numpy(nodes), torch.from_numpy(edges)
     n = nodes.shape[0]
     senders = torch.from_numpy(np.asarray(features["senders"]).astype(np.int64))
     receivers = torch.from_numpy(np.asarray(features["receivers"]).astype(np.int64))
+    if skip_padding:
+        keep = receivers < n
+        senders, receivers, edges = senders[keep], receivers[keep], edges[keep]
     if "embed" in params_t:
         pt = torch.from_numpy(np.where(particle_type < 0, particle_type + O.NodeType.SIZE, particle_type).astype(np.int64))
         nodes = torch.cat([nodes, params_t["embed"]["embeddings"][pt]], dim=-1)
@@ -48,6 +54,7 @@ def gns_apply(params_t, features, particle_type, num_mp_steps=10, blocks_per_ste
     el = _mlp(params_t, "enc_edge", edges, blocks_per_step)
     sc, rc = senders.clamp(max=n - 1), receivers.clamp(max=n - 1)
     real = receivers < n
+    inter = {"enc_n": nl.numpy().copy()} if return_intermediates else None
     for k in range(num_mp_steps):
         ein = torch.cat([nl[sc], nl[rc], el], dim=-1)
         e2 = _mlp(params_t, f"proc{k}_edge", ein, blocks_per_step)
@@ -56,5 +63,9 @@ def gns_apply(params_t, features, particle_type, num_mp_steps=10, blocks_per_ste
         n2 = _mlp(params_t, f"proc{k}_node", torch.cat([nl, agg[:n]], dim=-1), blocks_per_step)
         nl = n2 + nl
         el = e2 + el
+        if return_intermediates:
+            inter[f"n{k}"] = nl.numpy().copy()
     acc = _mlp(params_t, "decoder", nl, blocks_per_step)
+    if return_intermediates:
+        return {"acc": acc.numpy()}, inter
     return {"acc": acc.numpy()}

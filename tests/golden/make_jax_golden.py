@@ -1,0 +1,153 @@
+"""Pin the NETWORK layer of the oracle to the real reference: run lagrangebench (JAX / Haiku / jraph /
+e3nn-jax / jax-md) once and dump inputs, weights and outputs as small .npz fixtures.
+
+    python tests/golden/make_jax_golden.py [--ref /root/reference] [--out tests/golden]
+
+Needs an environment in which the reference imports (jax, jaxlib, dm-haiku, jraph, jax-sph,
+e3nn-jax, omegaconf - the pins of the reference's pyproject.toml).  None of them is installable in
+the build container (no network, no wheels), so the fixtures `jax_gns_*.npz` / `jax_segnn_*.npz` do
+not exist yet and the network layer of the oracle is "parity unpinned" (DESIGN.md section 2).  The
+moment someone runs this script on a machine with JAX and commits the .npz files,
+`tests/test_jax_golden.py` picks them up: the CPU oracle is checked against them in the
+`-m "not gpu"` suite and the HIP engine in the `-m gpu` suite.  Only DATA is written (positions,
+weights, outputs); no reference source is copied.
+
+What is dumped per case (all through the reference's public API, cited by file:line):
+  * a seeded particle cloud (N, T, dim) f32 + particle types + the metadata dict (JSON)
+  * case_builder(...) -> allocate_eval -> features dict + neighbors.idx (case_setup/case.py:62-269)
+  * hk.transform_with_state(GNS / SEGNN) params flattened as "<module>//<leaf>" -> array
+    (models/gns.py:35-171, models/segnn.py:403-610, runner.py:192-292)
+  * model.apply(params, state, (features, particle_type)) -> "acc"
+  * case.integrate(pred, positions) -> next position (case.py:230-259)
+  * a 5-step _eval_batched_rollout prediction (evaluate/rollout.py:78-178)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _cloud(n_side, dim, dx, isl, n_extra, seed, pbc=True):
+    """Jittered lattice advected by a smooth field: the same construction as
+    lagrangebench_amd/data/synthetic.py (small2d / small3d), kept independent of the product code."""
+    rng = np.random.default_rng(seed)
+    g = np.stack(np.meshgrid(*[np.arange(n_side)] * dim, indexing="ij"), -1).reshape(-1, dim)
+    box = np.full(dim, n_side * dx)
+    p = np.mod((g + 0.5) * dx + rng.normal(0, 0.1 * dx, g.shape), box)
+    T = isl + n_extra
+    out = np.empty((len(p), T, dim), np.float32)
+    k = 2 * np.pi / box[0]
+    for t in range(T):
+        out[:, t] = p
+        u = np.zeros_like(p)
+        u[:, 0] = np.sin(k * p[:, 0]) * np.cos(k * p[:, 1])
+        u[:, 1] = -np.cos(k * p[:, 0]) * np.sin(k * p[:, 1])
+        p = np.mod(p + 0.3 * dx * u + rng.normal(0, 0.01 * dx, p.shape), box)
+    return out, box
+
+
+def _metadata(dim, n, box, dx, rc, T):
+    return {"case": "golden", "dim": dim, "dx": dx, "dt": 1.0, "write_every": 1, "num_particles_max": n,
+            "periodic_boundary_conditions": [True] * dim, "bounds": [[0.0, float(b)] for b in box],
+            "default_connectivity_radius": rc, "sequence_length_train": T, "sequence_length_test": T,
+            "vel_mean": [0.0] * dim, "vel_std": [0.3 * dx] * dim, "acc_mean": [0.0] * dim,
+            "acc_std": [0.04 * dx] * dim}
+
+
+def _flatten(tree, prefix=""):
+    out = {}
+    for k, v in tree.items():
+        key = f"{prefix}//{k}" if prefix else k
+        if isinstance(v, dict) or hasattr(v, "items"):
+            out.update(_flatten(v, key))
+        else:
+            out[key] = np.asarray(v)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=HERE)
+    a = ap.parse_args()
+    sys.path.insert(0, a.ref)
+    try:
+        import jax
+        jax.config.update("jax_enable_x64", True)  # runner.py:35-36 (cfg.dtype == "float64")
+        import haiku as hk
+        import jax.numpy as jnp
+        import jmp
+        import lagrangebench
+        from lagrangebench import models
+        from lagrangebench.evaluate.rollout import _eval_batched_rollout, _forward_eval
+        from lagrangebench.models.utils import node_irreps
+        from lagrangebench.utils import NodeType, broadcast_from_batch
+    except ImportError as exc:
+        print(f"make_jax_golden: the reference does not import here ({exc}); nothing written.")
+        return 2
+
+    from functools import partial
+
+    for tag, dim, n_side, L in [("2d", 2, 14, 3), ("3d", 3, 8, 2)]:
+        isl, n_extra, dx = 6, 5, 0.05
+        rc = 1.45 * dx
+        pos, box = _cloud(n_side, dim, dx, isl, n_extra, seed=dim)
+        n = pos.shape[0]
+        ptype = np.zeros(n, np.int32)
+        ptype[: n // 8] = 1  # some SOLID_WALL particles: embedding rows + kinematic mask are exercised
+        md = _metadata(dim, n, box, dx, rc, isl + n_extra)
+        case = lagrangebench.case_builder(box=box, metadata=md, input_seq_length=isl,
+                                          cfg_neighbors={"backend": "jaxmd_vmap", "multiplier": 1.25},
+                                          cfg_model={"isotropic_norm": False, "magnitude_features": False},
+                                          noise_std=3e-4, external_force_fn=None, dtype=jnp.float64)
+        sample = (jnp.asarray(pos[:, :isl]), jnp.asarray(ptype))
+        features, nbrs = case.allocate_eval(sample)
+
+        def dump(model_name, model_fn, fname):
+            model = hk.without_apply_rng(hk.transform_with_state(model_fn))
+            policy = jmp.get_policy("params=float32,compute=float32,output=float32")  # runner.py:71-72
+            hk.mixed_precision.set_policy(getattr(models, model_name), policy)
+            params, state = model.init(jax.random.PRNGKey(7), (features, sample[1]))
+            pred, _ = model.apply(params, state, (features, sample[1]))
+            nxt = case.integrate(pred, sample[0])
+            fwd = jax.vmap(partial(_forward_eval, model_apply=model.apply, case_integrate=case.integrate),
+                           in_axes=(None, None, 0, 0, 0))
+            pre = jax.vmap(case.preprocess_eval, in_axes=(0, 0))
+            roll, _, _ = _eval_batched_rollout(
+                forward_eval_vmap=fwd, preprocess_eval_vmap=pre, case=case, params=params, state=state,
+                traj_batch_i=(jnp.asarray(pos[None]), jnp.asarray(ptype[None])), neighbors=nbrs,
+                metrics_computer_vmap=lambda p, t: {}, n_rollout_steps=n_extra, t_window=isl)
+            out = {"position": pos, "particle_type": ptype, "metadata_json": np.array(json.dumps(md)),
+                   "idx": np.asarray(nbrs.idx), "acc": np.asarray(pred["acc"]), "next_position": np.asarray(nxt),
+                   "rollout": np.asarray(roll)[0], "num_mp_steps": np.array(L)}
+            for k, v in features.items():
+                out[f"feat//{k}"] = np.asarray(v)
+            for k, v in _flatten(hk.data_structures.to_mutable_dict(params)).items():
+                out[f"param//{k}"] = v
+            np.savez_compressed(os.path.join(a.out, fname), **out)
+            print("wrote", fname, {k: v.shape for k, v in out.items() if k.startswith("param//")}.__len__(), "leaves")
+
+        dump("GNS", lambda x: models.GNS(particle_dimension=dim, latent_size=128, blocks_per_step=2,
+                                         num_mp_steps=L, num_particle_types=NodeType.SIZE,
+                                         particle_type_embedding_size=16)(x), f"jax_gns_{tag}.npz")
+        try:
+            from e3nn_jax import Irreps
+            irr = node_irreps(md, isl, False, False, False)
+            dump("SEGNN", lambda x: models.SEGNN(node_features_irreps=irr, edge_features_irreps=Irreps("1x1o + 1x0e"),
+                                                scalar_units=64, lmax_hidden=1, lmax_attributes=1,
+                                                output_irreps=Irreps("1x1o"), num_mp_steps=L, n_vels=isl - 1,
+                                                velocity_aggregate="avg", homogeneous_particles=False,
+                                                blocks_per_step=2, norm="none")(x), f"jax_segnn_{tag}.npz")
+        except ImportError as exc:
+            print("e3nn_jax missing, SEGNN fixture skipped:", exc)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,146 @@
+"""BASELINE.json configs [1]-[4] at FULL size, HIP engine vs the CPU oracle (round-1 VERDICT item 1).
+
+For every GNS config: one forward pass with per-layer node-latent taps and a 20-step device rollout,
+compared with the oracle (`oracle/lb_oracle.py` geometry + `oracle/lb_oracle_torch.py` network - the
+torch-CPU twin of the NumPy network, itself checked against it in tests/test_oracle_golden.py) on the
+same seeded inputs / weights.  For the SEGNN config: one full-size forward with per-layer taps.
+
+Tolerances (north_star): edge list bit-exact, per-layer node latents and accelerations within 1e-5
+relative (fp32), rollout MSE within 1e-5 absolute and 1e-3 relative of the oracle's.
+The oracle is NOT the reference JAX run (JAX cannot be installed here: parity of the network layer
+stays "unpinned") - what these tests add is that nothing size-dependent
+(tile walks, XCD partitioning, partial-sum slots, capacity growth) breaks parity at the sizes the
+benchmark runs.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import lb_oracle as O  # noqa: E402
+from oracle import lb_oracle_torch as OT  # noqa: E402
+from tests._common import hip_case, make_params, oracle_case, rel_err  # noqa: E402
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _torch_apply(L):
+    cache = {}
+
+    def apply(params, state, sample):
+        feats, ptype = sample
+        pt = cache.setdefault(id(params), OT.params_to_torch(params))
+        return OT.gns_apply(pt, feats, ptype, num_mp_steps=L, skip_padding=True), state
+    return apply
+
+
+# (case, BASELINE config index, steps compared with the oracle)
+GNS_CONFIGS = [("rpf2d", 1, 20), ("tgv3d", 2, 20), ("ldc3d", 3, 20)]
+
+
+@pytest.mark.parametrize("name,cfg_idx,n_steps", GNS_CONFIGS, ids=[c[0] for c in GNS_CONFIGS])
+def test_full_size_gns_forward_and_rollout_vs_oracle(name, cfg_idx, n_steps):
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.evaluate import infer
+    from lagrangebench_amd.models import GNS
+    L = 10
+    ds = make_case(name, n_trajs=1, extra_seq_length=n_steps)
+    dim, isl = len(ds.box), ds.input_seq_length
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    pos, pt = ds[0]
+    N = len(pt)
+    assert N >= 3000  # full size, not a scaled-down case
+
+    # ---- one forward: edge list bit-exact, every layer's node latents, accelerations
+    feats, nbrs = hcase.allocate_eval((pos[:, :isl], pt))
+    of, on = ocase.allocate_eval((pos[:, :isl].astype(np.float64), pt))
+    want = O.canonical_edges(on.idx, N)
+    ne = want.shape[1]
+    idx = _np(nbrs.idx)
+    assert int(_np(nbrs.n_edges)) == ne and (idx[:, :ne] == want).all() and (idx[:, ne:] == N).all()
+    params = make_params(ds, num_mp_steps=L, decoder_scale=1.0)
+    model = GNS(dim, 128, 2, L, 16)
+    handle = model.handle(feats.engine, params)
+    tap = handle.set_tap(True)
+    acc = _np(model.apply(params, {}, (feats, pt))[0]["acc"])
+    tap = _np(tap).copy()
+    handle.set_tap(False)
+    ref, inter = OT.gns_apply(OT.params_to_torch(params), of, pt, num_mp_steps=L, skip_padding=True,
+                              return_intermediates=True)
+    assert rel_err(tap[0][:N], inter["enc_n"]) < 1e-5
+    for k in range(L):
+        assert rel_err(tap[k + 1][:N], inter[f"n{k}"]) < 1e-5, f"layer {k}"
+    assert rel_err(acc, ref["acc"]) < 1e-5
+
+    # ---- 20-step rollout (for RPF2D the first 20 of the 400 steps of configs[1])
+    p2 = make_params(ds, num_mp_steps=L)
+    out = infer(model, hcase, ds, params=p2, cfg_eval_infer={"batch_size": 1, "metrics": ["mse"]},
+                n_rollout_steps=n_steps)
+    _, onb = ocase.allocate_eval((pos[:, :isl].astype(np.float64), pt))
+    preds_o, metrics_o, _ = O.eval_batched_rollout(_torch_apply(L), ocase, p2, {},
+                                                   (pos[None].astype(np.float64), pt[None]), onb,
+                                                   n_rollout_steps=n_steps, t_window=isl)
+    mse_h, mse_o = _np(out["rollout_0"]["mse"]), metrics_o[0]["mse"]
+    assert mse_h.shape == (n_steps,)
+    assert np.abs(mse_h - mse_o).max() <= 1e-5
+    assert np.allclose(mse_h, mse_o, rtol=1e-3, atol=1e-12), (mse_h, mse_o)
+
+
+def test_full_size_gns_positions_track_oracle_tgv3d():
+    """Per-step positions of the TGV3D-8k device rollout against the oracle's (a stronger statement
+    than the MSE: accelerations within 1e-5 relative => positions within ~1e-5 * acc_std)."""
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    L, n_steps = 10, 5
+    ds = make_case("tgv3d", n_trajs=1, extra_seq_length=n_steps)
+    isl = ds.input_seq_length
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    pos, pt = ds[0]
+    params = make_params(ds, num_mp_steps=L)
+    model = GNS(3, 128, 2, L, 16)
+    eng = hcase.engine(1)
+    eng.set_particle_type(pt[None])
+    pred, _ = eng.rollout(model.handle(eng, params), pos[None].astype(np.float64), n_steps)
+    _, onb = ocase.allocate_eval((pos[:, :isl].astype(np.float64), pt))
+    preds_o, _, _ = O.eval_batched_rollout(_torch_apply(L), ocase, params, {},
+                                           (pos[None].astype(np.float64), pt[None]), onb,
+                                           n_rollout_steps=n_steps, t_window=isl)
+    assert np.abs(_np(pred)[0] - preds_o[0]).max() < 1e-6 * float(ds.metadata["dx"])
+
+
+def test_full_size_segnn_dam2d_forward_vs_oracle():
+    """BASELINE configs[4] (DamBreak2D ~5.5k particles, SEGNN-10-64, free surface) at full size: one
+    forward pass, every layer's hidden state and the acceleration against oracle/segnn_oracle.py."""
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import SEGNN, node_irreps
+    from oracle import segnn_oracle as S
+    L = 10
+    ds = make_case("dam2d", n_trajs=1, extra_seq_length=2)
+    ds.magnitude_features = True
+    isl = ds.input_seq_length
+    irr = node_irreps(ds.metadata, isl, ds.external_force_fn is not None, True, False)
+    model = SEGNN(irr, "1x1o+1x0e", 64, 1, 1, "1x1o", num_mp_steps=L, n_vels=isl - 1, homogeneous_particles=False)
+    params = model.init_params(5)
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    pos, pt = ds[0]
+    N = len(pt)
+    assert N >= 5000
+    feats, nbrs = hcase.allocate_eval((pos[:, :isl], pt))
+    of, on = ocase.allocate_eval((pos[:, :isl].astype(np.float64), pt))
+    want = O.canonical_edges(on.idx, N)
+    assert (_np(nbrs.idx)[:, :want.shape[1]] == want).all()
+    sh = model.handle(feats.engine, params)
+    stap = sh.set_tap(True)
+    acc = _np(model.apply(params, {}, (feats, pt))[0]["acc"])
+    stap = _np(stap).copy()
+    sh.set_tap(False)
+    ref, lat = S.segnn_apply(params, of, pt, isl - 1, False, return_latents=True)
+    for k, f in enumerate(lat):
+        w = np.concatenate([f.s, f.v[:, :, 0], f.v[:, :, 1], f.v[:, :, 2]], axis=1)
+        assert rel_err(stap[k][:N], w) < 1e-5, f"layer {k}"
+    hid = float(np.abs(lat[-1].s).max())
+    assert np.abs(acc - ref["acc"]).max() < 1e-5 * max(hid, float(np.abs(ref["acc"]).max()))

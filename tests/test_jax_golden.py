@@ -1,0 +1,141 @@
+"""Consumers of the JAX-reference fixtures written by tests/golden/make_jax_golden.py.
+
+The fixtures (`tests/golden/jax_gns_{2d,3d}.npz`, `jax_segnn_*.npz`) hold inputs, Haiku weights and
+outputs of the REAL reference (lagrangebench on JAX).  They cannot be produced in the build
+container (JAX is not installable offline), so until somebody runs the generator on a JAX machine
+and commits the files these tests skip with that reason - and the network layer of the oracle
+stays "parity unpinned".  With the files present:
+  * CPU (`-m "not gpu"`): oracle/lb_oracle.py vs the reference - neighbor list, features, GNS
+    accelerations (1e-5 rel), integrator, 5-step rollout.
+  * GPU (`-m gpu`): the HIP engine vs the reference on the same inputs.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import lb_oracle as O
+from tests._common import rel_err
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GNS_FILES = sorted(glob.glob(os.path.join(GOLD, "jax_gns_*.npz")))
+SEGNN_FILES = sorted(glob.glob(os.path.join(GOLD, "jax_segnn_*.npz")))
+NO_FIXTURE = ("no JAX-reference fixture committed: run tests/golden/make_jax_golden.py where "
+              "lagrangebench imports (parity of the network layer is unpinned until then)")
+
+
+def _load(path):
+    z = np.load(path, allow_pickle=False)
+    md = json.loads(str(z["metadata_json"]))
+    hk = {}
+    for k in z.files:
+        if k.startswith("param//"):
+            parts = k.split("//")[1:]
+            hk.setdefault("/".join(parts[:-1]), {})[parts[-1]] = z[k]
+    return z, md, hk
+
+
+def _gns_params(hk, L):
+    from lagrangebench_amd.utils import gns_params_from_haiku
+    return gns_params_from_haiku(hk, L, 2)
+
+
+def test_generator_exists_and_is_skipped_cleanly_without_jax():
+    """The generator must be runnable as a plain script and must not write anything when the
+    reference does not import (exit code 2)."""
+    import subprocess
+    import sys
+    gen = os.path.join(GOLD, "make_jax_golden.py")
+    assert os.path.exists(gen)
+    try:
+        import jax  # noqa: F401
+        pytest.skip("JAX is importable here: run the generator for real instead")
+    except ImportError:
+        pass
+    before = set(os.listdir(GOLD))
+    r = subprocess.run([sys.executable, gen, "--ref", "/nonexistent"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "nothing written" in r.stdout
+    assert set(os.listdir(GOLD)) == before
+
+
+@pytest.mark.parametrize("path", GNS_FILES or [None])
+def test_oracle_matches_jax_reference_gns(path):
+    if path is None:
+        pytest.skip(NO_FIXTURE)
+    z, md, hk = _load(path)
+    L = int(z["num_mp_steps"])
+    pos, pt = z["position"], z["particle_type"]
+    isl = 6
+    box = np.array([b[1] - b[0] for b in md["bounds"]])
+    case = O.case_builder(box, md, isl, cfg_neighbors={"multiplier": 1.25},
+                          cfg_model={"isotropic_norm": False, "magnitude_features": False}, noise_std=3e-4)
+    feats, nbrs = case.allocate_eval((pos[:, :isl].astype(np.float64), pt))
+    n = len(pt)
+    assert nbrs.idx.shape == z["idx"].shape
+    assert (nbrs.idx == z["idx"]).all(), "edge ORDER differs from jax-md's"
+    for k in ("vel_hist", "rel_disp", "rel_dist"):
+        assert np.allclose(feats[k], z[f"feat//{k}"], rtol=0, atol=1e-12), k
+    params = _gns_params(hk, L)
+    acc = O.gns_apply(params, feats, pt, num_mp_steps=L)["acc"]
+    assert rel_err(acc, z["acc"]) < 1e-5
+    nxt = case.integrate({"acc": z["acc"]}, pos[:, :isl].astype(np.float64))
+    assert np.allclose(nxt, z["next_position"], rtol=0, atol=1e-12)
+
+    def apply(p, state, sample):
+        f, ptype = sample
+        return O.gns_apply(p, f, ptype, num_mp_steps=L, skip_padding=True), state
+    T = z["rollout"].shape[0]
+    pred, _, _ = O.eval_batched_rollout(apply, case, params, {}, (pos[None].astype(np.float64), pt[None]), nbrs,
+                                        n_rollout_steps=T, t_window=isl)
+    assert np.abs(pred[0] - z["rollout"]).max() < 1e-6 * md["dx"]
+    assert n == z["acc"].shape[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GNS_FILES or [None])
+def test_engine_matches_jax_reference_gns(path):
+    if path is None:
+        pytest.skip(NO_FIXTURE)
+    import torch
+    from lagrangebench_amd.case_setup import case_builder
+    from lagrangebench_amd.models import GNS
+    z, md, hk = _load(path)
+    L = int(z["num_mp_steps"])
+    pos, pt = z["position"], z["particle_type"]
+    isl, dim, n = 6, md["dim"], len(pt)
+    box = np.array([b[1] - b[0] for b in md["bounds"]])
+    case = case_builder(box, md, isl, cfg_neighbors={"multiplier": 1.25},
+                        cfg_model={"isotropic_norm": False, "magnitude_features": False}, noise_std=3e-4)
+    feats, nbrs = case.allocate_eval((pos[:, :isl], pt))
+    assert (O.canonical_edges(nbrs.idx.cpu().numpy(), n) == O.canonical_edges(z["idx"], n)).all()
+    params = _gns_params(hk, L)
+    model = GNS(dim, 128, 2, L, 16)
+    acc = model.apply(params, {}, (feats, pt))[0]["acc"].cpu().numpy()
+    assert rel_err(acc, z["acc"]) < 1e-5
+    eng = case.engine(1)
+    eng.set_particle_type(pt[None])
+    T = z["rollout"].shape[0]
+    pred, _ = eng.rollout(model.handle(eng, params), pos[None].astype(np.float64), T)
+    assert np.abs(pred.cpu().numpy()[0] - z["rollout"]).max() < 1e-6 * md["dx"]
+    assert torch.isfinite(pred).all()
+
+
+@pytest.mark.parametrize("path", SEGNN_FILES or [None])
+def test_oracle_matches_jax_reference_segnn(path):
+    if path is None:
+        pytest.skip(NO_FIXTURE)
+    from lagrangebench_amd.utils import segnn_params_from_haiku
+    from oracle import segnn_oracle as S
+    z, md, hk = _load(path)
+    L = int(z["num_mp_steps"])
+    pos, pt = z["position"], z["particle_type"]
+    isl = 6
+    box = np.array([b[1] - b[0] for b in md["bounds"]])
+    case = O.case_builder(box, md, isl, cfg_neighbors={"multiplier": 1.25},
+                          cfg_model={"isotropic_norm": False, "magnitude_features": False}, noise_std=3e-4)
+    feats, _ = case.allocate_eval((pos[:, :isl].astype(np.float64), pt))
+    params = segnn_params_from_haiku(hk, L)
+    acc = S.segnn_apply(params, feats, pt, isl - 1, False)["acc"]
+    assert rel_err(acc[:, :md["dim"]], z["acc"]) < 1e-5

@@ -181,3 +181,79 @@ def test_torch_cpu_baseline_matches_numpy_oracle():
     a = O.gns_apply(params, feats, pt, num_mp_steps=4)["acc"]
     b = OT.gns_apply(OT.params_to_torch(params), feats, pt, num_mp_steps=4)["acc"]
     assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max()
+
+
+# ------------------------------------------------------------------ free pins
+def test_gns_parameter_count_matches_published_1_2M():
+    """docs/pages/baselines.rst:62 publishes "1.2M" parameters for GNS-10-128; counted from the
+    reference's architecture (models/gns.py:35-133: embed 9x16, encoder 2 MLP+LN, 10 x (edge MLP+LN,
+    node MLP+LN), decoder MLP) that is 1 211 538 in 2D and 1 212 435 in 3D.
+    Pins the layer inventory / shapes of the oracle AND of the product's model class."""
+    from lagrangebench_amd.models import GNS
+    for dim, node_in, edge_in, want in [(2, 10, 3, 1_211_538), (3, 15, 4, 1_212_435)]:
+        p = O.gns_init(np.random.default_rng(0), node_in=node_in, edge_in=edge_in, particle_dimension=dim,
+                       num_mp_steps=10)
+        assert sum(v.size for d in p.values() for v in d.values()) == want
+        q = GNS(dim, 128, 2, 10, 16).init_params(0, node_in=node_in, edge_in=edge_in)
+        assert sum(v.size for d in q.values() for v in d.values()) == want
+        assert round(want / 1e6, 1) == 1.2
+    # GNS-5-64 (baselines.rst:54: "161K")
+    p = O.gns_init(np.random.default_rng(0), node_in=10, edge_in=3, particle_dimension=2, num_mp_steps=5, latent_size=64)
+    assert round(sum(v.size for d in p.values() for v in d.values()) / 1e3) == 161
+
+
+def test_tgv2d_capacity_rule_matches_reference_log(golden_dir):
+    """notebooks/tutorial.ipynb logs the neighbor-list capacity of the real 2D TGV dataset:
+    "(2, 21057)" at capacity_multiplier 1.25.  (i) 21057 is reachable by jax-md's rule
+    E_cap = int(occupancy * 1.25) (occupancy 16846 = 6.74 edges per particle incl. the self edge);
+    (ii) the oracle's neighbor list on the synthetic TGV2D cloud of the same N / box / r_c lands within
+    10 % of that occupancy and applies the same rule; (iii) the metadata block the reference printed
+    for this dataset goes through get_dataset_stats (data/utils.py:9-45) as expected."""
+    from lagrangebench_amd.data import make_case
+    from tests._common import oracle_case
+    with open(os.path.join(golden_dir, "tgv2d_metadata.json")) as f:
+        fx = json.load(f)
+    md, caps = fx["metadata"], fx["logged_capacity_changes"]
+    assert [21057, 21340] in caps
+    occ_ref = [o for o in range(16000, 18000) if int(o * 1.25) == 21057]
+    assert occ_ref == [16846]
+    ds = make_case("tgv2d", n_trajs=1, extra_seq_length=2)
+    assert len(ds[0][1]) == md["num_particles_max"] == 2500
+    assert abs(ds.metadata["default_connectivity_radius"] - md["default_connectivity_radius"]) < 1e-12
+    assert np.allclose(np.asarray(ds.metadata["bounds"]), np.asarray(md["bounds"]))
+    case = oracle_case(ds)
+    pos, pt = ds[0]
+    _, nbrs = case.allocate_eval((pos[:, :6].astype(np.float64), pt))
+    assert nbrs.idx.shape == (2, int(nbrs.occupancy * 1.25))
+    assert abs(nbrs.occupancy - 16846) / 16846 < 0.10
+    # the real metadata through the oracle's and the product's get_dataset_stats
+    from lagrangebench_amd.data.utils import get_dataset_stats
+    for fn in (O.get_dataset_stats, get_dataset_stats):
+        st = fn(md, False, 3e-4)
+        assert np.allclose(st["velocity"]["std"], np.sqrt(np.array(md["vel_std"]) ** 2 + 3e-4 ** 2), rtol=1e-12)
+        assert np.allclose(st["acceleration"]["std"], np.sqrt(np.array(md["acc_std"]) ** 2 + 3e-4 ** 2), rtol=1e-12)
+        iso = fn(md, True, 0.0)
+        assert np.allclose(iso["velocity"]["std"], np.sqrt(np.mean(np.array(md["vel_std"]) ** 2)))
+    # a real-metadata case builds (34 x 34 cell grid at r_c 0.029, SURVEY 8d config 1)
+    real = O.case_builder(np.array([1.0, 1.0]), md, 6, noise_std=3e-4)
+    _, nb2 = real.allocate_eval((pos[:, :6].astype(np.float64), pt))
+    assert nb2.occupancy == nbrs.occupancy
+
+
+def test_averaged_metrics_matches_reference_formula():
+    """evaluate/metrics.py:233-252 on hand-computed values: mse and mae both land in `loss` (2n entries),
+    e_kin contributes its `mse`; val/std* are emitted."""
+    torch = pytest.importorskip("torch")
+    from lagrangebench_amd.evaluate.metrics import averaged_metrics
+    ev = {
+        "rollout_0": {"mse": torch.tensor([1.0, 3.0]), "mae": torch.tensor([0.5, 0.5]), "mse1": torch.tensor([1.0]),
+                      "e_kin": {"predicted": torch.tensor([1.0]), "target": torch.tensor([2.0]), "mse": torch.tensor(4.0)}},
+        "rollout_1": {"mse": torch.tensor([5.0, 7.0]), "mae": torch.tensor([1.5, 2.5]), "mse1": torch.tensor([5.0]),
+                      "e_kin": {"predicted": torch.tensor([1.0]), "target": torch.tensor([2.0]), "mse": torch.tensor(2.0)}},
+    }
+    out = averaged_metrics(ev)
+    loss = [2.0, 0.5, 6.0, 2.0]  # per rollout: mean(mse), mean(mae)
+    assert out["val/loss"] == pytest.approx(np.mean(loss)) and out["val/stdloss"] == pytest.approx(np.std(loss))
+    assert out["val/mse1"] == pytest.approx(3.0) and out["val/stdmse1"] == pytest.approx(2.0)
+    assert out["val/e_kin"] == pytest.approx(3.0) and out["val/stde_kin"] == pytest.approx(1.0)
+    assert set(out) == {"val/loss", "val/mse1", "val/e_kin", "val/stdloss", "val/stdmse1", "val/stde_kin"}
