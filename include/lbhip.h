@@ -237,6 +237,19 @@ int lb_metrics(lb_engine* eng, const double* pred_dev, int32_t pred_T, const dou
 int lb_ekin(lb_engine* eng, const double* rollout_dev, int32_t T, int32_t stride, double dt, double dx,
             double* out_dev, int32_t n_out);
 
+/* MetricsComputer "sinkhorn" - evaluate/metrics.py:127-136,162-176,198-213: Sinkhorn divergence
+ * between the predicted and the target particle cloud of every stride-th frame,
+ * out[b][k] = S_eps(pred[b, k*stride], target[b, k*stride]), k < n_out = ceil(T/stride) with
+ * T = min(pred_T, target_T) frames compared.  Cost = squared case displacement rounded to float32,
+ * uniform weights, eps = 0.05 * mean(C_xy) shared by the xy / xx / yy problems, convergence
+ * `threshold` (the reference passes 1e-4) on the L1 marginal error checked every 10 iterations
+ * (ott-jax 0.4.6 sinkhorn_divergence, restated in oracle/sinkhorn_oracle.py).  Rollouts (B,T,N,dim)
+ * fp64; out (B,n_out) fp64 on the device; iters_out_host (optional, HOST, B*n_out*3 int32) receives
+ * the iteration counts of the three solves.  Host-synchronous (the stopping rule is data dependent). */
+int lb_sinkhorn(lb_engine* eng, const double* pred_dev, int32_t pred_T, const double* target_dev,
+                int32_t target_T, int32_t stride, double threshold, double* out_dev, int32_t n_out,
+                int32_t* iters_out_host);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------ */
 
 /* Enable per-kernel-class HIP-event timing on the engine stream.  Classes: see lb_timer_name. */

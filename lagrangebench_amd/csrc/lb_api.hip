@@ -813,6 +813,18 @@ extern "C" int lb_ekin(lb_engine* e, const double* rollout_dev, int32_t T, int32
   return lbk_ekin(e, rollout_dev, T, stride, n_out, dt, dx, out_dev);
 }
 
+extern "C" int lb_sinkhorn(lb_engine* e, const double* pred_dev, int32_t pred_T, const double* target_dev,
+                           int32_t target_T, int32_t stride, double threshold, double* out_dev, int32_t n_out,
+                           int32_t* iters_out_host) {
+  if (!e || !pred_dev || !target_dev || !out_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  if (stride < 1 || pred_T < 1 || target_T < 1) return lb_fail(LB_ERR_ARG, "need stride >= 1 and T >= 1");
+  if (!(threshold > 0)) return lb_fail(LB_ERR_ARG, "threshold must be > 0");
+  const int T = pred_T < target_T ? pred_T : target_T;
+  const int expect = (T + stride - 1) / stride;  // len(x[0::stride])
+  if (n_out != expect) return lb_fail(LB_ERR_ARG, "n_out must be ceil(T/stride) = %d", expect);
+  return lbk_sinkhorn(e, pred_dev, pred_T, target_dev, target_T, stride, n_out, threshold, out_dev, iters_out_host);
+}
+
 extern "C" int lb_metrics(lb_engine* e, const double* pred_dev, int32_t pred_T,
                           const double* target_dev, int32_t target_T, int32_t n_steps, double* mse,
                           double* mae) {

@@ -238,6 +238,10 @@ int lbk_case_integrate(lb_engine* e, int mode, const float* pred, const double* 
 int lbk_metrics(lb_engine* e, const double* pred, int pred_T, const double* target, int target_T,
                 int n_steps, double* mse, double* mae);
 
+// lb_sinkhorn.hip
+int lbk_sinkhorn(lb_engine* e, const double* pred, int pred_T, const double* target, int target_T, int stride,
+                 int n_out, double threshold, double* out_dev, int32_t* iters_host);
+
 int lbk_node_features_raw(lb_engine* e, float* xnode, int kpad);
 
 // lb_api.hip: the device-resident step loop shared by the models

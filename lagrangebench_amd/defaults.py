@@ -32,10 +32,10 @@ defaults = _wrap({
     "eval": {
         "n_rollout_steps": 20,                # defaults.py:113
         "rollout_dir": None,
-        "train": {"n_trajs": -1, "metrics_stride": 10, "batch_size": 1, "metrics": ["mse"],
-                  "out_type": "none"},
-        "infer": {"n_trajs": -1, "metrics_stride": 1, "batch_size": 2, "metrics": ["mse"],
-                  "out_type": "none", "n_extrap_steps": 0},   # defaults.py:136-148 (reference default adds e_kin, sinkhorn; sinkhorn is not built)
+        "train": {"n_trajs": 50, "metrics_stride": 10, "batch_size": 1, "metrics": ["mse"],
+                  "out_type": "none"},                       # defaults.py:121-134
+        "infer": {"n_trajs": -1, "metrics_stride": 1, "batch_size": 2, "metrics": ["mse", "e_kin", "sinkhorn"],
+                  "out_type": "pkl", "n_extrap_steps": 0},   # defaults.py:136-150
     },
     "neighbors": {"backend": "jaxmd_vmap", "multiplier": 1.25},  # defaults.py:170-175
 })

@@ -78,6 +78,26 @@ def gather_metrics(local: Dict[int, torch.Tensor], n_trajs: int, n_steps: int,
     return merged
 
 
+def gather_metric_dicts(local: Dict[str, dict]) -> Dict[str, dict]:
+    """All-gather the per-rollout metric dictionaries of evaluate.eval_rollout
+    ({"rollout_i": {"mse": (T,), "e_kin": {...}, ...}}) so that every rank returns the complete
+    MetricsDict.  A few hundred bytes per trajectory: one object all_gather (RCCL / gloo), tensors
+    travel as CPU tensors."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+
+    def cpu(x):
+        if isinstance(x, dict):
+            return {k: cpu(v) for k, v in x.items()}
+        return x.detach().cpu() if isinstance(x, torch.Tensor) else x
+    parts: List[Optional[dict]] = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, cpu(local))
+    merged: Dict[str, dict] = {}
+    for part in parts:
+        merged.update(part or {})
+    return dict(sorted(merged.items(), key=lambda kv: int(kv[0].rsplit("_", 1)[1])))
+
+
 def sharded_eval(run_trajs: Callable[[Sequence[int]], Dict[int, torch.Tensor]], n_trajs: int, n_steps: int,
                  device: Optional[torch.device] = None) -> Dict[int, torch.Tensor]:
     """Run ``run_trajs(my trajectory indices) -> {index: (n_steps,) metric}`` on every rank and

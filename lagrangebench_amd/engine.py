@@ -313,6 +313,21 @@ class RolloutEngine:
         check(self.lib.lb_ekin(self._h, ptr(r), T, int(stride), float(dt), float(dx), ptr(out), n_out), "lb_ekin")
         return out
 
+    def sinkhorn(self, pred: torch.Tensor, target: torch.Tensor, stride: int, threshold: float = 1e-4,
+                 return_iters: bool = False):
+        """Sinkhorn divergence of every stride-th frame pair of (B,T,N,dim) rollouts -> (B, n_out)."""
+        p = _dev(pred if pred.dim() == 4 else pred[None], torch.float64, self.device)
+        t = _dev(target if target.dim() == 4 else target[None], torch.float64, self.device)
+        T = min(p.shape[1], t.shape[1])
+        n_out = (T + stride - 1) // stride
+        out = torch.empty((self.B, n_out), dtype=torch.float64, device=self.device)
+        iters = (C.c_int32 * (self.B * n_out * 3))()
+        check(self.lib.lb_sinkhorn(self._h, ptr(p), p.shape[1], ptr(t), t.shape[1], int(stride), float(threshold),
+                                   ptr(out), n_out, iters), "lb_sinkhorn")
+        if return_iters:
+            return out, np.frombuffer(iters, dtype=np.int32).reshape(self.B, n_out, 3).copy()
+        return out
+
     def segment_sum(self, msg: torch.Tensor) -> torch.Tensor:
         msg = _dev(msg, torch.float32, self.device)
         out = torch.empty((self.B * self.N, msg.shape[1]), dtype=torch.float32, device=self.device)

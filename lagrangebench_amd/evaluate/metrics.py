@@ -1,9 +1,9 @@
 """Rollout metrics - mirror of lagrangebench/evaluate/metrics.py.
 
-Built: ``mse`` and ``mae`` (metrics.py:86-96,139-147) and ``e_kin`` (metrics.py:98-125,157-160),
-computed on the device by lb_metrics / lb_ekin.
-Not built yet: ``sinkhorn`` (OTT / POT optimal transport) raises
-NotImplementedError.
+``mse`` and ``mae`` (metrics.py:86-96,139-147), ``e_kin`` (metrics.py:98-125,157-160) and
+``sinkhorn`` (metrics.py:127-136,162-176, the default OTT backend) are computed on the device by
+lb_metrics / lb_ekin / lb_sinkhorn.  ``ot_backend="pot"`` (metrics.py:178-196: POT's sinkhorn2 with a
+fixed reg=0.1 through a host callback) is not built.
 """
 from __future__ import annotations
 
@@ -27,9 +27,10 @@ class MetricsComputer:
         if active_metrics is None:
             active_metrics = []
         assert all(m in self.METRICS for m in active_metrics)
-        for m in active_metrics:
-            if m == "sinkhorn":
-                raise NotImplementedError("metric 'sinkhorn' is not built yet (mse / mae / e_kin are)")
+        assert ot_backend in ["ott", "pot"]
+        if "sinkhorn" in active_metrics and ot_backend == "pot":
+            raise NotImplementedError("ot_backend='pot' is not built (the default 'ott' Sinkhorn divergence is)")
+        self.ot_backend = ot_backend
         self._active_metrics = list(active_metrics)
         self._dist_fn = dist_fn
         self._loss_ranges = loss_ranges if loss_ranges is not None else [1, 5, 10, 20, 50, 100]
@@ -64,6 +65,10 @@ class MetricsComputer:
                 out["e_kin"] = {"predicted": ek_p, "target": ek_t, "mse": mse_e}
             else:
                 out["e_kin"] = {"predicted": ek_p[0], "target": ek_t[0], "mse": mse_e[0]}
+        if "sinkhorn" in self._active_metrics:
+            # metrics.py:127-136: one divergence per stride-th frame pair
+            sk = eng.sinkhorn(pred, tgt[:, :T], self._stride)
+            out["sinkhorn"] = sk if batched else sk[0]
         for name in want:
             v = res[name] if batched else res[name][0]
             out[name] = v

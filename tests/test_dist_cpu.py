@@ -48,6 +48,12 @@ assert sorted(merged) == list(range(n_trajs)), sorted(merged)
 ref = run(range(n_trajs))                    # every rank recomputes everything as the check
 for i in range(n_trajs):
     assert torch.allclose(merged[i], ref[i].double(), rtol=0, atol=0), i
+# the product's eval_rollout gathers whole per-rollout metric dictionaries (nested, e_kin style)
+local = {f"rollout_{i}": {"mse": ref[i], "e_kin": {"mse": ref[i].mean()}} for i in mine}
+full = lbdist.gather_metric_dicts(local)
+assert list(full) == [f"rollout_{i}" for i in range(n_trajs)], list(full)
+for i in range(n_trajs):
+    assert torch.equal(full[f"rollout_{i}"]["mse"], ref[i]) and full[f"rollout_{i}"]["e_kin"]["mse"] == ref[i].mean()
 t = lbdist.max_over_ranks(1.0 + rank)
 assert t == 2.0
 lbdist.barrier()

@@ -1,0 +1,81 @@
+"""The N > 1 path with the PRODUCT engine: two ranks under torchrun run `evaluate.infer` on the HIP
+engine (rank-aware eval_rollout: batch b -> rank b % world, per-rollout metric dictionaries
+all-gathered) and must return exactly what one process returns.  Backend: "nccl" (= RCCL) when two
+GPUs are visible, else both ranks share cuda:0 and gather over "gloo" - the data path is identical,
+only the metric gather changes transport.  (reference: evaluate/rollout.py:226-253 - trajectories
+are independent)"""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["LB_ROOT"])
+import numpy as np, torch
+import torch.distributed as dist
+from lagrangebench_amd import dist as lbdist
+from lagrangebench_amd.data import make_case
+from lagrangebench_amd.evaluate import infer, averaged_metrics
+from lagrangebench_amd.models import GNS
+from tests._common import hip_case, make_params
+
+two_gpus = torch.cuda.device_count() >= 2
+rank, local_rank, world = lbdist.init(backend="nccl" if two_gpus else "gloo")
+assert world == 2 and dist.is_initialized()
+dev = torch.device("cuda", local_rank if two_gpus else 0)
+torch.cuda.set_device(dev)
+n_trajs, n_steps, L = 5, 4, 2
+ds = make_case("small3d", n_trajs=n_trajs, extra_seq_length=n_steps)
+params = make_params(ds, num_mp_steps=L)
+model = GNS(3, 128, 2, L, 16)
+case = hip_case(ds)
+cfg = {"batch_size": 2, "metrics": ["mse", "mae"], "out_type": "pkl"}
+out = infer(model, case, ds, params=params, cfg_eval_infer=cfg, n_rollout_steps=n_steps,
+            rollout_dir=os.environ["LB_OUT"])
+assert sorted(out) == [f"rollout_{i}" for i in range(n_trajs)], sorted(out)
+# the single-process answer, computed by every rank with the process group hidden from eval_rollout
+import lagrangebench_amd.evaluate.rollout as R
+real = torch.distributed.is_initialized
+torch.distributed.is_initialized = lambda: False
+try:
+    ref = infer(model, case, ds, params=params, cfg_eval_infer=dict(cfg, out_type="none"), n_rollout_steps=n_steps)
+finally:
+    torch.distributed.is_initialized = real
+for k in ref:
+    for m in ("mse", "mae", "mse1"):
+        assert torch.equal(out[k][m].cpu(), ref[k][m].cpu()), (k, m)
+assert averaged_metrics(out) == averaged_metrics(ref)
+t = lbdist.max_over_ranks(1.0 + rank, dev if two_gpus else None)
+assert t == 2.0
+lbdist.barrier(dev)
+if rank == 0:
+    files = sorted(os.listdir(os.environ["LB_OUT"]))
+    assert [f for f in files if f.startswith("rollout_")] == [f"rollout_{i}.pkl" for i in range(n_trajs)], files
+    assert sum(f.startswith("metrics") for f in files) == 1
+    print("DIST_GPU_OK", "nccl" if two_gpus else "gloo", averaged_metrics(out)["val/loss"])
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_run_infer_on_the_hip_engine(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "rollouts"
+    env = dict(os.environ, LB_ROOT=ROOT, LB_OUT=str(out), OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "DIST_GPU_OK" in r.stdout

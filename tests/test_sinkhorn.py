@@ -1,0 +1,109 @@
+"""The `sinkhorn` rollout metric (evaluate/metrics.py:127-136,162-176): oracle pins on CPU, HIP vs
+oracle on the GPU.  The optimiser is ott-jax's (third party, not installable here): the oracle
+restates its published algorithm and is pinned against closed forms of entropic OT, not against
+ott itself ("parity unpinned" for the iteration schedule, see oracle/sinkhorn_oracle.py)."""
+import numpy as np
+import pytest
+
+from oracle import lb_oracle as O
+from oracle import sinkhorn_oracle as SK
+
+
+def test_oracle_matches_closed_form_2x2():
+    """Uniform 2 x 2 entropic OT: P = [[t, 1/2-t], [1/2-t, t]], t/(1/2-t) = exp(-Delta/(2 eps)),
+    OT_eps = <P, C> + eps KL(P | a x b)."""
+    C = np.array([[0.3, 1.1], [0.9, 0.2]], np.float32)
+    a = b = np.array([0.5, 0.5])
+    for eps in (0.5, 0.2, 0.07):
+        reg, it, err = SK.sinkhorn_solve(C, a, b, eps, threshold=1e-10, max_iterations=20000)
+        Cd = C.astype(np.float64)
+        delta = Cd[0, 0] + Cd[1, 1] - Cd[0, 1] - Cd[1, 0]
+        s = np.exp(-delta / (2 * eps))
+        t = 0.5 * s / (1 + s)
+        P = np.array([[t, 0.5 - t], [0.5 - t, t]])
+        closed = (P * Cd).sum() + eps * (P * np.log(P / 0.25)).sum()
+        assert abs(reg - closed) < 1e-6 * abs(closed), (eps, reg, closed)
+    # parallel updates with momentum 0.5 (the symmetric-term schedule) reach the same optimum
+    reg_p, _, _ = SK.sinkhorn_solve(C, a, b, 0.2, threshold=1e-10, parallel=True, momentum=0.5, max_iterations=20000)
+    reg_s, _, _ = SK.sinkhorn_solve(C, a, b, 0.2, threshold=1e-10, max_iterations=20000)
+    assert abs(reg_p - reg_s) < 1e-8
+
+
+def test_oracle_divergence_properties():
+    """Single points: S_eps = C(x, y) (periodic displacement, float32 cost); identical clouds: 0;
+    symmetric; non-negative; grows with the perturbation."""
+    disp, _ = O.space_periodic(np.array([1.0, 1.0]))
+    x1, y1 = np.array([[0.05, 0.5]]), np.array([[0.95, 0.5]])
+    assert SK.sinkhorn_divergence(disp, x1, y1) == pytest.approx(float(np.float32(0.1 ** 2)), rel=1e-6)
+    rng = np.random.default_rng(0)
+    x = rng.random((200, 2))
+    assert abs(SK.sinkhorn_divergence(disp, x, x)) < 1e-8
+    ys = [np.mod(x + s * rng.standard_normal(x.shape), 1.0) for s in (0.005, 0.02)]
+    d = [SK.sinkhorn_divergence(disp, x, y) for y in ys]
+    assert 0 < d[0] < d[1]
+    assert SK.sinkhorn_divergence(disp, ys[0], x) == pytest.approx(d[0], rel=1e-3, abs=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small2d", "small3d"])
+def test_sinkhorn_engine_matches_oracle(name):
+    torch = pytest.importorskip("torch")
+    from lagrangebench_amd.data import make_case
+    from tests._common import hip_case, oracle_case
+    ds = make_case(name, n_trajs=2, extra_seq_length=6)
+    isl = ds.input_seq_length
+    hcase, ocase = hip_case(ds), oracle_case(ds)
+    pos = np.stack([ds[0][0], ds[1][0]]).astype(np.float64)     # (B, N, T, dim)
+    roll = np.transpose(pos, (0, 2, 1, 3))                       # (B, T, N, dim)
+    rng = np.random.default_rng(1)
+    dx = float(ds.metadata["dx"])
+    target = roll[:, isl:]
+    pred = target + 0.05 * dx * rng.standard_normal(target.shape) * np.arange(1, target.shape[1] + 1)[None, :, None, None]
+    eng = hcase.engine(2)
+    stride = 2
+    out, iters = eng.sinkhorn(torch.from_numpy(pred), torch.from_numpy(target), stride, return_iters=True)
+    out = out.cpu().numpy()
+    assert out.shape == (2, 3)
+    for b in range(2):
+        for k, t in enumerate(range(0, target.shape[1], stride)):
+            d, info = SK.sinkhorn_divergence(ocase.displacement, pred[b, t], target[b, t], return_info=True)
+            assert tuple(iters[b, k]) == info["iters"], (b, k, iters[b, k], info["iters"])
+            assert abs(out[b, k] - d) <= 1e-9 * info["reg"][0] + 1e-6 * abs(d), (out[b, k], d)
+    # identical clouds -> 0 (up to the convergence threshold)
+    z = eng.sinkhorn(torch.from_numpy(target), torch.from_numpy(target), 3).cpu().numpy()
+    assert np.abs(z).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_default_infer_metrics_run_including_sinkhorn():
+    """defaults.py:143 `eval.infer.metrics = ["mse", "e_kin", "sinkhorn"]`: a default-config
+    inference must produce all three (round-1 VERDICT "missing" item 1)."""
+    torch = pytest.importorskip("torch")
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.defaults import defaults
+    from lagrangebench_amd.evaluate import averaged_metrics, infer
+    from lagrangebench_amd.models import GNS
+    from tests._common import hip_case, make_params, oracle_case
+    assert list(defaults.eval.infer.metrics) == ["mse", "e_kin", "sinkhorn"]
+    n_steps, L = 4, 2
+    ds = make_case("small2d", n_trajs=2, extra_seq_length=n_steps)
+    ds.metadata.setdefault("dt", 1.0)
+    ds.metadata.setdefault("write_every", 1)
+    params = make_params(ds, num_mp_steps=L)
+    model = GNS(2, 128, 2, L, 16)
+    hcase = hip_case(ds)
+    out = infer(model, hcase, ds, params=params, cfg_eval_infer={"metrics_stride": 2}, n_rollout_steps=n_steps)
+    m = out["rollout_1"]
+    assert set(m) >= {"mse", "e_kin", "sinkhorn", "mse1"}
+    sk = m["sinkhorn"].cpu().numpy()
+    assert sk.shape == (2,) and np.isfinite(sk).all() and (sk > -1e-9).all()
+    avg = averaged_metrics(out)
+    assert {"val/loss", "val/e_kin", "val/sinkhorn", "val/stdsinkhorn"} <= set(avg)
+    # sinkhorn of the device rollout against the oracle's on the same predicted positions
+    eng = hcase.engine(1)
+    eng.set_particle_type(ds[1][1][None])
+    pred, _ = eng.rollout(model.handle(eng, params), ds[1][0][None].astype(np.float64), n_steps)
+    pred = pred.cpu().numpy()[0]
+    tgt = np.transpose(ds[1][0][:, ds.input_seq_length:], (1, 0, 2)).astype(np.float64)
+    want = SK.sinkhorn_rollout(oracle_case(ds).displacement, pred, tgt, 2)
+    assert np.allclose(sk, want, rtol=1e-5, atol=1e-12)
