@@ -1,0 +1,351 @@
+// lb_edge16v.hip - round-2 rewrite of the processor edge kernel (f16x2, fused segment_sum).
+//
+// Same mathematics, layouts and tile walk as k_edge16n in lb_edge16.hip (reference:
+// GNS._processor update_edge_features + jraph.segment_sum, models/gns.py:86-122); what changes is
+// the instruction stream.  Round-1 profile of k_edge16n (TGV3D-8k x 8): compute-only 205 us, memory
+// only 263 us, together 308 us - the matrix pipe itself is busy 86 us, the rest of the compute time
+// is VALU issue slots and LDS round trips that sit in series with the MFMAs:
+//   * 84 v_or_b32 per tile only to form LDS addresses past the 64 KiB ds offset field,
+//   * v_mov_b32_dpp + v_pk_fma_f32 pairs in the segmented scan (SLP-packed fmas cannot take a DPP
+//     source; packed fp32 VALU is slower beside MFMAs than two plain ones),
+//   * 20 VALU per fp16 hi/lo split of 8 values, a canonicalising v_max pair per ReLU,
+//   * under the 168-VGPR cap of three waves per SIMD the compiler serialised
+//     ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma in the second GEMM (one LDS round trip per MFMA).
+// Here:
+//   * two lane bases (W0 image, W1 image) keep every ds_read offset inside the 16-bit field;
+//   * the split is v_cvt_pk_f16_f32 + v_fma_mixlo/mixhi_f16 (12 VALU per 8 values), ReLU is an
+//     integer max, the scan is v_fmac_f32_dpp in fixed-order asm blocks (128 VALU per tile);
+//   * the GEMM is phase-pipelined with two 16-register fragment buffers: the `lo` fragments of
+//     block k+1 are fetched before the eight `hi` MFMAs of block k issue and the `hi` fragments
+//     before its four `lo` MFMAs, every accumulator is touched again only after four independent
+//     MFMAs (accumulate-chain spacing), phases are pinned with sched_barrier;
+//   * RELOAD: the edge latents are not kept in registers for the residual but read a second time
+//     (L2 / Infinity-Cache hit ~2 us after the first read) - the kernel then fits 128 VGPRs, i.e.
+//     FOUR waves per SIMD (one 1024-thread workgroup per CU) to hide HBM latency.
+#include <stdlib.h>
+
+#include "lb_device.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const f32x4* lds_cptr;
+#define MFMA16H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+// hi = fp16(x) (RNE), lo = fp16(x - hi) for 8 values: 4 v_cvt_pk_f16_f32 + 8 v_fma_mix{lo,hi}_f16
+// (the mixed-precision fma evaluates x*1.0 - float(hi) exactly in fp32 and rounds once to fp16).
+// One asm block: the hazard recogniser does not look inside inline asm, so the block ends with the
+// two wait states a VALU result needs before an MFMA may read it as SrcA/B.
+__device__ __forceinline__ void lb_split8v(const f32x4& x0, const f32x4& x1, h8& hi, h8& lo) {
+  union {
+    h8 v;
+    uint32_t u[4];
+  } H, L;
+  asm("v_cvt_pk_f16_f32 %0, %8, %9\n"
+      "v_cvt_pk_f16_f32 %1, %10, %11\n"
+      "v_cvt_pk_f16_f32 %2, %12, %13\n"
+      "v_cvt_pk_f16_f32 %3, %14, %15\n"
+      "v_fma_mixlo_f16 %4, %8, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"
+      "v_fma_mixlo_f16 %5, %10, 1.0, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"
+      "v_fma_mixlo_f16 %6, %12, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"
+      "v_fma_mixlo_f16 %7, %14, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"
+      "v_fma_mixhi_f16 %4, %9, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n"
+      "v_fma_mixhi_f16 %5, %11, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n"
+      "v_fma_mixhi_f16 %6, %13, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n"
+      "v_fma_mixhi_f16 %7, %15, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n"
+      "s_nop 1"
+      : "=&v"(H.u[0]), "=&v"(H.u[1]), "=&v"(H.u[2]), "=&v"(H.u[3]), "=&v"(L.u[0]), "=&v"(L.u[1]), "=&v"(L.u[2]),
+        "=&v"(L.u[3])
+      : "v"(x0[0]), "v"(x0[1]), "v"(x0[2]), "v"(x0[3]), "v"(x1[0]), "v"(x1[1]), "v"(x1[2]), "v"(x1[3]));
+  hi = H.v;
+  lo = L.v;
+}
+
+// acc[0..7] += W^T * v over 4 k-steps of 32 (f16x2: lo*hi + hi*lo + hi*hi), phase-pipelined LDS reads.
+// wbase: this lane's LDS pointer to fragment (p 0, mbo 0, part 0); fragment (p, mbo, part) sits
+// ((p*8 + mbo)*2 + part)*64 f32x4 further.  RELU applies max(x, 0) to v while it is split.
+template <bool RELU>
+__device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[8], f32x4 (&acc)[8]) {
+  auto frag = [&](int p, int mbo, int part) -> h8 {
+    return __builtin_bit_cast(h8, wbase[((p * 8 + mbo) * 2 + part) * 64]);
+  };
+  auto relu4 = [&](const f32x4& x) -> f32x4 {
+    if (!RELU) return x;
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float f = x[j];  // (bit_cast of a vector-element lvalue reads element 0: copy first)
+      r[j] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, f), 0));
+    }
+    return r;
+  };
+  h8 X[4], Y[4];  // X: lo fragments, Y: hi fragments of the current block (4 output blocks)
+  h8 bh, bl, nbh, nbl;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) X[c] = frag(0, c, 1);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) Y[c] = frag(0, c, 0);
+  lb_split8v(relu4(v[0]), relu4(v[1]), bh, bl);
+  SB();
+#pragma unroll
+  for (int blk = 0; blk < 8; ++blk) {
+    const int p = blk >> 1, q = blk & 1;
+    const int np = (blk + 1) >> 1, nq = (blk + 1) & 1;
+    f32x4* a4 = &acc[4 * q];
+    // phase 1: lo * hi
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a4[c] = MFMA16H(X[c], bh, a4[c]);
+    SB();
+    if (blk < 7) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) X[c] = frag(np, 4 * nq + c, 1);
+    }
+    // the next k-step's operand is split while this block's MFMAs run
+    if (q == 1 && p < 3) lb_split8v(relu4(v[2 * p + 2]), relu4(v[2 * p + 3]), nbh, nbl);
+    // phase 2: hi * lo, hi * hi
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a4[c] = MFMA16H(Y[c], bl, a4[c]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a4[c] = MFMA16H(Y[c], bh, a4[c]);
+    SB();
+    if (blk < 7) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Y[c] = frag(np, 4 * nq + c, 0);
+    }
+    if (q == 1 && p < 3) {
+      bh = nbh;
+      bl = nbl;
+    }
+    SB();
+  }
+}
+
+// x += row_shr:k(x) * m for 8 registers and k = 1, 2, 4, 8 in a fixed order: one v_fmac_f32_dpp per
+// register and step; a register is read through DPP again only 8 instructions after it was written
+// (the VALU-write -> DPP-read hazard needs 2 wait states; inline asm is invisible to the hazard
+// recogniser, hence the fixed order and the leading s_nop).
+__device__ __forceinline__ void lb_scan8(f32x4& a, f32x4& b, float m1, float m2, float m4, float m8) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_fmac_f32_dpp %0, %0, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %1, %1, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %2, %2, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %3, %3, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %4, %4, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %5, %5, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %6, %6, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %7, %7, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %0, %0, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %1, %1, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %2, %2, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %3, %3, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %4, %4, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %5, %5, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %6, %6, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %7, %7, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %0, %0, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %1, %1, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %2, %2, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %3, %3, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %4, %4, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %5, %5, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %6, %6, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %7, %7, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %0, %0, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %1, %1, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %2, %2, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %3, %3, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %4, %4, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %5, %5, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %6, %6, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_fmac_f32_dpp %7, %7, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "s_nop 1\n"
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+      : "v"(m1), "v"(m2), "v"(m4), "v"(m8));
+}
+
+// ABL (tools/edge16v_bench.hip only, 0 in the product): 1 no psr gathers, 2 no edge-latent loads,
+// 4 no stores, 8 no GEMMs, 16 no LayerNorm / scan (epilogue VALU).
+// SKIP: last processor layer - the updated edge latents have no reader (compile-time so that the
+// residual path is branch-free: a store under a branch costs a vmcnt(0) drain at the join).
+template <int WPS, bool RELOAD, bool SKIP, int ABL = 0>
+__global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
+  constexpr int THREADS = WPS * 256, WAVES = WPS * 4;
+  constexpr int NW0 = 4096;
+  __shared__ f32x4 sW[NW0 + 4096 + 96];
+  if (a.ctrl->overflow_step >= 0) return;
+  const int tid = threadIdx.x;
+  {
+    const f32x4* g0 = reinterpret_cast<const f32x4*>(a.w0p);
+    const f32x4* g1 = reinterpret_cast<const f32x4*>(a.w1p);
+    for (int i = tid; i < NW0; i += THREADS) sW[i] = g0[i];
+    for (int i = tid; i < 4096; i += THREADS) sW[NW0 + i] = g1[i];
+    if (tid < 96) {
+      const float* src = tid < 32 ? a.b1 : (tid < 64 ? a.ln_s : a.ln_o);
+      sW[NW0 + 4096 + tid] = reinterpret_cast<const f32x4*>(src)[tid & 31];
+    }
+  }
+  __syncthreads();
+  const int E = a.ctrl->n_edges_total;
+  const int ntiles = (E + 15) >> 4;
+  // the wave index is uniform: keep the whole tile walk (t, stride, bounds) in scalar registers
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * WAVES + wave;
+  const int stride = (gridDim.x >> 3) * WAVES;
+  const int t_lo = (int)(((int64_t)ntiles * xcd) >> 3), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) >> 3);
+  int t = t_lo + slot;
+  if (t >= t_hi) return;
+  // two lane bases so that every fragment offset fits the 16-bit ds offset field; the integer
+  // round trip through an asm keeps the compiler from folding them back into one base + 64 KiB
+  uint32_t off0 = (uint32_t)(uintptr_t)(lds_cptr)(sW + lane);
+  uint32_t off1 = (uint32_t)(uintptr_t)(lds_cptr)(sW + NW0 + lane);
+  uint32_t off2 = (uint32_t)(uintptr_t)(lds_cptr)(sW + NW0 + 4096 + g);
+  asm volatile("" : "+v"(off0), "+v"(off1), "+v"(off2));
+  const lds_cptr w0b = (lds_cptr)(uintptr_t)off0, w1b = (lds_cptr)(uintptr_t)off1, vecb = (lds_cptr)(uintptr_t)off2;
+  auto rowc_of = [&](int tt) -> int64_t {
+    const int row = tt * 16 + n;
+    return row < E ? row : E - 1;
+  };
+  const f32x4* psr4 = reinterpret_cast<const f32x4*>(a.psr);
+  const int n_iter = (t_hi - 1 - t) / stride + 1;
+  const int t_last = t + (n_iter - 1) * stride;
+  int s_c, r_c;
+  {
+    const int64_t rc = rowc_of(t);
+    s_c = a.senders[rc];
+    r_c = a.receivers[rc];
+    // waited for HERE: a wait at the loop header would also be executed on the back edge, where
+    // it drains the previous tile's stores
+    asm volatile("" : "+v"(s_c), "+v"(r_c));
+  }
+  for (int it = 0; it < n_iter; ++it, t += stride) {
+    f32x4 acc[8], ve[8];
+    const int r_cur = r_c;
+    const f32x4* er = reinterpret_cast<const f32x4*>(a.elat) + (int64_t)t * 512 + lane;
+    {
+      const f32x4* ps = psr4 + (int64_t)s_c * 64 + g;
+      const f32x4* pr = psr4 + (int64_t)r_c * 64 + 32 + g;
+      f32x4 p0[8];
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) {
+        ve[mb] = (ABL & 2) ? f32x4{1.f, 2.f, (float)t, (float)mb} : er[64 * mb];
+        p0[mb] = (ABL & 1) ? f32x4{.1f, .2f, (float)s_c, (float)mb} : ps[4 * mb];
+        acc[mb] = (ABL & 1) ? f32x4{.3f, .1f, (float)r_c, (float)mb} : pr[4 * mb];
+      }
+      const int64_t rn = rowc_of(min(t + stride, t_last));
+      s_c = a.senders[rn];
+      r_c = a.receivers[rn];
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mb][j] = acc[mb][j] + p0[mb][j];
+    }
+    // CSR bounds of this lane's receiver (which slot its segment sum goes to), fetched with the
+    // tile's other loads for the same reason the next indices are (see below)
+    int k0 = a.row_ptr[r_cur], k1 = a.row_ptr[r_cur + 1];
+    if constexpr (!(ABL & 8)) lb_gemm16v<false>(w0b, ve, acc);
+    f32x4 acc2[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc2[mb] = vecb[4 * mb];
+    if constexpr (!(ABL & 8)) {
+      lb_gemm16v<true>(w1b, acc, acc2);
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc2[mb][j] += acc[mb][j] + ve[mb][j];
+    }
+    if constexpr (RELOAD && !SKIP && !(ABL & 2)) {
+      // second read of the edge latents for the residual (first read ~2 us ago: L2 / MALL resident)
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) ve[mb] = er[64 * mb];
+    }
+    // take delivery of the next tile's indices HERE, while only loads are in flight: with stores
+    // pending too, gfx9's single vmcnt makes any later wait a full drain (vmcnt(0)) - at the loop
+    // top that would put the store latency of this tile in front of the next tile's loads
+    asm volatile("" : "+v"(s_c), "+v"(r_c), "+v"(k0), "+v"(k1));
+    float sm = 0.f;
+    if constexpr (!(ABL & 16))
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) sm += (acc2[mb][0] + acc2[mb][1]) + (acc2[mb][2] + acc2[mb][3]);
+    sm += __shfl_xor(sm, 16);
+    sm += __shfl_xor(sm, 32);
+    const float mean = sm * (1.0f / 128.0f);
+    float vs = 0.f;
+    if constexpr (!(ABL & 16))
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc2[mb][j] = acc2[mb][j] - mean;
+        vs = __builtin_fmaf(acc2[mb][j], acc2[mb][j], vs);
+      }
+    vs += __shfl_xor(vs, 16);
+    vs += __shfl_xor(vs, 32);
+    const float rs = 1.0f / sqrtf(vs * (1.0f / 128.0f) + 1e-5f);
+    f32x4 y[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const f32x4 sc = vecb[32 + 4 * mb], of = vecb[64 + 4 * mb];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[mb][j] = (ABL & 16) ? acc2[mb][j] : __builtin_fmaf(sc[j] * rs, acc2[mb][j], of[j]);
+    }
+    const int row = t * 16 + n;
+    const bool valid = row < E;
+    if constexpr (!SKIP && !(ABL & 4)) {
+      f32x4* ew = reinterpret_cast<f32x4*>(a.elat) + (int64_t)t * 512 + lane;
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = ve[mb][j] + y[mb][j];
+        ew[64 * mb] = o;
+      }
+    }
+    // fused jraph.segment_sum: segmented Hillis-Steele scan inside each 16-lane DPP row
+    const int rr = valid ? r_cur : (-1 - n);
+    const int r_prev = __builtin_amdgcn_update_dpp(-2, rr, 0x111, 0xF, 0xF, false);
+    const bool head = (n == 0) || (rr != r_prev);
+    const unsigned H = (unsigned)(__ballot(head) & 0xffffull);
+    const unsigned below = H & ((2u << n) - 1u);
+    const int segstart = 31 - __clz(below);
+    const bool tail = (n == 15) || ((H >> (n + 1)) & 1u);
+    const float m1 = (n >= 1 && segstart <= n - 1) ? 1.f : 0.f, m2 = (n >= 2 && segstart <= n - 2) ? 1.f : 0.f;
+    const float m4 = (n >= 4 && segstart <= n - 4) ? 1.f : 0.f, m8 = (n >= 8 && segstart <= n - 8) ? 1.f : 0.f;
+    if (!valid) {
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) y[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (!(ABL & 16))
+#pragma unroll
+    for (int mb = 0; mb < 8; mb += 2) lb_scan8(y[mb], y[mb + 1], m1, m2, m4, m8);
+    if (tail && valid && !(ABL & 4)) {
+      const bool complete = (k0 >> 4) == ((k1 - 1) >> 4);
+      float* dst = complete ? a.agg + (int64_t)rr * 128
+                            : a.part + ((int64_t)t * 2 + (k0 <= t * 16 ? 0 : 1)) * 128;
+      f32x4* d4 = reinterpret_cast<f32x4*>(dst) + g;
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) d4[4 * mb] = y[mb];
+    }
+  }
+}
+
+int lbk_edge16v(lb_engine* e, const lb_edge16_args& a, int variant) {
+#define LB_E16V(W, R)                                                                                   \
+  do {                                                                                                  \
+    if (a.skip_elat_store)                                                                              \
+      hipLaunchKernelGGL((k_edge16v<W, R, true>), dim3(256), dim3(W * 256), 0, e->stream, a);           \
+    else                                                                                                \
+      hipLaunchKernelGGL((k_edge16v<W, R, false>), dim3(256), dim3(W * 256), 0, e->stream, a);          \
+  } while (0)
+  switch (variant) {
+    case 0: LB_E16V(3, false); break;
+    case 1: LB_E16V(4, true); break;
+    case 2: LB_E16V(3, true); break;
+    default: return lb_fail(LB_ERR_ARG, "k_edge16v variant %d", variant);
+  }
+#undef LB_E16V
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
