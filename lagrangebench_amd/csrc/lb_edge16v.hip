@@ -164,6 +164,26 @@ __device__ __forceinline__ void lb_scan8(f32x4& a, f32x4& b, float m1, float m2,
       : "v"(m1), "v"(m2), "v"(m4), "v"(m8));
 }
 
+// Where does a receiver's segment sum go?  The node kernel (lb_load_agg16) reads `agg[r]` when all
+// edges of r lie in one 16-edge tile and otherwise, for every tile the row touches, the partial slot
+// `part[tile][k0 <= 16*tile ? 0 : 1]` (k0 = row_ptr[r]).  Both facts are visible from inside the tile:
+// slot 0 <=> the segment contains the tile's first lane; complete <=> the edge before the tile (if the
+// segment starts at lane 0) and the edge after it (if it ends at lane 15) belong to other receivers.
+// lb_edge_probe fetches those two receivers in ONE vector load (even lanes: edge 16t-1, odd lanes:
+// edge 16t+16) instead of two row_ptr gathers per lane.
+__device__ __forceinline__ int lb_edge_probe(const int32_t* __restrict__ receivers, int t, int lane, int E) {
+  int idx = t * 16 - 1 + 17 * (lane & 1);
+  idx = idx < 0 ? 0 : (idx < E ? idx : E - 1);
+  return receivers[idx];
+}
+__device__ __forceinline__ bool lb_seg_complete(int rb, int rr, int segstart, int n, int t, int E, int& slot01) {
+  const int r_before = __builtin_amdgcn_readlane(rb, 0), r_after = __builtin_amdgcn_readlane(rb, 1);
+  const bool starts_before = segstart == 0 && t > 0 && r_before == rr;
+  const bool ends_after = n == 15 && t * 16 + 16 < E && r_after == rr;
+  slot01 = segstart == 0 ? 0 : 1;
+  return !starts_before && !ends_after;
+}
+
 // ABL (tools/edge16v_bench.hip only, 0 in the product): 1 no psr gathers, 2 no edge-latent loads,
 // 4 no stores, 8 no GEMMs, 16 no LayerNorm / scan (epilogue VALU).
 // SKIP: last processor layer - the updated edge latents have no reader (compile-time so that the
@@ -229,7 +249,9 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
       f32x4 p0[8];
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb) {
-        ve[mb] = (ABL & 2) ? f32x4{1.f, 2.f, (float)t, (float)mb} : er[64 * mb];
+        // streamed once per layer: nontemporal unless the RELOAD variant wants the tile back from L2
+        ve[mb] = (ABL & 2) ? f32x4{1.f, 2.f, (float)t, (float)mb}
+                           : (RELOAD ? er[64 * mb] : __builtin_nontemporal_load(&er[64 * mb]));
         p0[mb] = (ABL & 1) ? f32x4{.1f, .2f, (float)s_c, (float)mb} : ps[4 * mb];
         acc[mb] = (ABL & 1) ? f32x4{.3f, .1f, (float)r_c, (float)mb} : pr[4 * mb];
       }
@@ -241,9 +263,10 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[mb][j] = acc[mb][j] + p0[mb][j];
     }
-    // CSR bounds of this lane's receiver (which slot its segment sum goes to), fetched with the
-    // tile's other loads for the same reason the next indices are (see below)
-    int k0 = a.row_ptr[r_cur], k1 = a.row_ptr[r_cur + 1];
+    // receivers of the edge just before and just after this tile (lane parity 0 / 1): tell whether a
+    // segment is cut by the tile boundary without touching row_ptr; fetched with the tile's other
+    // loads for the same reason the next indices are (see below)
+    int rb = lb_edge_probe(a.receivers, t, lane, E);
     if constexpr (!(ABL & 8)) lb_gemm16v<false>(w0b, ve, acc);
     f32x4 acc2[8];
 #pragma unroll
@@ -264,7 +287,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
     // take delivery of the next tile's indices HERE, while only loads are in flight: with stores
     // pending too, gfx9's single vmcnt makes any later wait a full drain (vmcnt(0)) - at the loop
     // top that would put the store latency of this tile in front of the next tile's loads
-    asm volatile("" : "+v"(s_c), "+v"(r_c), "+v"(k0), "+v"(k1));
+    asm volatile("" : "+v"(s_c), "+v"(r_c), "+v"(rb));
     float sm = 0.f;
     if constexpr (!(ABL & 16))
 #pragma unroll
@@ -300,7 +323,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = ve[mb][j] + y[mb][j];
-        ew[64 * mb] = o;
+        __builtin_nontemporal_store(o, &ew[64 * mb]);
       }
     }
     // fused jraph.segment_sum: segmented Hillis-Steele scan inside each 16-lane DPP row
@@ -321,14 +344,195 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
 #pragma unroll
     for (int mb = 0; mb < 8; mb += 2) lb_scan8(y[mb], y[mb + 1], m1, m2, m4, m8);
     if (tail && valid && !(ABL & 4)) {
-      const bool complete = (k0 >> 4) == ((k1 - 1) >> 4);
-      float* dst = complete ? a.agg + (int64_t)rr * 128
-                            : a.part + ((int64_t)t * 2 + (k0 <= t * 16 ? 0 : 1)) * 128;
+      int slot01;
+      const bool complete = lb_seg_complete(rb, rr, segstart, n, t, E, slot01);
+      float* dst = complete ? a.agg + (int64_t)rr * 128 : a.part + ((int64_t)t * 2 + slot01) * 128;
       f32x4* d4 = reinterpret_cast<f32x4*>(dst) + g;
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb) d4[4 * mb] = y[mb];
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_edge16p: the same tile body, fully software-pipelined inside each wave.  While tile t is in the
+// GEMMs, ALL loads of tile t+1 (edge latents + gathered sender/receiver projections + CSR bounds) and
+// the indices of tile t+2 are in flight, so the bytes a CU has outstanding no longer depend on how
+// the phases of its waves happen to line up (fine-grained arbitration keeps equal waves in lock step:
+// they all load, then all compute).  The prefetch sets cost 96 VGPRs -> WPS = 2 (256 VGPRs).
+// The edge latents are touched once per layer (562 MB >> L2 + Infinity Cache): their loads and stores
+// are nontemporal so that the streams do not push the gathered psr table out of L2 / MALL
+// (tools/stream_bench: 257 -> 233 us for this access pattern).
+// The first tile is peeled: a waitcnt at the loop header serves the entry and the back edge with ONE
+// static count, and the entry's smaller count would drain the previous tile's stores on every trip.
+struct lb_e16p_state {
+  f32x4 ve[8], ps[8], pr[8];  // next tile, in flight
+  int s_n, r_n;               // indices of the tile after next
+  int r_pref, rb;             // receiver of the next tile's lanes + its boundary probe
+};
+
+template <int WPS, bool SKIP, int ABL = 0>
+__global__ void __launch_bounds__(WPS * 256, WPS) k_edge16p(lb_edge16_args a) {
+  constexpr int THREADS = WPS * 256, WAVES = WPS * 4;
+  constexpr int NW0 = 4096;
+  __shared__ f32x4 sW[NW0 + 4096 + 96];
+  if (a.ctrl->overflow_step >= 0) return;
+  const int tid = threadIdx.x;
+  {
+    const f32x4* g0 = reinterpret_cast<const f32x4*>(a.w0p);
+    const f32x4* g1 = reinterpret_cast<const f32x4*>(a.w1p);
+    for (int i = tid; i < NW0; i += THREADS) sW[i] = g0[i];
+    for (int i = tid; i < 4096; i += THREADS) sW[NW0 + i] = g1[i];
+    if (tid < 96) {
+      const float* src = tid < 32 ? a.b1 : (tid < 64 ? a.ln_s : a.ln_o);
+      sW[NW0 + 4096 + tid] = reinterpret_cast<const f32x4*>(src)[tid & 31];
+    }
+  }
+  __syncthreads();
+  const int E = a.ctrl->n_edges_total;
+  const int ntiles = (E + 15) >> 4;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * WAVES + wave;
+  const int stride = (gridDim.x >> 3) * WAVES;
+  const int t_lo = (int)(((int64_t)ntiles * xcd) >> 3), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) >> 3);
+  int t = t_lo + slot;
+  if (t >= t_hi) return;
+  uint32_t off0 = (uint32_t)(uintptr_t)(lds_cptr)(sW + lane);
+  uint32_t off1 = (uint32_t)(uintptr_t)(lds_cptr)(sW + NW0 + lane);
+  uint32_t off2 = (uint32_t)(uintptr_t)(lds_cptr)(sW + NW0 + 4096 + g);
+  asm volatile("" : "+v"(off0), "+v"(off1), "+v"(off2));
+  const lds_cptr w0b = (lds_cptr)(uintptr_t)off0, w1b = (lds_cptr)(uintptr_t)off1, vecb = (lds_cptr)(uintptr_t)off2;
+  auto rowc_of = [&](int tt) -> int64_t {
+    const int row = tt * 16 + n;
+    return row < E ? row : E - 1;
+  };
+  const f32x4* psr4 = reinterpret_cast<const f32x4*>(a.psr);
+  const int n_iter = (t_hi - 1 - t) / stride + 1;
+  const int t_last = t + (n_iter - 1) * stride;
+
+  lb_e16p_state st;
+  // every load is unconditional (tile indices clamp to the wave's last tile): a load under a
+  // branch makes the compiler wait vmcnt(0) for the loop-carried registers
+  auto issue = [&](int tt, int s, int r) {
+    const f32x4* er = reinterpret_cast<const f32x4*>(a.elat) + (int64_t)tt * 512 + lane;
+    const f32x4* ps = psr4 + (int64_t)s * 64 + g;
+    const f32x4* pr = psr4 + (int64_t)r * 64 + 32 + g;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      st.ve[mb] = (ABL & 2) ? f32x4{1.f, 2.f, (float)tt, (float)mb} : __builtin_nontemporal_load(&er[64 * mb]);
+      st.ps[mb] = (ABL & 1) ? f32x4{.1f, .2f, (float)s, (float)mb} : ps[4 * mb];
+      st.pr[mb] = (ABL & 1) ? f32x4{.3f, .1f, (float)r, (float)mb} : pr[4 * mb];
+    }
+    st.r_pref = r;
+    st.rb = lb_edge_probe(a.receivers, tt, lane, E);
+  };
+  {
+    const int64_t rc = rowc_of(t);
+    int s0 = a.senders[rc], r0 = a.receivers[rc];
+    asm volatile("" : "+v"(s0), "+v"(r0));
+    issue(t, s0, r0);
+    const int64_t rn = rowc_of(min(t + stride, t_last));
+    st.s_n = a.senders[rn];
+    st.r_n = a.receivers[rn];
+  }
+
+  auto body = [&](int tc) {
+    // ---- take delivery of the prefetched tile
+    f32x4 acc[8], ve[8];
+    const int r_cur = st.r_pref;
+    int rb = st.rb;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      ve[mb] = st.ve[mb];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[mb][j] = st.ps[mb][j] + st.pr[mb][j];
+    }
+    asm volatile("" : "+v"(rb));
+    // ---- put the next tile's loads and the indices of the one after in flight
+    {
+      int s = st.s_n, r = st.r_n;
+      asm volatile("" : "+v"(s), "+v"(r));
+      issue(min(tc + stride, t_last), s, r);
+      const int64_t rn = rowc_of(min(tc + 2 * stride, t_last));
+      st.s_n = a.senders[rn];
+      st.r_n = a.receivers[rn];
+    }
+    if constexpr (!(ABL & 8)) lb_gemm16v<false>(w0b, ve, acc);
+    f32x4 acc2[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc2[mb] = vecb[4 * mb];
+    if constexpr (!(ABL & 8)) {
+      lb_gemm16v<true>(w1b, acc, acc2);
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc2[mb][j] += acc[mb][j] + ve[mb][j];
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) sm += (acc2[mb][0] + acc2[mb][1]) + (acc2[mb][2] + acc2[mb][3]);
+    sm += __shfl_xor(sm, 16);
+    sm += __shfl_xor(sm, 32);
+    const float mean = sm * (1.0f / 128.0f);
+    float vs = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc2[mb][j] = acc2[mb][j] - mean;
+        vs = __builtin_fmaf(acc2[mb][j], acc2[mb][j], vs);
+      }
+    vs += __shfl_xor(vs, 16);
+    vs += __shfl_xor(vs, 32);
+    const float rs = 1.0f / sqrtf(vs * (1.0f / 128.0f) + 1e-5f);
+    f32x4 y[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const f32x4 sc = vecb[32 + 4 * mb], of = vecb[64 + 4 * mb];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[mb][j] = __builtin_fmaf(sc[j] * rs, acc2[mb][j], of[j]);
+    }
+    const int row = tc * 16 + n;
+    const bool valid = row < E;
+    if constexpr (!SKIP && !(ABL & 4)) {
+      f32x4* ew = reinterpret_cast<f32x4*>(a.elat) + (int64_t)tc * 512 + lane;
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = ve[mb][j] + y[mb][j];
+        __builtin_nontemporal_store(o, &ew[64 * mb]);
+      }
+    }
+    const int rr = valid ? r_cur : (-1 - n);
+    const int r_prev = __builtin_amdgcn_update_dpp(-2, rr, 0x111, 0xF, 0xF, false);
+    const bool head = (n == 0) || (rr != r_prev);
+    const unsigned H = (unsigned)(__ballot(head) & 0xffffull);
+    const unsigned below = H & ((2u << n) - 1u);
+    const int segstart = 31 - __clz(below);
+    const bool tail = (n == 15) || ((H >> (n + 1)) & 1u);
+    const float m1 = (n >= 1 && segstart <= n - 1) ? 1.f : 0.f, m2 = (n >= 2 && segstart <= n - 2) ? 1.f : 0.f;
+    const float m4 = (n >= 4 && segstart <= n - 4) ? 1.f : 0.f, m8 = (n >= 8 && segstart <= n - 8) ? 1.f : 0.f;
+    if (!valid) {
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) y[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int mb = 0; mb < 8; mb += 2) lb_scan8(y[mb], y[mb + 1], m1, m2, m4, m8);
+    if (tail && valid && !(ABL & 4)) {
+      int slot01;
+      const bool complete = lb_seg_complete(rb, rr, segstart, n, tc, E, slot01);
+      float* dst = complete ? a.agg + (int64_t)rr * 128 : a.part + ((int64_t)tc * 2 + slot01) * 128;
+      f32x4* d4 = reinterpret_cast<f32x4*>(dst) + g;
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) d4[4 * mb] = y[mb];
+    }
+  };
+  body(t);  // peeled (see the header comment)
+  t += stride;
+  for (int it = 1; it < n_iter; ++it, t += stride) body(t);
 }
 
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a, int variant) {
@@ -343,6 +547,12 @@ int lbk_edge16v(lb_engine* e, const lb_edge16_args& a, int variant) {
     case 0: LB_E16V(3, false); break;
     case 1: LB_E16V(4, true); break;
     case 2: LB_E16V(3, true); break;
+    case 3:
+      if (a.skip_elat_store)
+        hipLaunchKernelGGL((k_edge16p<2, true>), dim3(256), dim3(512), 0, e->stream, a);
+      else
+        hipLaunchKernelGGL((k_edge16p<2, false>), dim3(256), dim3(512), 0, e->stream, a);
+      break;
     default: return lb_fail(LB_ERR_ARG, "k_edge16v variant %d", variant);
   }
 #undef LB_E16V

@@ -23,6 +23,8 @@
 //   parts are projected once per NODE (fused into the tail of the node kernel) and gathered as
 //   the accumulator's initial value, which halves the dominant MFMA work.
 //   Aggregation is an atomic-free segmented sum over the receiver-sorted CSR (deterministic).
+#include <stdlib.h>
+
 #include "lb_device.h"
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -611,7 +613,17 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
         b.agg = a.agg;
         b.part = a.part;
         b.skip_elat_store = (k == L - 1) && e->fused_agg && !g->tap;
-        rc = lbk_edge16(e, b, true, e->f16x2 != 0);
+        // LB_EDGE_KERNEL: "n" = round-1 k_edge16n, "v0".."v3" = k_edge16v / k_edge16p variants
+        static const int ev = [] {
+          const char* s = getenv("LB_EDGE_KERNEL");
+          if (!s || !s[0]) return 0;
+          if (s[0] == 'n') return -1;
+          return (s[0] == 'v' && s[1] >= '0' && s[1] <= '3') ? s[1] - '0' : 0;
+        }();
+        if (e->f16x2 && e->fused_agg && ev >= 0)
+          rc = lbk_edge16v(e, b, ev);
+        else
+          rc = lbk_edge16(e, b, true, e->f16x2 != 0);
         if (rc) return rc;
       } else {
         hipLaunchKernelGGL((k_edge_mlp<true>), dim3(edge_blocks), dim3(EDGE_THREADS), 0, s, a);

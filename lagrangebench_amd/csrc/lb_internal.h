@@ -277,3 +277,7 @@ void lb_pack_weight16h(const float* w, int K, int M, int Kpad, float* out, int M
 int lbk_node16h(lb_engine* e, const lb_node_args& a, const float* w0h, const float* w1h,
                 const float* wph, int npa, int npb, bool resid);
 int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc, bool f16x2);
+// lb_edge16v.hip: round-2 processor edge kernel (f16x2, fused aggregation); variant 0 = three waves per
+// SIMD, resident latents (default), 1 = four waves + second read, 2 = three waves + second read,
+// 3 = two waves, fully software-pipelined
+int lbk_edge16v(lb_engine* e, const lb_edge16_args& a, int variant);

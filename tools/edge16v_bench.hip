@@ -167,6 +167,13 @@ int main(int argc, char** argv) {
   report("k_edge16v<3 waves, resident e>", V(3, false, 0), true);
   report("k_edge16v<4 waves, reload e>", V(4, true, 0), true);
   report("k_edge16v<3 waves, reload e>", V(3, true, 0), true);
+#define P(W, ABL) [&] { hipLaunchKernelGGL((k_edge16p<W, false, ABL>), dim3(256), dim3(W * 256), 0, 0, a); }
+  report("k_edge16p<2 waves, full prefetch>", P(2, 0), true);
+  printf("--- ablation of k_edge16p<2 waves>\n");
+  report("  no loads", P(2, 3), false);
+  report("  no stores", P(2, 4), false);
+  report("  no loads, no stores (compute only)", P(2, 7), false);
+  report("  no GEMMs (memory + VALU)", P(2, 8), false);
   printf("--- ablation of <4 waves, reload e>\n");
   report("  no psr gathers", V(4, true, 1), false);
   report("  no e loads", V(4, true, 2), false);
@@ -175,14 +182,12 @@ int main(int argc, char** argv) {
   report("  no loads, no stores (compute only)", V(4, true, 7), false);
   report("  no GEMMs (memory + VALU)", V(4, true, 8), false);
   report("  no GEMMs, no loads/stores (VALU + LDS fill)", V(4, true, 15), false);
-  report("  no epilogue VALU, no loads/stores (GEMMs only)", V(4, true, 23), false);
   printf("--- ablation of <3 waves, resident e>\n");
   report("  no loads, no stores (compute only)", V(3, false, 7), false);
   report("  no GEMMs (memory + VALU)", V(3, false, 8), false);
   report("  no stores", V(3, false, 4), false);
   report("  no loads", V(3, false, 3), false);
   report("  no GEMMs, no loads/stores (VALU + LDS fill)", V(3, false, 15), false);
-  report("  no epilogue VALU, no loads/stores (GEMMs only)", V(3, false, 23), false);
   report("k_edge16n again", base, false);
   return 0;
 }
