@@ -31,6 +31,17 @@ typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const f32x4* lds_cptr;
 #define MFMA16H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 #define SB() __builtin_amdgcn_sched_barrier(0)
+// s_waitcnt immediate (gfx9 encoding) that waits only on lgkmcnt <= n
+#define LB_WAIT_LGKM(n) (0xC07F | ((n) << 8))
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+// packed fp32 helpers on the two halves of an f32x4 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: one
+// issue slot for two lanes-worth of work; the halves of an f32x4 are adjacent register pairs)
+__device__ __forceinline__ f32x2v lb_lo2(const f32x4& x) { return f32x2v{x[0], x[1]}; }
+__device__ __forceinline__ f32x2v lb_hi2(const f32x4& x) { return f32x2v{x[2], x[3]}; }
+__device__ __forceinline__ f32x4 lb_cat2(f32x2v a, f32x2v b) { return f32x4{a[0], a[1], b[0], b[1]}; }
+__device__ __forceinline__ f32x4 lb_pk_add(const f32x4& a, const f32x4& b) {
+  return lb_cat2(lb_lo2(a) + lb_lo2(b), lb_hi2(a) + lb_hi2(b));
+}
 
 // hi = fp16(x) (RNE), lo = fp16(x - hi) for 8 values: 4 v_cvt_pk_f16_f32 + 8 v_fma_mix{lo,hi}_f16
 // (the mixed-precision fma evaluates x*1.0 - float(hi) exactly in fp32 and rounds once to fp16).
@@ -92,7 +103,10 @@ __device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[8], 
     const int p = blk >> 1, q = blk & 1;
     const int np = (blk + 1) >> 1, nq = (blk + 1) & 1;
     f32x4* a4 = &acc[4 * q];
-    // phase 1: lo * hi
+    // phase 1: lo * hi.  ONE wait for the four `lo` fragments (the four `hi` reads issued after them may
+    // still be in flight): left alone the compiler waits before every MFMA, ~100 s_waitcnt per tile
+    // in a kernel that is bound by instruction issue
+    __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(4));
 #pragma unroll
     for (int c = 0; c < 4; ++c) a4[c] = MFMA16H(X[c], bh, a4[c]);
     SB();
@@ -102,7 +116,11 @@ __device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[8], 
     }
     // the next k-step's operand is split while this block's MFMAs run
     if (q == 1 && p < 3) lb_split8v(relu4(v[2 * p + 2]), relu4(v[2 * p + 3]), nbh, nbl);
-    // phase 2: hi * lo, hi * hi
+    // phase 2: hi * lo, hi * hi (wait for the `hi` fragments; the next block's `lo` reads stay in flight)
+    if (blk < 7)
+      __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(4));
+    else
+      __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(0));
 #pragma unroll
     for (int c = 0; c < 4; ++c) a4[c] = MFMA16H(Y[c], bl, a4[c]);
 #pragma unroll
@@ -117,6 +135,44 @@ __device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[8], 
       bl = nbl;
     }
     SB();
+  }
+}
+
+// LayerNorm over the 128 features of every edge (32 registers x the 4 lanes of a DPP-row column),
+// hk.LayerNorm(axis=-1, eps 1e-5) of models/utils.py:112, in packed fp32: pre -> y.
+template <bool ENABLE = true>
+__device__ __forceinline__ void lb_layernorm16(f32x4 (&pre)[8], lds_cptr vecb, f32x4 (&y)[8]) {
+  if constexpr (!ENABLE) {
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) y[mb] = pre[mb];
+    return;
+  }
+  f32x2v s2 = {0.f, 0.f};
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) s2 = s2 + (lb_lo2(pre[mb]) + lb_hi2(pre[mb]));
+  float sm = s2[0] + s2[1];
+  sm += __shfl_xor(sm, 16);
+  sm += __shfl_xor(sm, 32);
+  const float mean = sm * (1.0f / 128.0f);
+  const f32x2v m2 = {mean, mean};
+  f32x2v v2 = {0.f, 0.f};
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const f32x2v dl = lb_lo2(pre[mb]) - m2, dh = lb_hi2(pre[mb]) - m2;
+    v2 = __builtin_elementwise_fma(dl, dl, v2);
+    v2 = __builtin_elementwise_fma(dh, dh, v2);
+    pre[mb] = lb_cat2(dl, dh);
+  }
+  float vs = v2[0] + v2[1];
+  vs += __shfl_xor(vs, 16);
+  vs += __shfl_xor(vs, 32);
+  const float rs = 1.0f / sqrtf(vs * (1.0f / 128.0f) + 1e-5f);
+  const f32x2v r2 = {rs, rs};
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const f32x4 sc = vecb[32 + 4 * mb], of = vecb[64 + 4 * mb];
+    y[mb] = lb_cat2(__builtin_elementwise_fma(lb_lo2(sc) * r2, lb_lo2(pre[mb]), lb_lo2(of)),
+                    __builtin_elementwise_fma(lb_hi2(sc) * r2, lb_hi2(pre[mb]), lb_hi2(of)));
   }
 }
 
@@ -259,9 +315,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
       s_c = a.senders[rn];
       r_c = a.receivers[rn];
 #pragma unroll
-      for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[mb][j] = acc[mb][j] + p0[mb][j];
+      for (int mb = 0; mb < 8; ++mb) acc[mb] = lb_pk_add(acc[mb], p0[mb]);
     }
     // receivers of the edge just before and just after this tile (lane parity 0 / 1): tell whether a
     // segment is cut by the tile boundary without touching row_ptr; fetched with the tile's other
@@ -288,43 +342,14 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
     // pending too, gfx9's single vmcnt makes any later wait a full drain (vmcnt(0)) - at the loop
     // top that would put the store latency of this tile in front of the next tile's loads
     asm volatile("" : "+v"(s_c), "+v"(r_c), "+v"(rb));
-    float sm = 0.f;
-    if constexpr (!(ABL & 16))
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) sm += (acc2[mb][0] + acc2[mb][1]) + (acc2[mb][2] + acc2[mb][3]);
-    sm += __shfl_xor(sm, 16);
-    sm += __shfl_xor(sm, 32);
-    const float mean = sm * (1.0f / 128.0f);
-    float vs = 0.f;
-    if constexpr (!(ABL & 16))
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc2[mb][j] = acc2[mb][j] - mean;
-        vs = __builtin_fmaf(acc2[mb][j], acc2[mb][j], vs);
-      }
-    vs += __shfl_xor(vs, 16);
-    vs += __shfl_xor(vs, 32);
-    const float rs = 1.0f / sqrtf(vs * (1.0f / 128.0f) + 1e-5f);
     f32x4 y[8];
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-      const f32x4 sc = vecb[32 + 4 * mb], of = vecb[64 + 4 * mb];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) y[mb][j] = (ABL & 16) ? acc2[mb][j] : __builtin_fmaf(sc[j] * rs, acc2[mb][j], of[j]);
-    }
+    lb_layernorm16<!(ABL & 16)>(acc2, vecb, y);
     const int row = t * 16 + n;
     const bool valid = row < E;
     if constexpr (!SKIP && !(ABL & 4)) {
       f32x4* ew = reinterpret_cast<f32x4*>(a.elat) + (int64_t)t * 512 + lane;
 #pragma unroll
-      for (int mb = 0; mb < 8; ++mb) {
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = ve[mb][j] + y[mb][j];
-        __builtin_nontemporal_store(o, &ew[64 * mb]);
-      }
+      for (int mb = 0; mb < 8; ++mb) __builtin_nontemporal_store(lb_pk_add(ve[mb], y[mb]), &ew[64 * mb]);
     }
     // fused jraph.segment_sum: segmented Hillis-Steele scan inside each 16-lane DPP row
     const int rr = valid ? r_cur : (-1 - n);
@@ -445,8 +470,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16p(lb_edge16_args a) {
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
       ve[mb] = st.ve[mb];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[mb][j] = st.ps[mb][j] + st.pr[mb][j];
+      acc[mb] = lb_pk_add(st.ps[mb], st.pr[mb]);
     }
     asm volatile("" : "+v"(rb));
     // ---- put the next tile's loads and the indices of the one after in flight
@@ -470,41 +494,14 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16p(lb_edge16_args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc2[mb][j] += acc[mb][j] + ve[mb][j];
     }
-    float sm = 0.f;
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) sm += (acc2[mb][0] + acc2[mb][1]) + (acc2[mb][2] + acc2[mb][3]);
-    sm += __shfl_xor(sm, 16);
-    sm += __shfl_xor(sm, 32);
-    const float mean = sm * (1.0f / 128.0f);
-    float vs = 0.f;
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc2[mb][j] = acc2[mb][j] - mean;
-        vs = __builtin_fmaf(acc2[mb][j], acc2[mb][j], vs);
-      }
-    vs += __shfl_xor(vs, 16);
-    vs += __shfl_xor(vs, 32);
-    const float rs = 1.0f / sqrtf(vs * (1.0f / 128.0f) + 1e-5f);
     f32x4 y[8];
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-      const f32x4 sc = vecb[32 + 4 * mb], of = vecb[64 + 4 * mb];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) y[mb][j] = __builtin_fmaf(sc[j] * rs, acc2[mb][j], of[j]);
-    }
+    lb_layernorm16(acc2, vecb, y);
     const int row = tc * 16 + n;
     const bool valid = row < E;
     if constexpr (!SKIP && !(ABL & 4)) {
       f32x4* ew = reinterpret_cast<f32x4*>(a.elat) + (int64_t)tc * 512 + lane;
 #pragma unroll
-      for (int mb = 0; mb < 8; ++mb) {
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = ve[mb][j] + y[mb][j];
-        __builtin_nontemporal_store(o, &ew[64 * mb]);
-      }
+      for (int mb = 0; mb < 8; ++mb) __builtin_nontemporal_store(lb_pk_add(ve[mb], y[mb]), &ew[64 * mb]);
     }
     const int rr = valid ? r_cur : (-1 - n);
     const int r_prev = __builtin_amdgcn_update_dpp(-2, rr, 0x111, 0xF, 0xF, false);

@@ -169,6 +169,10 @@ int main(int argc, char** argv) {
   report("k_edge16v<3 waves, reload e>", V(3, true, 0), true);
 #define P(W, ABL) [&] { hipLaunchKernelGGL((k_edge16p<W, false, ABL>), dim3(256), dim3(W * 256), 0, 0, a); }
   report("k_edge16p<2 waves, full prefetch>", P(2, 0), true);
+
+
+
+
   printf("--- ablation of k_edge16p<2 waves>\n");
   report("  no loads", P(2, 3), false);
   report("  no stores", P(2, 4), false);
