@@ -532,7 +532,7 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
   };
   const size_t o_en_w0_h = put_packed16h(p, nin, D, kpad);
   const size_t o_en_w1_h = put_packed16h(p + (size_t)nin * D + D, D, D, D);
-  std::vector<size_t> o_pn_w0_h(L), o_pn_w1_h(L), o_pw_h(L);
+  std::vector<size_t> o_pn_w0_h(L), o_pn_w1_h(L), o_pw_h(L), o_pw_h2(L);
   Off o_enc_node = read_mlp(nin, kpad, D, D, true);
   const float* p_enc_edge = p;
   Off o_enc_edge = read_mlp(d->edge_in, 8, D, D, true);
@@ -557,6 +557,12 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
         }
       o_pw[k] = put_packed(wsr.data(), D, 2 * D, D, 2 * D);
       o_pw_h[k] = put_packed16h(wsr.data(), D, 2 * D, D, 2 * D);
+      {  // the same projection as two 128-wide halves [Ws | Wr]: uniform 32 KiB chunks for lb_node16s.hip
+        std::vector<float> two((size_t)2 * D * D);
+        lb_pack_weight16h(w0, D, D, D, two.data(), D);
+        lb_pack_weight16h(w0 + (size_t)D * D, D, D, D, two.data() + (size_t)D * D, D);
+        o_pw_h2[k] = put(two.data(), two.size());
+      }
       std::vector<float> bb(2 * D, 0.f);
       memcpy(bb.data() + D, b0, sizeof(float) * D);
       o_pb[k] = put(bb.data(), 2 * D);
@@ -620,6 +626,7 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     g->proc_node_w0_h.push_back(g->blob + o_pn_w0_h[k]);
     g->proc_node_w1_h.push_back(g->blob + o_pn_w1_h[k]);
     g->proj_w_h.push_back(g->blob + o_pw_h[k]);
+    g->proj_w_h2.push_back(g->blob + o_pw_h2[k]);
     g->proc_edge_w0_16h.push_back(g->blob + o_pe_w0_16h[k]);
     g->proc_edge_w1_16h.push_back(g->blob + o_pe_w1_16h[k]);
   }

@@ -1,0 +1,157 @@
+// lb_f16x2.h - device helpers shared by the f16x2 network kernels of round 2 (lb_edge16v.hip,
+// lb_node16s.hip): fp16 hi/lo split on the mixed-precision fma, the phase-pipelined MFMA block loop
+// over LDS-resident packed weights, packed-fp32 LayerNorm.  See lb_edge16v.hip for the why.
+#pragma once
+#include "lb_device.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const f32x4* lds_cptr;
+#define MFMA16H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define SB() __builtin_amdgcn_sched_barrier(0)
+// s_waitcnt immediate (gfx9 encoding) that waits only on lgkmcnt <= n
+#define LB_WAIT_LGKM(n) (0xC07F | ((n) << 8))
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+// packed fp32 helpers on the two halves of an f32x4 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: one
+// issue slot for two lanes-worth of work; the halves of an f32x4 are adjacent register pairs)
+__device__ __forceinline__ f32x2v lb_lo2(const f32x4& x) { return f32x2v{x[0], x[1]}; }
+__device__ __forceinline__ f32x2v lb_hi2(const f32x4& x) { return f32x2v{x[2], x[3]}; }
+__device__ __forceinline__ f32x4 lb_cat2(f32x2v a, f32x2v b) { return f32x4{a[0], a[1], b[0], b[1]}; }
+__device__ __forceinline__ f32x4 lb_pk_add(const f32x4& a, const f32x4& b) {
+  return lb_cat2(lb_lo2(a) + lb_lo2(b), lb_hi2(a) + lb_hi2(b));
+}
+
+// hi = fp16(x) (RNE), lo = fp16(x - hi) for 8 values: 4 v_cvt_pk_f16_f32 + 8 v_fma_mix{lo,hi}_f16
+// (the mixed-precision fma evaluates x*1.0 - float(hi) exactly in fp32 and rounds once to fp16).
+// One asm block: the hazard recogniser does not look inside inline asm, so the block ends with the
+// two wait states a VALU result needs before an MFMA may read it as SrcA/B.
+__device__ __forceinline__ void lb_split8v(const f32x4& x0, const f32x4& x1, h8& hi, h8& lo) {
+  union {
+    h8 v;
+    uint32_t u[4];
+  } H, L;
+  asm("v_cvt_pk_f16_f32 %0, %8, %9\n"
+      "v_cvt_pk_f16_f32 %1, %10, %11\n"
+      "v_cvt_pk_f16_f32 %2, %12, %13\n"
+      "v_cvt_pk_f16_f32 %3, %14, %15\n"
+      "v_fma_mixlo_f16 %4, %8, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"
+      "v_fma_mixlo_f16 %5, %10, 1.0, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"
+      "v_fma_mixlo_f16 %6, %12, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"
+      "v_fma_mixlo_f16 %7, %14, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"
+      "v_fma_mixhi_f16 %4, %9, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n"
+      "v_fma_mixhi_f16 %5, %11, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n"
+      "v_fma_mixhi_f16 %6, %13, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n"
+      "v_fma_mixhi_f16 %7, %15, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n"
+      "s_nop 1"
+      : "=&v"(H.u[0]), "=&v"(H.u[1]), "=&v"(H.u[2]), "=&v"(H.u[3]), "=&v"(L.u[0]), "=&v"(L.u[1]), "=&v"(L.u[2]),
+        "=&v"(L.u[3])
+      : "v"(x0[0]), "v"(x0[1]), "v"(x0[2]), "v"(x0[3]), "v"(x1[0]), "v"(x1[1]), "v"(x1[2]), "v"(x1[3]));
+  hi = H.v;
+  lo = L.v;
+}
+
+// acc[0..7] += W^T * v over NP k-steps of 32 (f16x2: lo*hi + hi*lo + hi*hi), phase-pipelined LDS reads.
+// wbase: this lane's LDS pointer to fragment (p 0, mbo 0, part 0); fragment (p, mbo, part) sits
+// ((p*8 + mbo)*2 + part)*64 f32x4 further.  RELU applies max(x, 0) to v while it is split.
+template <bool RELU, int NP = 4>
+__device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[2 * NP], f32x4 (&acc)[8]) {
+  auto frag = [&](int p, int mbo, int part) -> h8 {
+    return __builtin_bit_cast(h8, wbase[((p * 8 + mbo) * 2 + part) * 64]);
+  };
+  auto relu4 = [&](const f32x4& x) -> f32x4 {
+    if (!RELU) return x;
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float f = x[j];  // (bit_cast of a vector-element lvalue reads element 0: copy first)
+      r[j] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, f), 0));
+    }
+    return r;
+  };
+  h8 X[4], Y[4];  // X: lo fragments, Y: hi fragments of the current block (4 output blocks)
+  h8 bh, bl, nbh, nbl;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) X[c] = frag(0, c, 1);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) Y[c] = frag(0, c, 0);
+  lb_split8v(relu4(v[0]), relu4(v[1]), bh, bl);
+  SB();
+#pragma unroll
+  for (int blk = 0; blk < 2 * NP; ++blk) {
+    const int p = blk >> 1, q = blk & 1;
+    const int np = (blk + 1) >> 1, nq = (blk + 1) & 1;
+    f32x4* a4 = &acc[4 * q];
+    // phase 1: lo * hi.  ONE wait for the four `lo` fragments (the four `hi` reads issued after them may
+    // still be in flight): left alone the compiler waits before every MFMA, ~100 s_waitcnt per tile
+    // in a kernel that is bound by instruction issue
+    __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(4));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a4[c] = MFMA16H(X[c], bh, a4[c]);
+    SB();
+    if (blk < 2 * NP - 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) X[c] = frag(np, 4 * nq + c, 1);
+    }
+    // the next k-step's operand is split while this block's MFMAs run
+    if (q == 1 && p < NP - 1) lb_split8v(relu4(v[2 * p + 2]), relu4(v[2 * p + 3]), nbh, nbl);
+    // phase 2: hi * lo, hi * hi (wait for the `hi` fragments; the next block's `lo` reads stay in flight)
+    if (blk < 2 * NP - 1)
+      __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(4));
+    else
+      __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(0));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a4[c] = MFMA16H(Y[c], bl, a4[c]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a4[c] = MFMA16H(Y[c], bh, a4[c]);
+    SB();
+    if (blk < 2 * NP - 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Y[c] = frag(np, 4 * nq + c, 0);
+    }
+    if (q == 1 && p < NP - 1) {
+      bh = nbh;
+      bl = nbl;
+    }
+    SB();
+  }
+}
+
+// LayerNorm over the 128 features of every edge (32 registers x the 4 lanes of a DPP-row column),
+// hk.LayerNorm(axis=-1, eps 1e-5) of models/utils.py:112, in packed fp32: pre -> y.
+// lns / lno: this lane's LDS pointers to the scale / offset vectors (entry 4*mb = features 16mb+4g..).
+template <bool ENABLE = true>
+__device__ __forceinline__ void lb_layernorm16(f32x4 (&pre)[8], lds_cptr lns, lds_cptr lno, f32x4 (&y)[8]) {
+  if constexpr (!ENABLE) {
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) y[mb] = pre[mb];
+    return;
+  }
+  f32x2v s2 = {0.f, 0.f};
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) s2 = s2 + (lb_lo2(pre[mb]) + lb_hi2(pre[mb]));
+  float sm = s2[0] + s2[1];
+  sm += __shfl_xor(sm, 16);
+  sm += __shfl_xor(sm, 32);
+  const float mean = sm * (1.0f / 128.0f);
+  const f32x2v m2 = {mean, mean};
+  f32x2v v2 = {0.f, 0.f};
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const f32x2v dl = lb_lo2(pre[mb]) - m2, dh = lb_hi2(pre[mb]) - m2;
+    v2 = __builtin_elementwise_fma(dl, dl, v2);
+    v2 = __builtin_elementwise_fma(dh, dh, v2);
+    pre[mb] = lb_cat2(dl, dh);
+  }
+  float vs = v2[0] + v2[1];
+  vs += __shfl_xor(vs, 16);
+  vs += __shfl_xor(vs, 32);
+  const float rs = 1.0f / sqrtf(vs * (1.0f / 128.0f) + 1e-5f);
+  const f32x2v r2 = {rs, rs};
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const f32x4 sc = lns[4 * mb], of = lno[4 * mb];
+    y[mb] = lb_cat2(__builtin_elementwise_fma(lb_lo2(sc) * r2, lb_lo2(pre[mb]), lb_lo2(of)),
+                    __builtin_elementwise_fma(lb_hi2(sc) * r2, lb_hi2(pre[mb]), lb_hi2(of)));
+  }
+}
+

@@ -534,7 +534,13 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
     a.bp = L > 0 ? g->proj_b[0] : nullptr;
     a.psr = e->psr;
     lb_tic(e, LB_T_ENC_NODE);
-    if (e->f16x2) {
+    // LB_NODE_KERNEL=h selects the round-1 node kernel (lb_node16h.hip)
+    static const bool node_s = !(getenv("LB_NODE_KERNEL") && getenv("LB_NODE_KERNEL")[0] == 'h');
+    if (e->f16x2 && node_s) {
+      rc = lbk_node16s(e, a, g->enc_node_w0_h, g->enc_node_w1_h, L > 0 ? g->proj_w_h2[0] : nullptr,
+                       g->kq_node / 4, 0, false);
+      if (rc) return rc;
+    } else if (e->f16x2) {
       rc = lbk_node16h(e, a, g->enc_node_w0_h, g->enc_node_w1_h, L > 0 ? g->proj_w_h[0] : nullptr,
                        g->kq_node / 4, 0, false);
       if (rc) return rc;
@@ -657,7 +663,12 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       a.row_ptr = e->row_ptr;
       a.part = e->part;
       lb_tic(e, LB_T_NODE_MLP);
-      if (e->f16x2) {
+      static const bool node_s = !(getenv("LB_NODE_KERNEL") && getenv("LB_NODE_KERNEL")[0] == 'h');
+      if (e->f16x2 && node_s) {
+        rc = lbk_node16s(e, a, g->proc_node_w0_h[k], g->proc_node_w1_h[k],
+                         (k + 1 < L) ? g->proj_w_h2[k + 1] : nullptr, 4, 4, true);
+        if (rc) return rc;
+      } else if (e->f16x2) {
         rc = lbk_node16h(e, a, g->proc_node_w0_h[k], g->proc_node_w1_h[k],
                          (k + 1 < L) ? g->proj_w_h[k + 1] : nullptr, 4, 4, true);
         if (rc) return rc;

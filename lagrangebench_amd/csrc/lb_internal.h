@@ -198,6 +198,7 @@ struct lb_gns {
   const float* enc_node_w0_h;
   const float* enc_node_w1_h;
   std::vector<const float*> proc_node_w0_h, proc_node_w1_h, proj_w_h;
+  std::vector<const float*> proj_w_h2;  // projection packed as two 128-wide halves [Ws | Wr] (lb_node16s.hip)
   int kq_node;         // node_in(+emb) padded to a multiple of 32, in units of 8
   float* tap;
 };
@@ -276,6 +277,10 @@ void lb_pack_weight16h(const float* w, int K, int M, int Kpad, float* out, int M
 // lb_node16h.hip
 int lbk_node16h(lb_engine* e, const lb_node_args& a, const float* w0h, const float* w1h,
                 const float* wph, int npa, int npb, bool resid);
+// lb_node16s.hip: round-2 node kernel (one weight pass per CU through a direct-to-LDS ring);
+// wph2 = projection packed as [Ws | Wr] halves, or null
+int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const float* w1h,
+                const float* wph2, int npa, int npb, bool resid);
 int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc, bool f16x2);
 // lb_edge16v.hip: round-2 processor edge kernel (f16x2, fused aggregation); variant 0 = three waves per
 // SIMD, resident latents (default), 1 = four waves + second read, 2 = three waves + second read,
