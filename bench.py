@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--model", default="gns", choices=["gns", "segnn"],
                     help="gns: BASELINE.json's headline config; segnn: configs[4] (SEGNN-10-64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short sub-runs of the other BASELINE.json configs appended as `other_configs`")
     ap.add_argument("--shuffle", action="store_true",
                     help="randomly permute the particle ids (memory-locality ablation; default: lattice order)")
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -181,7 +183,10 @@ def main():
     # Algorithmic HBM bytes (SURVEY 8d "edge latents round-trip HBM" + node-side rows):
     #   read e (E*512) + write e (E*512) + sender/receiver ids (E*8) + projections read once (N*1024)
     #   + aggregated messages written once (N*512)
-    edge_bytes = E_tot * (2 * D * 4 + 8) + BN * (2 * D * 4 + D * 4)
+    # SURVEY 8d counts E*(2*D*4+8) + N*2*D*4 (= E*1032 + N*1024); the N*512 of aggregated messages the
+    # kernel also writes are left out of `achieved` (conservative) and listed under bytes_incl_agg
+    edge_bytes = E_tot * (2 * D * 4 + 8) + BN * (2 * D * 4)
+    edge_bytes_incl_agg = edge_bytes + BN * D * 4
     gbs_edge = edge_bytes / (us_edge * 1e-6) / 1e9
     # flops: algorithmic (reference formulation) 2*4*D*D per edge; executed products
     # 2*2*D*D per edge (sender/receiver part projected per node), x3 MFMA passes in f16x2
@@ -196,13 +201,22 @@ def main():
     mfma["frac"] = mfma["achieved"] / mfma["peak"]
     mfma["fp32_equivalent_algorithmic_tflops"] = flop_algo / (us_edge * 1e-6) / 1e12
     three = os.environ.get("LB_EDGE_WAVES", "3") == "3" and fused
-    kern = ("k_edge16n (PROC, f16x2, 3 waves/SIMD)" if (math_mode == "f16x2" and three)
-            else "k_edge16<PROC," + ("f16x2>" if math_mode == "f16x2" else "f32>"))
+    ek = os.environ.get("LB_EDGE_KERNEL", "v0")
+    if math_mode == "f16x2" and fused and not ek.startswith("n"):
+        kern = {"v1": "k_edge16v<4 waves/SIMD, second read of the latents>", "v2": "k_edge16v<3 waves/SIMD, second read>",
+                "v3": "k_edge16p<2 waves/SIMD, software-pipelined>"}.get(ek, "k_edge16v<3 waves/SIMD, resident latents> (PROC, f16x2, fused segment_sum)")
+        pmc_key = "k_edge16p" if ek == "v3" else "k_edge16v"
+    else:
+        kern = ("k_edge16n (PROC, f16x2, 3 waves/SIMD)" if (math_mode == "f16x2" and three)
+                else "k_edge16<PROC," + ("f16x2>" if math_mode == "f16x2" else "f32>"))
+        pmc_key = "k_edge16n" if three else "k_edge16<true, true"
     if math_mode == "f16x2":
         roof = {"kernel": kern, "bound": "hbm", "achieved": gbs_edge, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs_edge / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("k_edge16n" if three else "k_edge16<true, true", args.workload, B),
-                "us_per_launch": us_edge, "launches": int(n_edge), "bytes_per_launch": edge_bytes, "mfma": mfma}
+                "traffic": pmc_traffic(pmc_key, args.workload, B),
+                "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured by this run)",
+                "us_per_launch": us_edge, "launches": int(n_edge), "bytes_per_launch": edge_bytes,
+                "bytes_incl_agg": edge_bytes_incl_agg, "mfma": mfma}
     else:
         roof = {"kernel": kern, "bound": "mfma", "achieved": mfma["achieved"], "peak": mfma["peak"],
                 "unit": "TFLOP/s", "frac": mfma["frac"],
@@ -249,9 +263,60 @@ def main():
         "breakdown_ms_per_step": breakdown,
     }
 
+    if world == 1 and not args.no_other_configs:
+        del pred, traj, handle, eng
+        out["other_configs"] = other_configs(device)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ds, params, L, args.cpu_steps)
     print(json.dumps(out), flush=True)
+
+
+def other_configs(device):
+    """Short runs of the other BASELINE.json configs (configs[0], [1], [3], [4]) so that the driver's
+    single bench line carries them too: same step definition and timing (barrier + synchronize on both
+    sides of K steps, inputs resident), one line per (workload, batch)."""
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS, SEGNN, node_irreps
+    res = []
+    plan = [("tgv2d", "gns", 1, 20), ("tgv2d", "gns", 8, 20), ("rpf2d", "gns", 1, 400), ("ldc3d", "gns", 1, 20),
+            ("ldc3d", "gns", 8, 20), ("dam2d", "segnn", 1, 20), ("dam2d", "segnn", 8, 20)]
+    for workload, kind, B, K in plan:
+        try:
+            ds = make_case(workload, n_trajs=B, extra_seq_length=K)
+            dim, isl = len(ds.box), ds.input_seq_length
+            if kind == "gns":
+                model = GNS(dim, D, 2, 10, 16)
+                node_in, edge_in = gns_widths(ds)
+                params = model.init_params(1234, node_in, edge_in, decoder_scale=0.01)
+            else:
+                ds.magnitude_features = True
+                homog = bool(np.all(ds[0][1] == 0))
+                irr = node_irreps(ds.metadata, isl, ds.external_force_fn is not None, True, homog)
+                model = SEGNN(irr, "1x1o+1x0e", 64, 1, 1, "1x1o", num_mp_steps=10, n_vels=isl - 1,
+                              homogeneous_particles=homog)
+                params = model.init_params(1234)
+                params["output"]["wv"] = (params["output"]["wv"] * 0.01).astype(np.float32)
+            case = hip_case(ds)
+            pos = np.stack([ds[i][0] for i in range(B)])
+            pt = np.stack([ds[i][1] for i in range(B)])
+            eng = case.engine(B)
+            eng.set_particle_type(pt)
+            traj = eng.prepare_traj(pos)
+            handle = model.handle(eng, params)
+            eng.rollout(handle, traj, K)  # warm-up: same rollout (capacities grown)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            eng.rollout(handle, traj, K)
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            N = pos.shape[1]
+            res.append({"workload": f"{workload} {'GNS-10-128' if kind == 'gns' else 'SEGNN-10-64'}", "n_particles": int(N),
+                        "batch": B, "steps": K, "ms_per_step": round(1e3 * dt / K, 4),
+                        "value": B * N * K / dt, "unit": "particle-steps/s"})
+            del eng, traj, handle
+        except Exception as exc:  # a sub-run must never take the headline line down
+            res.append({"workload": workload, "batch": B, "error": repr(exc)[:200]})
+    return res
 
 
 def run_segnn(args, rank, world, device):

@@ -216,6 +216,15 @@ void lb_segnn_destroy(lb_segnn* segnn);
 /* SEGNN.__call__ -> {"acc": (B,N,dim) fp32} (segnn.py:595-610) on the current window + list. */
 int lb_segnn_forward(lb_engine* eng, lb_segnn* segnn, float* acc_out_dev);
 
+/* Arithmetic of the GNS GEMMs.  Default (LB_MATH unset) = mode 1: every fp32 operand is carried as an fp16
+ * hi/lo pair on the fp16 MFMA (fp32-class accuracy, ~5x fewer matrix-pipe cycles than the fp32 MFMA) WITH a
+ * sampled range guard: operands >= 2^15, operand tiles < 2^-10 or non-finite accelerations make
+ * lb_gns_forward / lb_rollout repeat their work in mode 0 and the engine stays there.  set_mode: -1 query,
+ * 0 exact fp32 MFMA, 1 guarded f16x2, 2 f16x2 without the switch (tests).  flags_out: guard bits raised
+ * and not yet consumed (1 large, 2 tiny, 4 non-finite).  The reference computes the model in fp32
+ * (runner.py:71-72). */
+int lb_math_mode(lb_engine* eng, int32_t set_mode, int32_t* mode_out, int32_t* flags_out);
+
 /* Debug/parity tap: hidden node state after the embedding and after each layer,
  * ((num_mp_steps+1), B*N, 128) fp32 rows [s(32) | vx(32) | vy(32) | vz(32)], or NULL. */
 int lb_segnn_set_tap(lb_segnn* segnn, float* hidden_out_dev);

@@ -73,6 +73,7 @@ _SIGS = {
     "lb_gns_forward": (C.c_int, [_P, _P, _P]),
     "lb_set_fused_aggregation": (C.c_int, [_P, C.c_int32]),
     "lb_gns_set_tap": (C.c_int, [_P, _P]),
+    "lb_math_mode": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lb_integrate": (C.c_int, [_P, _P, _P, _P, C.c_int32]),
     "lb_case_integrate": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P]),
     "lb_rollout": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_int32)]),

@@ -144,6 +144,7 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
     e->edge_tile = (t && atoi(t) == 32) ? 32 : 16;
     const char* m = getenv("LB_MATH");
     e->f16x2 = (m && !strcmp(m, "f32")) ? 0 : 1;
+    e->math_auto = m ? 0 : 1;  // LB_MATH given: that arithmetic, no guard-driven switch
   }
   lb_geom& g = e->g;
   memset(&g, 0, sizeof(g));
@@ -680,6 +681,41 @@ __global__ void k_acc_export(int64_t BN, int dim, const float* __restrict__ acc4
   for (int d = 0; d < dim; ++d) out[gi * dim + d] = acc4[gi * 4 + d];
 }
 
+// f16x2 range guard, host side: read (and clear) the flags the kernels raised since the last check.
+// Returns 1 when the engine was in guarded f16x2 mode and has just been switched to exact fp32 - the
+// caller then repeats its work; the switch is sticky for the engine.
+static int lb_math_check(lb_engine* e, int* switched) {
+  *switched = 0;
+  LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, e->stream));
+  LB_HIP(hipStreamSynchronize(e->stream));
+  const int flags = e->ctrl_host->math_flags;
+  if (!flags) return LB_OK;
+  LB_HIP(hipMemsetAsync(&e->ctrl->math_flags, 0, sizeof(int32_t), e->stream));
+  if (e->f16x2 && e->math_auto) {
+    fprintf(stderr,
+            "[lbhip] f16x2 range guard raised (%s%s%s): repeating in exact-fp32 MFMA arithmetic and staying there\n",
+            flags & LB_MATH_LARGE ? "operand >= 2^15 " : "", flags & LB_MATH_TINY ? "operand tile < 2^-10 " : "",
+            flags & LB_MATH_NONFINITE ? "non-finite acceleration" : "");
+    e->f16x2 = 0;
+    *switched = 1;
+  }
+  return LB_OK;
+}
+
+extern "C" int lb_math_mode(lb_engine* e, int32_t set_mode, int32_t* mode_out, int32_t* flags_out) {
+  if (!e) return lb_fail(LB_ERR_ARG, "null engine");
+  if (set_mode < -1 || set_mode > 2) return lb_fail(LB_ERR_ARG, "set_mode must be -1 (query), 0 (f32), 1 (f16x2, guarded) or 2 (f16x2, unguarded)");
+  if (set_mode >= 0) {
+    e->f16x2 = set_mode != 0;
+    e->math_auto = set_mode == 1;
+  }
+  LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, e->stream));
+  LB_HIP(hipStreamSynchronize(e->stream));
+  if (mode_out) *mode_out = e->f16x2 ? (e->math_auto ? 1 : 2) : 0;
+  if (flags_out) *flags_out = e->ctrl_host->math_flags;
+  return LB_OK;
+}
+
 extern "C" int lb_gns_forward(lb_engine* e, lb_gns* g, float* acc_out_dev) {
   if (!e || !g) return lb_fail(LB_ERR_ARG, "null argument");
   if (g->eng != e) return lb_fail(LB_ERR_ARG, "model was created for another engine");
@@ -687,6 +723,11 @@ extern "C" int lb_gns_forward(lb_engine* e, lb_gns* g, float* acc_out_dev) {
   if (e->g.force_kind == LB_FORCE_BUFFER && !e->force)
     return lb_fail(LB_ERR_STATE, "LB_FORCE_BUFFER engine: call lb_set_force first");
   LB_TRY(lbk_gns_forward(e, g));
+  if (e->f16x2 && e->math_auto) {  // guarded mode: one host sync per stand-alone forward (not the rollout path)
+    int switched = 0;
+    LB_TRY(lb_math_check(e, &switched));
+    if (switched) LB_TRY(lbk_gns_forward(e, g));
+  }
   if (acc_out_dev) {
     const int nb = (int)((e->BN + 255) / 256);
     hipLaunchKernelGGL(k_acc_export, dim3(nb), dim3(256), 0, e->stream, e->BN, e->g.dim, e->acc,
@@ -719,7 +760,19 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
                           int32_t n_steps, double* pred_out_dev, int32_t* n_realloc_out) {
   if (!e || !g || !traj_dev || !pred_out_dev) return lb_fail(LB_ERR_ARG, "null argument");
   if (g->eng != e) return lb_fail(LB_ERR_ARG, "model was created for another engine");
-  return lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, n_realloc_out);
+  LB_TRY(lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, n_realloc_out));
+  if (e->f16x2 && e->math_auto) {
+    // the guard is sampled on every launch; a raised flag anywhere in the rollout repeats ALL of it in
+    // fp32 (the step it was raised in is not recorded: a checkpoint either fits fp16's range or not)
+    int switched = 0;
+    LB_TRY(lb_math_check(e, &switched));
+    if (switched) {
+      int32_t n2 = 0;
+      LB_TRY(lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, &n2));
+      if (n_realloc_out) *n_realloc_out += n2;
+    }
+  }
+  return LB_OK;
 }
 
 // One rollout step (neighbor list -> model -> integrator) enqueued on e->stream.

@@ -171,7 +171,9 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
     // segment is cut by the tile boundary without touching row_ptr; fetched with the tile's other
     // loads for the same reason the next indices are (see below)
     int rb = lb_edge_probe(a.receivers, t, lane, E);
+    if (it == 0) lb_range_probe(a.ctrl, ve, 8);  // f16x2 range guard, first tile of every wave
     if constexpr (!(ABL & 8)) lb_gemm16v<false>(w0b, ve, acc);
+    if (it == 0) lb_range_probe(a.ctrl, acc, 8);
     f32x4 acc2[8];
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) acc2[mb] = vecb[4 * mb];
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16p(lb_edge16_args a) {
     st.r_n = a.receivers[rn];
   }
 
-  auto body = [&](int tc) {
+  auto body = [&](int tc, bool first) {
     // ---- take delivery of the prefetched tile
     f32x4 acc[8], ve[8];
     const int r_cur = st.r_pref;
@@ -332,7 +334,9 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16p(lb_edge16_args a) {
       st.s_n = a.senders[rn];
       st.r_n = a.receivers[rn];
     }
+    if (first) lb_range_probe(a.ctrl, ve, 8);
     if constexpr (!(ABL & 8)) lb_gemm16v<false>(w0b, ve, acc);
+    if (first) lb_range_probe(a.ctrl, acc, 8);
     f32x4 acc2[8];
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) acc2[mb] = vecb[4 * mb];
@@ -377,9 +381,9 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16p(lb_edge16_args a) {
       for (int mb = 0; mb < 8; ++mb) d4[4 * mb] = y[mb];
     }
   };
-  body(t);  // peeled (see the header comment)
+  body(t, true);  // peeled (see the header comment)
   t += stride;
-  for (int it = 1; it < n_iter; ++it, t += stride) body(t);
+  for (int it = 1; it < n_iter; ++it, t += stride) body(t, false);
 }
 
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a, int variant) {

@@ -21,6 +21,28 @@ __device__ __forceinline__ f32x4 lb_pk_add(const f32x4& a, const f32x4& b) {
   return lb_cat2(lb_lo2(a) + lb_lo2(b), lb_hi2(a) + lb_hi2(b));
 }
 
+// Range guard of the f16x2 arithmetic (sampled: one operand tile per wave and launch).  A value x is
+// carried as fp16 hi + fp16 lo: |x| >= 65504 overflows hi, and below 2^-14 * 2^11 the lo half leaves
+// the fp16 normal range (absolute floor 2^-25 instead of a relative 2^-22).  LayerNorm keeps GNS
+// latents O(1), but a trained checkpoint is not bound to: the kernels raise lb_ctrl::math_flags and
+// the host repeats the work on the exact-fp32 MFMA path (lb_api.hip: lb_math_check).
+__device__ __forceinline__ void lb_range_probe(const lb_ctrl* ctrl, const f32x4* v, int nvec) {
+  float m = 0.f;
+  for (int i = 0; i < nvec; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(v[i][j]));
+  bool bad = !(m == m) || m >= 32768.f;  // NaN / inf / close to the fp16 range
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  const bool any_bad = __any(bad);
+  if ((threadIdx.x & 63) == 0) {
+    int f = 0;
+    if (any_bad || m >= 32768.f) f |= LB_MATH_LARGE;
+    if (m > 0.f && m < 0.0009765625f) f |= LB_MATH_TINY;
+    if (f) atomicOr(const_cast<int32_t*>(&ctrl->math_flags), f);
+  }
+}
+
 // hi = fp16(x) (RNE), lo = fp16(x - hi) for 8 values: 4 v_cvt_pk_f16_f32 + 8 v_fma_mix{lo,hi}_f16
 // (the mixed-precision fma evaluates x*1.0 - float(hi) exactly in fp32 and rounds once to fp16).
 // One asm block: the hazard recogniser does not look inside inline asm, so the block ends with the

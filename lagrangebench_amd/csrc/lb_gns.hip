@@ -454,6 +454,9 @@ __global__ void __launch_bounds__(64) k_decoder(lb_dec_args a) {
   if (valid && h == 0) {
     f32x4 o = {acc2[0][0], acc2[0][1], acc2[0][2], acc2[0][3]};
     reinterpret_cast<f32x4*>(a.acc_out)[rowc] = o;
+    bool bad = false;
+    for (int d = 0; d < a.out_dim; ++d) bad |= !(fabsf(o[d]) <= 3.0e38f);
+    if (bad) atomicOr(const_cast<int32_t*>(&a.ctrl->math_flags), LB_MATH_NONFINITE);
   }
 }
 

@@ -28,7 +28,13 @@ struct lb_ctrl {
   int32_t density_error;   // stencil/row exceeded the LDS tile bounds
   int32_t max_deg;         // max receiver degree (this build)
   int32_t row_overflow;    // a row outgrew the per-node slots of the single-sweep update path
+  int32_t math_flags;      // f16x2 range guard: 1 = an operand >= 2^15 (fp16 overflow in reach), 2 = a
+                           // whole operand tile < 2^-10 (the fp16 `lo` halves go subnormal),
+                           // 4 = non-finite accelerations; checked by the host at its sync points
 };
+#define LB_MATH_LARGE 1
+#define LB_MATH_TINY 2
+#define LB_MATH_NONFINITE 4
 
 // Geometry + normalisation constants, passed by value to kernels.
 struct lb_geom {
@@ -118,6 +124,9 @@ struct lb_engine {
   int fused_agg;       // 1: aggregation fused into the edge kernel (default), 0: msg + k_segment_sum
   int edge_tile;       // 16: k_edge16 (16x16x4 MFMA, software-pipelined, default); 32: k_edge_mlp
   int f16x2;           // 1: GEMMs in fp16 hi/lo split arithmetic on the fp16 MFMA (fp32-class accuracy)
+  int math_auto;       // 1: f16x2 with the range guard - a raised lb_ctrl::math_flags makes the host repeat
+                       //    the work in exact-fp32 MFMA arithmetic and stay there (LB_MATH unset);
+                       // 0: the mode LB_MATH / lb_math_mode fixed
   float* acc;          // [BN][4] decoder output (dim padded to 4)
 
   // timers

@@ -159,6 +159,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 4)
       k1 = a.row_ptr[rowc + 1];
     }
   }
+  const bool probe = wave == 0;  // f16x2 range guard: one tile per workgroup samples its operands
 #define NS_BUF(c) lane_b[(c) % NS_SLOTS]
   constexpr int C1 = NCH0;      // first chunk of W1
   constexpr int CP = NCH0 + 2;  // first chunk of the projection
@@ -166,12 +167,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 4)
   // ---- GEMM1 over [input A | aggregated messages]
   if constexpr (NPB == 0) {
     NS_STEP(0);
+    if (probe) lb_range_probe(a.ctrl, va, 2 * NPA);
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) acc[mb] = vecp[4 * mb];
     lb_gemm16v<false, NPA>(NS_BUF(0), va, acc);
   } else {
     f32x4 h0[4], h1[4];
     NS_STEP(0);
+    if (probe) lb_range_probe(a.ctrl, va, 8);
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) acc[mb] = vecp[4 * mb];
     {
@@ -191,8 +194,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 4)
     lb_gemm16v<false, 2>(NS_BUF(2), h0, acc);
     NS_STEP(3);
     NS_REFILL(3);
+    if (probe) {
+      lb_range_probe(a.ctrl, h0, 4);
+      lb_range_probe(a.ctrl, h1, 4);
+    }
     lb_gemm16v<false, 2>(NS_BUF(3), h1, acc);
   }
+  if (probe) lb_range_probe(a.ctrl, acc, 8);
   // ---- GEMM2 (ReLU folded into the operand split)
   f32x4 acc2[8];
   NS_STEP(C1);
@@ -229,6 +237,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 4)
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) y[mb] = lb_pk_add(res[mb], y[mb]);
   }
+  if (probe) lb_range_probe(a.ctrl, y, 8);
   if (valid) {
     f32x4* nr = reinterpret_cast<f32x4*>(a.nlat) + row * 32 + g;
 #pragma unroll

@@ -254,6 +254,13 @@ class RolloutEngine:
         check(self.lib.lb_segnn_forward(self._h, segnn._h, ptr(out)), "lb_segnn_forward")
         return out
 
+    def math_mode(self, set_mode: int = -1) -> Tuple[int, int]:
+        """(mode, guard flags): 0 exact fp32 MFMA, 1 guarded f16x2 (default), 2 unguarded f16x2; flags: 1
+        large operand, 2 tiny operand tile, 4 non-finite acceleration (include/lbhip.h: lb_math_mode)."""
+        mode, flags = C.c_int32(), C.c_int32()
+        check(self.lib.lb_math_mode(self._h, int(set_mode), C.byref(mode), C.byref(flags)), "lb_math_mode")
+        return mode.value, flags.value
+
     def set_fused_aggregation(self, on: bool) -> None:
         check(self.lib.lb_set_fused_aggregation(self._h, int(bool(on))), "lb_set_fused_aggregation")
 

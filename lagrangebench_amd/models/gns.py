@@ -106,17 +106,32 @@ class GNS(BaseModel):
         return np.concatenate(out)
 
     # ------------------------------------------------------------------ engine binding
+    @staticmethod
+    def _fingerprint(params) -> tuple:
+        """Cheap content stamp of a parameter tree (a few strided samples + the sum of every leaf): an
+        in-place update of the weights (an optimiser step, a test editing one bias) must not reuse the
+        device copy made for the old values."""
+        out = []
+        for mod in sorted(params):
+            for leaf in sorted(params[mod]):
+                a = np.asarray(params[mod][leaf])
+                flat = a.reshape(-1)
+                out.append((mod, leaf, a.shape, float(flat.sum(dtype=np.float64)),
+                            float(flat[:: max(1, flat.size // 7)].astype(np.float64).sum())))
+        return tuple(out)
+
     def handle(self, engine, params):
         key = (id(engine), id(params))
         hit = self._handles.get(key)
-        if hit is not None and hit[1] is params:
+        stamp = self._fingerprint(params)
+        if hit is not None and hit[1] is params and hit[2] == stamp:
             return hit[0]
         d = GnsDesc()
         d.latent_size, d.blocks_per_step, d.num_mp_steps = self._latent_size, self._blocks_per_step, self._mp_steps
         d.embedding_size, d.num_particle_types = self._embedding_size, self._num_particle_types
         d.node_in, d.edge_in, d.out_dim = engine.node_in, engine.dim + 1, self._output_size
         h = engine.gns_create(d, self.flatten(params))
-        self._handles[key] = (h, params)
+        self._handles[key] = (h, params, stamp)
         return h
 
     def apply(self, params, state, sample):

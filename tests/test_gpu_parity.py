@@ -628,3 +628,66 @@ def test_full_size_ldc3d_properties():
     assert kin.any() and (~kin).any()
     truth = np.transpose(pos[0][:, isl:isl + n_steps], (1, 0, 2)).astype(np.float64)
     assert np.array_equal(a[0][:, kin], truth[:, kin])
+
+
+# ------------------------------------------------------------------ f16x2 range guard
+@pytest.mark.parametrize("kind", ["large", "tiny"])
+def test_f16x2_range_guard_falls_back_to_fp32(kind):
+    """The default arithmetic carries every fp32 GEMM operand as an fp16 hi/lo pair: fine for
+    LayerNorm-bounded latents, not for |x| >= 65504 (hi overflows) or for operand tiles far below
+    2^-10 (lo goes subnormal).  Adversarial weights drive the latents there; the sampled range guard
+    must notice, repeat the forward in exact-fp32 MFMA arithmetic (engine stays in mode 0) and match the
+    oracle to 1e-5 - while the unguarded f16x2 mode demonstrably does not."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    L = 3
+    ds = make_case("small3d", n_trajs=1, extra_seq_length=3)
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    isl = ds.input_seq_length
+    pos, pt = ds[0]
+    params = make_params(ds, num_mp_steps=L, decoder_scale=1.0)
+    if kind == "large":   # edge / node latents of layer 1 leave the fp16 range
+        params["proc0_edge/layer_norm"]["scale"] = (params["proc0_edge/layer_norm"]["scale"] * 8e4).astype(np.float32)
+        params["proc0_node/layer_norm"]["scale"] = (params["proc0_node/layer_norm"]["scale"] * 8e4).astype(np.float32)
+    else:                 # every latent ~1e-5: whole operand tiles below 2^-10
+        for k, v in params.items():
+            if "scale" in v:
+                v["scale"] = (v["scale"] * 1e-5).astype(np.float32)
+                v["offset"] = (v["offset"] * 1e-5).astype(np.float32)
+    of, _ = ocase.allocate_eval((pos[:, :isl].astype(np.float64), pt))
+    ref = O.gns_apply(params, of, pt, num_mp_steps=L, skip_padding=True)["acc"]
+    assert np.isfinite(ref).all()
+    model = GNS(3, 128, 2, L, 16)
+
+    feats, _ = hcase.allocate_eval((pos[:, :isl], pt))
+    eng = feats.engine
+    assert eng.math_mode()[0] == 1                       # guarded f16x2 is the default
+    acc = _np(model.apply(params, {}, (feats, pt))[0]["acc"])
+    assert eng.math_mode()[0] == 0                       # the guard switched the engine to fp32
+    assert rel_err(acc, ref) < 1e-5
+    # a benign model on a fresh engine stays in f16x2
+    hcase2 = hip_case(ds)
+    feats2, _ = hcase2.allocate_eval((pos[:, :isl], pt))
+    p_ok = make_params(ds, num_mp_steps=L, decoder_scale=1.0)
+    acc_ok = _np(model.apply(p_ok, {}, (feats2, pt))[0]["acc"])
+    assert feats2.engine.math_mode() == (1, 0)
+    assert rel_err(acc_ok, O.gns_apply(p_ok, of, pt, num_mp_steps=L, skip_padding=True)["acc"]) < 1e-5
+    # unguarded f16x2 on the adversarial weights: raises the flag and is wrong (documents why the guard exists)
+    hcase3 = hip_case(ds)
+    feats3, _ = hcase3.allocate_eval((pos[:, :isl], pt))
+    feats3.engine.math_mode(2)
+    acc_bad = _np(model.apply(params, {}, (feats3, pt))[0]["acc"])
+    mode, flags = feats3.engine.math_mode()
+    assert mode == 2 and flags != 0
+    if kind == "large":
+        assert not np.isfinite(acc_bad).all() or rel_err(acc_bad, ref) > 1e-5
+    # the device rollout takes the same decision
+    hcase4 = hip_case(ds)
+    e4 = hcase4.engine(1)
+    e4.set_particle_type(pt[None])
+    p_roll = {k: {kk: vv.copy() for kk, vv in v.items()} for k, v in params.items()}
+    p_roll["decoder/linear_1"]["w"] *= np.float32(1e-3 if kind == "large" else 1.0)
+    p_roll["decoder/linear_1"]["w"] *= np.float32(1e-6 if kind == "large" else 1.0)
+    pred, _ = e4.rollout(model.handle(e4, p_roll), pos[None].astype(np.float64), 2)
+    assert e4.math_mode()[0] == 0 and torch.isfinite(pred).all()
