@@ -245,6 +245,7 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   lb_ctrl c0;
   memset(&c0, 0, sizeof(c0));
   c0.overflow_step = -1;
+  c0.ln_inv_d = 1.0f / LB_D;
   if (hipMemcpy(e->ctrl, &c0, sizeof(c0), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemset(e->ptype, 0, sizeof(int32_t) * BN) != hipSuccess ||
       hipMemset(e->row_ptr, 0, sizeof(int32_t) * (BN + 1)) != hipSuccess) {
@@ -458,7 +459,8 @@ extern "C" int lb_segment_sum(lb_engine* e, const float* msg_dev, float* out_dev
 extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w, int64_t n_floats,
                              lb_gns** out) {
   if (!e || !d || !w || !out) return lb_fail(LB_ERR_ARG, "null argument");
-  if (d->latent_size != LB_D) return lb_fail(LB_ERR_UNSUPPORTED, "latent_size %d not built (128 only)", d->latent_size);
+  if (d->latent_size < 16 || d->latent_size > LB_D || d->latent_size % 16)
+    return lb_fail(LB_ERR_UNSUPPORTED, "latent_size %d not built (multiples of 16 up to 128)", d->latent_size);
   if (d->blocks_per_step != 2) return lb_fail(LB_ERR_UNSUPPORTED, "blocks_per_step %d not built (2 only)", d->blocks_per_step);
   if (d->out_dim != e->g.dim) return lb_fail(LB_ERR_ARG, "out_dim %d != case dim %d", d->out_dim, e->g.dim);
   if (d->node_in != e->g.node_in) return lb_fail(LB_ERR_ARG, "node_in %d != case feature width %d", d->node_in, e->g.node_in);
@@ -479,8 +481,68 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
                    mlp_len(d->edge_in, D, true) +
                    (int64_t)L * (mlp_len(3 * D, D, true) + mlp_len(2 * D, D, true)) +
                    mlp_len(D, d->out_dim, false);
-  if (expect != n_floats)
+  if (d->latent_size == D && expect != n_floats)
     return lb_fail(LB_ERR_ARG, "weight blob has %lld floats, expected %lld", (long long)n_floats, (long long)expect);
+
+  // A latent narrower than the 128-wide tiles (GNS-5-64, docs/pages/baselines.rst:54) runs on the same
+  // kernels: every Linear is zero-padded to 128 columns / its input blocks to 128-row strides, LayerNorm
+  // scale / offset are padded with zeros (the padded features stay exactly 0 through every layer) and the
+  // kernels divide by the true width (lb_ctrl::ln_inv_d / ln_pad).
+  std::vector<float> widened;
+  const int dl = d->latent_size;
+  if (dl != D) {
+    auto mlp_len_d = [&](int in, int outw, bool ln) -> int64_t {
+      return (int64_t)in * dl + dl + (int64_t)dl * outw + outw + (ln ? 2 * outw : 0);
+    };
+    const int64_t expect_d = (has_emb ? (int64_t)d->num_particle_types * emb : 0) + mlp_len_d(nin, dl, true) +
+                             mlp_len_d(d->edge_in, dl, true) +
+                             (int64_t)L * (mlp_len_d(3 * dl, dl, true) + mlp_len_d(2 * dl, dl, true)) +
+                             mlp_len_d(dl, d->out_dim, false);
+    if (expect_d != n_floats)
+      return lb_fail(LB_ERR_ARG, "weight blob has %lld floats, expected %lld", (long long)n_floats, (long long)expect_d);
+    const float* q = w;
+    auto copy = [&](size_t n) {
+      widened.insert(widened.end(), q, q + n);
+      q += n;
+    };
+    // one Linear (in_blocks x blk_in rows, out columns) -> (in_blocks x blk_pad rows, out_pad columns)
+    auto linear = [&](int in_blocks, int blk_in, int blk_pad, int out, int out_pad) {
+      const size_t base = widened.size();
+      widened.resize(base + (size_t)in_blocks * blk_pad * out_pad, 0.f);
+      for (int b = 0; b < in_blocks; ++b)
+        for (int r = 0; r < blk_in; ++r)
+          for (int c = 0; c < out; ++c)
+            widened[base + ((size_t)b * blk_pad + r) * out_pad + c] = q[((size_t)b * blk_in + r) * out + c];
+      q += (size_t)in_blocks * blk_in * out;
+    };
+    auto vec = [&](int n, int n_pad) {
+      const size_t base = widened.size();
+      widened.resize(base + n_pad, 0.f);
+      for (int i = 0; i < n; ++i) widened[base + i] = q[i];
+      q += n;
+    };
+    auto mlp = [&](int in_blocks, int blk_in, int blk_pad, int outw, int outw_pad, bool ln) {
+      linear(in_blocks, blk_in, blk_pad, dl, D);   // w0
+      vec(dl, D);                                  // b0
+      linear(1, dl, D, outw, outw_pad);            // w1
+      vec(outw, outw_pad);                         // b1
+      if (ln) {
+        vec(outw, outw_pad);
+        vec(outw, outw_pad);
+      }
+    };
+    if (has_emb) copy((size_t)d->num_particle_types * emb);
+    mlp(1, nin, nin, dl, D, true);
+    mlp(1, d->edge_in, d->edge_in, dl, D, true);
+    for (int k = 0; k < L; ++k) {
+      mlp(3, dl, D, dl, D, true);
+      mlp(2, dl, D, dl, D, true);
+    }
+    mlp(1, dl, D, d->out_dim, d->out_dim, false);
+    if (q - w != n_floats) return lb_fail(LB_ERR_ARG, "internal: widening walk mismatch");
+    w = widened.data();
+    n_floats = (int64_t)widened.size();
+  }
 
   std::vector<float> host;
   auto put = [&](const float* src, size_t n) -> size_t {
@@ -637,6 +699,10 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
   g->enc_node_w1_h = g->blob + o_en_w1_h;
   g->enc_edge_w0_16h = g->blob + o_ee_w0_16h;
   g->enc_edge_w1_16h = g->blob + o_ee_w1_16h;
+  {  // LayerNorm width of this model (read by every network kernel through the control block)
+    const float lnc[2] = {1.0f / (float)dl, (float)(D - dl)};
+    LB_HIP(hipMemcpy(&e->ctrl->ln_inv_d, lnc, sizeof(lnc), hipMemcpyHostToDevice));
+  }
   // node-sized network scratch
   e->g.kpad = kpad;
   const int64_t BN = e->BN;

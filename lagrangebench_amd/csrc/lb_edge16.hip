@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
     for (int mb = 0; mb < 8; ++mb) sm += (acc2[mb][0] + acc2[mb][1]) + (acc2[mb][2] + acc2[mb][3]);
     sm += __shfl_xor(sm, 16);
     sm += __shfl_xor(sm, 32);
-    const float mean = sm * (1.0f / 128.0f);
+    const float mean = sm * a.ctrl->ln_inv_d;
     float vs = 0.f;
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb)
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
       }
     vs += __shfl_xor(vs, 16);
     vs += __shfl_xor(vs, 32);
-    const float rs = 1.0f / sqrtf(vs * (1.0f / 128.0f) + 1e-5f);
+    const float rs = 1.0f / sqrtf(fmaxf(vs - a.ctrl->ln_pad * (mean * mean), 0.f) * a.ctrl->ln_inv_d + 1e-5f);
     f32x4 y[8];
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(E16N_THREADS, 3) k_edge16n(lb_edge16_args a) {
     for (int mb = 0; mb < 8; ++mb) sm += (acc2[mb][0] + acc2[mb][1]) + (acc2[mb][2] + acc2[mb][3]);
     sm += __shfl_xor(sm, 16);
     sm += __shfl_xor(sm, 32);
-    const float mean = sm * (1.0f / 128.0f);
+    const float mean = sm * a.ctrl->ln_inv_d;
     float vs = 0.f;
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb)
@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(E16N_THREADS, 3) k_edge16n(lb_edge16_args a) {
       }
     vs += __shfl_xor(vs, 16);
     vs += __shfl_xor(vs, 32);
-    const float rs = 1.0f / sqrtf(vs * (1.0f / 128.0f) + 1e-5f);
+    const float rs = 1.0f / sqrtf(fmaxf(vs - a.ctrl->ln_pad * (mean * mean), 0.f) * a.ctrl->ln_inv_d + 1e-5f);
     f32x4 y[8];
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {

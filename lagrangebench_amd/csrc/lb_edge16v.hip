@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
   }
   __syncthreads();
   const int E = a.ctrl->n_edges_total;
+  const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
   const int ntiles = (E + 15) >> 4;
   // the wave index is uniform: keep the whole tile walk (t, stride, bounds) in scalar registers
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
     // top that would put the store latency of this tile in front of the next tile's loads
     asm volatile("" : "+v"(s_c), "+v"(r_c), "+v"(rb));
     f32x4 y[8];
-    lb_layernorm16<!(ABL & 16)>(acc2, vecb + 32, vecb + 64, y);
+    lb_layernorm16<!(ABL & 16)>(acc2, vecb + 32, vecb + 64, y, ln_inv_d, ln_pad);
     const int row = t * 16 + n;
     const bool valid = row < E;
     if constexpr (!SKIP && !(ABL & 4)) {
@@ -267,6 +268,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16p(lb_edge16_args a) {
   }
   __syncthreads();
   const int E = a.ctrl->n_edges_total;
+  const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
   const int ntiles = (E + 15) >> 4;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -349,7 +351,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16p(lb_edge16_args a) {
         for (int j = 0; j < 4; ++j) acc2[mb][j] += acc[mb][j] + ve[mb][j];
     }
     f32x4 y[8];
-    lb_layernorm16(acc2, vecb + 32, vecb + 64, y);
+    lb_layernorm16(acc2, vecb + 32, vecb + 64, y, ln_inv_d, ln_pad);
     const int row = tc * 16 + n;
     const bool valid = row < E;
     if constexpr (!SKIP && !(ABL & 4)) {

@@ -142,7 +142,8 @@ __device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[2 * 
 // hk.LayerNorm(axis=-1, eps 1e-5) of models/utils.py:112, in packed fp32: pre -> y.
 // lns / lno: this lane's LDS pointers to the scale / offset vectors (entry 4*mb = features 16mb+4g..).
 template <bool ENABLE = true>
-__device__ __forceinline__ void lb_layernorm16(f32x4 (&pre)[8], lds_cptr lns, lds_cptr lno, f32x4 (&y)[8]) {
+__device__ __forceinline__ void lb_layernorm16(f32x4 (&pre)[8], lds_cptr lns, lds_cptr lno, f32x4 (&y)[8],
+                                               float inv_d = 1.0f / 128.0f, float pad = 0.f) {
   if constexpr (!ENABLE) {
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) y[mb] = pre[mb];
@@ -154,7 +155,7 @@ __device__ __forceinline__ void lb_layernorm16(f32x4 (&pre)[8], lds_cptr lns, ld
   float sm = s2[0] + s2[1];
   sm += __shfl_xor(sm, 16);
   sm += __shfl_xor(sm, 32);
-  const float mean = sm * (1.0f / 128.0f);
+  const float mean = sm * inv_d;
   const f32x2v m2 = {mean, mean};
   f32x2v v2 = {0.f, 0.f};
 #pragma unroll
@@ -167,7 +168,8 @@ __device__ __forceinline__ void lb_layernorm16(f32x4 (&pre)[8], lds_cptr lns, ld
   float vs = v2[0] + v2[1];
   vs += __shfl_xor(vs, 16);
   vs += __shfl_xor(vs, 32);
-  const float rs = 1.0f / sqrtf(vs * (1.0f / 128.0f) + 1e-5f);
+  // a latent narrower than 128 is zero-padded: the padded entries each contributed mean^2
+  const float rs = 1.0f / sqrtf(fmaxf(vs - pad * (mean * mean), 0.f) * inv_d + 1e-5f);
   const f32x2v r2 = {rs, rs};
 #pragma unroll
   for (int mb = 0; mb < 8; ++mb) {

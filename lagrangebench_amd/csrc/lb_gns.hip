@@ -105,14 +105,14 @@ __device__ __forceinline__ void lb_acc_init(f32x16 (&acc)[4], const float* __res
 // y = (scale * rsqrt(var + eps)) * (x - mean) + offset, biased variance, two passes.
 __device__ __forceinline__ void lb_layernorm(const f32x16 (&acc)[4], f32x4 (&y)[16],
                                              const float* __restrict__ ln_s,
-                                             const float* __restrict__ ln_o, int h) {
+                                             const float* __restrict__ ln_o, int h, const lb_ctrl* ctrl) {
   float s = 0.f;
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += acc[mb][r];
   s += __shfl_xor(s, 32);
-  const float mean = s * (1.0f / 128.0f);
+  const float mean = s * ctrl->ln_inv_d;
   float vs = 0.f;
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb)
@@ -122,7 +122,7 @@ __device__ __forceinline__ void lb_layernorm(const f32x16 (&acc)[4], f32x4 (&y)[
       vs += d * d;
     }
   vs += __shfl_xor(vs, 32);
-  const float var = vs * (1.0f / 128.0f);
+  const float var = fmaxf(vs - ctrl->ln_pad * (mean * mean), 0.f) * ctrl->ln_inv_d;
   const float rs = 1.0f / sqrtf(var + 1e-5f);
   const f32x4* s4 = reinterpret_cast<const f32x4*>(ln_s);
   const f32x4* o4 = reinterpret_cast<const f32x4*>(ln_o);
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(EDGE_THREADS, 2) k_edge_mlp(lb_edge_args a) {
     if constexpr (ABL & 8)
       lb_acc_to_v(acc2, y, false);
     else
-      lb_layernorm(acc2, y, a.ln_s, a.ln_o, h);
+      lb_layernorm(acc2, y, a.ln_s, a.ln_o, h, a.ctrl);
     if (valid && !((ABL & 4) && a.senders[0] != -12345)) {
       if (PROC) {
         if (!a.fused) {
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(64) k_node_mlp(lb_node_args a) {
     lb_gemm<16, 4, NODE_PF>(ld, vh, acc2);
   }
   f32x4 y[16];
-  lb_layernorm(acc2, y, a.ln_s, a.ln_o, h);
+  lb_layernorm(acc2, y, a.ln_s, a.ln_o, h, a.ctrl);
   if constexpr (RESID) {
     static_assert(NKQ_A == 16, "residual needs a 128-wide input");
 #pragma unroll

@@ -31,6 +31,8 @@ struct lb_ctrl {
   int32_t math_flags;      // f16x2 range guard: 1 = an operand >= 2^15 (fp16 overflow in reach), 2 = a
                            // whole operand tile < 2^-10 (the fp16 `lo` halves go subnormal),
                            // 4 = non-finite accelerations; checked by the host at its sync points
+  float ln_inv_d;          // LayerNorm over a latent narrower than the 128-wide tiles (zero-padded weights):
+  float ln_pad;            // mean = sum / d, var = (sum_128 (x-mean)^2 - pad * mean^2) / d, pad = 128 - d
 };
 #define LB_MATH_LARGE 1
 #define LB_MATH_TINY 2

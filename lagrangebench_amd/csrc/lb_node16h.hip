@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
   for (int mb = 0; mb < 8; ++mb) sm += (acc2[mb][0] + acc2[mb][1]) + (acc2[mb][2] + acc2[mb][3]);
   sm += __shfl_xor(sm, 16);
   sm += __shfl_xor(sm, 32);
-  const float mean = sm * (1.0f / 128.0f);
+  const float mean = sm * a.ctrl->ln_inv_d;
   float vs = 0.f;
 #pragma unroll
   for (int mb = 0; mb < 8; ++mb)
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
     }
   vs += __shfl_xor(vs, 16);
   vs += __shfl_xor(vs, 32);
-  const float rs = 1.0f / sqrtf(vs * (1.0f / 128.0f) + 1e-5f);
+  const float rs = 1.0f / sqrtf(fmaxf(vs - a.ctrl->ln_pad * (mean * mean), 0.f) * a.ctrl->ln_inv_d + 1e-5f);
   f32x4 y[8];
 #pragma unroll
   for (int mb = 0; mb < 8; ++mb) {

@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 4)
   }
   // ---- LayerNorm (+ residual)
   f32x4 y[8];
-  lb_layernorm16(acc2, vecp + 64, vecp + 96, y);
+  lb_layernorm16(acc2, vecp + 64, vecp + 96, y, a.ctrl->ln_inv_d, a.ctrl->ln_pad);
   if constexpr (RESID) {
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) y[mb] = lb_pk_add(res[mb], y[mb]);

@@ -365,13 +365,15 @@ class GnsHandle:
     def set_tap(self, on: bool = True) -> Optional[torch.Tensor]:
         e = self.engine
         if on:
-            self._tap = torch.zeros((self.desc.num_mp_steps + 1, e.B * e.N, self.desc.latent_size),
-                                    dtype=torch.float32, device=e.device)
+            # the kernels work on 128-wide rows (narrower latents are zero-padded): the tap buffer is
+            # 128 wide, the caller sees the first latent_size columns
+            self._tap = torch.zeros((self.desc.num_mp_steps + 1, e.B * e.N, 128), dtype=torch.float32,
+                                    device=e.device)
             check(e.lib.lb_gns_set_tap(self._h, ptr(self._tap)))
-        else:
-            self._tap = None
-            check(e.lib.lb_gns_set_tap(self._h, None))
-        return self._tap
+            return self._tap[:, :, :self.desc.latent_size]
+        self._tap = None
+        check(e.lib.lb_gns_set_tap(self._h, None))
+        return None
 
     def close(self):
         if self._h:

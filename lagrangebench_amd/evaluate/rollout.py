@@ -232,6 +232,9 @@ def infer(model, case, data_test, params=None, state=None, load_ckp: Optional[st
         params, state, _, _ = load_haiku(load_ckp)
         if isinstance(model, GNS) and "enc_node/linear_0" not in params:
             params = gns_params_from_haiku(params, model._mp_steps, model._blocks_per_step)
+        if isinstance(model, SEGNN) and "embedding_nodes" not in params:
+            from ..utils import segnn_params_from_haiku
+            params = segnn_params_from_haiku(params, model)
     if state is None:
         state = {}
     loader_test = _Loader(data_test, cfg.batch_size)

@@ -83,6 +83,7 @@ class SEGNN(BaseModel):
         if parse_irreps(edge_features_irreps) != (1, 1):
             raise NotImplementedError("SEGNN: edge_features_irreps must be '1x1o+1x0e'")
         self._node_ns, self._node_nv = parse_irreps(node_features_irreps)
+        self._node_irreps_str = str(node_features_irreps)
         self._hidden = weight_balanced_hidden(scalar_units)
         self._num_mp_steps = num_mp_steps
         self._blocks_per_step = blocks_per_step

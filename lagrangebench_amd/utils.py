@@ -212,3 +212,153 @@ def gns_params_to_haiku(params, num_mp_steps: int, blocks_per_step: int = 2, mod
         if f"{name}/layer_norm" in params:
             out[f"{module}/layer_norm{sfx}"] = dict(params[f"{name}/layer_norm"])
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# SEGNN checkpoints (models/segnn.py:30-128,252-362 + e3nn-jax 0.20.3's haiku Linear).
+#
+# Every O3TensorProduct of the reference owns ONE e3nn.haiku.Linear whose parameters are named
+# "w[i_in,i_out] <mul>x<ir_in>,<mul>x<ir_out>" (shape (mul_in, mul_out)) and "b[i_out] <mul>x0e"
+# ([mem] - e3nn-jax is not installable here; tests/golden/make_jax_golden.py dumps real names so that
+# tests/test_jax_golden.py can confirm this the day a JAX machine is available).  For lmax 1 the
+# engine needs, per block, ws = the 0e->0e matrix, wv = the 1o->1o matrix and b.
+#
+# Row order.  e3nn.tensor_product(x, y) emits one chunk per (x chunk, y chunk, ir_out) in loop order
+# and regroups them with a STABLE sort by irrep, so the rows of the 0e (and of the 1o) matrix follow the
+# chunk order of x: a "mul x 0e" chunk contributes its `mul` scalar-derived rows, a "mul x 1o" chunk its
+# `mul` vector-derived rows, in the order the chunks appear.  The engine (oracle/segnn_oracle.py:
+# tp_inputs) orders every OPERAND as [all scalar channels | all vector channels].  The two agree for
+# "32x0e+32x1o" operands and differ for the node features ("5x1o+1x1o+9x0e": vectors first) and for the
+# additional message features ("1x1o+1x0e"): `segnn_row_order` is that permutation.
+_W_RE = _re.compile(r"^w\[(\d+),(\d+)\]\s+(\d+)x(\d)([eo]),(\d+)x(\d)([eo])$")
+_B_RE = _re.compile(r"^b\[(\d+)\]\s+(\d+)x0e$")
+
+
+def _parse_chunks(irreps: str):
+    """"5x1o+1x1o+9x0e" -> [(5, 1), (1, 1), (9, 0)]."""
+    out = []
+    for term in str(irreps).replace(" ", "").split("+"):
+        m = _re.match(r"^(\d+)x(\d)([eo])$", term)
+        if not m:
+            raise ValueError(f"cannot parse irreps term {term!r}")
+        out.append((int(m.group(1)), int(m.group(2))))
+    return out
+
+
+def segnn_row_order(operands) -> np.ndarray:
+    """perm with engine_rows = e3nn_rows[perm] for a tensor-product input made of `operands`
+    (each a list of (mul, l) chunks in e3nn order)."""
+    e3nn_pos, pos = [], 0
+    for chunks in operands:          # position of every channel in e3nn's row order
+        per = []
+        for mul, l in chunks:
+            per.append((l, list(range(pos, pos + mul))))
+            pos += mul
+        e3nn_pos.append(per)
+    perm = []
+    for per in e3nn_pos:             # engine order: per operand, scalar channels then vector channels
+        for want in (0, 1):
+            for l, idx in per:
+                if l == want:
+                    perm += idx
+    return np.asarray(perm, dtype=np.int64)
+
+
+def _segnn_block_operands(model):
+    """Operand chunk lists of every O3TensorProduct of `model` (a lagrangebench_amd.models.SEGNN) in the
+    engine's block order (SEGNN.block_shapes)."""
+    C, B = model._hidden, model._blocks_per_step
+    hid = [(C, 0), (C, 1)]
+    ops = [[_parse_chunks(model._node_irreps_str)]]
+    for _ in range(model._num_mp_steps):
+        for i in range(B):
+            ops.append([hid, hid, [(1, 1), (1, 0)]] if i == 0 else [hid])     # "1x1o+1x0e" (runner.py:227)
+        for i in range(B):
+            ops.append([hid, hid] if i == 0 else [hid])
+    for _ in range(B):
+        ops.append([hid])
+    ops.append([hid])
+    return ops
+
+
+def _segnn_module_order(hk_params, num_mp_steps: int, blocks_per_step: int):
+    """Haiku module names -> the engine's block order.  Inside `layer_k` the message blocks are created
+    first (tp_0 .. tp_{B-1}), then the update blocks reuse the names and get Haiku's numeric suffix
+    (tp_0_1 ..): order by (suffix, index)."""
+    def find(pred, what):
+        hits = [k for k in hk_params if pred(k)]
+        if len(hits) != 1:
+            raise ValueError(f"SEGNN checkpoint: {len(hits)} modules match {what}: {hits}")
+        return hits[0]
+    order = [find(lambda k: "embedding_nodes" in k, "embedding_nodes")]
+    for n in range(num_mp_steps):
+        mods = []
+        for k in hk_params:
+            m = _re.search(rf"(?:^|/)layer_{n}(?:/|$).*?tp_(\d+)(?:_(\d+))?(?:/|$)", k)
+            if m:
+                mods.append(((int(m.group(2) or 0), int(m.group(1))), k))
+        mods.sort()
+        if len(mods) != 2 * blocks_per_step:
+            raise ValueError(f"SEGNN checkpoint: layer_{n} holds {len(mods)} tensor products, expected {2 * blocks_per_step}")
+        order += [k for _, k in mods]
+    for i in range(blocks_per_step):
+        order.append(find(lambda k, i=i: _re.search(rf"readout_{i}(?:/|$)", k) is not None, f"readout_{i}"))
+    order.append(find(lambda k: _re.search(r"(?:^|/)output(?:/|$)", k) is not None, "output"))
+    return order
+
+
+def segnn_params_from_haiku(hk_params, model):
+    """Haiku/e3nn SEGNN parameter dict -> this package's {block: {"ws", "wv", "b"}} layout
+    (lagrangebench_amd.models.SEGNN.block_shapes).  `model`: the SEGNN instance (its irreps fix the
+    row permutation)."""
+    shapes = model.block_shapes()
+    mods = _segnn_module_order(hk_params, model._num_mp_steps, model._blocks_per_step)
+    operands = _segnn_block_operands(model)
+    out = {}
+    for (name, K, ms, mv), mod, ops in zip(shapes, mods, operands):
+        ws = wv = b = None
+        for leaf, arr in hk_params[mod].items():
+            m = _W_RE.match(leaf)
+            if m:
+                l_in, l_out = int(m.group(4)), int(m.group(7))
+                if l_in != l_out:
+                    raise ValueError(f"{mod}/{leaf}: path between different irreps")
+                if l_in == 0:
+                    ws = np.asarray(arr, np.float32)
+                elif l_in == 1 and m.group(5) == "o":
+                    wv = np.asarray(arr, np.float32)
+                continue
+            if _B_RE.match(leaf):
+                b = np.asarray(arr, np.float32)
+        perm = segnn_row_order(ops)
+        if len(perm) != K:
+            raise ValueError(f"{name}: {len(perm)} tensor-product channels, expected {K}")
+        ws = np.zeros((K, ms), np.float32) if ws is None else ws[perm]
+        wv = np.zeros((K, mv), np.float32) if wv is None else wv[perm]
+        b = np.zeros((ms,), np.float32) if b is None else b
+        if ws.shape != (K, ms) or wv.shape != (K, mv) or b.shape != (ms,):
+            raise ValueError(f"{name} <- {mod}: got ws {ws.shape} wv {wv.shape} b {b.shape}, expected {(K, ms)} {(K, mv)} {(ms,)}")
+        out[name] = {"ws": ws, "wv": wv, "b": b}
+    return out
+
+
+def segnn_params_to_haiku(params, model, module: str = "segnn"):
+    """Inverse of segnn_params_from_haiku (e3nn leaf names, e3nn row order)."""
+    shapes = model.block_shapes()
+    operands = _segnn_block_operands(model)
+    B = model._blocks_per_step
+    names = ["o3_embedding/embedding_nodes"]
+    for n in range(model._num_mp_steps):
+        names += [f"layer_{n}/tp_{i}" for i in range(B)] + [f"layer_{n}/tp_{i}_1" for i in range(B)]
+    names += [f"o3_decoder/readout_{i}" for i in range(B)] + ["o3_decoder/output"]
+    out = {}
+    for (name, K, ms, mv), hk_name, ops in zip(shapes, names, operands):
+        inv = np.argsort(segnn_row_order(ops))
+        blk = params[name]
+        leaves = {}
+        if ms:
+            leaves[f"w[0,0] {K}x0e,{ms}x0e"] = np.asarray(blk["ws"], np.float32)[inv]
+            leaves[f"b[0] {ms}x0e"] = np.asarray(blk["b"], np.float32)
+        leaves[f"w[1,{1 if ms else 0}] {K}x1o,{mv}x1o"] = np.asarray(blk["wv"], np.float32)[inv]
+        out[f"{module}/{hk_name}/linear"] = leaves
+    return out

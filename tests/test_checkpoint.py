@@ -69,3 +69,38 @@ def test_haiku_name_mapping(scoped):
             assert np.array_equal(back[k][kk], p[k][kk]), (k, kk)
     with pytest.raises(ValueError):
         gns_params_from_haiku(hk, L + 1)
+
+
+def test_segnn_haiku_importer_round_trip_and_row_order(tmp_path):
+    """segnn_params_from_haiku: e3nn leaf names ("w[i,j] KxIR,MxIR", "b[0] Mx0e"), module order inside
+    layer_k (message tp_i, then update tp_i_1) and the row permutation between e3nn's chunk order and
+    the engine's [scalars | vectors] order per operand - checked by a save/load round trip through the
+    reference's checkpoint format and by the permutation on a hand-worked case."""
+    from lagrangebench_amd.models import SEGNN
+    from lagrangebench_amd.utils import (load_haiku, save_haiku, segnn_params_from_haiku, segnn_params_to_haiku,
+                                        segnn_row_order)
+    # "5x1o+1x1o+9x0e" (vel_hist, force, one-hot types): e3nn rows = 5 v, 1 v, 9 s; engine = 9 s, then 6 v
+    perm = segnn_row_order([[(5, 1), (1, 1), (9, 0)]])
+    assert perm.tolist() == list(range(6, 15)) + list(range(0, 6))
+    # message input: two hidden operands + "1x1o+1x0e"
+    C = 32
+    perm = segnn_row_order([[(C, 0), (C, 1)], [(C, 0), (C, 1)], [(1, 1), (1, 0)]])
+    assert perm[:4 * C].tolist() == list(range(4 * C)) and perm[4 * C:].tolist() == [4 * C + 1, 4 * C]
+    model = SEGNN("5x1o+1x1o+9x0e", "1x1o+1x0e", 64, 1, 1, "1x1o", num_mp_steps=2, n_vels=5, homogeneous_particles=False)
+    params = model.init_params(3)
+    for blk in params.values():
+        blk["b"] = np.random.default_rng(1).standard_normal(blk["b"].shape).astype(np.float32)
+    hk = segnn_params_to_haiku(params, model)
+    assert "segnn/layer_1/tp_0_1/linear" in hk and any(k.startswith("w[0,0] ") for k in hk["segnn/layer_0/tp_0/linear"])
+    ckp = str(tmp_path / "ckp")
+    save_haiku(ckp, hk, {}, None, {"step": 3, "loss": 0.5})
+    loaded, _, _, step = load_haiku(ckp)
+    back = segnn_params_from_haiku(loaded, model)
+    assert step == 3 and sorted(back) == sorted(params)
+    for name in params:
+        for leaf in ("ws", "wv", "b"):
+            assert np.array_equal(back[name][leaf], params[name][leaf]), (name, leaf)
+    # the embedding block really is permuted on disk (vectors first in e3nn's order)
+    emb = hk["segnn/o3_embedding/embedding_nodes/linear"]
+    w = next(v for k, v in emb.items() if k.startswith("w[0,0]"))
+    assert np.array_equal(w[:6], params["embedding_nodes"]["ws"][9:]) and np.array_equal(w[6:], params["embedding_nodes"]["ws"][:9])
