@@ -389,24 +389,40 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16p(lb_edge16_args a) {
 }
 
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a, int variant) {
-#define LB_E16V(W, R)                                                                                   \
+#define LB_E16V(W, R, G)                                                                                \
   do {                                                                                                  \
     if (a.skip_elat_store)                                                                              \
-      hipLaunchKernelGGL((k_edge16v<W, R, true>), dim3(256), dim3(W * 256), 0, e->stream, a);           \
+      hipLaunchKernelGGL((k_edge16v<W, R, true>), dim3(G), dim3(W * 256), 0, e->stream, a);             \
     else                                                                                                \
-      hipLaunchKernelGGL((k_edge16v<W, R, false>), dim3(256), dim3(W * 256), 0, e->stream, a);          \
+      hipLaunchKernelGGL((k_edge16v<W, R, false>), dim3(G), dim3(W * 256), 0, e->stream, a);            \
   } while (0)
-  switch (variant) {
-    case 0: LB_E16V(3, false); break;
-    case 1: LB_E16V(4, true); break;
-    case 2: LB_E16V(3, true); break;
-    case 3:
-      if (a.skip_elat_store)
-        hipLaunchKernelGGL((k_edge16p<2, true>), dim3(256), dim3(512), 0, e->stream, a);
-      else
-        hipLaunchKernelGGL((k_edge16p<2, false>), dim3(256), dim3(512), 0, e->stream, a);
-      break;
-    default: return lb_fail(LB_ERR_ARG, "k_edge16v variant %d", variant);
+  // Small graphs (one 2.5 k-particle trajectory = ~1000 tiles): a launch is the latency chain
+  // "stage 133 KiB of weights -> one tile per wave", so use lighter workgroups (one or two waves per
+  // SIMD: a wave computes alone on its SIMD) and no more workgroups than there are tiles for.  The tile
+  // count is bounded on the host by the frozen capacity (the real count lives on the device).
+  const int64_t tiles_cap = ((int64_t)e->e_cap * e->g.B + 15) / 16;
+  auto grid_for = [&](int waves_per_block) {
+    int64_t g = (tiles_cap + waves_per_block - 1) / waves_per_block;
+    g = (g + 7) / 8 * 8;  // the XCD-aware walk wants a multiple of 8
+    return (int)(g < 8 ? 8 : (g > 256 ? 256 : g));
+  };
+  if (variant == 0 && tiles_cap <= 256 * 4 * 2) {
+    LB_E16V(1, false, grid_for(4));
+  } else if (variant == 0 && tiles_cap <= 256 * 8 * 2) {
+    LB_E16V(2, false, grid_for(8));
+  } else {
+    switch (variant) {
+      case 0: LB_E16V(3, false, 256); break;
+      case 1: LB_E16V(4, true, 256); break;
+      case 2: LB_E16V(3, true, 256); break;
+      case 3:
+        if (a.skip_elat_store)
+          hipLaunchKernelGGL((k_edge16p<2, true>), dim3(256), dim3(512), 0, e->stream, a);
+        else
+          hipLaunchKernelGGL((k_edge16p<2, false>), dim3(256), dim3(512), 0, e->stream, a);
+        break;
+      default: return lb_fail(LB_ERR_ARG, "k_edge16v variant %d", variant);
+    }
   }
 #undef LB_E16V
   LB_HIP(hipGetLastError());

@@ -538,7 +538,10 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
     a.psr = e->psr;
     lb_tic(e, LB_T_ENC_NODE);
     // LB_NODE_KERNEL=h selects the round-1 node kernel (lb_node16h.hip)
-    static const bool node_s = !(getenv("LB_NODE_KERNEL") && getenv("LB_NODE_KERNEL")[0] == 'h');
+    // and below ~32 k nodes (a launch is then a latency chain per workgroup, where lb_node16h's two small
+    // co-resident workgroups measure faster: TGV2D-2.5k 19 vs 24 us per launch)
+    static const bool node_s_env = !(getenv("LB_NODE_KERNEL") && getenv("LB_NODE_KERNEL")[0] == 'h');
+    const bool node_s = node_s_env && BN >= 32768;
     if (e->f16x2 && node_s) {
       rc = lbk_node16s(e, a, g->enc_node_w0_h, g->enc_node_w1_h, L > 0 ? g->proj_w_h2[0] : nullptr,
                        g->kq_node / 4, 0, false);
@@ -666,7 +669,8 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       a.row_ptr = e->row_ptr;
       a.part = e->part;
       lb_tic(e, LB_T_NODE_MLP);
-      static const bool node_s = !(getenv("LB_NODE_KERNEL") && getenv("LB_NODE_KERNEL")[0] == 'h');
+      static const bool node_s_env = !(getenv("LB_NODE_KERNEL") && getenv("LB_NODE_KERNEL")[0] == 'h');
+      const bool node_s = node_s_env && BN >= 32768;
       if (e->f16x2 && node_s) {
         rc = lbk_node16s(e, a, g->proc_node_w0_h[k], g->proc_node_w1_h[k],
                          (k + 1 < L) ? g->proj_w_h2[k + 1] : nullptr, 4, 4, true);

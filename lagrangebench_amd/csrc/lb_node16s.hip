@@ -63,7 +63,7 @@ __device__ __forceinline__ void lb_load_agg_half(const lb_node_args& a, int64_t 
 // (NW 8, 2 slots): two workgroups per CU running out of phase, so that one's row loads / stores overlap
 // the other's MFMA steps (all waves of ONE workgroup move in lock step between the chunk barriers).
 template <int NPA, int NPB, bool RESID, bool PROJ, int NW, int NS_SLOTS>
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 4)
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? (NS_SLOTS == 4 ? 1 : 2) : 4)
     k_node16s(lb_node_args a, const f32x4* __restrict__ w0h, const f32x4* __restrict__ w1h,
               const f32x4* __restrict__ wph) {
   __shared__ f32x4 sB[NS_SLOTS][NS_CHUNK];
@@ -307,6 +307,10 @@ int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const flo
   static const int want = getenv("LB_NODE_NW") ? atoi(getenv("LB_NODE_NW")) : 8;
   const int nw = tiles < 8 * 256 ? 4 : (want == 16 ? 16 : 8);
   const int nblk = (int)((tiles + nw - 1) / nw);
+  // few workgroups (at most one per CU): a launch is a latency chain of chunk steps - give each
+  // workgroup the deep ring (three chunks in flight) instead of a second co-resident workgroup
+  static const bool want_deep = getenv("LB_NODE_DEEP") && getenv("LB_NODE_DEEP")[0] == '1';
+  const bool deep = want_deep && nw == 4 && nblk <= 256;  // measured slower than the 2-slot ring: off
   dim3 grid(nblk), block(nw * 64);
 #define LB_NS(A, B, R, P, W, S) \
   hipLaunchKernelGGL((k_node16s<A, B, R, P, W, S>), grid, block, 0, e->stream, a, w0, w1, wp)
@@ -316,6 +320,8 @@ int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const flo
       LB_NS(A, B, R, P, 16, 4);        \
     else if (nw == 8)                  \
       LB_NS(A, B, R, P, 8, 2);         \
+    else if (deep)                     \
+      LB_NS(A, B, R, P, 4, 4);         \
     else                               \
       LB_NS(A, B, R, P, 4, 2);         \
   } while (0)
