@@ -144,3 +144,36 @@ def test_full_size_segnn_dam2d_forward_vs_oracle():
         assert rel_err(stap[k][:N], w) < 1e-5, f"layer {k}"
     hid = float(np.abs(lat[-1].s).max())
     assert np.abs(acc - ref["acc"]).max() < 1e-5 * max(hid, float(np.abs(ref["acc"]).max()))
+
+
+def test_batched_40k_nodes_forward_vs_oracle():
+    """B = 5 TGV3D-8k trajectories = 40 000 nodes in one graph: the size class of the benchmark line
+    (lb_node16s single-pass node kernel from 32 k nodes, full 256-workgroup edge walk).  Per-layer
+    node latents and accelerations of the first and the last trajectory against the oracle."""
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    L, B = 10, 5
+    ds = make_case("tgv3d", n_trajs=B, extra_seq_length=2)
+    isl = ds.input_seq_length
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    pos = np.stack([ds[i][0] for i in range(B)])
+    pt = np.stack([ds[i][1] for i in range(B)])
+    N = pos.shape[1]
+    assert B * N >= 32768
+    params = make_params(ds, num_mp_steps=L, decoder_scale=1.0)
+    model = GNS(3, 128, 2, L, 16)
+    feats, nbrs = hcase.allocate_eval((pos[:, :, :isl], pt))
+    handle = model.handle(feats.engine, params)
+    tap = handle.set_tap(True)
+    acc = _np(model.apply(params, {}, (feats, pt))[0]["acc"])
+    tap = _np(tap).copy()
+    handle.set_tap(False)
+    pt_t = OT.params_to_torch(params)
+    for b in (0, B - 1):
+        of, on = ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))
+        assert (_np(nbrs.idx)[b][:, :int(_np(nbrs.n_edges)[b])] == O.canonical_edges(on.idx, N)).all()
+        ref, inter = OT.gns_apply(pt_t, of, pt[b], num_mp_steps=L, skip_padding=True, return_intermediates=True)
+        assert rel_err(tap[0][b * N:(b + 1) * N], inter["enc_n"]) < 1e-5
+        for k in range(L):
+            assert rel_err(tap[k + 1][b * N:(b + 1) * N], inter[f"n{k}"]) < 1e-5, (b, k)
+        assert rel_err(acc[b], ref["acc"]) < 1e-5

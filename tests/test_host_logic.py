@@ -110,3 +110,17 @@ def test_write_vtk_and_pkl2vtk(tmp_path):
     names = sorted(p.name for p in (tmp_path / "vtk").iterdir())
     assert names == ["rollout_0_0.vtk", "rollout_0_1.vtk", "rollout_0_2.vtk",
                      "rollout_0_ref_0.vtk", "rollout_0_ref_1.vtk", "rollout_0_ref_2.vtk"]
+
+
+def test_mfma_chain_report_tool_runs():
+    """tools/mfma_chain_check.py: compiles a kernel source to gfx950 assembly (no GPU
+    needed) and reports the spacing of dependent MFMA pairs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "mfma_chain_check.py"),
+                        os.path.join(root, "lagrangebench_amd", "csrc", "lb_edge16v.hip")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l for l in r.stdout.splitlines() if "k_edge16v" in l]
+    assert rows and all("mfma  192" in l for l in rows)
