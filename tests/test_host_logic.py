@@ -115,6 +115,7 @@ def test_write_vtk_and_pkl2vtk(tmp_path):
 def test_mfma_chain_report_tool_runs():
     """tools/mfma_chain_check.py: compiles a kernel source to gfx950 assembly (no GPU
     needed) and reports the spacing of dependent MFMA pairs."""
+    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -123,4 +124,4 @@ def test_mfma_chain_report_tool_runs():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     rows = [l for l in r.stdout.splitlines() if "k_edge16v" in l]
-    assert rows and all("mfma  192" in l for l in rows)
+    assert rows and all("mfma  192" in l for l in rows), r.stdout[-1500:]
