@@ -107,9 +107,10 @@ class CaseSetupFn:
         pos, ptype, batched = self._split(sample)
         isl = self.input_seq_length
         if mode == "train" and noise_std not in (0, 0.0) and pos.shape[2] > 1:
-            raise NotImplementedError(
-                "random-walk training noise (train/strats.py:12-58) is off the inference path and is "
-                "not built; call with noise_std=0")
+            # case.py:172-178: random-walk noise on the input window, targets shifted consistently
+            from ..train.strats import add_gns_noise
+            key, pos = add_gns_noise(key, pos.to(torch.float64), ptype, isl, float(noise_std),
+                                     lambda r, dr: self.shift(r, dr))
         B = pos.shape[0]
         eng = self.engine(B)
         eng.set_particle_type(ptype)

@@ -8,7 +8,11 @@ from typing import Any, Mapping
 
 
 class _AttrDict(dict):
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
 
     def __setattr__(self, k, v):
         self[k] = v
@@ -28,7 +32,14 @@ defaults = _wrap({
         "latent_dim": 128, "isotropic_norm": False, "magnitude_features": False,
         "lmax_attributes": 1, "lmax_hidden": 1, "segnn_norm": "none", "velocity_aggregate": "avg",
     },                                        # defaults.py:38-63
-    "train": {"noise_std": 3e-4},             # defaults.py:75
+    "train": {                                # defaults.py:66-109
+        "batch_size": 1, "step_max": 500_000, "num_workers": 4, "noise_std": 3e-4,
+        "optimizer": {"lr_start": 1e-4, "lr_final": 1e-6, "lr_decay_rate": 0.1, "lr_decay_steps": 1e5},
+        "pushforward": {"steps": [-1, 20000, 300000, 400000], "unrolls": [0, 1, 2, 3], "probs": [18, 2, 1, 1]},
+        "loss_weight": {"acc": 1.0, "vel": 0.0, "pos": 0.0},
+    },
+    "logging": {"log_steps": 1000, "eval_steps": 10000, "wandb": False, "wandb_project": None,
+                "wandb_entity": "lagrangebench", "ckp_dir": "ckp", "run_name": None},  # defaults.py:153-168
     "eval": {
         "n_rollout_steps": 20,                # defaults.py:113
         "rollout_dir": None,

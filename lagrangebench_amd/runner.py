@@ -2,8 +2,8 @@
 
 ``train_or_infer(cfg)`` (runner.py:25-143), ``setup_data`` (:146-189) and ``setup_model`` (:192-292)
 keep their signatures.  ``cfg`` is a nested mapping with the reference's keys (a dict or anything
-dict-like such as an OmegaConf DictConfig); missing keys fall back to ``defaults``.  Training
-(`mode: train | all`) is out of scope and raises.
+dict-like such as an OmegaConf DictConfig); missing keys fall back to ``defaults``.  `mode: train | all`
+runs ``train.Trainer`` (GNS only).
 """
 from __future__ import annotations
 
@@ -24,10 +24,10 @@ _RUN_DEFAULTS = {
     "mode": "infer", "load_ckp": None, "dtype": "float64", "seed": 0,
     "dataset": {"src": None, "name": None},
     "model": dict(defaults.model),
-    "train": {"noise_std": 3e-4, "pushforward": {"unrolls": [0]}},
+    "train": dict(defaults.train),
     "eval": {"test": False, "n_rollout_steps": 20, "rollout_dir": None,
              "infer": dict(defaults.eval.infer), "train": dict(defaults.eval.train)},
-    "logging": {"ckp_dir": None},
+    "logging": dict(defaults.logging, ckp_dir=None),
     "neighbors": dict(defaults.neighbors),
 }
 
@@ -81,8 +81,9 @@ def setup_model(cfg, metadata: Dict, homogeneous_particles: bool = False, has_ex
 def train_or_infer(cfg):
     """runner.py:25-143, inference route."""
     cfg = merge(_RUN_DEFAULTS, cfg)
-    if cfg.mode != "infer":
-        raise NotImplementedError("mode must be 'infer': training is out of scope for this engine")
+    mode = cfg.mode
+    if mode not in ("train", "infer", "all"):
+        raise ValueError("mode must be one of 'train', 'infer', 'all'")
     if cfg.dtype != "float64":
         raise NotImplementedError("only dtype=float64 is built")
     data_train, data_valid, data_test = setup_data(cfg)
@@ -97,6 +98,19 @@ def train_or_infer(cfg):
                            homogeneous_particles=particle_type.max() == particle_type.min(),
                            has_external_force=data_train.external_force_fn is not None,
                            normalization_stats=case.normalization_stats)
+    if mode in ("train", "all"):  # runner.py:74-117
+        import time
+        from .train import Trainer
+        print("Start training...")
+        if cfg.logging.run_name is None:
+            cfg.logging.run_name = f"{cfg.model.name}_{data_train.name}_{time.strftime('%Y%m%d-%H%M%S')}"
+        store_ckp = os.path.join(cfg.logging.ckp_dir, cfg.logging.run_name) if cfg.logging.ckp_dir else None
+        trainer = Trainer(model, case, data_train, data_valid, cfg.train, cfg.eval, cfg.logging,
+                          input_seq_length=cfg.model.input_seq_length, seed=cfg.seed)
+        trainer.train(step_max=cfg.train.step_max, load_ckp=cfg.load_ckp, store_ckp=store_ckp)
+        if mode == "train":
+            return 0
+        cfg.load_ckp = os.path.join(store_ckp, "best") if store_ckp else cfg.load_ckp
     print("Start inference...")
     model_dir = cfg.load_ckp
     assert model_dir, "model_dir must be specified for inference."

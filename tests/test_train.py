@@ -1,0 +1,196 @@
+"""Training step: lagrangebench_amd/train mirrors lagrangebench/train.
+
+CPU: the training tricks against the reference's own tests (tests/case_test.py:165-187 noise
+consistency, tests/pushforward_test.py:24-42 unroll sampling), the differentiable torch GNS against
+the NumPy oracle, its gradients against finite differences, the learning-rate schedule.
+GPU: the torch forward on engine-built graphs equals the HIP forward; the Trainer lowers the loss on
+the LJ dataset, writes reference-format checkpoints, and `train_or_infer(mode="all")` returns 0
+(tests/runner_test.py:14-57).
+"""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import lb_oracle as O  # noqa: E402
+from tests._common import feature_widths, make_params, oracle_case  # noqa: E402
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+LJ = os.path.join(ROOT, "golden", "3D_LJ_3_1214every1")
+
+
+def test_random_walk_noise_statistics_and_consistency():
+    """strats.py:12-83: kinematic particles stay clean, the noise of the last input frame is carried
+    onto the targets (so the target velocity is unchanged), and the velocity noise of the last input
+    step has standard deviation noise_std."""
+    from lagrangebench_amd.case_setup.case import make_displacement
+    from lagrangebench_amd.train import add_gns_noise
+    disp, shift = make_displacement(np.array([1.0, 1.0]), True)
+    n, isl, T = 4000, 6, 9
+    rng = np.random.default_rng(0)
+    pos = torch.from_numpy(rng.random((n, T, 2)))
+    pt = torch.zeros(n, dtype=torch.int64)
+    pt[:100] = 1
+    g = torch.Generator().manual_seed(3)
+    g2, noisy = add_gns_noise(g, pos, pt, isl, 3e-4, shift)
+    assert g2 is g and noisy.shape == pos.shape
+    d = disp(noisy, pos)
+    assert float(d[:100].abs().max()) == 0.0                       # kinematic: no noise
+    assert float(d[100:, 0].abs().max()) == 0.0                    # frame 0 is never perturbed
+    assert torch.allclose(d[:, isl:], d[:, isl - 1:isl].expand(-1, T - isl, -1), atol=1e-15)
+    vel_noise_last = (d[100:, isl - 1] - d[100:, isl - 2]).numpy() # noise of the last input velocity
+    assert abs(vel_noise_last.std() / 3e-4 - 1.0) < 0.05
+    # target velocity (frame isl -> isl+1) is untouched by the noise
+    v_clean = disp(pos[:, isl + 1], pos[:, isl])
+    v_noisy = disp(noisy[:, isl + 1], noisy[:, isl])
+    assert torch.allclose(v_clean, v_noisy, atol=1e-12)
+
+
+def test_push_forward_sampling_frequencies():
+    """tests/pushforward_test.py:24-42: before the first threshold only unroll 0; afterwards the
+    unlocked unroll lengths appear with the configured probability ratios."""
+    from lagrangebench_amd.train import push_forward_sample_steps
+    pf = {"steps": [-1, 20000, 50000, 100000], "unrolls": [0, 1, 3, 20], "probs": [4.05, 4.88, 1.25, 0.32]}
+    g = torch.Generator().manual_seed(1)
+    for step, n_open in [(1, 1), (30000, 2), (60000, 3), (150000, 4)]:
+        draws = []
+        for _ in range(4000):
+            g, u = push_forward_sample_steps(g, step, pf)
+            draws.append(u)
+        draws = np.array(draws)
+        assert set(np.unique(draws)) <= set(pf["unrolls"][:n_open])
+        p = np.array(pf["probs"][:n_open])
+        p = p / p.sum()
+        for u, pu in zip(pf["unrolls"][:n_open], p):
+            assert abs((draws == u).mean() - pu) < 0.03
+
+
+def test_learning_rate_schedule():
+    from lagrangebench_amd.train.trainer import exponential_decay
+    assert exponential_decay(0, 1e-4, 1e5, 0.1, 1e-6) == pytest.approx(1e-4)
+    assert exponential_decay(100000, 1e-4, 1e5, 0.1, 1e-6) == pytest.approx(1e-5)
+    assert exponential_decay(50000, 1e-4, 1e5, 0.1, 1e-6) == pytest.approx(1e-4 * 0.1 ** 0.5)
+    assert exponential_decay(10**7, 1e-4, 1e5, 0.1, 1e-6) == pytest.approx(1e-6)   # end_value
+
+
+def _oracle_inputs(name="small2d", L=2):
+    from lagrangebench_amd.data import make_case
+    ds = make_case(name, n_trajs=1, extra_seq_length=3)
+    case = oracle_case(ds)
+    pos, pt = ds[0]
+    feats, _ = case.allocate_eval((pos[:, :ds.input_seq_length].astype(np.float64), pt))
+    params = make_params(ds, num_mp_steps=L, decoder_scale=1.0)
+    return ds, feats, pt, params
+
+
+def test_torch_gns_matches_the_oracle_and_its_gradients_match_finite_differences():
+    from lagrangebench_amd.models.gns_torch import gns_apply_torch, gns_inputs_from_features, params_to_torch
+    L = 2
+    ds, feats, pt, params = _oracle_inputs(L=L)
+    ref = O.gns_apply(params, feats, pt, num_mp_steps=L, skip_padding=True)["acc"]
+    node, edge, snd, rcv, ptt = gns_inputs_from_features(feats, pt)
+    p32 = params_to_torch(params)
+    acc = gns_apply_torch(p32, node, edge, snd, rcv, ptt, L).numpy()
+    assert np.abs(acc - ref).max() <= 1e-5 * np.abs(ref).max()
+    # gradients in float64: autograd vs central differences of the same function
+    p64 = {m: {k: v.double().requires_grad_(True) for k, v in leaves.items()} for m, leaves in p32.items()}
+    target = torch.from_numpy(np.random.default_rng(0).standard_normal(ref.shape))
+
+    def loss_of(p):
+        out = gns_apply_torch(p, node.double(), edge.double(), snd, rcv, ptt, L)
+        return ((out - target) ** 2).sum(-1).mean()
+    loss = loss_of(p64)
+    loss.backward()
+    rng = np.random.default_rng(1)
+    for mod, leaf in [("enc_node/linear_0", "w"), ("proc1_edge/linear_1", "w"), ("proc0_node/layer_norm", "scale"),
+                      ("decoder/linear_1", "b"), ("embed", "embeddings"), ("proc0_edge/linear_0", "b")]:
+        t = p64[mod][leaf]
+        flat = t.detach().reshape(-1)
+        for idx in rng.integers(0, flat.numel(), size=3):
+            old = float(flat[idx])
+            h = 1e-6 * max(1.0, abs(old))
+            with torch.no_grad():
+                t.reshape(-1)[idx] = old + h
+                lp = float(loss_of(p64))
+                t.reshape(-1)[idx] = old - h
+                lm = float(loss_of(p64))
+                t.reshape(-1)[idx] = old
+            fd = (lp - lm) / (2 * h)
+            an = float(t.grad.reshape(-1)[idx])
+            assert abs(fd - an) <= 1e-6 + 1e-4 * abs(fd), (mod, leaf, idx, fd, an)
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_torch_forward_on_engine_graph_equals_hip_forward():
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    from lagrangebench_amd.models.gns_torch import gns_apply_torch, gns_inputs_from_features, params_to_torch
+    from tests._common import hip_case
+    L = 3
+    ds = make_case("small3d", n_trajs=2, extra_seq_length=3)
+    hcase = hip_case(ds)
+    isl = ds.input_seq_length
+    pos = np.stack([ds[0][0], ds[1][0]])
+    pt = np.stack([ds[0][1], ds[1][1]])
+    params = make_params(ds, num_mp_steps=L, decoder_scale=1.0)
+    model = GNS(3, 128, 2, L, 16)
+    feats, _ = hcase.allocate_eval((pos[:, :, :isl], pt))
+    acc_hip = model.apply(params, {}, (feats, pt))[0]["acc"]
+    feats.materialize()
+    pt_t = params_to_torch(params, device=acc_hip.device)
+    for b in range(2):
+        node, edge, snd, rcv, ptt = gns_inputs_from_features(feats, torch.as_tensor(pt), b)
+        acc_t = gns_apply_torch(pt_t, node, edge, snd, rcv, ptt, L)
+        err = float((acc_t - acc_hip[b]).abs().max() / acc_hip[b].abs().max())
+        assert err < 1e-5, err
+
+
+@pytest.mark.gpu
+def test_trainer_lowers_the_loss_and_runner_mode_all(tmp_path):
+    """tests/runner_test.py:14-57 runs train_or_infer end to end on the LJ dataset and expects 0."""
+    from lagrangebench_amd.case_setup import case_builder
+    from lagrangebench_amd.data import H5Dataset
+    from lagrangebench_amd.models import GNS
+    from lagrangebench_amd.runner import train_or_infer
+    from lagrangebench_amd.train import Trainer
+    from lagrangebench_amd.utils import load_haiku
+    ds_dir = tmp_path / "3D_LJ_3_1214every1"
+    shutil.copytree(LJ, ds_dir)
+    md = json.load(open(ds_dir / "metadata.json"))
+    md.setdefault("write_every", 1)
+    json.dump(md, open(ds_dir / "metadata.json", "w"))
+    isl, L = 6, 2
+    data_train = H5Dataset("train", str(ds_dir), name="lj3d", input_seq_length=isl, extra_seq_length=1)
+    data_valid = H5Dataset("valid", str(ds_dir), name="lj3d", input_seq_length=isl, extra_seq_length=10)
+    bounds = np.array(md["bounds"])
+    case = case_builder(bounds[:, 1] - bounds[:, 0], md, isl, noise_std=3e-4)
+    model = GNS(3, 128, 2, L, 16)
+    cfg_train = {"batch_size": 2, "noise_std": 3e-4,
+                 "optimizer": {"lr_start": 1e-3, "lr_final": 1e-5, "lr_decay_rate": 0.1, "lr_decay_steps": 200},
+                 "pushforward": {"steps": [-1, 20], "unrolls": [0, 1], "probs": [1, 1]}}
+    trainer = Trainer(model, case, data_train, data_valid, cfg_train=cfg_train,
+                      cfg_eval={"n_rollout_steps": 10, "train": {"n_trajs": 2, "metrics": ["mse"]}},
+                      cfg_logging={"log_steps": 5, "eval_steps": 30}, input_seq_length=isl, seed=0)
+    ckp = str(tmp_path / "ckp")
+    params, state, opt_state = trainer.train(step_max=60, store_ckp=ckp)
+    losses = [l for _, l in trainer.loss_log]
+    assert np.isfinite(losses).all() and np.mean(losses[-4:]) < 0.7 * np.mean(losses[:3]), losses
+    assert os.path.exists(os.path.join(ckp, "params_tree.pkl")) and os.path.exists(os.path.join(ckp, "best", "params_array.npy"))
+    loaded, _, _, step = load_haiku(ckp)
+    assert step in (30, 60) and any("MLP" in k for k in loaded)
+    # resume from the checkpoint for a few more steps (trainer.py:267-269)
+    p2, _, _ = trainer.train(step_max=step + 3, load_ckp=ckp)
+    assert set(p2) == set(params)
+    # the runner route of the reference's runner_test
+    cfg = {"mode": "all", "dataset": {"src": str(ds_dir), "name": "lj3d"},
+           "model": {"name": "gns", "num_mp_steps": 1, "input_seq_length": isl},
+           "train": {"step_max": 12, "batch_size": 1, "pushforward": {"steps": [-1], "unrolls": [0], "probs": [1]}},
+           "logging": {"log_steps": 5, "eval_steps": 5, "ckp_dir": str(tmp_path / "ckp2"), "run_name": "r"},
+           "eval": {"n_rollout_steps": 5, "train": {"n_trajs": 1, "metrics": ["mse"]},
+                    "infer": {"n_trajs": 1, "batch_size": 1, "metrics": ["mse"], "out_type": "none"}}}
+    assert train_or_infer(cfg) == 0
