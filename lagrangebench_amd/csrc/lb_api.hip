@@ -293,7 +293,7 @@ int lb_ensure_edges(lb_engine* e, int64_t need) {
   LB_TRY(lb_alloc(&e->efeat, (size_t)n * 8));
   LB_TRY(lb_alloc(&e->efeat64, (size_t)n * 4));
   LB_TRY(lb_alloc(&e->elat, (size_t)(n + 32) * LB_D));  // tile-blocked in the 16-row kernels: pad to a tile
-  LB_TRY(lb_alloc(&e->msg, (size_t)n * LB_D));
+  LB_TRY(lb_alloc(&e->msg, (size_t)(n + 32) * LB_D));  // also the second edge-latent buffer of the ping-pong
   e->e_alloc = n;
   return LB_OK;
 }

@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
     const int row = t * 16 + n;
     const bool valid = row < E;
     if constexpr (!SKIP && !(ABL & 4)) {
-      f32x4* ew = reinterpret_cast<f32x4*>(a.elat) + (int64_t)t * 512 + lane;
+      f32x4* ew = reinterpret_cast<f32x4*>(a.elat_out ? a.elat_out : a.elat) + (int64_t)t * 512 + lane;
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb) __builtin_nontemporal_store(lb_pk_add(ve[mb], y[mb]), &ew[64 * mb]);
     }
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16p(lb_edge16_args a) {
     const int row = tc * 16 + n;
     const bool valid = row < E;
     if constexpr (!SKIP && !(ABL & 4)) {
-      f32x4* ew = reinterpret_cast<f32x4*>(a.elat) + (int64_t)tc * 512 + lane;
+      f32x4* ew = reinterpret_cast<f32x4*>(a.elat_out ? a.elat_out : a.elat) + (int64_t)tc * 512 + lane;
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb) __builtin_nontemporal_store(lb_pk_add(ve[mb], y[mb]), &ew[64 * mb]);
     }

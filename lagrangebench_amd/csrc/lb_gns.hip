@@ -632,10 +632,19 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
           if (s[0] == 'n') return -1;
           return (s[0] == 'v' && s[1] >= '0' && s[1] <= '4') ? s[1] - '0' : 0;
         }();
-        if (e->f16x2 && e->fused_agg && ev >= 0)
+        if (e->f16x2 && e->fused_agg && ev >= 0) {
+          // LB_EDGE_PINGPONG=1: layer k reads one buffer and writes the other (the stand-alone message
+          // buffer is free in fused mode).  The bare stream measures ~4 % faster out of place
+          // (tools/stream_bench), the kernel does not (2.767 vs 2.766 ms per step): off by default
+          static const bool pingpong = getenv("LB_EDGE_PINGPONG") && getenv("LB_EDGE_PINGPONG")[0] == '1';
+          if (pingpong) {
+            b.elat = (k & 1) ? e->msg : e->elat;
+            b.elat_out = (k & 1) ? e->elat : e->msg;
+          }
           rc = lbk_edge16v(e, b, ev);
-        else
+        } else {
           rc = lbk_edge16(e, b, true, e->f16x2 != 0);
+        }
         if (rc) return rc;
       } else {
         hipLaunchKernelGGL((k_edge_mlp<true>), dim3(edge_blocks), dim3(EDGE_THREADS), 0, s, a);

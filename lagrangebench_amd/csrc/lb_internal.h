@@ -154,6 +154,8 @@ struct lb_edge16_args {  // lb_edge16.hip
   const int32_t* receivers;
   const float* efeat;  // ENC input [E][8]
   float* elat;         // [E][128] in/out
+  float* elat_out;     // k_edge16v / k_edge16p only: where the updated latents go (null = in place); the
+                       // layers ping-pong between two buffers - an out-of-place stream measures ~4 % faster
   float* msg;          // [E][128] out (PROC, !fused)
   const float* psr;    // [BN][256]
   const float* w0p;    // 16-packed: PROC 128x128 (edge rows of W0), ENC 16x128

@@ -103,9 +103,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (NS_SLOTS == 4 ? 1 : 2) : 4
       // cannot tell the ring slots apart and puts s_waitcnt vmcnt(0) in front of the next ds_read -
       // i.e. every step would wait for the refill it has just issued
       if (piece * 64 < nvec) {
-        const f32x4* gp = src + piece * 64 + lane;
+        // scalar chunk base + 32-bit lane offset: no 64-bit VGPR address pair per piece
+        const uint32_t voff = (uint32_t)(piece * 64 + lane) * 16u;
         const uint32_t lo = (uint32_t)(uintptr_t)(lds_ptr)(slot + piece * 64);
-        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lo) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lo) : "memory");
       }
     }
   };
