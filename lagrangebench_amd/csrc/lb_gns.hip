@@ -630,7 +630,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
           const char* s = getenv("LB_EDGE_KERNEL");
           if (!s || !s[0]) return 0;
           if (s[0] == 'n') return -1;
-          return (s[0] == 'v' && s[1] >= '0' && s[1] <= '4') ? s[1] - '0' : 0;
+          return (s[0] == 'v' && s[1] >= '0' && s[1] <= '6') ? s[1] - '0' : 0;
         }();
         if (e->f16x2 && e->fused_agg && ev >= 0) {
           // LB_EDGE_PINGPONG=1: layer k reads one buffer and writes the other (the stand-alone message

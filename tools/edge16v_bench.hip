@@ -165,6 +165,17 @@ int main(int argc, char** argv) {
 #define V(W, R, ABL) [&] { hipLaunchKernelGGL((k_edge16v<W, R, false, ABL>), dim3(256), dim3(W * 256), 0, 0, a); }
   report("k_edge16n (round 1, 3 waves/SIMD)", base, true);
   report("k_edge16v<3 waves, resident e>", V(3, false, 0), true);
+#define VP(W) [&] { hipLaunchKernelGGL((k_edge16v<W, false, false, 0, true>), dim3(256), dim3(W * 256), 0, 0, a); }
+  report("k_edge16v<3 waves, resident e, GEMM priority>", VP(3), true);
+  report("k_edge16v<3 waves, resident e> again", V(3, false, 0), true);
+  report("k_edge16v<2 waves, resident e>", V(2, false, 0), true);
+  report("k_edge16v<2 waves, resident e, GEMM priority>", VP(2), true);
+#define LP(W, ABL) [&] { hipLaunchKernelGGL((k_edge16l<W, false, ABL>), dim3(256), dim3(W * 256), 0, 0, a); }
+  report("k_edge16l<2 waves, late prefetch, priority>", LP(2, 0), true);
+  report("  k_edge16l no stores", LP(2, 4), false);
+  report("  k_edge16l compute only", LP(2, 7), false);
+  report("  k_edge16l no GEMMs", LP(2, 8), false);
+  report("k_edge16v<1 wave, resident e>", V(1, false, 0), true);
   report("k_edge16v<4 waves, reload e>", V(4, true, 0), true);
   report("k_edge16v<3 waves, reload e>", V(3, true, 0), true);
 #define P(W, ABL) [&] { hipLaunchKernelGGL((k_edge16p<W, false, ABL>), dim3(256), dim3(W * 256), 0, 0, a); }
