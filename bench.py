@@ -54,10 +54,10 @@ def pmc_traffic(kernel_substr: str, workload: str, batch: int):
     try:
         with open(path) as f:
             tab = json.load(f)
-        ent = tab.get(f"{workload}_b{batch}", {})
-        for k, v in ent.items():
-            if kernel_substr in k:
-                return v["hbm_bytes_per_launch"]
+        for key in (f"{workload}_b{batch}", f"{workload}_b{batch}_r01"):   # _r01: kernels only profiled in round 1
+            for k, v in sorted(tab.get(key, {}).items()):
+                if kernel_substr in k:
+                    return v["hbm_bytes_per_launch"]
     except Exception:
         pass
     return None
@@ -204,7 +204,9 @@ def main():
     ek = os.environ.get("LB_EDGE_KERNEL", "v0")
     if math_mode == "f16x2" and fused and not ek.startswith("n"):
         kern = {"v1": "k_edge16v<4 waves/SIMD, second read of the latents>", "v2": "k_edge16v<3 waves/SIMD, second read>",
-                "v3": "k_edge16p<2 waves/SIMD, software-pipelined>"}.get(ek, "k_edge16v<3 waves/SIMD, resident latents> (PROC, f16x2, fused segment_sum)")
+                "v3": "k_edge16p<2 waves/SIMD, software-pipelined>", "v4": "k_edge16l<2 waves/SIMD, late prefetch>",
+                "v5": "k_edge16v<2 waves/SIMD, resident latents>", "v6": "k_edge16v<3 waves/SIMD, resident latents>"}.get(
+                    ek, "k_edge16v<2 waves/SIMD, resident latents, GEMM-phase priority> (PROC, f16x2, fused segment_sum)")
         pmc_key = "k_edge16p" if ek == "v3" else "k_edge16v"
     else:
         kern = ("k_edge16n (PROC, f16x2, 3 waves/SIMD)" if (math_mode == "f16x2" and three)
@@ -384,7 +386,8 @@ def run_segnn(args, rank, world, device):
                    "weights": "U(-1,1) e3nn-style init (seed 1234), output x0.01", "n_realloc": int(n_realloc)},
         "steps_per_s_per_traj": K / dt,
         "roofline": {"kernel": kname, "bound": "mfma", "achieved": tf,
-                     "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+                     "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                     "traffic": pmc_traffic("k_sg_msg", "segnn_" + args.workload, B),
                      "us_per_launch": us_msg, "launches": int(n_msg), "flop_per_launch_executed": flop_exec,
                      "flop_per_launch_algorithmic": flop_algo,
                      "fp32_equivalent_algorithmic_tflops": flop_algo / (us_msg * 1e-6) / 1e12,

@@ -62,9 +62,16 @@ void lb_tic(lb_engine* e, int cls) {
   e->trecs.push_back(r);
 }
 
+void lb_tic_single(lb_engine* e, int cls) {
+  lb_tic(e, cls);
+  e->ext_armed = e->timers_on;
+  e->ext_used = false;
+}
+
 void lb_toc(lb_engine* e) {
   if (!e->timers_on || e->trecs.empty()) return;
-  (void)hipEventRecord(e->trecs.back().b, e->stream);
+  if (!(e->ext_armed && e->ext_used)) (void)hipEventRecord(e->trecs.back().b, e->stream);
+  e->ext_armed = e->ext_used = false;
 }
 
 static void lb_timers_collect(lb_engine* e) {

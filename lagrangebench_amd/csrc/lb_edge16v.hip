@@ -562,9 +562,9 @@ int lbk_edge16v(lb_engine* e, const lb_edge16_args& a, int variant) {
 #define LB_E16V(W, R, G)                                                                                \
   do {                                                                                                  \
     if (a.skip_elat_store)                                                                              \
-      hipLaunchKernelGGL((k_edge16v<W, R, true, 0, true>), dim3(G), dim3(W * 256), 0, e->stream, a);    \
+      LB_LAUNCH_TIMED(e, (k_edge16v<W, R, true, 0, true>), dim3(G), dim3(W * 256), a);                  \
     else                                                                                                \
-      hipLaunchKernelGGL((k_edge16v<W, R, false, 0, true>), dim3(G), dim3(W * 256), 0, e->stream, a);   \
+      LB_LAUNCH_TIMED(e, (k_edge16v<W, R, false, 0, true>), dim3(G), dim3(W * 256), a);                 \
   } while (0)
   // Small graphs (one 2.5 k-particle trajectory = ~1000 tiles): a launch is the latency chain
   // "stage 133 KiB of weights -> one tile per wave", so use lighter workgroups (one or two waves per

@@ -606,7 +606,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       a.row_ptr = e->row_ptr;
       a.agg = e->agg;
       a.part = e->part;
-      lb_tic(e, LB_T_EDGE_MLP);
+      lb_tic_single(e, LB_T_EDGE_MLP);
       if (e->edge_tile == 16) {
         lb_edge16_args b{};
         b.ctrl = a.ctrl;
@@ -677,7 +677,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       a.tile_shift = e->edge_tile == 16 ? 4 : 5;
       a.row_ptr = e->row_ptr;
       a.part = e->part;
-      lb_tic(e, LB_T_NODE_MLP);
+      lb_tic_single(e, LB_T_NODE_MLP);
       static const bool node_s_env = !(getenv("LB_NODE_KERNEL") && getenv("LB_NODE_KERNEL")[0] == 'h');
       const bool node_s = node_s_env && BN >= 32768;
       if (e->f16x2 && node_s) {

@@ -1,6 +1,7 @@
 // lb_internal.h - engine object, device control block and kernel launchers shared by the
 // translation units of liblbhip.so.  gfx950 only (wave64, MFMA f32 32x32x2).
 #pragma once
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -134,6 +135,7 @@ struct lb_engine {
   // timers
   bool timers_on;
   std::vector<lb_timer_rec> trecs;
+  bool ext_armed = false, ext_used = false;  // single-kernel timer classes: events bound to the dispatch itself
   std::vector<hipEvent_t> epool;
   double t_ms[LB_T_COUNT];
   int64_t t_n[LB_T_COUNT];
@@ -229,6 +231,22 @@ int lb_fail(int code, const char* fmt, ...);
 
 void lb_tic(lb_engine* e, int cls);
 void lb_toc(lb_engine* e);
+// Timer classes that consist of ONE kernel (processor edge / node MLP): between lb_tic_single and lb_toc
+// the launcher uses LB_LAUNCH_TIMED, which binds the class's two events to the dispatch itself
+// (hipExtLaunchKernelGGL start/stop events), so the elapsed time is the kernel's own begin -> end - the
+// number rocprofv3 --kernel-trace reports - without the dispatch gap and marker packets that a
+// record / launch / record bracket adds (~15-20 us per launch).
+void lb_tic_single(lb_engine* e, int cls);
+#define LB_LAUNCH_TIMED(e, kern, grid, block, ...)                                                        \
+  do {                                                                                                    \
+    if ((e)->ext_armed && !(e)->ext_used) {                                                               \
+      hipExtLaunchKernelGGL(kern, grid, block, 0, (e)->stream, (e)->trecs.back().a, (e)->trecs.back().b, \
+                            0, __VA_ARGS__);                                                              \
+      (e)->ext_used = true;                                                                               \
+    } else {                                                                                              \
+      hipLaunchKernelGGL(kern, grid, block, 0, (e)->stream, __VA_ARGS__);                                 \
+    }                                                                                                     \
+  } while (0)
 
 // lb_api.hip
 int lb_ensure_edges(lb_engine* e, int64_t need);

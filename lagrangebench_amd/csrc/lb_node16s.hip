@@ -314,7 +314,7 @@ int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const flo
   const bool deep = want_deep && nw == 4 && nblk <= 256;  // measured slower than the 2-slot ring: off
   dim3 grid(nblk), block(nw * 64);
 #define LB_NS(A, B, R, P, W, S) \
-  hipLaunchKernelGGL((k_node16s<A, B, R, P, W, S>), grid, block, 0, e->stream, a, w0, w1, wp)
+  LB_LAUNCH_TIMED(e, (k_node16s<A, B, R, P, W, S>), grid, block, a, w0, w1, wp)
 #define LB_NS_W(A, B, R, P)            \
   do {                                 \
     if (nw == 16)                      \

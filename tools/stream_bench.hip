@@ -18,7 +18,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int WPS, int TPW, int MODE>
 __global__ void __launch_bounds__(WPS * 256, WPS) k_stream(const f32x4* __restrict__ src, f32x4* __restrict__ dst,
                                                            const f32x4* __restrict__ psr, const int* __restrict__ snd,
-                                                           const int* __restrict__ rcv, int ntiles) {
+                                                           const int* __restrict__ rcv, int ntiles, int rev) {
   constexpr int WAVES = WPS * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -38,7 +38,8 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_stream(const f32x4* __restri
     f32x4 v[TPW][8], p[TPW][8];
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
-      const int tt = min(t + u * stride, t_hi - 1);
+      const int tf = min(t + u * stride, t_hi - 1);
+      const int tt = rev ? ntiles - 1 - tf : tf;
       const f32x4* er = src + (int64_t)tt * 512 + lane;
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb)
@@ -54,8 +55,9 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_stream(const f32x4* __restri
     }
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
-      const int tt = t + u * stride;
-      if (tt >= t_hi) break;
+      const int tf = t + u * stride;
+      if (tf >= t_hi) break;
+      const int tt = rev ? ntiles - 1 - tf : tf;
       if (MODE & 1) {
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) v[u][mb] = v[u][mb] + p[u][mb];
@@ -123,23 +125,35 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(rcv, r.data(), E * 4, hipMemcpyHostToDevice);
   }
   const double rw = (double)E * 1024;
-#define RUN(name, W, T, M, bytes)                                                                          \
+#define RUN(name, W, T, M, bytes) RUNR(name, W, T, M, bytes, 0)
+#define RUNR(name, W, T, M, bytes, ALT)                                                                        \
   do {                                                                                                     \
+    int flip = 0;                                                                                          \
     auto l = [&] {                                                                                         \
-      hipLaunchKernelGGL((k_stream<W, T, M>), dim3(256), dim3(W * 256), 0, 0, src, dst, psr, snd, rcv, ntiles); \
+      flip ^= (ALT);                                                                                       \
+      hipLaunchKernelGGL((k_stream<W, T, M>), dim3(256), dim3(W * 256), 0, 0, src, dst, psr, snd, rcv, ntiles, flip); \
     };                                                                                                     \
     const float us = time_it(l, 100);                                                                      \
     printf("%-58s %7.1f us  %5.2f TB/s HBM\n", name, us, (bytes) / us * 1e-6);                              \
     fflush(stdout);                                                                                        \
   } while (0)
   for (int i = 0; i < 3; ++i) {
-    auto l = [&] { hipLaunchKernelGGL((k_stream<4, 1, 0>), dim3(256), dim3(1024), 0, 0, src, dst, psr, snd, rcv, ntiles); };
+    auto l = [&] { hipLaunchKernelGGL((k_stream<4, 1, 0>), dim3(256), dim3(1024), 0, 0, src, dst, psr, snd, rcv, ntiles, 0); };
     (void)time_it(l, 500);
   }
   printf("E=%lld: read+write %.3f GB; copy ceiling 6.29 TB/s = %.0f us\n", (long long)E, rw * 1e-9, rw / 6.29e6);
   RUN("in place r+w                  3 waves/SIMD", 3, 1, 0, rw);
   RUN("in place r+w                  4 waves/SIMD", 4, 1, 0, rw);
   RUN("in place r+w                  2 waves/SIMD 2 tiles/wave", 2, 2, 0, rw);
+  // boustrophedon: every other launch walks the tiles in reverse, so the tail the previous launch wrote
+  // (still in the 256 MiB Infinity Cache) is what the next launch reads first
+  RUNR("in place r+w, alternate direction    4 waves/SIMD", 4, 1, 0, rw, 1);
+  RUNR("in place r+w nt both, alternate dir  4 waves/SIMD", 4, 1, 192, rw, 1);
+  RUNR("in place r+w nt loads, alternate dir 4 waves/SIMD", 4, 1, 128, rw, 1);
+  RUNR("in place r+w nt stores, alternate    4 waves/SIMD", 4, 1, 64, rw, 1);
+  RUNR("r+w + gathers, alternate direction   3 waves/SIMD", 3, 1, 1, rw, 1);
+  RUNR("r+w + gathers nt both, alternate dir 3 waves/SIMD", 3, 1, 193, rw, 1);
+  RUNR("r+w + gathers 2 tiles/wave, alt dir  2 waves/SIMD", 2, 2, 1, rw, 1);
   RUN("in place r+w, nt stores       4 waves/SIMD", 4, 1, 64, rw);
   RUN("in place r+w, nt loads        4 waves/SIMD", 4, 1, 128, rw);
   RUN("in place r+w, nt both         4 waves/SIMD", 4, 1, 192, rw);
