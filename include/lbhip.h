@@ -66,8 +66,9 @@ typedef struct lb_case_desc {
 
 /* GNS hyper-parameters: models/gns.py:36-63 (runner.py:205-216). */
 typedef struct lb_gns_desc {
-  int32_t latent_size;        /* 128 (GNS-10-128); 64 not built yet */
-  int32_t blocks_per_step;    /* num_mlp_layers; only 2 is built */
+  int32_t latent_size;        /* 128 (GNS-10-128); any multiple of 16 up to 128 (GNS-5-64) runs zero-padded */
+  int32_t blocks_per_step;    /* num_mlp_layers >= 1 (models/utils.py:100-115); 2 = the fused kernels, other depths
+                               * run one Linear per launch (csrc/lb_gns_generic.hip) */
   int32_t num_mp_steps;
   int32_t embedding_size;     /* particle_type_embedding_size (16) */
   int32_t num_particle_types; /* NodeType.SIZE = 9; <= 1 disables the embedding */

@@ -117,18 +117,6 @@ extern "C" int lb_timer_get(lb_engine* e, int32_t cls, double* ms_out, int64_t* 
 }
 
 // ---------------------------------------------------------------------------------- engine
-template <typename T>
-static int lb_alloc(T** p, size_t n) {
-  *p = nullptr;
-  if (n == 0) n = 1;
-  LB_HIP(hipMalloc((void**)p, n * sizeof(T)));
-  return LB_OK;
-}
-#define LB_TRY(x)          \
-  do {                     \
-    int _rc = (x);         \
-    if (_rc) return _rc;   \
-  } while (0)
 
 extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engine** out) {
   if (!d || !out) return lb_fail(LB_ERR_ARG, "null argument");
@@ -468,11 +456,12 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
   if (!e || !d || !w || !out) return lb_fail(LB_ERR_ARG, "null argument");
   if (d->latent_size < 16 || d->latent_size > LB_D || d->latent_size % 16)
     return lb_fail(LB_ERR_UNSUPPORTED, "latent_size %d not built (multiples of 16 up to 128)", d->latent_size);
-  if (d->blocks_per_step != 2) return lb_fail(LB_ERR_UNSUPPORTED, "blocks_per_step %d not built (2 only)", d->blocks_per_step);
   if (d->out_dim != e->g.dim) return lb_fail(LB_ERR_ARG, "out_dim %d != case dim %d", d->out_dim, e->g.dim);
   if (d->node_in != e->g.node_in) return lb_fail(LB_ERR_ARG, "node_in %d != case feature width %d", d->node_in, e->g.node_in);
   if (d->edge_in != e->g.dim + 1) return lb_fail(LB_ERR_ARG, "edge_in %d != dim+1", d->edge_in);
   if (d->num_mp_steps < 0 || d->num_mp_steps > 64) return lb_fail(LB_ERR_ARG, "bad num_mp_steps");
+  // any MLP depth other than the published two Linears runs on the one-Linear-per-launch kernels
+  if (d->blocks_per_step != 2) return lb_gns_create_generic(e, d, w, n_floats, out);
   const int D = LB_D, L = d->num_mp_steps;
   const bool has_emb = d->num_particle_types > 1;
   const int emb = has_emb ? d->embedding_size : 0;
@@ -732,6 +721,9 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
 extern "C" void lb_gns_destroy(lb_gns* g) {
   if (!g) return;
   if (g->blob) (void)hipFree(g->blob);
+  for (float* b : g->gen_hn)
+    if (b) (void)hipFree(b);
+  if (g->gen_he) (void)hipFree(g->gen_he);
   delete g;
 }
 

@@ -508,6 +508,7 @@ int lbk_segment_sum(lb_engine* e, const float* msg, float* out, int D) {
 
 // ================================================================================= forward
 int lbk_gns_forward(lb_engine* e, lb_gns* g) {
+  if (g->generic) return lbk_gns_forward_generic(e, g);
   hipStream_t s = e->stream;
   const int64_t BN = e->BN;
   const int ntile_n = (int)((BN + LB_TILE - 1) / LB_TILE);

@@ -194,6 +194,16 @@ struct lb_node_args {
   const float* part;
 };
 
+struct lb_gen_lin {                 // one Linear of the generic path
+  std::vector<const float*> wh, wf;  // per 128-row input block: f16x2 (hi|lo) and fp32 fragment packings
+  const float* b;                    // [128]
+};
+struct lb_gen_mlp {
+  std::vector<lb_gen_lin> lin;
+  const float* ln_s = nullptr;
+  const float* ln_o = nullptr;
+};
+
 struct lb_gns {
   lb_gns_desc desc;
   lb_engine* eng;
@@ -216,6 +226,13 @@ struct lb_gns {
   std::vector<const float*> proj_w_h2;  // projection packed as two 128-wide halves [Ws | Wr] (lb_node16s.hip)
   int kq_node;         // node_in(+emb) padded to a multiple of 32, in units of 8
   float* tap;
+  // num_mlp_layers != 2 (lb_gns_generic.hip): one packed 128x128 Linear per input block, both packings
+  bool generic = false;
+  lb_gen_mlp g_enc_node, g_enc_edge, g_dec;
+  std::vector<lb_gen_mlp> g_proc_edge, g_proc_node;
+  float* gen_hn[3] = {nullptr, nullptr, nullptr};  // node-sized hidden / projection scratch
+  float* gen_he = nullptr;                          // edge-sized hidden scratch (tile-blocked)
+  int64_t gen_he_cap = 0;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -227,6 +244,19 @@ int lb_fail(int code, const char* fmt, ...);
     if (_e != hipSuccess)                                                              \
       return lb_fail(LB_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), \
                      __FILE__, __LINE__);                                              \
+  } while (0)
+
+template <typename T>
+static inline int lb_alloc(T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  LB_HIP(hipMalloc((void**)p, n * sizeof(T)));
+  return LB_OK;
+}
+#define LB_TRY(x)          \
+  do {                     \
+    int _rc = (x);         \
+    if (_rc) return _rc;   \
   } while (0)
 
 void lb_tic(lb_engine* e, int cls);
@@ -298,6 +328,9 @@ int lbk_sg_update(lb_engine* e, float* f, const float* agg, const float* nattr, 
 
 // lb_gns.hip
 int lbk_gns_forward(lb_engine* e, lb_gns* g);
+// lb_gns_generic.hip: num_mlp_layers != 2
+int lb_gns_create_generic(lb_engine* e, const lb_gns_desc* d, const float* w, int64_t n_floats, lb_gns** out);
+int lbk_gns_forward_generic(lb_engine* e, lb_gns* g);
 int lbk_segment_sum(lb_engine* e, const float* msg, float* out, int D);
 void lb_pack_weight(const float* w, int K, int M, int Kpad, int Mpad, float* out);
 

@@ -31,11 +31,6 @@
 #include "lb_device.h"
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-#define LB_TRY(x)        \
-  do {                   \
-    int _rc = (x);       \
-    if (_rc) return _rc; \
-  } while (0)
 
 static constexpr float SG_Y0 = 0.28209479177387814f;      // 1 / (2 sqrt(pi))
 static constexpr float SG_Y1 = 0.4886025119029199f;       // sqrt(3 / (4 pi))

@@ -748,3 +748,63 @@ def test_gns_narrow_latent_parity(name, latent, L):
         _, nb = ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))
         _, m, _ = O.eval_batched_rollout(apply, ocase, p2, {}, (pos[b:b + 1].astype(np.float64), pt[b:b + 1]), nb, 3, isl)
         assert np.allclose(_np(out[f"rollout_{b}"]["mse"]), m[0]["mse"], rtol=1e-3, atol=1e-12)
+
+
+# ------------------------------------------------------------------ MLP depths other than 2
+@pytest.mark.parametrize("name,nl,latent,L", [("small2d", 1, 128, 3), ("small3d", 3, 128, 2), ("small2d", 4, 64, 2),
+                                              ("small3d", 1, 64, 2)])
+def test_gns_num_mlp_layers_parity(name, nl, latent, L):
+    """models/utils.py:100-115 build_mlp takes any num_hidden_layers >= 1 (defaults.py: num_mlp_layers 2
+    for every published model).  Depths other than 2 run on the one-Linear-per-launch kernels of
+    lb_gns_generic.hip: per-layer node latents and accelerations against the oracle in both arithmetic
+    modes, and a short device rollout."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.evaluate import infer
+    from lagrangebench_amd.models import GNS
+    ds = make_case(name, n_trajs=2, extra_seq_length=4)
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    isl, dim = ds.input_seq_length, len(ds.box)
+    node_in, edge_in = feature_widths(ds)
+    params = O.gns_init(np.random.default_rng(7), node_in=node_in, edge_in=edge_in, particle_dimension=dim,
+                        num_mp_steps=L, latent_size=latent, blocks_per_step=nl)
+    assert f"enc_node/linear_{nl - 1}" in params and f"enc_node/linear_{nl}" not in params
+    r2 = np.random.default_rng(8)
+    for k, v in params.items():
+        if "b" in v:
+            v["b"] = (0.1 * r2.standard_normal(v["b"].shape)).astype(np.float32)
+        if "scale" in v:
+            v["scale"] = (1.0 + 0.2 * r2.standard_normal(v["scale"].shape)).astype(np.float32)
+            v["offset"] = (0.1 * r2.standard_normal(v["offset"].shape)).astype(np.float32)
+    model = GNS(dim, latent, nl, L, 16)
+    pos = np.stack([ds[0][0], ds[1][0]])
+    pt = np.stack([ds[0][1], ds[1][1]])
+    N = pos.shape[1]
+    for mode in (1, 0):
+        feats, _ = hip_case(ds).allocate_eval((pos[:, :, :isl], pt))
+        feats.engine.math_mode(mode)
+        handle = model.handle(feats.engine, params)
+        tap = handle.set_tap(True)
+        acc = _np(model.apply(params, {}, (feats, pt))[0]["acc"])
+        tap = _np(tap).copy()
+        for b in range(2):
+            of, _ = ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))
+            ref, inter = O.gns_apply(params, of, pt[b], num_mp_steps=L, blocks_per_step=nl, skip_padding=True,
+                                     return_intermediates=True)
+            assert rel_err(tap[0][b * N:(b + 1) * N], inter["enc_n"]) < 1e-5, (mode, "enc")
+            for k in range(L):
+                assert rel_err(tap[k + 1][b * N:(b + 1) * N], inter[f"n{k}"]) < 1e-5, (mode, k)
+            assert rel_err(acc[b], ref["acc"]) < 1e-5, mode
+        handle.set_tap(False)
+    last = f"decoder/linear_{nl - 1}"
+    p2 = {k: {kk: vv.copy() for kk, vv in v.items()} for k, v in params.items()}
+    p2[last]["w"] *= np.float32(0.01)
+    p2[last]["b"] *= np.float32(0.01)
+    out = infer(model, hcase, ds, params=p2, cfg_eval_infer={"batch_size": 2, "metrics": ["mse"]}, n_rollout_steps=3)
+
+    def apply(p, state, sample):
+        return O.gns_apply(p, sample[0], sample[1], num_mp_steps=L, blocks_per_step=nl, skip_padding=True), state
+    for b in range(2):
+        _, nb = ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))
+        _, m, _ = O.eval_batched_rollout(apply, ocase, p2, {}, (pos[b:b + 1].astype(np.float64), pt[b:b + 1]), nb, 3, isl)
+        assert np.allclose(_np(out[f"rollout_{b}"]["mse"]), m[0]["mse"], rtol=1e-3, atol=1e-12)
