@@ -558,6 +558,96 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16p(lb_edge16_args a) {
   for (int it = 1; it < n_iter; ++it, t += stride) body(t, false);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_edge_enc16v: the ENCODER edge MLP (gns.py:73-84), e0 = LayerNorm(W1 relu(W0 f + b0) + b1) over the
+// edge features f = (rel_disp, rel_dist) the neighbor search wrote (8 floats per edge, zero padded).
+// Write-bound: 32 B read and 512 B written per edge.  Same tile walk, block loop, LayerNorm and
+// nontemporal tile-blocked store as k_edge16v; the first Linear is ONE k-step of 32 (4 KiB of W0 in LDS);
+// no gathers, no residual, no aggregation - ~100 VGPRs, WPS waves per SIMD.  The next tile's features
+// are fetched one tile ahead and taken delivery of before this tile's stores (in-order vmcnt).
+template <int WPS>
+__global__ void __launch_bounds__(WPS * 256, WPS) k_edge_enc16v(lb_edge16_args a) {
+  constexpr int THREADS = WPS * 256, WAVES = WPS * 4;
+  constexpr int NW0 = 1024;
+  __shared__ f32x4 sW[NW0 + 4096 + 128];  // W0 | W1 | b1 | ln scale | ln offset | b0
+  if (a.ctrl->overflow_step >= 0) return;
+  const int tid = threadIdx.x;
+  {
+    const f32x4* g0 = reinterpret_cast<const f32x4*>(a.w0p);
+    const f32x4* g1 = reinterpret_cast<const f32x4*>(a.w1p);
+    for (int i = tid; i < NW0; i += THREADS) sW[i] = g0[i];
+    for (int i = tid; i < 4096; i += THREADS) sW[NW0 + i] = g1[i];
+    if (tid < 128) {
+      const float* src = tid < 32 ? a.b1 : (tid < 64 ? a.ln_s : (tid < 96 ? a.ln_o : a.b0));
+      sW[NW0 + 4096 + tid] = reinterpret_cast<const f32x4*>(src)[tid & 31];
+    }
+  }
+  __syncthreads();
+  const int E = a.ctrl->n_edges_total;
+  const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
+  const int ntiles = (E + 15) >> 4;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * WAVES + wave;
+  const int stride = (gridDim.x >> 3) * WAVES;
+  const int t_lo = (int)(((int64_t)ntiles * xcd) >> 3), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) >> 3);
+  int t = t_lo + slot;
+  if (t >= t_hi) return;
+  const lds_cptr w0b = (lds_cptr)(sW + lane), w1b = (lds_cptr)(sW + NW0 + lane);
+  const lds_cptr vecb = (lds_cptr)(sW + NW0 + 4096 + g);
+  const f32x4* ef4 = reinterpret_cast<const f32x4*>(a.efeat);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  auto feat_of = [&](int tt) -> f32x4 {
+    const int row = tt * 16 + n;
+    const int64_t rc = row < E ? row : E - 1;
+    return ef4[rc * 2 + (g & 1)];
+  };
+  const int n_iter = (t_hi - 1 - t) / stride + 1;
+  const int t_last = t + (n_iter - 1) * stride;
+  f32x4 f_n = feat_of(t);
+  asm volatile("" : "+v"(f_n));
+  for (int it = 0; it < n_iter; ++it, t += stride) {
+    const f32x4 v2[2] = {g < 2 ? f_n : zero, zero};
+    f_n = feat_of(min(t + stride, t_last));
+    f32x4 acc[8], acc2[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc[mb] = vecb[96 + 4 * mb];
+    lb_gemm16v<false, 1>(w0b, v2, acc);
+    if (it == 0) lb_range_probe(a.ctrl, acc, 8);
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc2[mb] = vecb[4 * mb];
+    lb_gemm16v<true>(w1b, acc, acc2);
+    asm volatile("" : "+v"(f_n));
+    f32x4 y[8];
+    lb_layernorm16<true>(acc2, vecb + 32, vecb + 64, y, ln_inv_d, ln_pad);
+    f32x4* ew = reinterpret_cast<f32x4*>(a.elat) + (int64_t)t * 512 + lane;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) __builtin_nontemporal_store(y[mb], &ew[64 * mb]);
+  }
+}
+
+int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a) {
+  const int64_t tiles_cap = ((int64_t)e->e_cap * e->g.B + 15) / 16;
+  auto grid_for = [&](int waves_per_block) {
+    int64_t g = (tiles_cap + waves_per_block - 1) / waves_per_block;
+    g = (g + 7) / 8 * 8;
+    return (int)(g < 8 ? 8 : (g > 256 ? 256 : g));
+  };
+  static const int wps_env = getenv("LB_ENC_WPS") ? atoi(getenv("LB_ENC_WPS")) : 4;
+  if (tiles_cap <= 256 * 4 * 2)
+    hipLaunchKernelGGL((k_edge_enc16v<1>), dim3(grid_for(4)), dim3(256), 0, e->stream, a);
+  else if (tiles_cap <= 256 * 8 * 2)
+    hipLaunchKernelGGL((k_edge_enc16v<2>), dim3(grid_for(8)), dim3(512), 0, e->stream, a);
+  else if (wps_env == 2)
+    hipLaunchKernelGGL((k_edge_enc16v<2>), dim3(256), dim3(512), 0, e->stream, a);
+  else if (wps_env == 3)
+    hipLaunchKernelGGL((k_edge_enc16v<3>), dim3(256), dim3(768), 0, e->stream, a);
+  else
+    hipLaunchKernelGGL((k_edge_enc16v<4>), dim3(256), dim3(1024), 0, e->stream, a);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a, int variant) {
 #define LB_E16V(W, R, G)                                                                                \
   do {                                                                                                  \

@@ -580,7 +580,9 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       b.b1 = a.b1;
       b.ln_s = a.ln_s;
       b.ln_o = a.ln_o;
-      rc = lbk_edge16(e, b, false, e->f16x2 != 0);
+      // LB_ENC_KERNEL=h: the round-1 encoder kernel (k_edge16<ENC>)
+      static const bool enc_v = !(getenv("LB_ENC_KERNEL") && getenv("LB_ENC_KERNEL")[0] == 'h');
+      rc = (e->f16x2 && enc_v) ? lbk_edge_enc16v(e, b) : lbk_edge16(e, b, false, e->f16x2 != 0);
       if (rc) return rc;
     } else {
       hipLaunchKernelGGL((k_edge_mlp<false>), dim3(edge_blocks), dim3(EDGE_THREADS), 0, s, a);

@@ -350,3 +350,4 @@ int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc, bool f16x2);
 // SIMD, resident latents (default), 1 = four waves + second read, 2 = three waves + second read,
 // 3 = two waves, fully software-pipelined
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a, int variant);
+int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a);
