@@ -154,6 +154,11 @@ int main(int argc, char** argv) {
   RUNR("r+w + gathers, alternate direction   3 waves/SIMD", 3, 1, 1, rw, 1);
   RUNR("r+w + gathers nt both, alternate dir 3 waves/SIMD", 3, 1, 193, rw, 1);
   RUNR("r+w + gathers 2 tiles/wave, alt dir  2 waves/SIMD", 2, 2, 1, rw, 1);
+  RUNR("r+w + gathers nt loads, alt dir      3 waves/SIMD", 3, 1, 129, rw, 1);
+  RUNR("r+w + gathers nt stores, alt dir     3 waves/SIMD", 3, 1, 65, rw, 1);
+  RUNR("r+w + gathers nt loads, alt dir      2 waves/SIMD", 2, 1, 129, rw, 1);
+  RUNR("r+w + gathers nt both                2 waves/SIMD", 2, 1, 193, rw, 0);
+  RUNR("r+w + gathers 2 tiles/wave nt loads, alt dir 2 w/SIMD", 2, 2, 129, rw, 1);
   RUN("in place r+w, nt stores       4 waves/SIMD", 4, 1, 64, rw);
   RUN("in place r+w, nt loads        4 waves/SIMD", 4, 1, 128, rw);
   RUN("in place r+w, nt both         4 waves/SIMD", 4, 1, 192, rw);
