@@ -106,8 +106,8 @@ def main():
     if world != args.gpus:
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = lbdist.local_device(local_rank)
+    torch.cuda.set_device(device)
 
     if args.model == "segnn":
         return run_segnn(args, rank, world, device)

@@ -19,15 +19,30 @@ def env_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def local_device(local_rank: int) -> torch.device:
+    """cuda:<local_rank>; on a box with fewer GPUs than ranks (the one-GPU test box running a two-rank
+    smoke test over gloo) the ranks share the devices round-robin."""
+    n = torch.cuda.device_count()
+    return torch.device("cuda", local_rank % n if n else 0)
+
+
+def _coll_device(device: Optional[torch.device]) -> torch.device:
+    """Where collective payloads live: the rank's GPU under RCCL, host memory under gloo."""
+    if device is not None and dist.is_initialized() and dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return device if device is not None else torch.device("cpu")
+
+
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # LB_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses duplicate devices)
+            backend = os.environ.get("LB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_device(local_rank))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
@@ -49,7 +64,7 @@ def barrier(device: Optional[torch.device] = None) -> None:
 def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -63,7 +78,7 @@ def gather_metrics(local: Dict[int, torch.Tensor], n_trajs: int, n_steps: int,
         return dict(local)
     world = dist.get_world_size()
     per = (n_trajs + world - 1) // world
-    dev = device if device is not None else torch.device("cpu")
+    dev = _coll_device(device)
     block = torch.full((per, 1 + n_steps), -1.0, dtype=torch.float64, device=dev)
     for slot, (idx, v) in enumerate(sorted(local.items())):
         block[slot, 0] = float(idx)

@@ -84,3 +84,30 @@ def test_two_ranks_run_infer_on_the_hip_engine(tmp_path):
             f.write(r.stdout + "\n=====\n" + r.stderr)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-6000:]
     assert "DIST_GPU_OK" in r.stdout
+
+
+def test_bench_two_ranks_on_this_box():
+    """`bench.py --gpus 2` as the driver launches it (python -m torch.distributed.run, one rank per GPU).  With
+    one GPU visible the two ranks share it and the metric gather / max-over-ranks travel over gloo
+    (LB_DIST_BACKEND); with two GPUs it is the RCCL path itself.  Checks the contract fields of the JSON line
+    and that the aggregate counts both ranks' trajectories."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 2:
+        env["LB_DIST_BACKEND"] = "gloo"
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "3", "--batch", "2", "--workload", "tgv2d", "--no-cpu-baseline", "--no-other-configs"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 3 and d["scaling"] == "weak"
+    n = d["config"]["n_particles"]
+    assert abs(d["value"] - 2 * 2 * n * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]   # whole-job aggregate
+    assert d["roofline"]["frac"] > 0 and d["unit"] == "particle-steps/s"
