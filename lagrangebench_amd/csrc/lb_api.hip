@@ -570,11 +570,25 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     off_embed = put(p, (size_t)d->num_particle_types * emb);
     p += (size_t)d->num_particle_types * emb;
   }
+  // f16x2 carries a weight as fp16 hi + fp16 lo with an ABSOLUTE floor of 2^-25 on the pair: a matrix whose
+  // entries are uniformly small (rms < 2^-7) would lose the 1e-5 class - noted here, acted on below
+  double w_rms_min = 1e30;
+  auto note_rms = [&](const float* m, size_t n) {
+    double s2 = 0;
+    size_t nz = 0;
+    for (size_t i = 0; i < n; ++i) {
+      s2 += (double)m[i] * m[i];
+      nz += m[i] != 0.f;
+    }
+    if (nz) w_rms_min = std::min(w_rms_min, std::sqrt(s2 / (double)nz));
+  };
   // generic 2-layer MLP reader; k0pad = padded K of layer 0; outp = padded out width
   auto read_mlp = [&](int in, int k0pad, int outw, int outp, bool ln) -> Off {
     Off o{};
+    note_rms(p, (size_t)in * D);
     o.w0 = put_packed(p, in, D, k0pad, D); p += (size_t)in * D;
     o.b0 = put(p, D); p += D;
+    if (ln) note_rms(p, (size_t)D * outw);  // (the decoder's output Linear is rescaled instead, see below)
     o.w1 = put_packed(p, D, outw, D, outp); p += (size_t)D * outw;
     {
       std::vector<float> b(outp, 0.f);
@@ -644,7 +658,27 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     o_pn_w1_h[k] = put_packed16h(p + (size_t)2 * D * D + D, D, D, D);
     o_pn[k] = read_mlp(2 * D, 2 * D, D, D, true);
   }
+  const float* p_dec = p;
   Off o_dec = read_mlp(D, D, d->out_dim, 32, false);
+  const size_t o_dec_w0_h = put_packed16h(p_dec, D, D, D);
+  const size_t o_dec_w0_f = put_packed16(p_dec, D, D, D);
+  // decoder head: the f16x2 copy is packed times 2^s (max |w| -> [0.25, 0.5)) and the kernel multiplies the result
+  // by 2^-s: exact, and independent of the output normalisation a checkpoint was trained with
+  float dec_unscale = 1.f;
+  size_t o_dec_w1_h;
+  {
+    const float* w1d = p_dec + (size_t)D * D + D;
+    const size_t n = (size_t)D * d->out_dim;
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w1d[i]));
+    int sh = 0;
+    if (mx > 0.f && std::isfinite(mx)) sh = std::max(-60, std::min(60, (int)std::floor(std::log2(0.5 / (double)mx))));
+    std::vector<float> scaled(w1d, w1d + n);
+    for (float& x : scaled) x = std::ldexp(x, sh);
+    dec_unscale = std::ldexp(1.f, -sh);
+    o_dec_w1_h = put_packed16h(scaled.data(), D, d->out_dim, D, 16);
+  }
+  const size_t o_dec_w1_f = put_packed16(p_dec + (size_t)D * D + D, D, d->out_dim, D);
   if (p - w != n_floats) return lb_fail(LB_ERR_ARG, "internal: blob walk mismatch");
 
   lb_gns* g = new lb_gns();
@@ -689,6 +723,11 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     g->proc_edge_w0_16h.push_back(g->blob + o_pe_w0_16h[k]);
     g->proc_edge_w1_16h.push_back(g->blob + o_pe_w1_16h[k]);
   }
+  g->dec_unscale = dec_unscale;
+  g->dec_w0_h = g->blob + o_dec_w0_h;
+  g->dec_w0_f = g->blob + o_dec_w0_f;
+  g->dec_w1_h = g->blob + o_dec_w1_h;
+  g->dec_w1_f = g->blob + o_dec_w1_f;
   g->enc_edge_w0_16 = g->blob + o_ee_w0_16;
   g->enc_edge_w1_16 = g->blob + o_ee_w1_16;
   g->enc_node_w0_h = g->blob + o_en_w0_h;
@@ -698,6 +737,11 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
   {  // LayerNorm width of this model (read by every network kernel through the control block)
     const float lnc[2] = {1.0f / (float)dl, (float)(D - dl)};
     LB_HIP(hipMemcpy(&e->ctrl->ln_inv_d, lnc, sizeof(lnc), hipMemcpyHostToDevice));
+  }
+  if (w_rms_min < 0.0078125 && e->f16x2 && e->math_auto) {
+    fprintf(stderr, "[lbhip] a weight matrix has rms %.3g < 2^-7: its fp16 hi/lo split would fall short of the 1e-5 class - "
+                    "this engine uses exact-fp32 MFMA arithmetic\n", w_rms_min);
+    e->f16x2 = 0;
   }
   // node-sized network scratch
   e->g.kpad = kpad;

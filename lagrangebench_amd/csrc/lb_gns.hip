@@ -712,7 +712,14 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
     a.acc_out = e->acc;
     a.out_dim = g->desc.out_dim;
     lb_tic(e, LB_T_DECODER);
-    hipLaunchKernelGGL(k_decoder, dim3(ntile_n), dim3(64), 0, s, a);
+    // LB_DEC_KERNEL=h: round 1's one-wave-per-tile fp32 kernel
+    static const bool dec16 = !(getenv("LB_DEC_KERNEL") && getenv("LB_DEC_KERNEL")[0] == 'h');
+    if (dec16 && e->edge_tile == 16) {
+      rc = lbk_decoder16(e, g);
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL(k_decoder, dim3(ntile_n), dim3(64), 0, s, a);
+    }
     lb_toc(e);
   }
   LB_HIP(hipGetLastError());

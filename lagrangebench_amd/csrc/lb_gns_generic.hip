@@ -18,6 +18,7 @@
 // guard fired) and the same LayerNorm code as the fused kernels, so the 1e-5 parity bar applies.
 // A latent narrower than 128 is zero-padded exactly as in lb_gns_create (lb_ctrl::ln_inv_d / ln_pad).
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -204,6 +205,122 @@ static int lbk_dense16(lb_engine* e, const lb_dense_args& a, int64_t rows_bound,
   return LB_OK;
 }
 
+// ---------------------------------------------------------------------------------- decoder
+// k_decoder16: the decoder MLP of the default depth (gns.py:125-133: Linear 128 -> 128, ReLU, Linear 128 ->
+// out_dim, no LayerNorm) on the 16-row tile scheme: W0 and the one 16-column block of W1 that holds the
+// out_dim outputs resident in LDS, node latents read once (row-major), the hidden layer stays in registers,
+// one f32x4 per node written.  Replaces round 1's one-wave-per-32-rows fp32 kernel (k_decoder: 45 us per
+// launch on 64 k nodes, weights re-read from global memory by every wave).
+struct lb_dec16_args {
+  const lb_ctrl* ctrl;
+  int64_t n_rows;
+  const float* nlat;
+  const float* w0;   // packed 128 x 128 (f16x2 hi|lo or fp32 fragments)
+  const float* b0;   // [128]
+  const float* w1;   // f16x2: packed 128 x 16 (lb_pack_weight16h, Mpad 16); fp32: packed 128 x 128, block 0 used
+  const float* b1;   // [>= 4]
+  float unscale;     // result of the w1 product is multiplied by this (power of two) before b1 is added
+  float* acc_out;    // [rows][4]
+  int out_dim;
+};
+
+template <bool F16>
+__global__ void __launch_bounds__(GD_THREADS, 2) k_decoder16(lb_dec16_args a) {
+  constexpr int NW1 = F16 ? 512 : 4096;
+  __shared__ f32x4 sW[4096 + NW1 + 33];
+  if (a.ctrl->overflow_step >= 0) return;
+  const int tid = threadIdx.x;
+  {
+    const f32x4* g0 = reinterpret_cast<const f32x4*>(a.w0);
+    const f32x4* g1 = reinterpret_cast<const f32x4*>(a.w1);
+    for (int i = tid; i < 4096; i += GD_THREADS) sW[i] = g0[i];
+    for (int i = tid; i < NW1; i += GD_THREADS) sW[4096 + i] = g1[i];
+    if (tid < 32) sW[4096 + NW1 + tid] = reinterpret_cast<const f32x4*>(a.b0)[tid];
+    if (tid == 32) sW[4096 + NW1 + 32] = reinterpret_cast<const f32x4*>(a.b1)[0];
+  }
+  __syncthreads();
+  const int ntiles = (int)((a.n_rows + 15) >> 4);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const lds_cptr lw0 = (lds_cptr)sW + lane, lw1 = (lds_cptr)sW + 4096 + lane;
+  const lds_cptr lb0 = (lds_cptr)sW + 4096 + NW1 + g;
+  const f32x4 b1v = sW[4096 + NW1 + 32];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  bool probed = false;
+  for (int t = blockIdx.x * GD_WAVES + wave; t < ntiles; t += gridDim.x * GD_WAVES) {
+    const int64_t row = (int64_t)t * 16 + n;
+    const bool valid = row < a.n_rows;
+    const int64_t rowc = valid ? row : a.n_rows - 1;
+    f32x4 v[8], acc[8];
+    const f32x4* xr = reinterpret_cast<const f32x4*>(a.nlat) + rowc * 32 + g;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) v[mb] = xr[4 * mb];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc[mb] = lb0[4 * mb];
+    f32x4 o = zero;  // C layout: lane (n, g) holds outputs 4g .. 4g+3 of row n
+    if constexpr (F16) {
+      if (!probed) {
+        lb_range_probe(a.ctrl, v, 8);
+        probed = true;
+      }
+      lb_gemm16v<false, 4>(lw0, v, acc);
+      if (t < (int)gridDim.x * GD_WAVES) lb_range_probe(a.ctrl, acc, 8);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        f32x4 r0, r1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          r0[j] = fmaxf(acc[2 * p][j], 0.f);
+          r1[j] = fmaxf(acc[2 * p + 1][j], 0.f);
+        }
+        h8 bh, bl;
+        lb_split8v(r0, r1, bh, bl);
+        const h8 ah = __builtin_bit_cast(h8, lw1[(p * 2 + 0) * 64]);
+        const h8 al = __builtin_bit_cast(h8, lw1[(p * 2 + 1) * 64]);
+        o = MFMA16H(al, bh, o);
+        o = MFMA16H(ah, bl, o);
+        o = MFMA16H(ah, bh, o);
+      }
+    } else {
+      lb_gemm16f(lw0, v, acc);
+#pragma unroll
+      for (int step = 0; step < 32; ++step) {
+        const f32x4 a0 = lw1[(step * 2) * 64];
+        o = MFMA16F(a0[0], fmaxf(acc[step >> 2][step & 3], 0.f), o);
+      }
+    }
+    if (valid && g == 0) {
+      o = o * a.unscale + b1v;
+      reinterpret_cast<f32x4*>(a.acc_out)[row] = o;
+      bool bad = false;
+      for (int d = 0; d < a.out_dim; ++d) bad |= !(fabsf(o[d]) <= 3.0e38f);
+      if (bad) atomicOr(const_cast<int32_t*>(&a.ctrl->math_flags), LB_MATH_NONFINITE);
+    }
+  }
+}
+
+int lbk_decoder16(lb_engine* e, lb_gns* g) {
+  lb_dec16_args a{};
+  a.ctrl = e->ctrl;
+  a.n_rows = e->BN;
+  a.nlat = e->nlat;
+  a.w0 = e->f16x2 ? g->dec_w0_h : g->dec_w0_f;
+  a.b0 = g->dec.b0;
+  a.w1 = e->f16x2 ? g->dec_w1_h : g->dec_w1_f;
+  a.b1 = g->dec.b1;
+  a.unscale = e->f16x2 ? g->dec_unscale : 1.f;
+  a.acc_out = e->acc;
+  a.out_dim = g->desc.out_dim;
+  const int64_t tiles = std::max<int64_t>(1, (e->BN + 15) / 16);
+  const int grid = (int)std::min<int64_t>(512, (tiles + GD_WAVES - 1) / GD_WAVES);
+  if (e->f16x2)
+    hipLaunchKernelGGL((k_decoder16<true>), dim3(grid), dim3(GD_THREADS), 0, e->stream, a);
+  else
+    hipLaunchKernelGGL((k_decoder16<false>), dim3(grid), dim3(GD_THREADS), 0, e->stream, a);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
 // ---------------------------------------------------------------------------------- model build
 // Blob order (models/gns.py GNS.flatten): [embed] then per MLP, in module-creation order,
 // linear_0 .. linear_{n-1} as (w [in][out], b [out]) and, if present, LayerNorm scale, offset.
@@ -235,6 +352,16 @@ int lb_gns_create_generic(lb_engine* e, const lb_gns_desc* d, const float* w, in
   const float* p = w;
   const float* p_end = w + n_floats;
   bool short_blob = false;
+  double w_rms_min = 1e30;  // see lb_gns_create: uniformly small weight matrices fall out of the f16x2 accuracy class
+  auto note_rms = [&](const float* m, size_t n) {
+    double s2 = 0;
+    size_t nz = 0;
+    for (size_t i = 0; i < n; ++i) {
+      s2 += (double)m[i] * m[i];
+      nz += m[i] != 0.f;
+    }
+    if (nz) w_rms_min = std::min(w_rms_min, std::sqrt(s2 / (double)nz));
+  };
   // one Linear: in_blocks x blk_in input rows (each block padded to 128 k's), `outw` columns (padded to 128)
   auto read_linear = [&](int in_blocks, int blk_in, int outw) -> LinOff {
     LinOff o;
@@ -244,6 +371,7 @@ int lb_gns_create_generic(lb_engine* e, const lb_gns_desc* d, const float* w, in
       o.b = 0;
       return o;
     }
+    note_rms(p, (size_t)in_blocks * blk_in * outw);
     std::vector<float> tmp((size_t)128 * 128);
     for (int b = 0; b < in_blocks; ++b) {
       const float* src = p + (size_t)b * blk_in * outw;
@@ -344,6 +472,11 @@ int lb_gns_create_generic(lb_engine* e, const lb_gns_desc* d, const float* w, in
       lb_gns_destroy(g);
       return lb_fail(LB_ERR_HIP, "control block upload failed");
     }
+  }
+  if (w_rms_min < 0.0078125 && e->f16x2 && e->math_auto) {
+    fprintf(stderr, "[lbhip] a weight matrix has rms %.3g < 2^-7: its fp16 hi/lo split would fall short of the 1e-5 class - "
+                    "this engine uses exact-fp32 MFMA arithmetic\n", w_rms_min);
+    e->f16x2 = 0;
   }
   e->g.kpad = kpad;
   const int64_t BN = e->BN;

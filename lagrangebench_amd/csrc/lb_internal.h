@@ -226,6 +226,12 @@ struct lb_gns {
   std::vector<const float*> proj_w_h2;  // projection packed as two 128-wide halves [Ws | Wr] (lb_node16s.hip)
   int kq_node;         // node_in(+emb) padded to a multiple of 32, in units of 8
   float* tap;
+  // decoder on the 16-row tile scheme (k_decoder16): W0 and the out_dim block of W1, both packings
+  const float* dec_w0_h = nullptr;
+  const float* dec_w0_f = nullptr;
+  const float* dec_w1_h = nullptr;
+  const float* dec_w1_f = nullptr;
+  float dec_unscale = 1.f;  // the f16x2 copy of the decoder's output Linear is packed times a power of two
   // num_mlp_layers != 2 (lb_gns_generic.hip): one packed 128x128 Linear per input block, both packings
   bool generic = false;
   lb_gen_mlp g_enc_node, g_enc_edge, g_dec;
@@ -331,6 +337,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g);
 // lb_gns_generic.hip: num_mlp_layers != 2
 int lb_gns_create_generic(lb_engine* e, const lb_gns_desc* d, const float* w, int64_t n_floats, lb_gns** out);
 int lbk_gns_forward_generic(lb_engine* e, lb_gns* g);
+int lbk_decoder16(lb_engine* e, lb_gns* g);
 int lbk_segment_sum(lb_engine* e, const float* msg, float* out, int D);
 void lb_pack_weight(const float* w, int K, int M, int Kpad, int Mpad, float* out);
 
