@@ -9,17 +9,19 @@
 // three matrices (320 KiB as fp16 hi|lo) through registers into a two-slot LDS ring: 1000 workgroups x
 // 320 KiB = 320 MB of L2 -> LDS traffic per launch for 164 MB of node data, and ten
 // load -> wait -> ds_write -> barrier steps per 64 nodes.  Measured 73 us = 0.28 of the HBM roofline.
-// Here (the node count per launch is small: 64 k nodes = 4000 16-node tiles = 15.6 per CU):
-//   * one workgroup per CU holds up to 16 tiles (NW = 16 waves, one tile each, four per SIMD, <= 128
-//     VGPRs): TGV3D-8k x 8 is exactly one round of 250 workgroups and the weights cross L2 -> LDS once
-//     per CU (82 MB per launch instead of 320 MB);
+// Here (64 k nodes = 4000 16-node tiles = 15.6 per CU):
+//   * workgroups of NW waves, one 16-node tile per wave.  Default NW = 8, two workgroups per CU (<= 128 VGPRs):
+//     TGV3D-8k x 8 is one round of 500 workgroups, the weights cross L2 -> LDS twice per CU (164 MB per launch
+//     instead of 320 MB).  NW = 16 (LB_NODE_NW=16: one workgroup per CU, 82 MB) measures 4 us slower, NW = 4 is
+//     used for small launches so that more CUs take part;
 //   * the stream is 10 uniform 32 KiB chunks (2 k-steps x 8 output blocks x hi|lo; the projection is
-//     packed as [Ws | Wr] halves so that its chunks have the same shape) landing in a FOUR-slot ring
-//     via global_load_lds_dwordx4 (no staging registers, three chunks in flight), one barrier per chunk;
+//     packed as [Ws | Wr] halves so that its chunks have the same shape) landing in a two-slot (NW 16: four-slot)
+//     ring via global_load_lds_dwordx4 (no staging registers), one barrier per chunk;
 //   * per-wave register diet for four waves per SIMD: the aggregated messages arrive in two halves
 //     into the registers the node-latent half just released, the projection runs as two 128-wide
 //     halves, the residual re-reads the node row (L2 hit) instead of keeping it for the whole pass;
 //   * the inner block loop / split / LayerNorm are the ones of lb_edge16v.hip (lb_f16x2.h).
+// Measured 52-54 us per launch; where the time goes: profiles/r02_node16s_ablation.txt, DESIGN.md section 4.
 #include <stdlib.h>
 
 #include "lb_f16x2.h"
