@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short sub-runs of the other BASELINE.json configs appended as `other_configs`")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not re-measure roofline.traffic with two nested rocprofv3 PMC passes (use profiles/pmc_traffic.json)")
     ap.add_argument("--shuffle", action="store_true",
                     help="randomly permute the particle ids (memory-locality ablation; default: lattice order)")
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -265,12 +267,66 @@ def main():
         "breakdown_ms_per_step": breakdown,
     }
 
+    # roofline.traffic measured by THIS run: two nested rocprofv3 passes of the same command (FETCH_SIZE, WRITE_SIZE:
+    # the counters do not fit one pass; --kernel-trace + --pmc only), after the timed region; any failure or a
+    # missing rocprofv3 falls back to the committed table above
+    if world == 1 and not args.no_pmc and os.environ.get("LB_BENCH_PMC", "1") != "0":
+        live = measure_traffic(args)
+        if live:
+            for key, dst in ((pmc_key, out["roofline"]), ("k_segment_sum", out["roofline_aggregate"])):
+                hit = [v for k, v in sorted(live.items()) if key in k]
+                if hit:
+                    dst["traffic"] = hit[0]
+                    dst["traffic_source"] = ("measured by this run: nested rocprofv3 --kernel-trace --pmc FETCH_SIZE / "
+                                             "WRITE_SIZE passes (separate), (2*FETCH + WRITE) * 1 KiB per launch")
     if world == 1 and not args.no_other_configs:
         del pred, traj, handle, eng
         out["other_configs"] = other_configs(device)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ds, params, L, args.cpu_steps)
     print(json.dumps(out), flush=True)
+
+
+def measure_traffic(args, timeout_s=240):
+    """HBM bytes per launch of every kernel of this workload from two nested rocprofv3 PMC passes
+    (tools/pmc_traffic.py: averages over the real launches; FETCH_SIZE doubled per MI355X_MICROARCH.md).
+    Returns {kernel name: bytes} or None.  Bounded: each pass runs in its own process group under a timeout."""
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_traffic as PT
+        per = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="lbpmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--no-cpu-baseline", "--no-other-configs", "--no-pmc", "--steps", "5", "--warmup", "10",
+                   "--workload", args.workload, "--batch", str(args.batch), "--mp-steps", str(args.mp_steps),
+                   "--model", args.model]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                shutil.rmtree(d, ignore_errors=True)
+                return None
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if p.returncode != 0 or not dbs:
+                shutil.rmtree(d, ignore_errors=True)
+                return None
+            per[ctr] = PT.per_kernel(dbs[0], ctr)
+            shutil.rmtree(d, ignore_errors=True)
+        return {k: int((2 * f + per["WRITE_SIZE"].get(k, 0.0)) * 1024) for k, f in per["FETCH_SIZE"].items()}
+    except Exception as ex:  # measurement extra: never let it take the bench line down
+        log(f"[bench] PMC traffic pass failed ({ex}); using profiles/pmc_traffic.json")
+        return None
 
 
 def other_configs(device):
