@@ -209,6 +209,7 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   A(lb_alloc(&e->win, (size_t)d->isl * d->dim * BN));
   A(lb_alloc(&e->ptype, (size_t)BN));
   A(lb_alloc(&e->ctrl, 1));
+  A(lb_alloc(&e->blocks_done, 1));
   A(lb_alloc(&e->cell_of, (size_t)BN));
   A(lb_alloc(&e->cell_count, 2 * nc));  // cell_count | cell_fill contiguous (one memset)
   A(lb_alloc(&e->cell_start, nc + 1));
@@ -242,6 +243,7 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   c0.overflow_step = -1;
   c0.ln_inv_d = 1.0f / LB_D;
   if (hipMemcpy(e->ctrl, &c0, sizeof(c0), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(e->blocks_done, 0, sizeof(int32_t)) != hipSuccess ||
       hipMemset(e->ptype, 0, sizeof(int32_t) * BN) != hipSuccess ||
       hipMemset(e->row_ptr, 0, sizeof(int32_t) * (BN + 1)) != hipSuccess) {
     lb_engine_destroy(e);
@@ -259,7 +261,7 @@ extern "C" void lb_engine_destroy(lb_engine* e) {
                   e->cell_part, e->deg, e->row_ptr, e->scan_part, e->cpos, e->tmp_send, e->tmp_feat, e->tmp_feat64,
                   e->senders, e->receivers, e->efeat, e->efeat64,
                   e->overflow, e->nedges_b, e->xnode, e->nlat, e->agg, e->psr, e->elat, e->msg,
-                  e->part, e->acc};
+                  e->part, e->acc, e->blocks_done};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->ctrl_host) (void)hipHostFree(e->ctrl_host);

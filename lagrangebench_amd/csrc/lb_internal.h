@@ -87,6 +87,7 @@ struct lb_engine {
   int32_t* ptype;     // [B*N]
   double* force;      // [B*N*dim] (LB_FORCE_BUFFER) or null
   lb_ctrl* ctrl;      // device
+  int32_t* blocks_done = nullptr;  // k_integrate: workgroups that have read the step counter (the last one advances it)
   lb_ctrl* ctrl_host; // pinned mirror
   int32_t* host_flag;     // pinned + device-mapped: first overflowing step (-1 = none), written by
   int32_t* host_flag_dev; //   k_row_scan so lb_rollout can stop enqueuing without a stream sync

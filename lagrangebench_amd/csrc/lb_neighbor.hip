@@ -152,6 +152,97 @@ __global__ void k_cell_fill(lb_geom g, int64_t BN, const double* __restrict__ wi
   for (int d = 0; d < g.dim; ++d) cpos[(int64_t)d * BN + slot] = lb_pos(win, g, BN, step, g.isl - 1, d, gi);
 }
 
+// Small problems (<= LB_SMALL_N = 4096 particles and cells in the whole batch; measured: TGV2D-2.5k 0.423 -> 0.415,
+// RPF2D-3.2k 0.532 -> 0.517 ms per step, but slower than the multi-launch path from ~8 k particles): cell binning in ONE single-workgroup
+// launch instead of memset + count + two scan passes + fill (each ~4-5 us of launch floor on a 2.5 k-particle
+// trajectory, where the whole step is 0.4 ms).  Same arithmetic and same outputs as the multi-launch path
+// (the order of the particles INSIDE a cell is arbitrary in both: the rows are sorted by sender id later).
+#define LB_SMALL_N 4096
+#define LB_SMALL_T 1024
+__global__ void __launch_bounds__(LB_SMALL_T)
+    k_cells_small(lb_geom g, int64_t BN, const double* __restrict__ win, lb_ctrl* __restrict__ ctrl,
+                  int32_t* __restrict__ cell_of, int32_t* __restrict__ cell_start, int32_t* __restrict__ cell_part,
+                  double* __restrict__ cpos, int ncell_tot) {
+  __shared__ int s_cnt[LB_SMALL_N];
+  __shared__ int s_scan[LB_SMALL_T];
+  __shared__ int s_max;
+  if (ctrl->overflow_step >= 0) return;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    ctrl->max_deg = 0;
+    ctrl->row_overflow = 0;
+    s_max = 0;
+  }
+  for (int c = tid; c < ncell_tot; c += LB_SMALL_T) s_cnt[c] = 0;
+  __syncthreads();
+  const int step = ctrl->step;
+  constexpr int PER = LB_SMALL_N / LB_SMALL_T;
+  int gcs[PER], rk[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int64_t gi = tid + (int64_t)LB_SMALL_T * k;
+    gcs[k] = -1;
+    rk[k] = 0;
+    if (gi < BN) {
+      const int b = (int)(gi / g.N);
+      int h = 0, mult = 1;
+      for (int d = 0; d < g.dim; ++d) {
+        double p = lb_pos(win, g, BN, step, g.isl - 1, d, gi);
+        int c = __double2int_rz(p / g.cell_size[d]);  // jnp.array(position / cell_size, dtype=i32)
+        c = c < 0 ? 0 : (c >= g.ncell[d] ? g.ncell[d] - 1 : c);
+        h += c * mult;
+        mult *= g.ncell[d];
+      }
+      const int gc = b * g.ncells + h;
+      cell_of[gi] = gc;
+      gcs[k] = gc;
+      rk[k] = atomicAdd(&s_cnt[gc], 1);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the counts: thread t owns the cells [t*per, (t+1)*per)
+  const int per = (ncell_tot + LB_SMALL_T - 1) / LB_SMALL_T;
+  const int c_lo = tid * per;
+  int sum = 0, mx = 0;
+  for (int j = 0; j < per; ++j) {
+    const int c = c_lo + j;
+    const int v = c < ncell_tot ? s_cnt[c] : 0;
+    sum += v;
+    mx = max(mx, v);
+  }
+  s_scan[tid] = sum;
+  if (mx > 0) atomicMax(&s_max, mx);
+  __syncthreads();
+  for (int off = 1; off < LB_SMALL_T; off <<= 1) {  // Hillis-Steele inclusive
+    const int add = (tid >= off) ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += add;
+    __syncthreads();
+  }
+  int run = s_scan[tid] - sum;
+  for (int j = 0; j < per; ++j) {
+    const int c = c_lo + j;
+    if (c < ncell_tot) {
+      const int v = s_cnt[c];
+      s_cnt[c] = run;  // the counts become the cell starts
+      cell_start[c] = run;
+      run += v;
+    }
+  }
+  if (tid == LB_SMALL_T - 1) cell_start[ncell_tot] = s_scan[tid];
+  if (tid == 0) ctrl->max_cell_occ = s_max;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int64_t gi = tid + (int64_t)LB_SMALL_T * k;
+    if (gi < BN) {
+      const int slot = s_cnt[gcs[k]] + rk[k];
+      cell_part[slot] = (int32_t)gi;
+      for (int d = 0; d < g.dim; ++d) cpos[(int64_t)d * BN + slot] = lb_pos(win, g, BN, step, g.isl - 1, d, gi);
+    }
+  }
+}
+
 // -------------------------------------------------------------------------- stencil search
 struct lb_nl_args {
   const int32_t* cell_of;   // [BN] global cell id of each particle
@@ -506,14 +597,13 @@ __global__ void __launch_bounds__(256)
 // ------------------------------------------------------------------------------- row scan
 // After the two-level scan of the degrees: per-trajectory edge counts, did_buffer_overflow flags
 // and the control block, all on the device (no host sync).
-__global__ void __launch_bounds__(256)
-    k_row_finish(lb_geom g, const int32_t* __restrict__ row_ptr, int n, lb_ctrl* __restrict__ ctrl,
-                 int32_t* __restrict__ overflow, int32_t* __restrict__ nedges_b,
-                 int32_t cell_capacity, int32_t e_cap, int64_t e_alloc, int frozen,
-                 int32_t* host_flag) {
-  if (ctrl->overflow_step >= 0) return;
-  __shared__ int s_any;
-  if (threadIdx.x == 0) s_any = 0;
+// (shared by k_row_finish and the single-workgroup k_rows_small; called by every thread of ONE workgroup)
+__device__ __forceinline__ void lb_row_finish_body(const lb_geom& g, const int32_t* __restrict__ row_ptr, int n,
+                                                   lb_ctrl* __restrict__ ctrl, int32_t* __restrict__ overflow,
+                                                   int32_t* __restrict__ nedges_b, int32_t cell_capacity,
+                                                   int32_t e_cap, int64_t e_alloc, int frozen, int32_t* host_flag,
+                                                   int* s_any) {
+  if (threadIdx.x == 0) *s_any = 0;
   __syncthreads();
   for (int b = threadIdx.x; b < g.B; b += blockDim.x) {
     const int eb = row_ptr[(b + 1) * g.N] - row_ptr[b * g.N];
@@ -524,18 +614,67 @@ __global__ void __launch_bounds__(256)
     if (frozen)
       ov = (eb > e_cap) || (g.use_cell_list && ctrl->max_cell_occ > cell_capacity) || ctrl->row_overflow;
     overflow[b] = ov;
-    if (ov) atomicExch(&s_any, 1);
+    if (ov) atomicExch(s_any, 1);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     const int total = row_ptr[n];
     ctrl->n_edges_unclamped = total;
     ctrl->n_edges_total = (int)min((int64_t)total, e_alloc);
-    if (frozen && (s_any || (int64_t)total > e_alloc) && ctrl->overflow_step < 0) {
+    if (frozen && (*s_any || (int64_t)total > e_alloc) && ctrl->overflow_step < 0) {
       ctrl->overflow_step = ctrl->step;
       if (host_flag) *host_flag = ctrl->step;  // pinned host memory: visible once this kernel retires
     }
   }
+}
+
+__global__ void __launch_bounds__(256)
+    k_row_finish(lb_geom g, const int32_t* __restrict__ row_ptr, int n, lb_ctrl* __restrict__ ctrl,
+                 int32_t* __restrict__ overflow, int32_t* __restrict__ nedges_b,
+                 int32_t cell_capacity, int32_t e_cap, int64_t e_alloc, int frozen,
+                 int32_t* host_flag) {
+  if (ctrl->overflow_step >= 0) return;
+  __shared__ int s_any;
+  lb_row_finish_body(g, row_ptr, n, ctrl, overflow, nedges_b, cell_capacity, e_cap, e_alloc, frozen, host_flag,
+                     &s_any);
+}
+
+// Small problems: degree scan (both passes) + k_row_finish in one single-workgroup launch.
+__global__ void __launch_bounds__(LB_SMALL_T)
+    k_rows_small(lb_geom g, const int32_t* __restrict__ deg, int32_t* __restrict__ row_ptr, int n,
+                 lb_ctrl* __restrict__ ctrl, int32_t* __restrict__ overflow, int32_t* __restrict__ nedges_b,
+                 int32_t cell_capacity, int32_t e_cap, int64_t e_alloc, int frozen, int32_t* host_flag) {
+  __shared__ int s_scan[LB_SMALL_T];
+  __shared__ int s_any;
+  if (ctrl->overflow_step >= 0) return;
+  const int tid = threadIdx.x;
+  constexpr int PER = LB_SMALL_N / LB_SMALL_T;
+  int v[PER], sum = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = tid * PER + k;
+    v[k] = i < n ? deg[i] : 0;
+    sum += v[k];
+  }
+  s_scan[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < LB_SMALL_T; off <<= 1) {
+    const int add = (tid >= off) ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += add;
+    __syncthreads();
+  }
+  int run = s_scan[tid] - sum;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = tid * PER + k;
+    if (i < n) row_ptr[i] = run;
+    run += v[k];
+  }
+  if (tid == LB_SMALL_T - 1) row_ptr[n] = s_scan[tid];
+  __syncthreads();  // row_ptr written by this workgroup is visible to it
+  lb_row_finish_body(g, row_ptr, n, ctrl, overflow, nedges_b, cell_capacity, e_cap, e_alloc, frozen, host_flag,
+                     &s_any);
 }
 
 // ----------------------------------------------------------------------------------- host
@@ -583,19 +722,28 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   hipStream_t s = e->stream;
   const int frozen = e->e_cap > 0;
 
+  // LB_SMALL_FUSED=0: always the multi-launch bookkeeping
+  static const bool small_ok = !(getenv("LB_SMALL_FUSED") && getenv("LB_SMALL_FUSED")[0] == '0');
+  const bool small_rows = small_ok && BN <= LB_SMALL_N;
+  const bool small_cells = small_rows && ncell_tot <= LB_SMALL_N;
   lb_tic(e, LB_T_CELLS);
-  LB_HIP(hipMemsetAsync(e->cell_count, 0, sizeof(int32_t) * 2 * (size_t)ncell_tot, s));
-  // (max_cell_occ, max_deg, row_overflow are reset by k_cell_count)
-  const int nb = (int)((BN + 255) / 256);
-  hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, s, g, BN, e->win, e->ctrl, e->cell_of,
-                     e->cell_count);
-  const int nsb_c = (ncell_tot + SCAN_CHUNK - 1) / SCAN_CHUNK;
-  hipLaunchKernelGGL(k_scan_partials, dim3(nsb_c), dim3(SCAN_THREADS), 0, s, e->cell_count, ncell_tot,
-                     e->scan_part, e->ctrl, &e->ctrl->max_cell_occ);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nsb_c), dim3(SCAN_THREADS), 0, s, e->cell_count,
-                     e->cell_start, ncell_tot, e->scan_part, e->ctrl);
-  hipLaunchKernelGGL(k_cell_fill, dim3(nb), dim3(256), 0, s, g, BN, e->win, e->ctrl, e->cell_of,
-                     e->cell_start, e->cell_fill, e->cell_part, e->cpos);
+  if (small_cells) {
+    hipLaunchKernelGGL(k_cells_small, dim3(1), dim3(LB_SMALL_T), 0, s, g, BN, e->win, e->ctrl, e->cell_of,
+                       e->cell_start, e->cell_part, e->cpos, ncell_tot);
+  } else {
+    LB_HIP(hipMemsetAsync(e->cell_count, 0, sizeof(int32_t) * 2 * (size_t)ncell_tot, s));
+    // (max_cell_occ, max_deg, row_overflow are reset by k_cell_count)
+    const int nb = (int)((BN + 255) / 256);
+    hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, s, g, BN, e->win, e->ctrl, e->cell_of,
+                       e->cell_count);
+    const int nsb_c = (ncell_tot + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(k_scan_partials, dim3(nsb_c), dim3(SCAN_THREADS), 0, s, e->cell_count, ncell_tot,
+                       e->scan_part, e->ctrl, &e->ctrl->max_cell_occ);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nsb_c), dim3(SCAN_THREADS), 0, s, e->cell_count,
+                       e->cell_start, ncell_tot, e->scan_part, e->ctrl);
+    hipLaunchKernelGGL(k_cell_fill, dim3(nb), dim3(256), 0, s, g, BN, e->win, e->ctrl, e->cell_of,
+                       e->cell_start, e->cell_fill, e->cell_part, e->cpos);
+  }
   lb_toc(e);
 
   lb_tic(e, LB_T_NEIGH);
@@ -623,14 +771,20 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   } else {
     lb_launch_nl<NL_COUNT>(e, small, a);
   }
-  const int nsb_r = (int)((BN + SCAN_CHUNK - 1) / SCAN_CHUNK);
-  hipLaunchKernelGGL(k_scan_partials, dim3(nsb_r), dim3(SCAN_THREADS), 0, s, e->deg, (int)BN,
-                     e->scan_part, e->ctrl, (int32_t*)nullptr);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nsb_r), dim3(SCAN_THREADS), 0, s, e->deg, e->row_ptr, (int)BN,
-                     e->scan_part, e->ctrl);
-  hipLaunchKernelGGL(k_row_finish, dim3(1), dim3(256), 0, s, g, e->row_ptr, (int)BN, e->ctrl,
-                     e->overflow, e->nedges_b, e->cell_capacity, e->e_cap, e->e_alloc, frozen,
-                     e->host_flag_dev);
+  if (small_rows) {
+    hipLaunchKernelGGL(k_rows_small, dim3(1), dim3(LB_SMALL_T), 0, s, g, e->deg, e->row_ptr, (int)BN, e->ctrl,
+                       e->overflow, e->nedges_b, e->cell_capacity, e->e_cap, e->e_alloc, frozen,
+                       e->host_flag_dev);
+  } else {
+    const int nsb_r = (int)((BN + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    hipLaunchKernelGGL(k_scan_partials, dim3(nsb_r), dim3(SCAN_THREADS), 0, s, e->deg, (int)BN,
+                       e->scan_part, e->ctrl, (int32_t*)nullptr);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nsb_r), dim3(SCAN_THREADS), 0, s, e->deg, e->row_ptr, (int)BN,
+                       e->scan_part, e->ctrl);
+    hipLaunchKernelGGL(k_row_finish, dim3(1), dim3(256), 0, s, g, e->row_ptr, (int)BN, e->ctrl,
+                       e->overflow, e->nedges_b, e->cell_capacity, e->e_cap, e->e_alloc, frozen,
+                       e->host_flag_dev);
+  }
   if (rows) {
     hipLaunchKernelGGL(k_nl_compact, dim3((int)((BN + 15) / 16)), dim3(256), 0, s, BN, e->ctrl, e->deg,
                        e->row_ptr, e->maxd, e->tmp_send, e->tmp_feat,

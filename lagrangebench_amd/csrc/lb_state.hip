@@ -154,15 +154,26 @@ int lbk_node_features_raw(lb_engine* e, float* xnode, int kpad) {
 }
 
 // ------------------------------------------------------------------------------ integrator
+// The step counter is advanced by the LAST workgroup to finish (every workgroup has read ctrl->step by
+// then): no separate one-thread launch at the end of every step.
 __global__ void k_integrate(lb_geom g, int64_t BN, double* __restrict__ win,
-                            const lb_ctrl* __restrict__ ctrl, const int32_t* __restrict__ ptype,
+                            lb_ctrl* __restrict__ ctrl, int32_t* __restrict__ blocks_done,
+                            const int32_t* __restrict__ ptype,
                             const float* __restrict__ acc, int acc_stride,
                             const double* __restrict__ target, const double* __restrict__ traj,
                             int T, double* __restrict__ pred, int pred_T) {
   if (ctrl->overflow_step >= 0) return;
   int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gi >= BN) return;
   const int step = ctrl->step;
+  __syncthreads();  // every thread of this workgroup holds `step` before the workgroup can report completion
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(blocks_done, 1) == (int)gridDim.x - 1) {
+      *blocks_done = 0;
+      ctrl->step = step + 1;
+    }
+  }
+  if (gi >= BN) return;
   const int b = (int)(gi / g.N), i = (int)(gi % g.N);
   const int pt = ptype[gi];
   const bool kinematic = (pt == 1) || (pt == 2) || (pt == -1);  // utils.py:28-35
@@ -214,18 +225,12 @@ int lbk_case_integrate(lb_engine* e, int mode, const float* pred, const double* 
   return LB_OK;
 }
 
-__global__ void k_advance(lb_ctrl* ctrl) {
-  if (ctrl->overflow_step >= 0) return;
-  ctrl->step += 1;
-}
-
 int lbk_integrate(lb_engine* e, const float* acc, int acc_stride, const double* target,
                   const double* traj, int T, double* pred, int pred_T) {
   const int nb = (int)((e->BN + 255) / 256);
   lb_tic(e, LB_T_INTEGRATE);
   hipLaunchKernelGGL(k_integrate, dim3(nb), dim3(256), 0, e->stream, e->g, e->BN, e->win, e->ctrl,
-                     e->ptype, acc, acc_stride, target, traj, T, pred, pred_T);
-  hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, e->stream, e->ctrl);
+                     e->blocks_done, e->ptype, acc, acc_stride, target, traj, T, pred, pred_T);
   lb_toc(e);
   LB_HIP(hipGetLastError());
   return LB_OK;
