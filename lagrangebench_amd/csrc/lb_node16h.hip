@@ -121,14 +121,28 @@ __device__ __forceinline__ void lb_load_agg16(const lb_node_args& a, int64_t gno
   const int t0 = k0 >> a.tile_shift, t1 = (k1 - 1) >> a.tile_shift;
   const bool single = t0 == t1;
   const int nsrc = (k1 <= k0) ? 0 : (single ? 1 : t1 - t0 + 1);
+  auto slot_of = [&](int t) -> const f32x4* {
+    const float* src = single ? a.agg + gnode * 128
+                              : a.part + ((int64_t)t * 2 + (k0 <= (t << a.tile_shift) ? 0 : 1)) * 128;
+    return reinterpret_cast<const f32x4*>(src) + g;
+  };
+  // the first two sources are fetched TOGETHER (a row of ~17 edges nearly always straddles one tile
+  // boundary): summed source by source every source is its own dependent round trip - this kernel runs
+  // the small launches, which are latency chains
+  const f32x4* s0 = slot_of(t0);
+  const f32x4* s1 = nsrc >= 2 ? slot_of(t0 + 1) : s0;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 a1[8];
 #pragma unroll
-  for (int mb = 0; mb < 8; ++mb) v[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; __any(s < nsrc); ++s) {
+  for (int mb = 0; mb < 8; ++mb) {
+    v[mb] = s0[4 * mb];
+    a1[mb] = s1[4 * mb];
+  }
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) v[mb] = (nsrc >= 1 ? v[mb] : zero) + (nsrc >= 2 ? a1[mb] : zero);
+  for (int s = 2; __any(s < nsrc); ++s) {
     if (s < nsrc) {
-      const int t = t0 + s;
-      const float* src = single ? a.agg + gnode * 128
-                                : a.part + ((int64_t)t * 2 + (k0 <= (t << a.tile_shift) ? 0 : 1)) * 128;
-      const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + g;
+      const f32x4* s4 = slot_of(t0 + s);
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb) v[mb] = v[mb] + s4[4 * mb];
     }
@@ -137,11 +151,16 @@ __device__ __forceinline__ void lb_load_agg16(const lb_node_args& a, int64_t gno
 
 // NPA: k-steps (of 32) of input A (encoder features or node latents); NPB: 4 when the aggregated
 // messages are a second input (processor), else 0.
-template <int NPA, int NPB, bool RESID, bool PROJ>
-__global__ void __launch_bounds__(N16_THREADS, 2)
+// LOADERS (small launches, at most one workgroup per CU): four extra waves do nothing but move the weight
+// chunks global -> registers -> LDS, two chunks in flight in their registers and a four-slot ring, so that a
+// chunk has two full steps to arrive instead of one: a launch on a 2.5 k-particle graph is a latency chain of
+// ten chunk steps (the four compute waves need ~0.4 us per chunk, an L2 round trip is > 1 us).
+template <int NPA, int NPB, bool RESID, bool PROJ, bool LOADERS = false>
+__global__ void __launch_bounds__(LOADERS ? 2 * N16_THREADS : N16_THREADS, LOADERS ? 1 : 2)
     k_node16h(lb_node_args a, const f32x4* __restrict__ w0h, const f32x4* __restrict__ w1h,
               const f32x4* __restrict__ wph) {
-  __shared__ f32x4 sB[2][CHUNK_VEC];
+  constexpr int NSLOT = LOADERS ? 4 : 2;
+  __shared__ f32x4 sB[NSLOT][CHUNK_VEC];
   __shared__ f32x4 sP[192];  // per-feature vectors, see below
   if (a.ctrl->overflow_step >= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -177,8 +196,43 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
   // into the same registers, then chunk c is consumed; one barrier per step.  Two 4-wave workgroups
   // share a CU (2 x 67 KiB of LDS), so the prologue / epilogue memory phases of one overlap the
   // MFMA phase of the other.
+  if constexpr (LOADERS) {
+    if (wave >= N16_WAVES) {
+      const int lt = tid - N16_THREADS;
+      f32x4 set[2][N16_STG];
+      auto issue = [&](int c) {
+        const f32x4* src;
+        int nvec;
+        chunk_src(c, src, nvec);
+#pragma unroll
+        for (int i = 0; i < N16_STG; ++i) {
+          const int idx = lt + i * N16_THREADS;
+          set[c & 1][i] = src[idx < nvec ? idx : 0];
+        }
+      };
+      auto commit = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < N16_STG; ++i) sB[c & 3][lt + i * N16_THREADS] = set[c & 1][i];
+      };
+      issue(0);
+      if (n_chunks > 1) issue(1);
+      commit(0);
+      if (n_chunks > 1) commit(1);
+      if (n_chunks > 2) issue(2);
+      if (n_chunks > 3) issue(3);
+      __syncthreads();
+#pragma unroll
+      for (int st = 0; st < n_chunks; ++st) {
+        if (st + 2 < n_chunks) commit(st + 2);
+        if (st + 4 < n_chunks) issue(st + 4);
+        __syncthreads();
+      }
+      return;
+    }
+  }
   f32x4 stg[N16_STG];
   auto stage_issue = [&](int c) {
+    if constexpr (LOADERS) return;
     const f32x4* src;
     int nvec;
     chunk_src(c, src, nvec);
@@ -189,6 +243,7 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
     }
   };
   auto stage_commit = [&](int c) {
+    if constexpr (LOADERS) return;
 #pragma unroll
     for (int i = 0; i < N16_STG; ++i) sB[c & 1][tid + i * N16_THREADS] = stg[i];
   };
@@ -223,7 +278,7 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
 #pragma unroll
   for (int ch = 0; ch < NCH0; ++ch, ++c) {
     stage_step(c);
-    const f32x4* buf = sB[c & 1];
+    const f32x4* buf = sB[c & (NSLOT - 1)];
     h8 bh[2], bl[2];
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
@@ -252,7 +307,7 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch, ++c) {
     stage_step(c);
-    const f32x4* buf = sB[c & 1];
+    const f32x4* buf = sB[c & (NSLOT - 1)];
     h8 bh[2], bl[2];
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) lb_split8n(acc[2 * (2 * ch + pp)], acc[2 * (2 * ch + pp) + 1], bh[pp], bl[pp]);
@@ -298,7 +353,7 @@ __global__ void __launch_bounds__(N16_THREADS, 2)
 #pragma unroll
     for (int p = 0; p < 4; ++p, ++c) {
       stage_step(c);
-      const f32x4* buf = sB[c & 1];
+      const f32x4* buf = sB[c & (NSLOT - 1)];
       h8 bh, bl;
       lb_split8n(y[2 * p], y[2 * p + 1], bh, bl);
       lb_chunk_proj16(buf, lane, bh, bl, accp);
@@ -318,14 +373,21 @@ int lbk_node16h(lb_engine* e, const lb_node_args& a, const float* w0h, const flo
   const f32x4* w0 = reinterpret_cast<const f32x4*>(w0h);
   const f32x4* w1 = reinterpret_cast<const f32x4*>(w1h);
   const f32x4* wp = reinterpret_cast<const f32x4*>(wph);
-  dim3 grid(nblk), block(N16_THREADS);
+  // LB_NODE_LOADERS=0: no loader waves
+  static const bool want_loaders = !(getenv("LB_NODE_LOADERS") && getenv("LB_NODE_LOADERS")[0] == '0');
+  const bool loaders = want_loaders && nblk <= 256;
+  dim3 grid(nblk), block(loaders ? 2 * N16_THREADS : N16_THREADS);
   const bool proj = wph != nullptr;
-#define LB_N16(A, B, R)                                                                          \
-  do {                                                                                           \
-    if (proj)                                                                                    \
-      hipLaunchKernelGGL((k_node16h<A, B, R, true>), grid, block, 0, e->stream, a, w0, w1, wp);  \
-    else                                                                                         \
-      hipLaunchKernelGGL((k_node16h<A, B, R, false>), grid, block, 0, e->stream, a, w0, w1, wp); \
+#define LB_N16(A, B, R)                                                                                 \
+  do {                                                                                                  \
+    if (proj && loaders)                                                                                \
+      hipLaunchKernelGGL((k_node16h<A, B, R, true, true>), grid, block, 0, e->stream, a, w0, w1, wp);   \
+    else if (proj)                                                                                      \
+      hipLaunchKernelGGL((k_node16h<A, B, R, true>), grid, block, 0, e->stream, a, w0, w1, wp);         \
+    else if (loaders)                                                                                   \
+      hipLaunchKernelGGL((k_node16h<A, B, R, false, true>), grid, block, 0, e->stream, a, w0, w1, wp);  \
+    else                                                                                                \
+      hipLaunchKernelGGL((k_node16h<A, B, R, false>), grid, block, 0, e->stream, a, w0, w1, wp);        \
   } while (0)
   if (npa == 4 && npb == 4 && resid)
     LB_N16(4, 4, true);
