@@ -99,21 +99,26 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
   constexpr int THREADS = WPS * 256, WAVES = WPS * 4;
   constexpr int NW0 = 4096;
   __shared__ f32x4 sW[NW0 + 4096 + 96];
-  if (a.ctrl->overflow_step >= 0) return;
+  // Prologue order (matters for small graphs, where a launch is a latency chain): the control block is read,
+  // the weight loads are issued into registers, the first tile's indices are requested while those are in
+  // flight, and only then the weights are written to LDS - "flag -> weights -> barrier -> indices -> gathers" was
+  // four dependent round trips, this is three.  The poison flag is acted on before anything is stored; the
+  // loads issued before that are in bounds whatever the state (n_edges_total is clamped to the allocation).
+  const int poisoned = a.ctrl->overflow_step;
+  const int E = a.ctrl->n_edges_total;
+  const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
   const int tid = threadIdx.x;
+  constexpr int NST = (NW0 + 4096 + THREADS - 1) / THREADS;
+  f32x4 st[NST];
   {
     const f32x4* g0 = reinterpret_cast<const f32x4*>(a.w0p);
     const f32x4* g1 = reinterpret_cast<const f32x4*>(a.w1p);
-    for (int i = tid; i < NW0; i += THREADS) sW[i] = g0[i];
-    for (int i = tid; i < 4096; i += THREADS) sW[NW0 + i] = g1[i];
-    if (tid < 96) {
-      const float* src = tid < 32 ? a.b1 : (tid < 64 ? a.ln_s : a.ln_o);
-      sW[NW0 + 4096 + tid] = reinterpret_cast<const f32x4*>(src)[tid & 31];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int i = tid + k * THREADS;
+      st[k] = i < NW0 ? g0[i] : g1[(i < NW0 + 4096 ? i : NW0 + 4095) - NW0];
     }
   }
-  __syncthreads();
-  const int E = a.ctrl->n_edges_total;
-  const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
   const int ntiles = (E + 15) >> 4;
   // the wave index is uniform: keep the whole tile walk (t, stride, bounds) in scalar registers
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,6 +127,29 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
   const int stride = (gridDim.x >> 3) * WAVES;
   const int t_lo = (int)(((int64_t)ntiles * xcd) >> 3), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) >> 3);
   int t = t_lo + slot;
+  auto rowc_of = [&](int tt) -> int64_t {
+    const int row = tt * 16 + n;
+    return row < E ? row : (E > 0 ? E - 1 : 0);
+  };
+  int s_c = 0, r_c = 0;
+  if (t < t_hi) {
+    const int64_t rc = rowc_of(t);
+    s_c = a.senders[rc];
+    r_c = a.receivers[rc];
+  }
+  if (poisoned >= 0) return;
+  {
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int i = tid + k * THREADS;
+      if (i < NW0 + 4096) sW[i] = st[k];
+    }
+    if (tid < 96) {
+      const float* src = tid < 32 ? a.b1 : (tid < 64 ? a.ln_s : a.ln_o);
+      sW[NW0 + 4096 + tid] = reinterpret_cast<const f32x4*>(src)[tid & 31];
+    }
+  }
+  __syncthreads();
   if (t >= t_hi) return;
   // two lane bases so that every fragment offset fits the 16-bit ds offset field; the integer
   // round trip through an asm keeps the compiler from folding them back into one base + 64 KiB
@@ -130,22 +158,12 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
   uint32_t off2 = (uint32_t)(uintptr_t)(lds_cptr)(sW + NW0 + 4096 + g);
   asm volatile("" : "+v"(off0), "+v"(off1), "+v"(off2));
   const lds_cptr w0b = (lds_cptr)(uintptr_t)off0, w1b = (lds_cptr)(uintptr_t)off1, vecb = (lds_cptr)(uintptr_t)off2;
-  auto rowc_of = [&](int tt) -> int64_t {
-    const int row = tt * 16 + n;
-    return row < E ? row : E - 1;
-  };
   const f32x4* psr4 = reinterpret_cast<const f32x4*>(a.psr);
   const int n_iter = (t_hi - 1 - t) / stride + 1;
   const int t_last = t + (n_iter - 1) * stride;
-  int s_c, r_c;
-  {
-    const int64_t rc = rowc_of(t);
-    s_c = a.senders[rc];
-    r_c = a.receivers[rc];
-    // waited for HERE: a wait at the loop header would also be executed on the back edge, where
-    // it drains the previous tile's stores
-    asm volatile("" : "+v"(s_c), "+v"(r_c));
-  }
+  // (the first tile's indices were waited for above, by the barrier: a wait at the loop header would also be
+  // executed on the back edge, where it drains the previous tile's stores)
+  asm volatile("" : "+v"(s_c), "+v"(r_c));
   for (int it = 0; it < n_iter; ++it, t += stride) {
     f32x4 acc[8], ve[8];
     const int r_cur = r_c;

@@ -110,14 +110,14 @@ __device__ __forceinline__ void lb_chunk_proj16(const f32x4* __restrict__ buf, i
 }
 
 // node's aggregated messages, 16-row layout (lane (n,g) owns chunks 4*mb + g of the 128-float row)
-__device__ __forceinline__ void lb_load_agg16(const lb_node_args& a, int64_t gnode, int g, f32x4 (&v)[8]) {
+__device__ __forceinline__ void lb_load_agg16(const lb_node_args& a, int64_t gnode, int g, int k0, int k1,
+                                              f32x4 (&v)[8]) {
   if (!a.fused) {
     const f32x4* gr = reinterpret_cast<const f32x4*>(a.agg) + gnode * 32 + g;
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) v[mb] = gr[4 * mb];
     return;
   }
-  const int k0 = a.row_ptr[gnode], k1 = a.row_ptr[gnode + 1];
   const int t0 = k0 >> a.tile_shift, t1 = (k1 - 1) >> a.tile_shift;
   const bool single = t0 == t1;
   const int nsrc = (k1 <= k0) ? 0 : (single ? 1 : t1 - t0 + 1);
@@ -162,7 +162,11 @@ __global__ void __launch_bounds__(LOADERS ? 2 * N16_THREADS : N16_THREADS, LOADE
   constexpr int NSLOT = LOADERS ? 4 : 2;
   __shared__ f32x4 sB[NSLOT][CHUNK_VEC];
   __shared__ f32x4 sP[192];  // per-feature vectors, see below
-  if (a.ctrl->overflow_step >= 0) return;
+  // the poison flag is READ first but only acted on once the first loads are in flight: branching on it here
+  // would put a full round trip in front of every load of a launch that is a latency chain.  Only loads that
+  // are in bounds whatever the state are issued before the check (rows, row_ptr, weights); the partial-sum slots
+  // addressed THROUGH row_ptr are not (an overflowing step's row_ptr may point past the allocation).
+  const int poisoned = a.ctrl->overflow_step;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
   constexpr int NP0 = NPA + NPB;
@@ -216,6 +220,7 @@ __global__ void __launch_bounds__(LOADERS ? 2 * N16_THREADS : N16_THREADS, LOADE
       };
       issue(0);
       if (n_chunks > 1) issue(1);
+      if (poisoned >= 0) return;
       commit(0);
       if (n_chunks > 1) commit(1);
       if (n_chunks > 2) issue(2);
@@ -265,7 +270,13 @@ __global__ void __launch_bounds__(LOADERS ? 2 * N16_THREADS : N16_THREADS, LOADE
     for (int mb = 0; mb < 2 * NPA; ++mb) va[mb] = xr[4 * mb];
   }
   f32x4 vb[NPB > 0 ? 8 : 1];
-  if constexpr (NPB > 0) lb_load_agg16(a, rowc, g, vb);
+  int k0 = 0, k1 = 0;
+  if (NPB > 0 && a.fused) {
+    k0 = a.row_ptr[rowc];
+    k1 = a.row_ptr[rowc + 1];
+  }
+  if (poisoned >= 0) return;
+  if constexpr (NPB > 0) lb_load_agg16(a, rowc, g, k0, k1, vb);
   stage_commit(0);
   if (n_chunks > 1) stage_issue(1);
   __syncthreads();
