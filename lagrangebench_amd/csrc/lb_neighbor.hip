@@ -360,9 +360,8 @@ __global__ void __launch_bounds__(NL_THREADS)
     }
     if (MODE != NL_FILL && lane == 0) {
       a.deg[gr] = count;
-      // one hot word: 64k same-address atomics would serialise (~12 ns each); almost every row is
-      // filtered out by the plain (monotonic, possibly stale) read
-      if (count > *(volatile int32_t*)&ctrl->max_deg) atomicMax(&ctrl->max_deg, count);
+      // (ctrl->max_deg is reduced by the degree scan that follows: a read of that ONE address by every wave
+      // serialises at its L2 channel - it was 150 of the 165 us of this kernel on 64 k receivers)
     }
     if (MODE == NL_COUNT) continue;
     if (count > LB_MAX_ROW) {
@@ -511,7 +510,7 @@ __global__ void __launch_bounds__(64 * NLW_WAVES)
   }
   if (MODE != NL_FILL && lane == 0) {
     a.deg[gr] = count;
-    if (count > *(volatile int32_t*)&ctrl->max_deg) atomicMax(&ctrl->max_deg, count);
+    // (ctrl->max_deg is reduced by the degree scan that follows, see k_nl)
   }
   if (MODE == NL_COUNT) return;
   if (count > LB_MAX_ROW) {
@@ -649,15 +648,21 @@ __global__ void __launch_bounds__(LB_SMALL_T)
   if (ctrl->overflow_step >= 0) return;
   const int tid = threadIdx.x;
   constexpr int PER = LB_SMALL_N / LB_SMALL_T;
-  int v[PER], sum = 0;
+  __shared__ int s_maxdeg;
+  if (tid == 0) s_maxdeg = 0;
+  __syncthreads();
+  int v[PER], sum = 0, mx = 0;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int i = tid * PER + k;
     v[k] = i < n ? deg[i] : 0;
     sum += v[k];
+    mx = max(mx, v[k]);
   }
   s_scan[tid] = sum;
+  if (mx > 0) atomicMax(&s_maxdeg, mx);
   __syncthreads();
+  if (tid == 0) ctrl->max_deg = s_maxdeg;  // max receiver degree of this build (the search kernels no longer track it)
   for (int off = 1; off < LB_SMALL_T; off <<= 1) {
     const int add = (tid >= off) ? s_scan[tid - off] : 0;
     __syncthreads();
@@ -778,7 +783,7 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   } else {
     const int nsb_r = (int)((BN + SCAN_CHUNK - 1) / SCAN_CHUNK);
     hipLaunchKernelGGL(k_scan_partials, dim3(nsb_r), dim3(SCAN_THREADS), 0, s, e->deg, (int)BN,
-                       e->scan_part, e->ctrl, (int32_t*)nullptr);
+                       e->scan_part, e->ctrl, &e->ctrl->max_deg);
     hipLaunchKernelGGL(k_scan_apply, dim3(nsb_r), dim3(SCAN_THREADS), 0, s, e->deg, e->row_ptr, (int)BN,
                        e->scan_part, e->ctrl);
     hipLaunchKernelGGL(k_row_finish, dim3(1), dim3(256), 0, s, g, e->row_ptr, (int)BN, e->ctrl,
