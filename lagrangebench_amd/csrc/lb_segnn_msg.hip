@@ -169,14 +169,17 @@ struct lb_sg_msg_args {
 template <int DBG, int NT>
 __global__ void __launch_bounds__(NT, NT / 256) k_sg_msg(lb_sg_msg_args a) {
   __shared__ f32x4 sW[SGM_IMAGE];
-  if (a.ctrl->overflow_step >= 0) return;
+  // the control block is read first and the poison flag acted on after the weight image is staged (LDS only):
+  // neither the flag nor the edge count is a round trip of its own in front of the loads
+  const int poisoned = a.ctrl->overflow_step;
+  const int E = a.ctrl->n_edges_total;
   const int tid = threadIdx.x;
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.image);
     for (int i = tid; i < SGM_IMAGE; i += NT) sW[i] = src[i];
   }
+  if (poisoned >= 0) return;
   __syncthreads();
-  const int E = a.ctrl->n_edges_total;
   const int ntiles = (E + 15) >> 4;
   const int lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -397,12 +400,13 @@ struct lb_sg_upd_args {
 
 __global__ void __launch_bounds__(SGM_THREADS, 2) k_sg_upd(lb_sg_upd_args a) {
   __shared__ f32x4 sW[SGU_IMAGE];
-  if (a.ctrl->overflow_step >= 0) return;
+  const int poisoned = a.ctrl->overflow_step;  // acted on after the staging loads are in flight, see k_sg_msg
   const int tid = threadIdx.x;
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.image);
     for (int i = tid; i < SGU_IMAGE; i += SGM_THREADS) sW[i] = src[i];
   }
+  if (poisoned >= 0) return;
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
