@@ -588,7 +588,8 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge_enc16v(lb_edge16_args a
   constexpr int THREADS = WPS * 256, WAVES = WPS * 4;
   constexpr int NW0 = 1024;
   __shared__ f32x4 sW[NW0 + 4096 + 128];  // W0 | W1 | b1 | ln scale | ln offset | b0
-  if (a.ctrl->overflow_step >= 0) return;
+  const int poisoned = a.ctrl->overflow_step;  // acted on after the staging loads are in flight
+  const int E = a.ctrl->n_edges_total;
   const int tid = threadIdx.x;
   {
     const f32x4* g0 = reinterpret_cast<const f32x4*>(a.w0p);
@@ -600,8 +601,8 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge_enc16v(lb_edge16_args a
       sW[NW0 + 4096 + tid] = reinterpret_cast<const f32x4*>(src)[tid & 31];
     }
   }
+  if (poisoned >= 0) return;
   __syncthreads();
-  const int E = a.ctrl->n_edges_total;
   const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
   const int ntiles = (E + 15) >> 4;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);

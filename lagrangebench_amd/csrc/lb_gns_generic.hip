@@ -79,7 +79,8 @@ __device__ __forceinline__ void lb_gemm16f(lds_cptr wl, const f32x4 (&v)[8], f32
 template <bool F16, bool RELU_IN>
 __global__ void __launch_bounds__(GD_THREADS, 2) k_dense16(lb_dense_args a) {
   __shared__ f32x4 sW[4096 + 96];  // packed weights | bias | ln scale | ln offset
-  if (a.ctrl->overflow_step >= 0) return;
+  const int poisoned = a.ctrl->overflow_step;  // acted on after the staging loads are in flight
+  const int n_edges = a.ctrl->n_edges_total;
   const int tid = threadIdx.x;
   {
     const f32x4* gw = reinterpret_cast<const f32x4*>(a.w);
@@ -89,8 +90,9 @@ __global__ void __launch_bounds__(GD_THREADS, 2) k_dense16(lb_dense_args a) {
       sW[4096 + tid] = src ? reinterpret_cast<const f32x4*>(src)[tid & 31] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
+  if (poisoned >= 0) return;
   __syncthreads();
-  const int64_t R = a.n_rows < 0 ? (int64_t)a.ctrl->n_edges_total : a.n_rows;
+  const int64_t R = a.n_rows < 0 ? (int64_t)n_edges : a.n_rows;
   const int ntiles = (int)((R + 15) >> 4);
   const int lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -228,7 +230,7 @@ template <bool F16>
 __global__ void __launch_bounds__(GD_THREADS, 2) k_decoder16(lb_dec16_args a) {
   constexpr int NW1 = F16 ? 512 : 4096;
   __shared__ f32x4 sW[4096 + NW1 + 33];
-  if (a.ctrl->overflow_step >= 0) return;
+  const int poisoned = a.ctrl->overflow_step;  // acted on after the staging loads are in flight
   const int tid = threadIdx.x;
   {
     const f32x4* g0 = reinterpret_cast<const f32x4*>(a.w0);
@@ -238,6 +240,7 @@ __global__ void __launch_bounds__(GD_THREADS, 2) k_decoder16(lb_dec16_args a) {
     if (tid < 32) sW[4096 + NW1 + tid] = reinterpret_cast<const f32x4*>(a.b0)[tid];
     if (tid == 32) sW[4096 + NW1 + 32] = reinterpret_cast<const f32x4*>(a.b1)[0];
   }
+  if (poisoned >= 0) return;
   __syncthreads();
   const int ntiles = (int)((a.n_rows + 15) >> 4);
   const int lane = tid & 63, wave = tid >> 6;
