@@ -653,9 +653,7 @@ int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a) {
     return (int)(g < 8 ? 8 : (g > 256 ? 256 : g));
   };
   static const int wps_env = getenv("LB_ENC_WPS") ? atoi(getenv("LB_ENC_WPS")) : 4;
-  if (tiles_cap <= 256 * 4 * 2)
-    hipLaunchKernelGGL((k_edge_enc16v<1>), dim3(grid_for(4)), dim3(256), 0, e->stream, a);
-  else if (tiles_cap <= 256 * 8 * 2)
+  if (tiles_cap <= 256 * 8 * 2)
     hipLaunchKernelGGL((k_edge_enc16v<2>), dim3(grid_for(8)), dim3(512), 0, e->stream, a);
   else if (wps_env == 2)
     hipLaunchKernelGGL((k_edge_enc16v<2>), dim3(256), dim3(512), 0, e->stream, a);
@@ -676,18 +674,17 @@ int lbk_edge16v(lb_engine* e, const lb_edge16_args& a, int variant) {
       LB_LAUNCH_TIMED(e, (k_edge16v<W, R, false, 0, true>), dim3(G), dim3(W * 256), a);                 \
   } while (0)
   // Small graphs (one 2.5 k-particle trajectory = ~1000 tiles): a launch is the latency chain
-  // "stage 133 KiB of weights -> one tile per wave", so use lighter workgroups (one or two waves per
-  // SIMD: a wave computes alone on its SIMD) and no more workgroups than there are tiles for.  The tile
-  // count is bounded on the host by the frozen capacity (the real count lives on the device).
+  // "stage 133 KiB of weights -> one tile per wave", so launch no more workgroups than there are tiles for.
+  // The tile count is bounded on the host by the frozen capacity (the real count lives on the device).
   const int64_t tiles_cap = ((int64_t)e->e_cap * e->g.B + 15) / 16;
   auto grid_for = [&](int waves_per_block) {
     int64_t g = (tiles_cap + waves_per_block - 1) / waves_per_block;
     g = (g + 7) / 8 * 8;  // the XCD-aware walk wants a multiple of 8
     return (int)(g < 8 ? 8 : (g > 256 ? 256 : g));
   };
-  if (variant == 0 && tiles_cap <= 256 * 4 * 2) {
-    LB_E16V(1, false, grid_for(4));
-  } else if (variant == 0 && tiles_cap <= 256 * 8 * 2) {
+  if (variant == 0 && tiles_cap <= 256 * 8 * 2) {
+    // (one wave per SIMD, i.e. twice the workgroups, measures slower: 17 vs 13.8 us per launch on a 20 k-edge
+    // graph - every workgroup stages the 133 KiB of weights; three waves per SIMD: 15.4 us)
     LB_E16V(2, false, grid_for(8));
   } else {
     switch (variant) {
