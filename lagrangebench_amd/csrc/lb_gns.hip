@@ -539,10 +539,11 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
     a.psr = e->psr;
     lb_tic(e, LB_T_ENC_NODE);
     // LB_NODE_KERNEL=h selects the round-1 node kernel (lb_node16h.hip)
-    // and below ~32 k nodes (a launch is then a latency chain per workgroup, where lb_node16h's two small
-    // co-resident workgroups measure faster: TGV2D-2.5k 19 vs 24 us per launch)
+    // and up to 16 k nodes (a launch is then a latency chain per workgroup: lb_node16h with its loader waves
+    // measures faster - TGV2D-2.5k 15 vs 24 us per launch; from 24 k nodes lb_node16s wins by 13 %)
     static const bool node_s_env = !(getenv("LB_NODE_KERNEL") && getenv("LB_NODE_KERNEL")[0] == 'h');
-    const bool node_s = node_s_env && BN >= 32768;
+    static const int64_t node_s_min = getenv("LB_NODE_S_MIN") ? atoll(getenv("LB_NODE_S_MIN")) : 16385;
+    const bool node_s = node_s_env && BN >= node_s_min;
     if (e->f16x2 && node_s) {
       rc = lbk_node16s(e, a, g->enc_node_w0_h, g->enc_node_w1_h, L > 0 ? g->proj_w_h2[0] : nullptr,
                        g->kq_node / 4, 0, false);
@@ -682,7 +683,8 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       a.part = e->part;
       lb_tic_single(e, LB_T_NODE_MLP);
       static const bool node_s_env = !(getenv("LB_NODE_KERNEL") && getenv("LB_NODE_KERNEL")[0] == 'h');
-      const bool node_s = node_s_env && BN >= 32768;
+      static const int64_t node_s_min = getenv("LB_NODE_S_MIN") ? atoll(getenv("LB_NODE_S_MIN")) : 16385;
+    const bool node_s = node_s_env && BN >= node_s_min;
       if (e->f16x2 && node_s) {
         rc = lbk_node16s(e, a, g->proc_node_w0_h[k], g->proc_node_w1_h[k],
                          (k + 1 < L) ? g->proj_w_h2[k + 1] : nullptr, 4, 4, true);

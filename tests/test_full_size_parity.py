@@ -148,7 +148,7 @@ def test_full_size_segnn_dam2d_forward_vs_oracle():
 
 def test_batched_40k_nodes_forward_vs_oracle():
     """B = 5 TGV3D-8k trajectories = 40 000 nodes in one graph: the size class of the benchmark line
-    (lb_node16s single-pass node kernel from 32 k nodes, full 256-workgroup edge walk).  Per-layer
+    (lb_node16s single-pass node kernel from 16 k nodes, full 256-workgroup edge walk).  Per-layer
     node latents and accelerations of the first and the last trajectory against the oracle."""
     from lagrangebench_amd.data import make_case
     from lagrangebench_amd.models import GNS
