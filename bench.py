@@ -302,6 +302,9 @@ def measure_traffic(args, timeout_s=240):
     import tempfile
     if not shutil.which("rocprofv3"):
         return None
+    # already running under a profiler (e.g. the driver wraps this command in rocprofv3): no nested tracing
+    if any(k.startswith(("ROCP_", "ROCPROF", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import pmc_traffic as PT
