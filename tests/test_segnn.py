@@ -277,3 +277,37 @@ def test_segnn_rollout_parity(name, scale):
                                            n_steps, isl)
         dx = float(ds.metadata["dx"]) if "dx" in ds.metadata else 1.0 / 16
         assert np.abs(pred[b] - np.asarray(ref)[0]).max() < 1e-6 * dx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sym", ["cycle_xyz", "reflect_x", "swap_xy_reflect_z"])
+def test_segnn_engine_is_equivariant_under_box_symmetries(sym):
+    """The reference pins its equivariant models through an equivariance property (tests/models_test.py:70-87:
+    rotate the inputs, the outputs rotate with them).  Here on the whole ENGINE path - neighbor search, features,
+    SEGNN on the HIP kernels - with the symmetries a cubic periodic box admits (axis permutations, reflections):
+    transforming the position window must transform the predicted accelerations, up to fp32 re-association of
+    the sums (the cell hashing, hence the edge order inside the tiles, changes with the transform)."""
+    _need_gpu()
+    ds, model, params, homog = _setup("small3d", 1.0, 3, True)
+    assert ds.external_force_fn is None and bool(np.all(np.asarray(ds.metadata["periodic_boundary_conditions"])))
+    box = np.asarray(ds.box, np.float64)
+    assert np.allclose(box, box[0])          # cubic: the transforms below map the box onto itself
+    isl = ds.input_seq_length
+    pos, pt = ds[0][0].astype(np.float64), ds[0][1]
+    perm, sign = {"cycle_xyz": ([1, 2, 0], [1, 1, 1]), "reflect_x": ([0, 1, 2], [-1, 1, 1]),
+                  "swap_xy_reflect_z": ([1, 0, 2], [1, 1, -1])}[sym]
+    sign = np.asarray(sign, np.float64)
+
+    def transform_pos(p):       # p (N, T, 3) -> R p  (reflections about the box centre, positions stay in [0, L))
+        q = p[..., perm]
+        return np.where(sign < 0, np.mod(box[0] - q, box[0]), q)
+
+    def acc_of(p):
+        feats, _ = hip_case(ds).allocate_eval((p[None, :, :isl], pt[None]))
+        pred, _ = model.apply(params, {}, (feats, pt[None]))
+        return _np(pred["acc"])[0].astype(np.float64)
+    a0 = acc_of(pos)
+    a1 = acc_of(transform_pos(pos))
+    want = a0[:, perm] * sign
+    assert rel_err(a1, want) < 2e-5, (sym, rel_err(a1, want))
+    assert rel_err(a1, a0) > 1e-2           # the transform is not a no-op for this model / input
