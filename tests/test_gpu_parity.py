@@ -808,3 +808,33 @@ def test_gns_num_mlp_layers_parity(name, nl, latent, L):
         _, nb = ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))
         _, m, _ = O.eval_batched_rollout(apply, ocase, p2, {}, (pos[b:b + 1].astype(np.float64), pt[b:b + 1]), nb, 3, isl)
         assert np.allclose(_np(out[f"rollout_{b}"]["mse"]), m[0]["mse"], rtol=1e-3, atol=1e-12)
+
+
+# ------------------------------------------------------------------ symmetries of the engine path
+def test_gns_permutation_and_translation_properties():
+    """Size-independent properties of the whole path (neighbor search -> features -> GNS) that hold whatever
+    the weights are: relabelling the particles permutes the accelerations; translating a periodic system leaves
+    them unchanged (GNS sees relative positions and velocities only - no `bound` feature in a periodic box).
+    Exact up to fp32 re-association: cell membership and the order of the edges inside the tiles change."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    ds = make_case("small3d", n_trajs=1, extra_seq_length=3)
+    isl, L = ds.input_seq_length, 3
+    pos, pt = ds[0][0].astype(np.float64), ds[0][1]
+    N = len(pt)
+    box = np.asarray(ds.box, np.float64)
+    params = make_params(ds, num_mp_steps=L, decoder_scale=1.0)
+    model = GNS(3, 128, 2, L, 16)
+
+    def acc_of(p, ptype):
+        feats, nbrs = hip_case(ds).allocate_eval((p[None, :, :isl], ptype[None]))
+        return _np(model.apply(params, {}, (feats, ptype[None]))[0]["acc"])[0].astype(np.float64), int(_np(nbrs.n_edges)[0])
+    a0, e0 = acc_of(pos, pt)
+    perm = np.random.default_rng(3).permutation(N)
+    a1, e1 = acc_of(pos[perm], pt[perm])
+    assert e1 == e0 and rel_err(a1, a0[perm]) < 1e-5
+    shift = np.array([0.37, 0.11, 0.73]) * box
+    a2, e2 = acc_of(np.mod(pos + shift, box), pt)
+    # (a pair exactly at the cutoff could flip under the 1-ulp change of its distance: none does here)
+    assert e2 == e0 and rel_err(a2, a0) < 1e-5
