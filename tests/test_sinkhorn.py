@@ -107,3 +107,36 @@ def test_default_infer_metrics_run_including_sinkhorn():
     tgt = np.transpose(ds[1][0][:, ds.input_seq_length:], (1, 0, 2)).astype(np.float64)
     want = SK.sinkhorn_rollout(oracle_case(ds).displacement, pred, tgt, 2)
     assert np.allclose(sk, want, rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_sinkhorn_full_size_properties():
+    """TGV3D-8k (BASELINE configs[2], 8000 x 8000 periodic cost per frame - far beyond what the NumPy oracle
+    finishes in seconds): the defining properties of the divergence on the device path at full size - zero
+    on identical clouds, symmetric in its arguments, positive and growing with the perturbation, invariant
+    under a relabelling of the particles of one cloud (the transport problem does not see particle ids)."""
+    torch = pytest.importorskip("torch")
+    from lagrangebench_amd.data import make_case
+    from tests._common import hip_case
+    ds = make_case("tgv3d", n_trajs=1, extra_seq_length=2)
+    isl = ds.input_seq_length
+    pos = ds[0][0].astype(np.float64)                            # (N, T, dim)
+    N = pos.shape[0]
+    assert N >= 8000
+    box = np.asarray(ds.box, np.float64)
+    dx = float(ds.metadata["dx"])
+    rng = np.random.default_rng(5)
+    x = pos[:, isl]                                              # one frame
+    noise = rng.standard_normal(x.shape)
+    y1 = np.mod(x + 0.05 * dx * noise, box)
+    y2 = np.mod(x + 0.20 * dx * noise, box)
+    eng = hip_case(ds).engine(1)
+
+    def div(a, b):
+        return float(eng.sinkhorn(torch.from_numpy(a[None, None]), torch.from_numpy(b[None, None]), 1).cpu().numpy()[0, 0])
+    d_xx, d_1, d_1r, d_2 = div(x, x), div(y1, x), div(x, y1), div(y2, x)
+    assert abs(d_xx) < 1e-8
+    assert d_1 > 0 and d_2 > 4 * d_1                             # ~ quadratic in the displacement
+    assert abs(d_1 - d_1r) <= 1e-3 * d_1                         # symmetric up to the convergence threshold
+    perm = rng.permutation(N)
+    assert abs(div(y1[perm], x) - d_1) <= 1e-6 * d_1
