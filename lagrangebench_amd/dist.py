@@ -35,7 +35,9 @@ def _coll_device(device: Optional[torch.device]) -> torch.device:
 
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    # LB_DIST_FORCE_INIT=1: initialise the process group even for one rank (smoke test of the RCCL path on a one-GPU box)
+    force = os.environ.get("LB_DIST_FORCE_INIT") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             # LB_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses duplicate devices)
             backend = os.environ.get("LB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")

@@ -5,6 +5,8 @@ GPUs are visible, else both ranks share cuda:0 and gather over "gloo" - the data
 only the metric gather changes transport.  (reference: evaluate/rollout.py:226-253 - trajectories
 are independent)"""
 import os
+
+import numpy as np
 import socket
 import subprocess
 import sys
@@ -111,3 +113,22 @@ def test_bench_two_ranks_on_this_box():
     n = d["config"]["n_particles"]
     assert abs(d["value"] - 2 * 2 * n * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]   # whole-job aggregate
     assert d["roofline"]["frac"] > 0 and d["unit"] == "particle-steps/s"
+
+
+def test_bench_one_rank_over_rccl():
+    """The RCCL transport itself on this box: bench.py with a one-rank process group on backend "nccl" (= RCCL):
+    library load, communicator creation, the metric all_gather and the max-over-ranks all_reduce on GPU tensors -
+    everything of the N > 1 path except a second GPU."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    env = dict(os.environ, LB_DIST_FORCE_INIT="1", LB_DIST_BACKEND="nccl", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "3", "--batch", "2",
+           "--workload", "tgv2d", "--no-cpu-baseline", "--no-other-configs", "--no-pmc"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and np.isfinite(d["mse20_mean"])
