@@ -5,12 +5,11 @@ GPUs are visible, else both ranks share cuda:0 and gather over "gloo" - the data
 only the metric gather changes transport.  (reference: evaluate/rollout.py:226-253 - trajectories
 are independent)"""
 import os
-
-import numpy as np
 import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
