@@ -468,8 +468,8 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
   const bool has_emb = d->num_particle_types > 1;
   const int emb = has_emb ? d->embedding_size : 0;
   const int nin = d->node_in + emb;
-  if (nin > 64) return lb_fail(LB_ERR_UNSUPPORTED, "node input width %d > 64 not built", nin);
-  const int kpad = nin <= 32 ? 32 : 64;
+  if (nin > 128) return lb_fail(LB_ERR_UNSUPPORTED, "node input width %d > 128 not built", nin);
+  const int kpad = (nin + 31) / 32 * 32;  // 32 .. 128
 
   // expected blob length
   auto mlp_len = [&](int in, int outw, bool ln) -> int64_t {

@@ -554,8 +554,12 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       if (rc) return rc;
     } else if (g->kq_node == 4)
       hipLaunchKernelGGL((k_node_mlp<4, 0, false>), dim3(ntile_n), dim3(64), 0, s, a);
-    else
+    else if (g->kq_node == 8)
       hipLaunchKernelGGL((k_node_mlp<8, 0, false>), dim3(ntile_n), dim3(64), 0, s, a);
+    else if (g->kq_node == 12)
+      hipLaunchKernelGGL((k_node_mlp<12, 0, false>), dim3(ntile_n), dim3(64), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_node_mlp<16, 0, false>), dim3(ntile_n), dim3(64), 0, s, a);
     lb_toc(e);
   }
   {

@@ -333,8 +333,8 @@ int lb_gns_create_generic(lb_engine* e, const lb_gns_desc* d, const float* w, in
   const bool has_emb = d->num_particle_types > 1;
   const int emb = has_emb ? d->embedding_size : 0;
   const int nin = d->node_in + emb;
-  if (nin > 64) return lb_fail(LB_ERR_UNSUPPORTED, "node input width %d > 64 not built", nin);
-  const int kpad = nin <= 32 ? 32 : 64;
+  if (nin > 128) return lb_fail(LB_ERR_UNSUPPORTED, "node input width %d > 128 not built", nin);
+  const int kpad = (nin + 31) / 32 * 32;  // 32 .. 128
 
   std::vector<float> host;
   auto put = [&](const float* src, size_t n) -> size_t {

@@ -406,6 +406,10 @@ int lbk_node16h(lb_engine* e, const lb_node_args& a, const float* w0h, const flo
     LB_N16(1, 0, false);
   else if (npa == 2 && npb == 0 && !resid)
     LB_N16(2, 0, false);
+  else if (npa == 3 && npb == 0 && !resid)
+    LB_N16(3, 0, false);
+  else if (npa == 4 && npb == 0 && !resid)
+    LB_N16(4, 0, false);
   else
     return lb_fail(LB_ERR_UNSUPPORTED, "k_node16h<%d,%d,%d> not instantiated", npa, npb, (int)resid);
   LB_HIP(hipGetLastError());

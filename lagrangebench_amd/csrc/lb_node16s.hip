@@ -341,6 +341,10 @@ int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const flo
     LB_NS_P(1, 0, false);
   else if (npa == 2 && npb == 0 && !resid)
     LB_NS_P(2, 0, false);
+  else if (npa == 3 && npb == 0 && !resid)
+    LB_NS_P(3, 0, false);
+  else if (npa == 4 && npb == 0 && !resid)
+    LB_NS_P(4, 0, false);
   else
     return lb_fail(LB_ERR_UNSUPPORTED, "k_node16s<%d,%d,%d> not instantiated", npa, npb, (int)resid);
   LB_HIP(hipGetLastError());

@@ -838,3 +838,33 @@ def test_gns_permutation_and_translation_properties():
     a2, e2 = acc_of(np.mod(pos + shift, box), pt)
     # (a pair exactly at the cutoff could flip under the 1-ulp change of its distance: none does here)
     assert e2 == e0 and rel_err(a2, a0) < 1e-5
+
+
+# ------------------------------------------------------------------ wide node inputs
+@pytest.mark.parametrize("isl,nl", [(14, 2), (22, 2), (14, 3)])
+def test_gns_wide_node_input_parity(isl, nl):
+    """Long input windows: node_in = K*dim [+K] [+2 dim] [+dim] + 16 grows past 64 features from input_seq_length 14
+    in 3D with magnitude features (68 -> three 32-wide k-steps; 100 at isl 22 -> four).  models/gns.py:135-157
+    takes any width; the engine supports up to 128.  Forward against the oracle in both arithmetic modes."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    L = 2
+    ds = make_case("small3d", n_trajs=2, extra_seq_length=2, input_seq_length=isl)
+    ds.magnitude_features = True
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    node_in, edge_in = feature_widths(ds)
+    assert node_in + 16 > 64
+    params = O.gns_init(np.random.default_rng(11), node_in=node_in, edge_in=edge_in, particle_dimension=3,
+                        num_mp_steps=L, blocks_per_step=nl)
+    model = GNS(3, 128, nl, L, 16)
+    pos = np.stack([ds[0][0], ds[1][0]])
+    pt = np.stack([ds[0][1], ds[1][1]])
+    for mode in (1, 0):
+        feats, _ = hip_case(ds).allocate_eval((pos[:, :, :isl], pt))
+        feats.engine.math_mode(mode)
+        acc = _np(model.apply(params, {}, (feats, pt))[0]["acc"])
+        for b in range(2):
+            of, _ = ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))
+            ref = O.gns_apply(params, of, pt[b], num_mp_steps=L, blocks_per_step=nl, skip_padding=True)["acc"]
+            assert rel_err(acc[b], ref) < 1e-5, (mode, b)
