@@ -639,6 +639,8 @@ def test_f16x2_range_guard_falls_back_to_fp32(kind):
     must notice, repeat the forward in exact-fp32 MFMA arithmetic (engine stays in mode 0) and match the
     oracle to 1e-5 - while the unguarded f16x2 mode demonstrably does not."""
     _need_gpu()
+    if os.environ.get("LB_MATH"):
+        pytest.skip("LB_MATH pins the arithmetic: the guard-driven switch is what this test is about")
     from lagrangebench_amd.data import make_case
     from lagrangebench_amd.models import GNS
     L = 3
