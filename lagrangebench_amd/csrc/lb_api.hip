@@ -8,7 +8,11 @@
 #include <algorithm>
 #include <cmath>
 
+#include <initializer_list>
+#include <tuple>
+
 #include "lb_internal.h"
+#include "lb_msplit.h"
 
 thread_local std::string g_lb_err;
 
@@ -682,6 +686,64 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
   }
   const size_t o_dec_w1_f = put_packed16(p_dec + (size_t)D * D + D, D, d->out_dim, D);
   if (p - w != n_floats) return lb_fail(LB_ERR_ARG, "internal: blob walk mismatch");
+  // M-split images (lb_msplit.hip): one block per MLP = [W0 | W1 | projection of the next edge MLP]
+  auto put_ms = [&](std::initializer_list<std::tuple<const float*, int, int, int, int, bool>> mats) -> size_t {
+    std::vector<float> img;
+    for (const auto& m : mats) {
+      const float* src; int K, M, nkb, npw; bool perm;
+      std::tie(src, K, M, nkb, npw, perm) = m;
+      const size_t base = img.size();
+      img.resize(base + (size_t)nkb * npw * 4096);
+      lb_pack_ms(src, K, M, nkb, npw, perm, img.data() + base);
+    }
+    return put(img.data(), img.size());
+  };
+  // walk the blob once more for the source pointers (same order as above)
+  size_t o_ms_enc_node, o_ms_enc_edge;
+  std::vector<size_t> o_ms_pe(L), o_ms_pn(L);
+  {
+    const float* q = w + (has_emb ? (size_t)d->num_particle_types * emb : 0);
+    auto wsr_of = [&](const float* w0e, std::vector<float>& wsr) {  // [Ws | Wr] of an edge MLP's first Linear
+      wsr.assign((size_t)D * 2 * D, 0.f);
+      for (int kk = 0; kk < D; ++kk)
+        for (int m = 0; m < D; ++m) {
+          wsr[(size_t)kk * 2 * D + m] = w0e[(size_t)kk * D + m];
+          wsr[(size_t)kk * 2 * D + D + m] = w0e[(size_t)(D + kk) * D + m];
+        }
+    };
+    const float* en_w0 = q;
+    const float* en_w1 = q + (size_t)nin * D + D;
+    q += (size_t)nin * D + D + (size_t)D * D + D + 2 * D;
+    const float* ee_w0 = q;
+    const float* ee_w1 = q + (size_t)d->edge_in * D + D;
+    q += (size_t)d->edge_in * D + D + (size_t)D * D + D + 2 * D;
+    std::vector<const float*> pe_w0(L), pe_w1(L), pn_w0(L), pn_w1(L);
+    for (int k = 0; k < L; ++k) {
+      pe_w0[k] = q;
+      pe_w1[k] = q + (size_t)3 * D * D + D;
+      q += (size_t)3 * D * D + D + (size_t)D * D + D + 2 * D;
+      pn_w0[k] = q;
+      pn_w1[k] = q + (size_t)2 * D * D + D;
+      q += (size_t)2 * D * D + D + (size_t)D * D + D + 2 * D;
+    }
+    std::vector<float> wsr;
+    if (L > 0) {
+      wsr_of(pe_w0[0], wsr);
+      o_ms_enc_node = put_ms({{en_w0, nin, D, kpad / 32, 1, true}, {en_w1, D, D, 4, 1, true}, {wsr.data(), D, 2 * D, 4, 2, true}});
+    } else {
+      o_ms_enc_node = put_ms({{en_w0, nin, D, kpad / 32, 1, true}, {en_w1, D, D, 4, 1, true}});
+    }
+    o_ms_enc_edge = put_ms({{ee_w0, d->edge_in, D, 1, 1, false}, {ee_w1, D, D, 4, 1, true}});
+    for (int k = 0; k < L; ++k) {
+      o_ms_pe[k] = put_ms({{pe_w0[k] + (size_t)2 * D * D, D, D, 4, 1, true}, {pe_w1[k], D, D, 4, 1, true}});
+      if (k + 1 < L) {
+        wsr_of(pe_w0[k + 1], wsr);
+        o_ms_pn[k] = put_ms({{pn_w0[k], 2 * D, D, 8, 1, true}, {pn_w1[k], D, D, 4, 1, true}, {wsr.data(), D, 2 * D, 4, 2, true}});
+      } else {
+        o_ms_pn[k] = put_ms({{pn_w0[k], 2 * D, D, 8, 1, true}, {pn_w1[k], D, D, 4, 1, true}});
+      }
+    }
+  }
 
   lb_gns* g = new lb_gns();
   g->desc = *d;
@@ -724,6 +786,12 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     g->proj_w_h2.push_back(g->blob + o_pw_h2[k]);
     g->proc_edge_w0_16h.push_back(g->blob + o_pe_w0_16h[k]);
     g->proc_edge_w1_16h.push_back(g->blob + o_pe_w1_16h[k]);
+  }
+  g->ms_enc_node = g->blob + o_ms_enc_node;
+  g->ms_enc_edge = g->blob + o_ms_enc_edge;
+  for (int k = 0; k < L; ++k) {
+    g->ms_proc_edge.push_back(g->blob + o_ms_pe[k]);
+    g->ms_proc_node.push_back(g->blob + o_ms_pn[k]);
   }
   g->dec_unscale = dec_unscale;
   g->dec_w0_h = g->blob + o_dec_w0_h;

@@ -26,70 +26,6 @@
 
 #include "lb_f16x2.h"
 
-// x += row_shr:k(x) * m for 8 registers and k = 1, 2, 4, 8 in a fixed order: one v_fmac_f32_dpp per
-// register and step; a register is read through DPP again only 8 instructions after it was written
-// (the VALU-write -> DPP-read hazard needs 2 wait states; inline asm is invisible to the hazard
-// recogniser, hence the fixed order and the leading s_nop).
-__device__ __forceinline__ void lb_scan8(f32x4& a, f32x4& b, float m1, float m2, float m4, float m8) {
-  asm volatile(
-      "s_nop 1\n"
-      "v_fmac_f32_dpp %0, %0, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %1, %1, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %2, %2, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %3, %3, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %4, %4, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %5, %5, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %6, %6, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %7, %7, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %0, %0, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %1, %1, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %2, %2, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %3, %3, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %4, %4, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %5, %5, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %6, %6, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %7, %7, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %0, %0, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %1, %1, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %2, %2, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %3, %3, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %4, %4, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %5, %5, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %6, %6, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %7, %7, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %0, %0, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %1, %1, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %2, %2, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %3, %3, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %4, %4, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %5, %5, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %6, %6, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_fmac_f32_dpp %7, %7, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "s_nop 1\n"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
-      : "v"(m1), "v"(m2), "v"(m4), "v"(m8));
-}
-
-// Where does a receiver's segment sum go?  The node kernel (lb_load_agg16) reads `agg[r]` when all
-// edges of r lie in one 16-edge tile and otherwise, for every tile the row touches, the partial slot
-// `part[tile][k0 <= 16*tile ? 0 : 1]` (k0 = row_ptr[r]).  Both facts are visible from inside the tile:
-// slot 0 <=> the segment contains the tile's first lane; complete <=> the edge before the tile (if the
-// segment starts at lane 0) and the edge after it (if it ends at lane 15) belong to other receivers.
-// lb_edge_probe fetches those two receivers in ONE vector load (even lanes: edge 16t-1, odd lanes:
-// edge 16t+16) instead of two row_ptr gathers per lane.
-__device__ __forceinline__ int lb_edge_probe(const int32_t* __restrict__ receivers, int t, int lane, int E) {
-  int idx = t * 16 - 1 + 17 * (lane & 1);
-  idx = idx < 0 ? 0 : (idx < E ? idx : E - 1);
-  return receivers[idx];
-}
-__device__ __forceinline__ bool lb_seg_complete(int rb, int rr, int segstart, int n, int t, int E, int& slot01) {
-  const int r_before = __builtin_amdgcn_readlane(rb, 0), r_after = __builtin_amdgcn_readlane(rb, 1);
-  const bool starts_before = segstart == 0 && t > 0 && r_before == rr;
-  const bool ends_after = n == 15 && t * 16 + 16 < E && r_after == rr;
-  slot01 = segstart == 0 ? 0 : 1;
-  return !starts_before && !ends_after;
-}
-
 // ABL (tools/edge16v_bench.hip only, 0 in the product): 1 no psr gathers, 2 no edge-latent loads,
 // 4 no stores, 8 no GEMMs, 16 no LayerNorm / scan (epilogue VALU).
 // SKIP: last processor layer - the updated edge latents have no reader (compile-time so that the

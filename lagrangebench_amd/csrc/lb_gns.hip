@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "lb_device.h"
+#include "lb_msplit.h"
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -507,8 +508,23 @@ int lbk_segment_sum(lb_engine* e, const float* msg, float* out, int D) {
 }
 
 // ================================================================================= forward
+// Small graphs (one trajectory per GPU) run on the M-split kernels of lb_msplit.hip: LB_MSPLIT=0 / 1 forces the
+// choice, LB_MS_MAX_TILES moves the size threshold (16-edge tiles of the frozen capacity).
+static bool lb_use_msplit(const lb_engine* e) {
+  static const int env = getenv("LB_MSPLIT") ? atoi(getenv("LB_MSPLIT")) : -1;
+  static const int64_t max_tiles = getenv("LB_MS_MAX_TILES") ? atoll(getenv("LB_MS_MAX_TILES")) : 16384;
+  if (!e->f16x2 || !e->fused_agg || e->edge_tile != 16 || env == 0) return false;
+  if (env == 1) return true;
+  return ((int64_t)e->e_cap * e->g.B + 15) / 16 <= max_tiles;
+}
+
 int lbk_gns_forward(lb_engine* e, lb_gns* g) {
   if (g->generic) return lbk_gns_forward_generic(e, g);
+  const bool ms_all = lb_use_msplit(e);
+  // LB_MS_PARTS (debug / ablation): bit 0 encoder node, 1 encoder edge, 2 processor edge, 3 processor node
+  static const int ms_parts = getenv("LB_MS_PARTS") ? atoi(getenv("LB_MS_PARTS")) : 15;
+  const bool ms_en = ms_all && (ms_parts & 1), ms_ee = ms_all && (ms_parts & 2);
+  const bool ms_pe = ms_all && (ms_parts & 4), ms_pn = ms_all && (ms_parts & 8);
   hipStream_t s = e->stream;
   const int64_t BN = e->BN;
   const int ntile_n = (int)((BN + LB_TILE - 1) / LB_TILE);
@@ -544,7 +560,22 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
     static const bool node_s_env = !(getenv("LB_NODE_KERNEL") && getenv("LB_NODE_KERNEL")[0] == 'h');
     static const int64_t node_s_min = getenv("LB_NODE_S_MIN") ? atoll(getenv("LB_NODE_S_MIN")) : 16385;
     const bool node_s = node_s_env && BN >= node_s_min;
-    if (e->f16x2 && node_s) {
+    if (ms_en) {
+      lb_nms_args m{};
+      m.ctrl = e->ctrl;
+      m.n_rows = BN;
+      m.xin = e->xnode;
+      m.nlat = e->nlat;
+      m.w = g->ms_enc_node;
+      m.b0 = a.b0;
+      m.b1 = a.b1;
+      m.ln_s = a.ln_s;
+      m.ln_o = a.ln_o;
+      m.bp = a.bp;
+      m.psr = e->psr;
+      rc = lbk_node_ms(e, m, g->kq_node / 4, false, false, L > 0);
+      if (rc) return rc;
+    } else if (e->f16x2 && node_s) {
       rc = lbk_node16s(e, a, g->enc_node_w0_h, g->enc_node_w1_h, L > 0 ? g->proj_w_h2[0] : nullptr,
                        g->kq_node / 4, 0, false);
       if (rc) return rc;
@@ -574,7 +605,19 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
     a.ln_s = g->enc_edge.ln_s;
     a.ln_o = g->enc_edge.ln_o;
     lb_tic(e, LB_T_ENC_EDGE);
-    if (e->edge_tile == 16) {
+    if (ms_ee) {
+      lb_ems_args m{};
+      m.ctrl = e->ctrl;
+      m.efeat = e->efeat;
+      m.elat = e->elat;
+      m.w = g->ms_enc_edge;
+      m.b0 = a.b0;
+      m.b1 = a.b1;
+      m.ln_s = a.ln_s;
+      m.ln_o = a.ln_o;
+      rc = lbk_edge_enc_ms(e, m);
+      if (rc) return rc;
+    } else if (e->edge_tile == 16) {
       lb_edge16_args b{};
       b.ctrl = a.ctrl;
       b.efeat = a.efeat;
@@ -615,7 +658,23 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       a.agg = e->agg;
       a.part = e->part;
       lb_tic_single(e, LB_T_EDGE_MLP);
-      if (e->edge_tile == 16) {
+      if (ms_pe) {
+        lb_ems_args m{};
+        m.ctrl = e->ctrl;
+        m.senders = e->senders;
+        m.receivers = e->receivers;
+        m.elat = e->elat;
+        m.psr = e->psr;
+        m.w = g->ms_proc_edge[k];
+        m.b1 = a.b1;
+        m.ln_s = a.ln_s;
+        m.ln_o = a.ln_o;
+        m.agg = e->agg;
+        m.part = e->part;
+        m.skip_elat_store = (k == L - 1) && !g->tap;
+        rc = lbk_edge_ms(e, m);
+        if (rc) return rc;
+      } else if (e->edge_tile == 16) {
         lb_edge16_args b{};
         b.ctrl = a.ctrl;
         b.senders = a.senders;
@@ -689,7 +748,26 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       static const bool node_s_env = !(getenv("LB_NODE_KERNEL") && getenv("LB_NODE_KERNEL")[0] == 'h');
       static const int64_t node_s_min = getenv("LB_NODE_S_MIN") ? atoll(getenv("LB_NODE_S_MIN")) : 16385;
     const bool node_s = node_s_env && BN >= node_s_min;
-      if (e->f16x2 && node_s) {
+      if (ms_pn) {
+        lb_nms_args m{};
+        m.ctrl = e->ctrl;
+        m.n_rows = BN;
+        m.xin = e->nlat;
+        m.agg = e->agg;
+        m.row_ptr = e->row_ptr;
+        m.part = e->part;
+        m.fused = 1;
+        m.nlat = e->nlat;
+        m.w = g->ms_proc_node[k];
+        m.b0 = a.b0;
+        m.b1 = a.b1;
+        m.ln_s = a.ln_s;
+        m.ln_o = a.ln_o;
+        m.bp = a.bp;
+        m.psr = e->psr;
+        rc = lbk_node_ms(e, m, 4, true, true, k + 1 < L);
+        if (rc) return rc;
+      } else if (e->f16x2 && node_s) {
         rc = lbk_node16s(e, a, g->proc_node_w0_h[k], g->proc_node_w1_h[k],
                          (k + 1 < L) ? g->proj_w_h2[k + 1] : nullptr, 4, 4, true);
         if (rc) return rc;

@@ -233,6 +233,10 @@ struct lb_gns {
   const float* dec_w1_h = nullptr;
   const float* dec_w1_f = nullptr;
   float dec_unscale = 1.f;  // the f16x2 copy of the decoder's output Linear is packed times a power of two
+  // M-split images (lb_msplit.hip, small graphs): per MLP [W0 | W1 (| projection of the NEXT edge MLP)]
+  const float* ms_enc_node = nullptr;
+  const float* ms_enc_edge = nullptr;
+  std::vector<const float*> ms_proc_edge, ms_proc_node;
   // num_mlp_layers != 2 (lb_gns_generic.hip): one packed 128x128 Linear per input block, both packings
   bool generic = false;
   lb_gen_mlp g_enc_node, g_enc_edge, g_dec;

@@ -1,0 +1,665 @@
+// lb_msplit.hip - "M-split" network kernels for SMALL graphs (one trajectory per GPU: the BASELINE configs as
+// literally stated), round 3.
+//
+// Reference functions replaced: GNS._encoder / _processor (edge + node update, jraph.segment_sum, residuals) of
+// lagrangebench/models/gns.py:65-124, build_mlp (hk.nets.MLP + hk.LayerNorm) of models/utils.py:100-115.
+//
+// Why a second kernel family.  The round-2 kernels give every WAVE a whole 16-row tile and all 128 output features,
+// so a wave needs the complete weight matrices: 128 KiB (edge MLP) are staged global -> registers -> LDS by every
+// workgroup of every launch, 320 KiB (node MLP + next projection) are streamed through an LDS ring in ten
+// barrier-separated chunks.  On a 64 k-node batch that staging is amortised over dozens of tiles per wave; on ONE
+// 2.5 k - 8 k particle trajectory a wave has ~1 tile, a launch is the latency chain "stage weights -> one tile" and
+// the step is 30 such chains (round 2: 13 + 15 us per layer on TGV2D-2.5k, of which ~2 us is arithmetic).
+// Here the 4 waves of a workgroup split the OUTPUT features (M) of every Linear instead of the rows:
+//   * wave w owns output blocks 2w, 2w+1 (32 features) of each 128-wide Linear (four blocks of the 256-wide
+//     projection), so it needs 1/4 of every matrix - 32 KiB of an edge MLP, 80 KiB of node MLP + projection - which
+//     it loads STRAIGHT INTO REGISTERS as MFMA A-operand fragments (128 / 320 VGPRs): no LDS staging, no chunk
+//     barriers, the loads are in flight while the tile's indices / gathers are;
+//   * the B operand (a 16-row tile of activations, fp16 hi | lo) is exchanged through LDS in MFMA fragment order:
+//     8 KiB per tile and Linear instead of 128 - 320 KiB of weights; the register-chaining trick of the round-2
+//     kernels survives as a K-permutation folded into the packed weights (lane (n, g) of wave w holds features
+//     32w + 16c + 4g + j in the C layout and writes them as elements 4c + j of k-group g of k-block w);
+//   * LayerNorm statistics are combined across the 4 waves with Chan's parallel (mean, M2) update: one exchange;
+//   * cross-lane reductions use DPP rotations and gfx950's v_permlane16/32_swap - no ds_bpermute round trips;
+//   * two independent workgroups share a CU (edge kernels: <= 256 VGPRs), so one's barrier / LDS / memory latency
+//     is the other's issue slot.
+// Arithmetic = the f16x2 scheme of lb_f16x2.h (lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x32_f16, fp32 accumulate).
+// The f16x2 range guard is EXHAUSTIVE here: every GEMM operand of every tile is folded into a running maximum
+// (LARGE / non-finite) and a per-tile maximum combined across the waves (TINY), one atomicOr per wave and launch.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "lb_f16x2.h"
+#include "lb_msplit.h"
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------ host packing
+static uint16_t ms_f32_to_f16(float f) {
+  const _Float16 h = (_Float16)f;  // RNE
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+static float ms_f16_to_f32(uint16_t u) {
+  _Float16 h;
+  memcpy(&h, &u, 2);
+  return (float)h;
+}
+
+// W is (K, M) row-major (haiku Linear).  out[((mb*nkb + kb)*2 + part)*64 + lane] (16 B = 8 halfs each): the A
+// fragment of output block mb (features 16 mb ..) and k-block kb; part 0 = hi, 1 = lo.  (wv, npw only enumerate the
+// blocks: mb = wv*npw + c - the image does not depend on how the waves split them.)
+// perm: k-block kb, k-group kg, element i <-> input feature 32 kb + 16 (i >> 2) + 4 kg + (i & 3) (the C-layout
+// exchange above); natural: 32 kb + 8 kg + i.
+void lb_pack_ms(const float* w, int K, int M, int nkb, int npw, bool perm, float* out) {
+  uint16_t* o = reinterpret_cast<uint16_t*>(out);
+  for (int wv = 0; wv < 8; ++wv)
+    for (int c = 0; c < npw; ++c)
+      for (int kb = 0; kb < nkb; ++kb)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int i = 0; i < 8; ++i) {
+            const int kg = lane >> 4;
+            const int m = 16 * (wv * npw + c) + (lane & 15);
+            const int k = perm ? 32 * kb + 16 * (i >> 2) + 4 * kg + (i & 3) : 32 * kb + 8 * kg + i;
+            const float x = (k < K && m < M) ? w[(size_t)k * M + m] : 0.f;
+            const uint16_t hi = ms_f32_to_f16(x);
+            const uint16_t lo = ms_f32_to_f16(x - ms_f16_to_f32(hi));
+            const size_t f = (((size_t)(wv * npw + c) * nkb + kb) * 2) * 64;
+            o[(f + lane) * 8 + i] = hi;
+            o[(f + 64 + lane) * 8 + i] = lo;
+          }
+}
+
+// ------------------------------------------------------------------------------------------ device helpers
+typedef float f32x2m __attribute__((ext_vector_type(2)));
+typedef _Float16 h2m __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2m __attribute__((ext_vector_type(2)));
+
+#define MS_WAVES 4
+#define MS_THREADS (MS_WAVES * 64)
+
+// sum / max over the four lanes {n, n+16, n+32, n+48} (same row n, the four k-groups): gfx950 row swaps.
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second,
+// v_permlane32_swap the upper half of the first with the lower half of the second (tools/permlane_check.hip), so
+// with both operands = x the two results are the two addends of the xor-16 / xor-32 butterfly.  Inline asm: through
+// __builtin_amdgcn_permlane16_swap hipcc 7.2 emits the swap and then adds the FIRST result to itself (the second
+// tied output is lost in a larger kernel); the leading s_nop is the VALU-write -> permlane-read wait the hazard
+// recogniser cannot insert inside an asm block.
+__device__ __forceinline__ void ms_swap16(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void ms_swap32(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float ms_sum_g(float x) {
+  float a = x, b = x;
+  ms_swap16(a, b);
+  a = b = a + b;
+  ms_swap32(a, b);
+  return a + b;
+}
+__device__ __forceinline__ float ms_max_g(float x) {
+  float a = x, b = x;
+  ms_swap16(a, b);
+  a = b = fmaxf(a, b);
+  ms_swap32(a, b);
+  return fmaxf(a, b);
+}
+// max over the whole wave (every lane gets it): rotations inside the 16-lane DPP rows, then the row swaps
+__device__ __forceinline__ float ms_wave_max(float m) {
+#define MS_ROR(k) m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x120 + (k), 0xF, 0xF, false)))
+  MS_ROR(8);
+  MS_ROR(4);
+  MS_ROR(2);
+  MS_ROR(1);
+#undef MS_ROR
+  return ms_max_g(m);
+}
+__device__ __forceinline__ float ms_absmax4(const f32x4& x) {
+  return fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+}
+
+// 8 values (this wave's two output blocks of one row) -> fp16 hi (RNE) and lo = fp16(x - hi), as one B-fragment
+// k-block entry: elements 0-3 from block c = 0, 4-7 from c = 1
+template <bool RELU>
+__device__ __forceinline__ void ms_split8(const f32x4& x0, const f32x4& x1, h8& hi, h8& lo) {
+  f32x2m a[4] = {{x0[0], x0[1]}, {x0[2], x0[3]}, {x1[0], x1[1]}, {x1[2], x1[3]}};
+  h2m hh[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (RELU) a[i] = f32x2m{fmaxf(a[i][0], 0.f), fmaxf(a[i][1], 0.f)};
+    hh[i] = __builtin_convertvector(a[i], h2m);
+    ll[i] = __builtin_convertvector(a[i] - __builtin_convertvector(hh[i], f32x2m), h2m);
+  }
+  hi = h8{hh[0][0], hh[0][1], hh[1][0], hh[1][1], hh[2][0], hh[2][1], hh[3][0], hh[3][1]};
+  lo = h8{ll[0][0], ll[0][1], ll[1][0], ll[1][1], ll[2][0], ll[2][1], ll[3][0], ll[3][1]};
+}
+
+// write this wave's 32 features x 16 rows (C layout) as k-block kb of a tile's B-fragment image [kb][part][lane]
+template <bool RELU>
+__device__ __forceinline__ void ms_stage(f32x4* img, int kb, int lane, const f32x4& x0, const f32x4& x1) {
+  h8 hi, lo;
+  ms_split8<RELU>(x0, x1, hi, lo);
+  img[(kb * 2 + 0) * 64 + lane] = __builtin_bit_cast(f32x4, hi);
+  img[(kb * 2 + 1) * 64 + lane] = __builtin_bit_cast(f32x4, lo);
+}
+
+// acc[c] += W_c^T B over NKB k-blocks for this wave's NB output blocks: weights from registers, B fragments from the
+// tile's LDS image; the NB accumulate chains are interleaved pass by pass (lo*hi, hi*lo, hi*hi)
+template <int NKB, int NB>
+__device__ __forceinline__ void ms_gemm(const f32x4* img, int lane, const h8 (&wh)[NB][NKB], const h8 (&wl)[NB][NKB],
+                                        f32x4 (&acc)[NB]) {
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const h8 bh = __builtin_bit_cast(h8, img[(kb * 2 + 0) * 64 + lane]);
+    const h8 bl = __builtin_bit_cast(h8, img[(kb * 2 + 1) * 64 + lane]);
+#pragma unroll
+    for (int c = 0; c < NB; ++c) acc[c] = MFMA16H(wl[c][kb], bh, acc[c]);
+#pragma unroll
+    for (int c = 0; c < NB; ++c) acc[c] = MFMA16H(wh[c][kb], bl, acc[c]);
+#pragma unroll
+    for (int c = 0; c < NB; ++c) acc[c] = MFMA16H(wh[c][kb], bh, acc[c]);
+  }
+}
+template <int NKB, int NB>
+__device__ __forceinline__ void ms_wload(const f32x4* wb, int mb0, h8 (&wh)[NB][NKB], h8 (&wl)[NB][NKB]) {
+#pragma unroll
+  for (int c = 0; c < NB; ++c)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      wh[c][kb] = __builtin_bit_cast(h8, wb[(((mb0 + c) * NKB + kb) * 2 + 0) * 64]);
+      wl[c][kb] = __builtin_bit_cast(h8, wb[(((mb0 + c) * NKB + kb) * 2 + 1) * 64]);
+    }
+}
+
+// LayerNorm over the 128 features of a row that are spread over the 4 waves (32 each): every wave contributes
+// (sum, M2 about its own mean) per row; combined with the parallel-variance update (Chan et al.).
+__device__ __forceinline__ f32x2m ms_ln_local(const f32x4& x0, const f32x4& x1) {
+  const float s = ms_sum_g(((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3])));
+  const float mu = s * 0.03125f;
+  float m2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float d0 = x0[j] - mu, d1 = x1[j] - mu;
+    m2 += d0 * d0 + d1 * d1;
+  }
+  return f32x2m{s, ms_sum_g(m2)};
+}
+// red: [16 rows][4 waves] (sum, M2) of one tile
+__device__ __forceinline__ void ms_ln_combine(const f32x2m* red, int n, float inv_d, float pad, float& mean,
+                                              float& rs) {
+  const f32x4* r4 = reinterpret_cast<const f32x4*>(red + n * 4);
+  const f32x4 a = r4[0], b = r4[1];
+  const float sw[4] = {a[0], a[2], b[0], b[2]}, mw[4] = {a[1], a[3], b[1], b[3]};
+  mean = ((sw[0] + sw[1]) + (sw[2] + sw[3])) * inv_d;
+  float m2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float dm = sw[q] * 0.03125f - mean;
+    m2 += mw[q] + 32.f * (dm * dm);
+  }
+  // a latent narrower than 128 is zero-padded: each padded entry contributed mean^2 to the centred sum
+  rs = 1.0f / sqrtf(fmaxf(m2 - pad * (mean * mean), 0.f) * inv_d + 1e-5f);
+}
+
+// running range-guard state of a wave (see the header)
+struct ms_guard {
+  float big;  // max |x| over every operand seen
+  int flags;
+  __device__ __forceinline__ float see(const f32x4& x0, const f32x4& x1) {
+    const float m = fmaxf(ms_absmax4(x0), ms_absmax4(x1));
+    big = fmaxf(big, m);
+    if (!(m == m)) flags |= LB_MATH_LARGE;  // NaN
+    return m;
+  }
+  // tile-wide maximum of an operand, combined over the 4 waves through `slot` (4 floats, written before a barrier)
+  __device__ __forceinline__ void tile_max(const float* slot) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(slot);
+    const float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+    if (m > 0.f && m < 0.0009765625f) flags |= LB_MATH_TINY;
+  }
+  __device__ __forceinline__ void commit(const lb_ctrl* ctrl, int lane) {
+    const float m = ms_wave_max(big);
+    int f = flags;
+    if (!(m < 32768.f)) f |= LB_MATH_LARGE;  // close to the fp16 range, inf
+    const bool any_nan = __any(f & LB_MATH_LARGE), any_tiny = __any(f & LB_MATH_TINY);
+    f = (any_nan ? LB_MATH_LARGE : 0) | (any_tiny ? LB_MATH_TINY : 0);
+    if (lane == 0 && f) atomicOr(const_cast<int32_t*>(&ctrl->math_flags), f);
+  }
+};
+
+// XCD-aware unit walk (block b runs on XCD b % 8): every XCD owns a contiguous eighth of the units
+struct ms_walk {
+  int q, stride, n_iter, q_last;
+  __device__ __forceinline__ bool init(int nq) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    stride = gridDim.x >> 3;
+    const int q_lo = (int)(((int64_t)nq * xcd) >> 3), q_hi = (int)(((int64_t)nq * (xcd + 1)) >> 3);
+    q = q_lo + slot;
+    if (q >= q_hi) return false;
+    n_iter = (q_hi - 1 - q) / stride + 1;
+    q_last = q + (n_iter - 1) * stride;
+    return true;
+  }
+};
+
+// =========================================================================================== edge kernels
+// Processor edge MLP + residual + fused segment_sum (gns.py:86-101,117-122), one tile of 16 edges per iteration.
+// Per tile and wave: 2 KiB of latents (blocks 2w, 2w+1 of the tile-blocked layout = exactly the C layout of this
+// wave's output blocks: also the residual operand), four 16-B gathers (sender / receiver projection slices) as
+// accumulator start, 24 + 24 MFMAs, an 8-register segmented scan.  The next tile's loads are issued before this
+// tile's GEMMs and taken delivery of before its stores (gfx9's single in-order vmcnt: a wait behind the stores
+// would be a store drain).
+template <bool SKIP>
+__global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
+  __shared__ f32x4 sB1[4 * 2 * 64];
+  __shared__ f32x4 sB2[4 * 2 * 64];
+  __shared__ __attribute__((aligned(16))) f32x2m sRed[16 * 4];
+  __shared__ __attribute__((aligned(16))) float sMx[2][4];
+  const int poisoned = a.ctrl->overflow_step;
+  const int E = a.ctrl->n_edges_total;
+  const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  // this wave's weight fragments, straight into registers (in bounds whatever the state)
+  h8 w0h[2][4], w0l[2][4], w1h[2][4], w1l[2][4];
+  {
+    const f32x4* wb = reinterpret_cast<const f32x4*>(a.w) + lane;
+    ms_wload<4, 2>(wb, 2 * w, w0h, w0l);
+    ms_wload<4, 2>(wb + 8 * 4 * 2 * 64, 2 * w, w1h, w1l);
+  }
+  f32x4 b1v[2], lns[2], lno[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    b1v[c] = reinterpret_cast<const f32x4*>(a.b1)[8 * w + 4 * c + g];
+    lns[c] = reinterpret_cast<const f32x4*>(a.ln_s)[8 * w + 4 * c + g];
+    lno[c] = reinterpret_cast<const f32x4*>(a.ln_o)[8 * w + 4 * c + g];
+  }
+  const int ntiles = (E + 15) >> 4;
+  ms_walk wk;
+  if (poisoned >= 0 || !wk.init(ntiles)) return;  // uniform over the workgroup
+  const f32x4* psr4 = reinterpret_cast<const f32x4*>(a.psr);
+  const f32x4* elat4 = reinterpret_cast<const f32x4*>(a.elat);
+
+  f32x4 nve[2], nps[2], npr[2];
+  int nr, nrb, s_i, r_i;
+  auto load_idx = [&](int t) {
+    const int row = t * 16 + n;
+    const int rc = row < E ? row : E - 1;
+    s_i = a.senders[rc];
+    r_i = a.receivers[rc];
+  };
+  auto issue = [&](int t) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      nve[c] = elat4[((int64_t)t * 8 + 2 * w + c) * 64 + lane];
+      nps[c] = psr4[(int64_t)s_i * 64 + 8 * w + 4 * c + g];
+      npr[c] = psr4[(int64_t)r_i * 64 + 32 + 8 * w + 4 * c + g];
+    }
+    nr = r_i;
+    nrb = lb_edge_probe(a.receivers, t, lane, E);
+  };
+  int t = wk.q;
+  load_idx(t);
+  issue(t);
+  load_idx(min(t + wk.stride, wk.q_last));
+  ms_guard guard{0.f, 0};
+
+  for (int it = 0; it < wk.n_iter; ++it, t += wk.stride) {
+    f32x4 ve[2], acc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      ve[c] = nve[c];
+      acc[c] = nps[c] + npr[c];
+    }
+    const int rcur = nr, rb = nrb;
+    ms_stage<false>(sB1, w, lane, ve[0], ve[1]);
+    {
+      const float m = ms_wave_max(guard.see(ve[0], ve[1]));
+      if (lane == 0) sMx[0][w] = m;
+    }
+    // the next tile's loads (and the indices of the one after) go out before this tile's GEMMs
+    issue(min(t + wk.stride, wk.q_last));
+    load_idx(min(t + 2 * wk.stride, wk.q_last));
+    __syncthreads();
+    ms_gemm<4, 2>(sB1, lane, w0h, w0l, acc);
+    guard.tile_max(sMx[0]);
+    ms_stage<true>(sB2, w, lane, acc[0], acc[1]);
+    {
+      const float m = ms_wave_max(guard.see(acc[0], acc[1]));
+      if (lane == 0) sMx[1][w] = m;
+    }
+    __syncthreads();
+    f32x4 acc2[2] = {b1v[0], b1v[1]};
+    ms_gemm<4, 2>(sB2, lane, w1h, w1l, acc2);
+    guard.tile_max(sMx[1]);
+    {
+      const f32x2m p = ms_ln_local(acc2[0], acc2[1]);
+      if (g == 0) sRed[n * 4 + w] = p;
+    }
+    __syncthreads();
+    float mean, rs;
+    ms_ln_combine(sRed, n, ln_inv_d, ln_pad, mean, rs);
+    f32x4 y[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[c][j] = (lns[c][j] * rs) * (acc2[c][j] - mean) + lno[c][j];
+    // take delivery of the prefetched tile HERE, while only loads are in flight
+    asm volatile("" : "+v"(nve[0]), "+v"(nve[1]), "+v"(nps[0]), "+v"(nps[1]), "+v"(npr[0]), "+v"(npr[1]), "+v"(nrb));
+    const int row = t * 16 + n;
+    const bool valid = row < E;
+    if (!SKIP) {
+      f32x4* ew = reinterpret_cast<f32x4*>(a.elat) + ((int64_t)t * 8 + 2 * w) * 64 + lane;
+      ew[0] = ve[0] + y[0];  // residual (gns.py:120-122)
+      ew[64] = ve[1] + y[1];
+    }
+    // fused jraph.segment_sum: segmented Hillis-Steele scan over the 16 edges of the DPP row
+    const int rr = valid ? rcur : (-1 - n);
+    const int r_prev = __builtin_amdgcn_update_dpp(-2, rr, 0x111, 0xF, 0xF, false);
+    const bool head = (n == 0) || (rr != r_prev);
+    const unsigned H = (unsigned)(__ballot(head) & 0xffffull);
+    const unsigned below = H & ((2u << n) - 1u);
+    const int segstart = 31 - __clz(below);
+    const bool tail = (n == 15) || ((H >> (n + 1)) & 1u);
+    const float m1 = (n >= 1 && segstart <= n - 1) ? 1.f : 0.f, m2 = (n >= 2 && segstart <= n - 2) ? 1.f : 0.f;
+    const float m4 = (n >= 4 && segstart <= n - 4) ? 1.f : 0.f, m8 = (n >= 8 && segstart <= n - 8) ? 1.f : 0.f;
+    if (!valid) {
+      y[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      y[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    lb_scan8(y[0], y[1], m1, m2, m4, m8);
+    if (tail && valid) {
+      int slot01;
+      const bool complete = lb_seg_complete(rb, rr, segstart, n, t, E, slot01);
+      float* dst = complete ? a.agg + (int64_t)rr * 128 : a.part + ((int64_t)t * 2 + slot01) * 128;
+      f32x4* d4 = reinterpret_cast<f32x4*>(dst) + 8 * w + g;
+      d4[0] = y[0];
+      d4[4] = y[1];
+    }
+  }
+  guard.commit(a.ctrl, lane);
+}
+
+// Encoder edge MLP (gns.py:73-84): e0 = LayerNorm(W1 relu(W0 f + b0) + b1), f = (rel_disp, rel_dist) zero-padded
+// to 8 floats.  The first Linear is ONE k-block whose B operand every wave builds itself from the 32-B feature row
+// (natural k order: only k-group 0 is non-zero) - no exchange; then as above without gathers / residual / scan.
+__global__ void __launch_bounds__(MS_THREADS, 2) k_edge_enc_ms(lb_ems_args a) {
+  __shared__ f32x4 sB2[4 * 2 * 64];
+  __shared__ __attribute__((aligned(16))) f32x2m sRed[16 * 4];
+  __shared__ __attribute__((aligned(16))) float sMx[4];
+  const int poisoned = a.ctrl->overflow_step;
+  const int E = a.ctrl->n_edges_total;
+  const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  h8 w0h[2][1], w0l[2][1], w1h[2][4], w1l[2][4];
+  {
+    const f32x4* wb = reinterpret_cast<const f32x4*>(a.w) + lane;
+    ms_wload<1, 2>(wb, 2 * w, w0h, w0l);
+    ms_wload<4, 2>(wb + 8 * 1 * 2 * 64, 2 * w, w1h, w1l);
+  }
+  f32x4 b0v[2], b1v[2], lns[2], lno[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    b0v[c] = reinterpret_cast<const f32x4*>(a.b0)[8 * w + 4 * c + g];
+    b1v[c] = reinterpret_cast<const f32x4*>(a.b1)[8 * w + 4 * c + g];
+    lns[c] = reinterpret_cast<const f32x4*>(a.ln_s)[8 * w + 4 * c + g];
+    lno[c] = reinterpret_cast<const f32x4*>(a.ln_o)[8 * w + 4 * c + g];
+  }
+  const int ntiles = (E + 15) >> 4;
+  ms_walk wk;
+  if (poisoned >= 0 || !wk.init(ntiles)) return;
+  const f32x4* ef4 = reinterpret_cast<const f32x4*>(a.efeat);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 fn[2];
+  auto issue = [&](int t) {
+    const int row = t * 16 + n;
+    const int64_t rc = row < E ? row : E - 1;
+    fn[0] = ef4[rc * 2];
+    fn[1] = ef4[rc * 2 + 1];
+  };
+  int t = wk.q;
+  issue(t);
+  ms_guard guard{0.f, 0};
+  for (int it = 0; it < wk.n_iter; ++it, t += wk.stride) {
+    f32x4 acc[2] = {b0v[0], b0v[1]};
+    {
+      h8 bh, bl;
+      lb_split8v(g == 0 ? fn[0] : zero, g == 0 ? fn[1] : zero, bh, bl);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[c] = MFMA16H(w0l[c][0], bh, acc[c]);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[c] = MFMA16H(w0h[c][0], bl, acc[c]);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[c] = MFMA16H(w0h[c][0], bh, acc[c]);
+    }
+    issue(min(t + wk.stride, wk.q_last));
+    ms_stage<true>(sB2, w, lane, acc[0], acc[1]);
+    {
+      const float m = ms_wave_max(guard.see(acc[0], acc[1]));
+      if (lane == 0) sMx[w] = m;
+    }
+    __syncthreads();
+    f32x4 acc2[2] = {b1v[0], b1v[1]};
+    ms_gemm<4, 2>(sB2, lane, w1h, w1l, acc2);
+    guard.tile_max(sMx);
+    {
+      const f32x2m p = ms_ln_local(acc2[0], acc2[1]);
+      if (g == 0) sRed[n * 4 + w] = p;
+    }
+    __syncthreads();
+    float mean, rs;
+    ms_ln_combine(sRed, n, ln_inv_d, ln_pad, mean, rs);
+    asm volatile("" : "+v"(fn[0]), "+v"(fn[1]));
+    f32x4* ew = reinterpret_cast<f32x4*>(a.elat) + ((int64_t)t * 8 + 2 * w) * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f32x4 y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = (lns[c][j] * rs) * (acc2[c][j] - mean) + lno[c][j];
+      ew[64 * c] = y;
+    }
+    // (sB2 / sRed / sMx are next written after barriers every wave reaches only once it is done reading them)
+  }
+  guard.commit(a.ctrl, lane);
+}
+
+// =========================================================================================== node kernel
+// Node MLP (+ residual + projection for the next edge MLP): encoder node branch (gns.py:65-72) with NKA k-blocks of
+// input features, or processor update_node_features (gns.py:103-113,120-122) with NKA = 4 latents + 4 k-blocks of
+// aggregated messages.  Wave w owns output blocks 2w, 2w+1 of both Linears and 4w .. 4w+3 of the 256-wide
+// projection: 320 registers of weights (one wave per SIMD, 512 registers each).
+template <int NKA, bool AGG, bool RESID, bool PROJ>
+__global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a) {
+  constexpr int NK0 = NKA + (AGG ? 4 : 0);
+  __shared__ f32x4 sB1[NK0 * 2 * 64];
+  __shared__ f32x4 sB2[4 * 2 * 64];
+  __shared__ f32x4 sB3[4 * 2 * 64];
+  __shared__ __attribute__((aligned(16))) f32x2m sRed[16 * 4];
+  __shared__ __attribute__((aligned(16))) float sMx[3][4];
+  const int poisoned = a.ctrl->overflow_step;
+  const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  h8 w0h[2][NK0], w0l[2][NK0], w1h[2][4], w1l[2][4], wph[PROJ ? 4 : 1][4], wpl[PROJ ? 4 : 1][4];
+  {
+    const f32x4* wb = reinterpret_cast<const f32x4*>(a.w) + lane;
+    ms_wload<NK0, 2>(wb, 2 * w, w0h, w0l);
+    const f32x4* wb1 = wb + 8 * NK0 * 2 * 64;
+    ms_wload<4, 2>(wb1, 2 * w, w1h, w1l);
+    if constexpr (PROJ) ms_wload<4, 4>(wb1 + 8 * 4 * 2 * 64, 4 * w, wph, wpl);
+  }
+  f32x4 b0v[2], b1v[2], lns[2], lno[2], bpv[4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    b0v[c] = reinterpret_cast<const f32x4*>(a.b0)[8 * w + 4 * c + g];
+    b1v[c] = reinterpret_cast<const f32x4*>(a.b1)[8 * w + 4 * c + g];
+    lns[c] = reinterpret_cast<const f32x4*>(a.ln_s)[8 * w + 4 * c + g];
+    lno[c] = reinterpret_cast<const f32x4*>(a.ln_o)[8 * w + 4 * c + g];
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    bpv[c] = PROJ ? reinterpret_cast<const f32x4*>(a.bp)[16 * w + 4 * c + g] : f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (int)((a.n_rows + 15) >> 4);
+  ms_walk wk;
+  if (poisoned >= 0 || !wk.init(ntiles)) return;
+  const f32x4* xin4 = reinterpret_cast<const f32x4*>(a.xin);
+  const bool has_x = w < NKA;  // this wave holds an input k-block (uniform)
+  ms_guard guard{0.f, 0};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+  int t = wk.q;
+  for (int it = 0; it < wk.n_iter; ++it, t += wk.stride) {
+    const int64_t row = (int64_t)t * 16 + n;
+    const bool valid = row < a.n_rows;
+    const int64_t rc = valid ? row : a.n_rows - 1;
+    f32x4 xa[2] = {zero, zero}, ag[2] = {zero, zero};
+    if (has_x) {
+      xa[0] = xin4[rc * (8 * NKA) + 8 * w + g];
+      xa[1] = xin4[rc * (8 * NKA) + 8 * w + 4 + g];
+    }
+    if constexpr (AGG) {
+      if (!a.fused) {
+        ag[0] = reinterpret_cast<const f32x4*>(a.agg)[rc * 32 + 8 * w + g];
+        ag[1] = reinterpret_cast<const f32x4*>(a.agg)[rc * 32 + 8 * w + 4 + g];
+      } else {
+        // one source when the receiver's CSR row lies inside one 16-edge tile (agg[r]), else the per-tile
+        // partial slots in tile order (epilogues of k_edge_ms / k_edge16v)
+        const int k0 = a.row_ptr[rc], k1 = a.row_ptr[rc + 1];
+        const int t0 = k0 >> 4, t1 = (k1 - 1) >> 4;
+        const bool single = t0 == t1;
+        const int nsrc = (k1 <= k0) ? 0 : (single ? 1 : t1 - t0 + 1);
+        auto slot_of = [&](int tt) -> const f32x4* {
+          const float* src = single ? a.agg + rc * 128 : a.part + ((int64_t)tt * 2 + (k0 <= (tt << 4) ? 0 : 1)) * 128;
+          return reinterpret_cast<const f32x4*>(src) + 8 * w + g;
+        };
+        // the first two sources together (a row of ~7-17 edges usually straddles at most one tile boundary)
+        const f32x4* s0 = slot_of(t0);
+        const f32x4* s1 = nsrc >= 2 ? slot_of(t0 + 1) : s0;
+        const f32x4 v00 = s0[0], v01 = s0[4], v10 = s1[0], v11 = s1[4];
+        ag[0] = (nsrc >= 1 ? v00 : zero) + (nsrc >= 2 ? v10 : zero);
+        ag[1] = (nsrc >= 1 ? v01 : zero) + (nsrc >= 2 ? v11 : zero);
+        for (int s = 2; __any(s < nsrc); ++s)
+          if (s < nsrc) {
+            const f32x4* sp = slot_of(t0 + s);
+            ag[0] = ag[0] + sp[0];
+            ag[1] = ag[1] + sp[4];
+          }
+      }
+    }
+    {
+      float m = 0.f;
+      if (has_x) {
+        ms_stage<false>(sB1, w, lane, xa[0], xa[1]);
+        m = guard.see(xa[0], xa[1]);
+      }
+      if constexpr (AGG) {
+        ms_stage<false>(sB1, NKA + w, lane, ag[0], ag[1]);
+        m = fmaxf(m, guard.see(ag[0], ag[1]));
+      }
+      m = ms_wave_max(m);
+      if (lane == 0) sMx[0][w] = m;
+    }
+    __syncthreads();
+    f32x4 acc[2] = {b0v[0], b0v[1]};
+    ms_gemm<NK0, 2>(sB1, lane, w0h, w0l, acc);
+    guard.tile_max(sMx[0]);
+    ms_stage<true>(sB2, w, lane, acc[0], acc[1]);
+    {
+      const float m = ms_wave_max(guard.see(acc[0], acc[1]));
+      if (lane == 0) sMx[1][w] = m;
+    }
+    __syncthreads();
+    f32x4 acc2[2] = {b1v[0], b1v[1]};
+    ms_gemm<4, 2>(sB2, lane, w1h, w1l, acc2);
+    guard.tile_max(sMx[1]);
+    {
+      const f32x2m p = ms_ln_local(acc2[0], acc2[1]);
+      if (g == 0) sRed[n * 4 + w] = p;
+    }
+    __syncthreads();
+    float mean, rs;
+    ms_ln_combine(sRed, n, ln_inv_d, ln_pad, mean, rs);
+    f32x4 y[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[c][j] = (lns[c][j] * rs) * (acc2[c][j] - mean) + lno[c][j];
+      if constexpr (RESID) y[c] = xa[c] + y[c];
+      if (valid) reinterpret_cast<f32x4*>(a.nlat)[rc * 32 + 8 * w + 4 * c + g] = y[c];
+    }
+    if constexpr (PROJ) {
+      ms_stage<false>(sB3, w, lane, y[0], y[1]);
+      {
+        const float m = ms_wave_max(guard.see(y[0], y[1]));
+        if (lane == 0) sMx[2][w] = m;
+      }
+      __syncthreads();
+      guard.tile_max(sMx[2]);
+      f32x4 accp[4] = {bpv[0], bpv[1], bpv[2], bpv[3]};
+      ms_gemm<4, 4>(sB3, lane, wph, wpl, accp);
+      if (valid) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) reinterpret_cast<f32x4*>(a.psr)[rc * 64 + 16 * w + 4 * c + g] = accp[c];
+      }
+    }
+  }
+  guard.commit(a.ctrl, lane);
+}
+
+// =========================================================================================== launchers
+// one tile per workgroup and iteration; two edge workgroups / one node workgroup per CU
+static int ms_grid(int64_t tiles, int per_cu) {
+  int64_t gq = (tiles + 7) / 8 * 8;  // the XCD-aware walk wants a multiple of 8
+  const int64_t cap = 256 * per_cu;
+  return (int)(gq < 8 ? 8 : (gq > cap ? cap : gq));
+}
+
+int lbk_edge_ms(lb_engine* e, const lb_ems_args& a) {
+  const int64_t tiles_cap = ((int64_t)e->e_cap * e->g.B + 15) / 16;
+  const dim3 grid(ms_grid(tiles_cap, 2)), block(MS_THREADS);
+  if (a.skip_elat_store)
+    LB_LAUNCH_TIMED(e, (k_edge_ms<true>), grid, block, a);
+  else
+    LB_LAUNCH_TIMED(e, (k_edge_ms<false>), grid, block, a);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
+int lbk_edge_enc_ms(lb_engine* e, const lb_ems_args& a) {
+  const int64_t tiles_cap = ((int64_t)e->e_cap * e->g.B + 15) / 16;
+  hipLaunchKernelGGL(k_edge_enc_ms, dim3(ms_grid(tiles_cap, 2)), dim3(MS_THREADS), 0, e->stream, a);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
+int lbk_node_ms(lb_engine* e, const lb_nms_args& a, int nka, bool agg, bool resid, bool proj) {
+  const int64_t tiles = (a.n_rows + 15) / 16;
+  const dim3 grid(ms_grid(tiles, 1)), block(MS_THREADS);
+#define LB_NMS(A, G, R)                                                          \
+  do {                                                                           \
+    if (proj)                                                                    \
+      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, true>), grid, block, a);            \
+    else                                                                         \
+      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, false>), grid, block, a);           \
+  } while (0)
+  if (nka == 4 && agg && resid)
+    LB_NMS(4, true, true);
+  else if (nka == 1 && !agg && !resid)
+    LB_NMS(1, false, false);
+  else if (nka == 2 && !agg && !resid)
+    LB_NMS(2, false, false);
+  else if (nka == 3 && !agg && !resid)
+    LB_NMS(3, false, false);
+  else if (nka == 4 && !agg && !resid)
+    LB_NMS(4, false, false);
+  else
+    return lb_fail(LB_ERR_UNSUPPORTED, "k_node_ms<%d,%d,%d> not instantiated", nka, (int)agg, (int)resid);
+#undef LB_NMS
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}

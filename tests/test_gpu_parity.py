@@ -455,10 +455,11 @@ def test_full_size_tgv3d_properties():
     e2 = hcase.engine(2)
     e2.set_particle_type(np.stack([pt, pt]))
     p2, _ = e2.rollout(model.handle(e2, params), np.stack([pos, pos]).astype(np.float64), n_steps)
-    # slot 0 sees the same 16-edge tiles as the B=1 run: bit-identical.  Slot 1's edges start at an
-    # arbitrary offset of the concatenated list, so its receivers are cut by different tile boundaries
-    # and the fp32 partial sums associate differently: equal to fp32 round-off, not bitwise.
-    assert np.array_equal(_np(p2[0]), _np(p1[0]))
+    # Equal to fp32 round-off, not bitwise: slot 1's edges start at an arbitrary offset of the concatenated list,
+    # so its receivers are cut by different tile boundaries and the fp32 partial sums associate differently; and
+    # one 8 k-particle trajectory runs on the small-graph (M-split) kernels while the batch of two is past their
+    # size threshold (the two families sum the same products in a different order).
+    assert np.abs(_np(p2[0]) - _np(p1[0])).max() < 1e-7 * float(ds.metadata["dx"])
     assert np.abs(_np(p2[1]) - _np(p1[0])).max() < 1e-7 * float(ds.metadata["dx"])
 
     # decoder weights zero, bias b: acc == b for every particle, so the rollout is the closed form
@@ -623,7 +624,9 @@ def test_full_size_ldc3d_properties():
     e1 = hcase.engine(1)
     e1.set_particle_type(pt[:1])
     solo, _ = e1.rollout(model.handle(e1, params), pos[:1].astype(np.float64), n_steps)
-    assert np.array_equal(_np(solo)[0], a[0])
+    # one trajectory runs on the small-graph (M-split) kernels, the batch of two may be past their size
+    # threshold: the same products summed in another order - equal to fp32 round-off, not bitwise
+    assert np.abs(_np(solo)[0] - a[0]).max() < 1e-7 * float(ds.metadata["dx"])
     kin = (pt[0] == 1) | (pt[0] == 2)
     assert kin.any() and (~kin).any()
     truth = np.transpose(pos[0][:, isl:isl + n_steps], (1, 0, 2)).astype(np.float64)
