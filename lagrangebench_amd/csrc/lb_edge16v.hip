@@ -30,7 +30,10 @@
 // 4 no stores, 8 no GEMMs, 16 no LayerNorm / scan (epilogue VALU).
 // SKIP: last processor layer - the updated edge latents have no reader (compile-time so that the
 // residual path is branch-free: a store under a branch costs a vmcnt(0) drain at the join).
-template <int WPS, bool RELOAD, bool SKIP, int ABL = 0, bool PRIO = false>
+// NT: the edge latents are streamed with nontemporal loads / stores (batches whose latents exceed the 256 MiB
+// Infinity Cache); a single trajectory's latents (tens of MB) are read back from the cache by the next layer, so
+// small graphs use plain accesses.
+template <int WPS, bool RELOAD, bool SKIP, int ABL = 0, bool PRIO = false, bool NT = true>
 __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
   constexpr int THREADS = WPS * 256, WAVES = WPS * 4;
   constexpr int NW0 = 4096;
@@ -112,7 +115,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
       for (int mb = 0; mb < 8; ++mb) {
         // streamed once per layer: nontemporal unless the RELOAD variant wants the tile back from L2
         ve[mb] = (ABL & 2) ? f32x4{1.f, 2.f, (float)t, (float)mb}
-                           : (RELOAD ? er[64 * mb] : __builtin_nontemporal_load(&er[64 * mb]));
+                           : ((RELOAD || !NT) ? er[64 * mb] : __builtin_nontemporal_load(&er[64 * mb]));
         p0[mb] = (ABL & 1) ? f32x4{.1f, .2f, (float)s_c, (float)mb} : ps[4 * mb];
         acc[mb] = (ABL & 1) ? f32x4{.3f, .1f, (float)r_c, (float)mb} : pr[4 * mb];
       }
@@ -161,7 +164,12 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
     if constexpr (!SKIP && !(ABL & 4)) {
       f32x4* ew = reinterpret_cast<f32x4*>(a.elat_out ? a.elat_out : a.elat) + (int64_t)t * 512 + lane;
 #pragma unroll
-      for (int mb = 0; mb < 8; ++mb) __builtin_nontemporal_store(lb_pk_add(ve[mb], y[mb]), &ew[64 * mb]);
+      for (int mb = 0; mb < 8; ++mb) {
+        if constexpr (NT)
+          __builtin_nontemporal_store(lb_pk_add(ve[mb], y[mb]), &ew[64 * mb]);
+        else
+          ew[64 * mb] = lb_pk_add(ve[mb], y[mb]);
+      }
     }
     // fused jraph.segment_sum: segmented Hillis-Steele scan inside each 16-lane DPP row
     const int rr = valid ? r_cur : (-1 - n);
@@ -609,6 +617,8 @@ int lbk_edge16v(lb_engine* e, const lb_edge16_args& a, int variant) {
     else                                                                                                \
       LB_LAUNCH_TIMED(e, (k_edge16v<W, R, false, 0, true>), dim3(G), dim3(W * 256), a);                 \
   } while (0)
+  // latents of the whole graph <= 96 MiB (LB_EDGE_NT_MIN_TILES tiles): cache-resident between layers, plain accesses
+  static const int64_t nt_min_tiles = getenv("LB_EDGE_NT_MIN_TILES") ? atoll(getenv("LB_EDGE_NT_MIN_TILES")) : 12288;
   // Small graphs (one 2.5 k-particle trajectory = ~1000 tiles): a launch is the latency chain
   // "stage 133 KiB of weights -> one tile per wave", so launch no more workgroups than there are tiles for.
   // The tile count is bounded on the host by the frozen capacity (the real count lives on the device).
@@ -622,6 +632,11 @@ int lbk_edge16v(lb_engine* e, const lb_edge16_args& a, int variant) {
     // (one wave per SIMD, i.e. twice the workgroups, measures slower: 17 vs 13.8 us per launch on a 20 k-edge
     // graph - every workgroup stages the 133 KiB of weights; three waves per SIMD: 15.4 us)
     LB_E16V(2, false, grid_for(8));
+  } else if (variant == 0 && tiles_cap < nt_min_tiles) {
+    if (a.skip_elat_store)
+      LB_LAUNCH_TIMED(e, (k_edge16v<2, false, true, 0, true, false>), dim3(256), dim3(512), a);
+    else
+      LB_LAUNCH_TIMED(e, (k_edge16v<2, false, false, 0, true, false>), dim3(256), dim3(512), a);
   } else {
     switch (variant) {
       case 0: LB_E16V(2, false, 256); break;   // default: two waves per SIMD measure faster than three

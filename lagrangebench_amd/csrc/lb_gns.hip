@@ -508,23 +508,38 @@ int lbk_segment_sum(lb_engine* e, const float* msg, float* out, int D) {
 }
 
 // ================================================================================= forward
-// Small graphs (one trajectory per GPU) run on the M-split kernels of lb_msplit.hip: LB_MSPLIT=0 / 1 forces the
-// choice, LB_MS_MAX_TILES moves the size threshold (16-edge tiles of the frozen capacity).
-static bool lb_use_msplit(const lb_engine* e) {
+// Small graphs (one trajectory per GPU) run on the M-split kernels of lb_msplit.hip.  Measured (round 3, B = 1):
+// the node kernel beats the LDS-ring kernels up to the 16 k-node mark where lb_node16s takes over (TGV2D-2.5k 15.4 ->
+// 9.4 us, LDC3D-8k 19.3 -> 15.5 us per launch); the edge kernels win on the 2D graphs (TGV2D 13.3 -> 13.0, RPF2D) but
+// repeat the per-tile index / segment arithmetic in each of their four waves, so from ~3 k tiles the wave-per-tile
+// kernel is faster (LDC3D-8k: 38 vs 44 us).  LB_MSPLIT=0 / 1 forces the choice for all of them,
+// LB_MS_MAX_TILES / LB_MS_MAX_NODES move the thresholds.
+static int lb_msplit_env() {
   static const int env = getenv("LB_MSPLIT") ? atoi(getenv("LB_MSPLIT")) : -1;
-  static const int64_t max_tiles = getenv("LB_MS_MAX_TILES") ? atoll(getenv("LB_MS_MAX_TILES")) : 16384;
+  return env;
+}
+static bool lb_use_msplit_edge(const lb_engine* e) {
+  static const int64_t max_tiles = getenv("LB_MS_MAX_TILES") ? atoll(getenv("LB_MS_MAX_TILES")) : 3072;
+  const int env = lb_msplit_env();
   if (!e->f16x2 || !e->fused_agg || e->edge_tile != 16 || env == 0) return false;
   if (env == 1) return true;
   return ((int64_t)e->e_cap * e->g.B + 15) / 16 <= max_tiles;
 }
+static bool lb_use_msplit_node(const lb_engine* e) {
+  static const int64_t max_nodes = getenv("LB_MS_MAX_NODES") ? atoll(getenv("LB_MS_MAX_NODES")) : 16384;
+  const int env = lb_msplit_env();
+  if (!e->f16x2 || !e->fused_agg || e->edge_tile != 16 || env == 0) return false;
+  if (env == 1) return true;
+  return e->BN <= max_nodes;
+}
 
 int lbk_gns_forward(lb_engine* e, lb_gns* g) {
   if (g->generic) return lbk_gns_forward_generic(e, g);
-  const bool ms_all = lb_use_msplit(e);
   // LB_MS_PARTS (debug / ablation): bit 0 encoder node, 1 encoder edge, 2 processor edge, 3 processor node
   static const int ms_parts = getenv("LB_MS_PARTS") ? atoi(getenv("LB_MS_PARTS")) : 15;
-  const bool ms_en = ms_all && (ms_parts & 1), ms_ee = ms_all && (ms_parts & 2);
-  const bool ms_pe = ms_all && (ms_parts & 4), ms_pn = ms_all && (ms_parts & 8);
+  const bool ms_e = lb_use_msplit_edge(e), ms_n = lb_use_msplit_node(e);
+  const bool ms_en = ms_n && (ms_parts & 1), ms_ee = ms_e && (ms_parts & 2);
+  const bool ms_pe = ms_e && (ms_parts & 4), ms_pn = ms_n && (ms_parts & 8);
   hipStream_t s = e->stream;
   const int64_t BN = e->BN;
   const int ntile_n = (int)((BN + LB_TILE - 1) / LB_TILE);

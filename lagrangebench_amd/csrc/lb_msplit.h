@@ -17,6 +17,7 @@ struct lb_ems_args {      // edge kernels
   float* agg;             // [BN][128] rows complete inside one tile
   float* part;            // [tiles][2][128] segments cut by a tile boundary
   int skip_elat_store;    // last processor layer: the updated edge latents have no reader
+  long long* dbg;         // LB_MS_DBG=1: shader-clock stamps of workgroup 0 (null in the product path)
 };
 
 struct lb_nms_args {      // node kernel
@@ -35,6 +36,7 @@ struct lb_nms_args {      // node kernel
   const float* ln_o;
   const float* bp;        // [256] projection bias
   float* psr;             // out [rows][256]
+  long long* dbg;         // LB_MS_DBG=1: shader-clock stamps of workgroup 0 (null in the product path)
 };
 
 void lb_pack_ms(const float* w, int K, int M, int nkb, int npw, bool perm, float* out);

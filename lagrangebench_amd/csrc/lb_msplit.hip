@@ -26,6 +26,7 @@
 // Arithmetic = the f16x2 scheme of lb_f16x2.h (lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x32_f16, fp32 accumulate).
 // The f16x2 range guard is EXHAUSTIVE here: every GEMM operand of every tile is folded into a running maximum
 // (LARGE / non-finite) and a per-tile maximum combined across the waves (TINY), one atomicOr per wave and launch.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -78,6 +79,11 @@ typedef float f32x2m __attribute__((ext_vector_type(2)));
 typedef _Float16 h2m __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2m __attribute__((ext_vector_type(2)));
 
+// LB_MS_DBG=1 (debug): wave 0 of workgroup 0 stamps the shader clock at phase boundaries
+#define MS_STAMP(k)                                                              \
+  do {                                                                           \
+    if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[k] = clock64();      \
+  } while (0)
 #define MS_WAVES 4
 #define MS_THREADS (MS_WAVES * 64)
 
@@ -264,20 +270,7 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
   const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
-  // this wave's weight fragments, straight into registers (in bounds whatever the state)
-  h8 w0h[2][4], w0l[2][4], w1h[2][4], w1l[2][4];
-  {
-    const f32x4* wb = reinterpret_cast<const f32x4*>(a.w) + lane;
-    ms_wload<4, 2>(wb, 2 * w, w0h, w0l);
-    ms_wload<4, 2>(wb + 8 * 4 * 2 * 64, 2 * w, w1h, w1l);
-  }
-  f32x4 b1v[2], lns[2], lno[2];
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    b1v[c] = reinterpret_cast<const f32x4*>(a.b1)[8 * w + 4 * c + g];
-    lns[c] = reinterpret_cast<const f32x4*>(a.ln_s)[8 * w + 4 * c + g];
-    lno[c] = reinterpret_cast<const f32x4*>(a.ln_o)[8 * w + 4 * c + g];
-  }
+  MS_STAMP(0);
   const int ntiles = (E + 15) >> 4;
   ms_walk wk;
   if (poisoned >= 0 || !wk.init(ntiles)) return;  // uniform over the workgroup
@@ -302,10 +295,26 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
     nr = r_i;
     nrb = lb_edge_probe(a.receivers, t, lane, E);
   };
+  // Launch prologue = the latency chain "control block -> indices -> gathers": the first tile's loads go out
+  // BEFORE the weights (vmcnt retires in order: a wait for the gathers must not cover the 32 KiB of weights)
   int t = wk.q;
   load_idx(t);
   issue(t);
   load_idx(min(t + wk.stride, wk.q_last));
+  // this wave's weight fragments, straight into registers
+  h8 w0h[2][4], w0l[2][4], w1h[2][4], w1l[2][4];
+  {
+    const f32x4* wb = reinterpret_cast<const f32x4*>(a.w) + lane;
+    ms_wload<4, 2>(wb, 2 * w, w0h, w0l);
+    ms_wload<4, 2>(wb + 8 * 4 * 2 * 64, 2 * w, w1h, w1l);
+  }
+  f32x4 b1v[2], lns[2], lno[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    b1v[c] = reinterpret_cast<const f32x4*>(a.b1)[8 * w + 4 * c + g];
+    lns[c] = reinterpret_cast<const f32x4*>(a.ln_s)[8 * w + 4 * c + g];
+    lno[c] = reinterpret_cast<const f32x4*>(a.ln_o)[8 * w + 4 * c + g];
+  }
   ms_guard guard{0.f, 0};
 
   for (int it = 0; it < wk.n_iter; ++it, t += wk.stride) {
@@ -316,6 +325,7 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
       acc[c] = nps[c] + npr[c];
     }
     const int rcur = nr, rb = nrb;
+    if (it < 3) MS_STAMP(1 + 8 * it);
     ms_stage<false>(sB1, w, lane, ve[0], ve[1]);
     {
       const float m = ms_wave_max(guard.see(ve[0], ve[1]));
@@ -324,7 +334,9 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
     // the next tile's loads (and the indices of the one after) go out before this tile's GEMMs
     issue(min(t + wk.stride, wk.q_last));
     load_idx(min(t + 2 * wk.stride, wk.q_last));
+    if (it < 3) MS_STAMP(2 + 8 * it);
     __syncthreads();
+    if (it < 3) MS_STAMP(3 + 8 * it);
     ms_gemm<4, 2>(sB1, lane, w0h, w0l, acc);
     guard.tile_max(sMx[0]);
     ms_stage<true>(sB2, w, lane, acc[0], acc[1]);
@@ -332,7 +344,9 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
       const float m = ms_wave_max(guard.see(acc[0], acc[1]));
       if (lane == 0) sMx[1][w] = m;
     }
+    if (it < 3) MS_STAMP(4 + 8 * it);
     __syncthreads();
+    if (it < 3) MS_STAMP(5 + 8 * it);
     f32x4 acc2[2] = {b1v[0], b1v[1]};
     ms_gemm<4, 2>(sB2, lane, w1h, w1l, acc2);
     guard.tile_max(sMx[1]);
@@ -340,7 +354,9 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
       const f32x2m p = ms_ln_local(acc2[0], acc2[1]);
       if (g == 0) sRed[n * 4 + w] = p;
     }
+    if (it < 3) MS_STAMP(6 + 8 * it);
     __syncthreads();
+    if (it < 3) MS_STAMP(7 + 8 * it);
     float mean, rs;
     ms_ln_combine(sRed, n, ln_inv_d, ln_pad, mean, rs);
     f32x4 y[2];
@@ -350,6 +366,7 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
       for (int j = 0; j < 4; ++j) y[c][j] = (lns[c][j] * rs) * (acc2[c][j] - mean) + lno[c][j];
     // take delivery of the prefetched tile HERE, while only loads are in flight
     asm volatile("" : "+v"(nve[0]), "+v"(nve[1]), "+v"(nps[0]), "+v"(nps[1]), "+v"(npr[0]), "+v"(npr[1]), "+v"(nrb));
+    if (it < 3) MS_STAMP(8 + 8 * it);
     const int row = t * 16 + n;
     const bool valid = row < E;
     if (!SKIP) {
@@ -381,7 +398,9 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
       d4[4] = y[1];
     }
   }
+  MS_STAMP(30);
   guard.commit(a.ctrl, lane);
+  MS_STAMP(31);
 }
 
 // Encoder edge MLP (gns.py:73-84): e0 = LayerNorm(W1 relu(W0 f + b0) + b1), f = (rel_disp, rel_dist) zero-padded
@@ -472,19 +491,90 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_enc_ms(lb_ems_args a) {
 // Node MLP (+ residual + projection for the next edge MLP): encoder node branch (gns.py:65-72) with NKA k-blocks of
 // input features, or processor update_node_features (gns.py:103-113,120-122) with NKA = 4 latents + 4 k-blocks of
 // aggregated messages.  Wave w owns output blocks 2w, 2w+1 of both Linears and 4w .. 4w+3 of the 256-wide
-// projection: 320 registers of weights (one wave per SIMD, 512 registers each).
-template <int NKA, bool AGG, bool RESID, bool PROJ>
+// projection: 320 registers of weights (one wave per SIMD, 512 registers each).  T tiles of 16 nodes per iteration
+// (their loads are in flight together; the weights are reused from registers).
+template <int NKA, bool AGG, bool RESID, bool PROJ, int T>
 __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a) {
   constexpr int NK0 = NKA + (AGG ? 4 : 0);
-  __shared__ f32x4 sB1[NK0 * 2 * 64];
-  __shared__ f32x4 sB2[4 * 2 * 64];
-  __shared__ f32x4 sB3[4 * 2 * 64];
-  __shared__ __attribute__((aligned(16))) f32x2m sRed[16 * 4];
-  __shared__ __attribute__((aligned(16))) float sMx[3][4];
+  __shared__ f32x4 sB1[T][NK0 * 2 * 64];
+  __shared__ f32x4 sB2[T][4 * 2 * 64];
+  __shared__ f32x4 sB3[PROJ ? T : 1][4 * 2 * 64];
+  __shared__ __attribute__((aligned(16))) f32x2m sRed[T][16 * 4];
+  __shared__ __attribute__((aligned(16))) float sMx[3][T][4];
   const int poisoned = a.ctrl->overflow_step;
   const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
+  const int ntiles = (int)((a.n_rows + 15) >> 4);
+  ms_walk wk;
+  if (poisoned >= 0 || !wk.init((ntiles + T - 1) / T)) return;
+  const f32x4* xin4 = reinterpret_cast<const f32x4*>(a.xin);
+  const bool has_x = w < NKA;  // this wave holds an input k-block (uniform)
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+  // one iteration's inputs: rows + (fused aggregation) the per-row sources.  Issued BEFORE the weights on the
+  // first iteration (vmcnt retires in order: the wait for the rows must not cover 80 KiB of weights).
+  f32x4 xa[T][2], ag[T][2];
+  bool valid[T];
+  int64_t rcv[T];
+  auto load_rows = [&](int q) {
+    int k0[T], k1[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      const int64_t row = ((int64_t)q * T + i) * 16 + n;
+      valid[i] = row < a.n_rows;
+      rcv[i] = valid[i] ? row : a.n_rows - 1;
+      xa[i][0] = xa[i][1] = zero;
+      if (has_x) {
+        xa[i][0] = xin4[rcv[i] * (8 * NKA) + 8 * w + g];
+        xa[i][1] = xin4[rcv[i] * (8 * NKA) + 8 * w + 4 + g];
+      }
+      if constexpr (AGG) {
+        if (a.fused) {
+          k0[i] = a.row_ptr[rcv[i]];
+          k1[i] = a.row_ptr[rcv[i] + 1];
+        }
+      }
+    }
+    if constexpr (AGG) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        const int64_t rc = rcv[i];
+        if (!a.fused) {
+          ag[i][0] = reinterpret_cast<const f32x4*>(a.agg)[rc * 32 + 8 * w + g];
+          ag[i][1] = reinterpret_cast<const f32x4*>(a.agg)[rc * 32 + 8 * w + 4 + g];
+        } else {
+          // one source when the receiver's CSR row lies inside one 16-edge tile (agg[r]), else the per-tile
+          // partial slots in tile order (epilogues of k_edge_ms / k_edge16v)
+          const int t0 = k0[i] >> 4, t1 = (k1[i] - 1) >> 4;
+          const bool single = t0 == t1;
+          const int nsrc = (k1[i] <= k0[i]) ? 0 : (single ? 1 : t1 - t0 + 1);
+          const int kk0 = k0[i];
+          auto slot_of = [&](int tt) -> const f32x4* {
+            const float* src = single ? a.agg + rc * 128 : a.part + ((int64_t)tt * 2 + (kk0 <= (tt << 4) ? 0 : 1)) * 128;
+            return reinterpret_cast<const f32x4*>(src) + 8 * w + g;
+          };
+          // the first two sources together (a row of ~7-17 edges usually straddles at most one tile boundary)
+          const f32x4* s0 = slot_of(t0);
+          const f32x4* s1 = nsrc >= 2 ? slot_of(t0 + 1) : s0;
+          const f32x4 v00 = s0[0], v01 = s0[4], v10 = s1[0], v11 = s1[4];
+          ag[i][0] = (nsrc >= 1 ? v00 : zero) + (nsrc >= 2 ? v10 : zero);
+          ag[i][1] = (nsrc >= 1 ? v01 : zero) + (nsrc >= 2 ? v11 : zero);
+          for (int s = 2; __any(s < nsrc); ++s)
+            if (s < nsrc) {
+              const f32x4* sp = slot_of(t0 + s);
+              ag[i][0] = ag[i][0] + sp[0];
+              ag[i][1] = ag[i][1] + sp[4];
+            }
+        }
+      }
+    }
+  };
+  MS_STAMP(0);
+  int q = wk.q;
+  load_rows(q);
+  MS_STAMP(1);
+
   h8 w0h[2][NK0], w0l[2][NK0], w1h[2][4], w1l[2][4], wph[PROJ ? 4 : 1][4], wpl[PROJ ? 4 : 1][4];
   {
     const f32x4* wb = reinterpret_cast<const f32x4*>(a.w) + lane;
@@ -503,129 +593,142 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a) {
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c)
-    bpv[c] = PROJ ? reinterpret_cast<const f32x4*>(a.bp)[16 * w + 4 * c + g] : f32x4{0.f, 0.f, 0.f, 0.f};
-  const int ntiles = (int)((a.n_rows + 15) >> 4);
-  ms_walk wk;
-  if (poisoned >= 0 || !wk.init(ntiles)) return;
-  const f32x4* xin4 = reinterpret_cast<const f32x4*>(a.xin);
-  const bool has_x = w < NKA;  // this wave holds an input k-block (uniform)
+    bpv[c] = PROJ ? reinterpret_cast<const f32x4*>(a.bp)[16 * w + 4 * c + g] : zero;
   ms_guard guard{0.f, 0};
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
-  int t = wk.q;
-  for (int it = 0; it < wk.n_iter; ++it, t += wk.stride) {
-    const int64_t row = (int64_t)t * 16 + n;
-    const bool valid = row < a.n_rows;
-    const int64_t rc = valid ? row : a.n_rows - 1;
-    f32x4 xa[2] = {zero, zero}, ag[2] = {zero, zero};
-    if (has_x) {
-      xa[0] = xin4[rc * (8 * NKA) + 8 * w + g];
-      xa[1] = xin4[rc * (8 * NKA) + 8 * w + 4 + g];
-    }
-    if constexpr (AGG) {
-      if (!a.fused) {
-        ag[0] = reinterpret_cast<const f32x4*>(a.agg)[rc * 32 + 8 * w + g];
-        ag[1] = reinterpret_cast<const f32x4*>(a.agg)[rc * 32 + 8 * w + 4 + g];
-      } else {
-        // one source when the receiver's CSR row lies inside one 16-edge tile (agg[r]), else the per-tile
-        // partial slots in tile order (epilogues of k_edge_ms / k_edge16v)
-        const int k0 = a.row_ptr[rc], k1 = a.row_ptr[rc + 1];
-        const int t0 = k0 >> 4, t1 = (k1 - 1) >> 4;
-        const bool single = t0 == t1;
-        const int nsrc = (k1 <= k0) ? 0 : (single ? 1 : t1 - t0 + 1);
-        auto slot_of = [&](int tt) -> const f32x4* {
-          const float* src = single ? a.agg + rc * 128 : a.part + ((int64_t)tt * 2 + (k0 <= (tt << 4) ? 0 : 1)) * 128;
-          return reinterpret_cast<const f32x4*>(src) + 8 * w + g;
-        };
-        // the first two sources together (a row of ~7-17 edges usually straddles at most one tile boundary)
-        const f32x4* s0 = slot_of(t0);
-        const f32x4* s1 = nsrc >= 2 ? slot_of(t0 + 1) : s0;
-        const f32x4 v00 = s0[0], v01 = s0[4], v10 = s1[0], v11 = s1[4];
-        ag[0] = (nsrc >= 1 ? v00 : zero) + (nsrc >= 2 ? v10 : zero);
-        ag[1] = (nsrc >= 1 ? v01 : zero) + (nsrc >= 2 ? v11 : zero);
-        for (int s = 2; __any(s < nsrc); ++s)
-          if (s < nsrc) {
-            const f32x4* sp = slot_of(t0 + s);
-            ag[0] = ag[0] + sp[0];
-            ag[1] = ag[1] + sp[4];
-          }
-      }
-    }
-    {
+  MS_STAMP(2);
+  for (int it = 0; it < wk.n_iter; ++it, q += wk.stride) {
+    if (it > 0) load_rows(q);
+    if (it < 2) MS_STAMP(3 + 12 * it);
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
       float m = 0.f;
       if (has_x) {
-        ms_stage<false>(sB1, w, lane, xa[0], xa[1]);
-        m = guard.see(xa[0], xa[1]);
+        ms_stage<false>(sB1[i], w, lane, xa[i][0], xa[i][1]);
+        m = guard.see(xa[i][0], xa[i][1]);
       }
       if constexpr (AGG) {
-        ms_stage<false>(sB1, NKA + w, lane, ag[0], ag[1]);
-        m = fmaxf(m, guard.see(ag[0], ag[1]));
+        ms_stage<false>(sB1[i], NKA + w, lane, ag[i][0], ag[i][1]);
+        m = fmaxf(m, guard.see(ag[i][0], ag[i][1]));
       }
       m = ms_wave_max(m);
-      if (lane == 0) sMx[0][w] = m;
+      if (lane == 0) sMx[0][i][w] = m;
     }
+    if (it < 2) MS_STAMP(4 + 12 * it);
     __syncthreads();
-    f32x4 acc[2] = {b0v[0], b0v[1]};
-    ms_gemm<NK0, 2>(sB1, lane, w0h, w0l, acc);
-    guard.tile_max(sMx[0]);
-    ms_stage<true>(sB2, w, lane, acc[0], acc[1]);
-    {
-      const float m = ms_wave_max(guard.see(acc[0], acc[1]));
-      if (lane == 0) sMx[1][w] = m;
-    }
-    __syncthreads();
-    f32x4 acc2[2] = {b1v[0], b1v[1]};
-    ms_gemm<4, 2>(sB2, lane, w1h, w1l, acc2);
-    guard.tile_max(sMx[1]);
-    {
-      const f32x2m p = ms_ln_local(acc2[0], acc2[1]);
-      if (g == 0) sRed[n * 4 + w] = p;
-    }
-    __syncthreads();
-    float mean, rs;
-    ms_ln_combine(sRed, n, ln_inv_d, ln_pad, mean, rs);
-    f32x4 y[2];
+    if (it < 2) MS_STAMP(5 + 12 * it);
+    f32x4 acc[T][2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) y[c][j] = (lns[c][j] * rs) * (acc2[c][j] - mean) + lno[c][j];
-      if constexpr (RESID) y[c] = xa[c] + y[c];
-      if (valid) reinterpret_cast<f32x4*>(a.nlat)[rc * 32 + 8 * w + 4 * c + g] = y[c];
+    for (int i = 0; i < T; ++i) {
+      acc[i][0] = b0v[0];
+      acc[i][1] = b0v[1];
+      ms_gemm<NK0, 2>(sB1[i], lane, w0h, w0l, acc[i]);
     }
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      guard.tile_max(sMx[0][i]);
+      ms_stage<true>(sB2[i], w, lane, acc[i][0], acc[i][1]);
+      const float m = ms_wave_max(guard.see(acc[i][0], acc[i][1]));
+      if (lane == 0) sMx[1][i][w] = m;
+    }
+    if (it < 2) MS_STAMP(6 + 12 * it);
+    __syncthreads();
+    if (it < 2) MS_STAMP(7 + 12 * it);
+    f32x4 acc2[T][2];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      acc2[i][0] = b1v[0];
+      acc2[i][1] = b1v[1];
+      ms_gemm<4, 2>(sB2[i], lane, w1h, w1l, acc2[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      guard.tile_max(sMx[1][i]);
+      const f32x2m p = ms_ln_local(acc2[i][0], acc2[i][1]);
+      if (g == 0) sRed[i][n * 4 + w] = p;
+    }
+    if (it < 2) MS_STAMP(8 + 12 * it);
+    __syncthreads();
+    if (it < 2) MS_STAMP(9 + 12 * it);
+    f32x4 y[T][2];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      float mean, rs;
+      ms_ln_combine(sRed[i], n, ln_inv_d, ln_pad, mean, rs);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[i][c][j] = (lns[c][j] * rs) * (acc2[i][c][j] - mean) + lno[c][j];
+        if constexpr (RESID) y[i][c] = xa[i][c] + y[i][c];
+        if (valid[i]) reinterpret_cast<f32x4*>(a.nlat)[rcv[i] * 32 + 8 * w + 4 * c + g] = y[i][c];
+      }
+      if constexpr (PROJ) {
+        ms_stage<false>(sB3[i], w, lane, y[i][0], y[i][1]);
+        const float m = ms_wave_max(guard.see(y[i][0], y[i][1]));
+        if (lane == 0) sMx[2][i][w] = m;
+      }
+    }
+    if (it < 2) MS_STAMP(10 + 12 * it);
     if constexpr (PROJ) {
-      ms_stage<false>(sB3, w, lane, y[0], y[1]);
-      {
-        const float m = ms_wave_max(guard.see(y[0], y[1]));
-        if (lane == 0) sMx[2][w] = m;
-      }
       __syncthreads();
-      guard.tile_max(sMx[2]);
-      f32x4 accp[4] = {bpv[0], bpv[1], bpv[2], bpv[3]};
-      ms_gemm<4, 4>(sB3, lane, wph, wpl, accp);
-      if (valid) {
+      if (it < 2) MS_STAMP(11 + 12 * it);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) reinterpret_cast<f32x4*>(a.psr)[rc * 64 + 16 * w + 4 * c + g] = accp[c];
+      for (int i = 0; i < T; ++i) {
+        guard.tile_max(sMx[2][i]);
+        f32x4 accp[4] = {bpv[0], bpv[1], bpv[2], bpv[3]};
+        ms_gemm<4, 4>(sB3[i], lane, wph, wpl, accp);
+        if (valid[i]) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) reinterpret_cast<f32x4*>(a.psr)[rcv[i] * 64 + 16 * w + 4 * c + g] = accp[c];
+        }
       }
     }
+    if (it < 2) MS_STAMP(12 + 12 * it);
   }
+  MS_STAMP(30);
   guard.commit(a.ctrl, lane);
+  MS_STAMP(31);
 }
 
 // =========================================================================================== launchers
 // one tile per workgroup and iteration; two edge workgroups / one node workgroup per CU
+// LB_MS_DBG=1: every launch is followed by a device sync and a dump of workgroup 0's stamps (debug only)
+static long long* ms_dbg_buf() {
+  static const bool on = getenv("LB_MS_DBG") && getenv("LB_MS_DBG")[0] == '1';
+  static long long* buf = nullptr;
+  if (on && !buf) {
+    if (hipMalloc((void**)&buf, 32 * sizeof(long long)) != hipSuccess) buf = nullptr;
+  }
+  if (buf) (void)hipMemset(buf, 0, 32 * sizeof(long long));
+  return buf;
+}
+static void ms_dbg_dump(const char* what, long long* buf) {
+  if (!buf) return;
+  long long h[32];
+  (void)hipDeviceSynchronize();
+  if (hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+  fprintf(stderr, "[ms_dbg] %s:", what);
+  for (int k = 0; k < 32; ++k)
+    if (h[k]) fprintf(stderr, " %d:%lld", k, h[k] - h[0]);
+  fprintf(stderr, "\n");
+}
+
 static int ms_grid(int64_t tiles, int per_cu) {
   int64_t gq = (tiles + 7) / 8 * 8;  // the XCD-aware walk wants a multiple of 8
   const int64_t cap = 256 * per_cu;
   return (int)(gq < 8 ? 8 : (gq > cap ? cap : gq));
 }
 
-int lbk_edge_ms(lb_engine* e, const lb_ems_args& a) {
+int lbk_edge_ms(lb_engine* e, const lb_ems_args& a_in) {
+  lb_ems_args a = a_in;
+  a.dbg = ms_dbg_buf();
   const int64_t tiles_cap = ((int64_t)e->e_cap * e->g.B + 15) / 16;
   const dim3 grid(ms_grid(tiles_cap, 2)), block(MS_THREADS);
   if (a.skip_elat_store)
     LB_LAUNCH_TIMED(e, (k_edge_ms<true>), grid, block, a);
   else
     LB_LAUNCH_TIMED(e, (k_edge_ms<false>), grid, block, a);
+  ms_dbg_dump("edge", a.dbg);
   LB_HIP(hipGetLastError());
   return LB_OK;
 }
@@ -637,15 +740,24 @@ int lbk_edge_enc_ms(lb_engine* e, const lb_ems_args& a) {
   return LB_OK;
 }
 
-int lbk_node_ms(lb_engine* e, const lb_nms_args& a, int nka, bool agg, bool resid, bool proj) {
+int lbk_node_ms(lb_engine* e, const lb_nms_args& a_in, int nka, bool agg, bool resid, bool proj) {
+  lb_nms_args a = a_in;
+  a.dbg = ms_dbg_buf();
   const int64_t tiles = (a.n_rows + 15) / 16;
-  const dim3 grid(ms_grid(tiles, 1)), block(MS_THREADS);
+  // more than one tile per CU: two tiles per iteration (both tiles' loads in flight together)
+  static const int t_env = getenv("LB_MS_NODE_T") ? atoi(getenv("LB_MS_NODE_T")) : 0;
+  const bool t2 = t_env ? t_env == 2 : tiles > 256;
+  const dim3 grid(ms_grid(t2 ? (tiles + 1) / 2 : tiles, 1)), block(MS_THREADS);
 #define LB_NMS(A, G, R)                                                          \
   do {                                                                           \
-    if (proj)                                                                    \
-      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, true>), grid, block, a);            \
+    if (proj && t2)                                                              \
+      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, true, 2>), grid, block, a);         \
+    else if (proj)                                                               \
+      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, true, 1>), grid, block, a);         \
+    else if (t2)                                                                 \
+      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, false, 2>), grid, block, a);        \
     else                                                                         \
-      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, false>), grid, block, a);           \
+      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, false, 1>), grid, block, a);        \
   } while (0)
   if (nka == 4 && agg && resid)
     LB_NMS(4, true, true);
@@ -660,6 +772,7 @@ int lbk_node_ms(lb_engine* e, const lb_nms_args& a, int nka, bool agg, bool resi
   else
     return lb_fail(LB_ERR_UNSUPPORTED, "k_node_ms<%d,%d,%d> not instantiated", nka, (int)agg, (int)resid);
 #undef LB_NMS
+  ms_dbg_dump("node", a.dbg);
   LB_HIP(hipGetLastError());
   return LB_OK;
 }
