@@ -101,10 +101,19 @@ def main():
     ap.add_argument("--shuffle", action="store_true",
                     help="randomly permute the particle ids (memory-locality ablation; default: lattice order)")
     ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step timed region is repeated this many times; value / ms_per_step = the median")
+    ap.add_argument("--cpu-baseline-only", default=None, metavar="WORKLOAD",
+                    help="(internal) run only the CPU baseline leg of WORKLOAD and print its JSON object")
+    ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 (LB_MATH=f32 arithmetic) sub-run")
     args = ap.parse_args()
+    if args.cpu_baseline_only:   # legs one after the other in this process: they must not compete for the cores
+        print(json.dumps({w: cpu_baseline_leg(w, args.mp_steps) for w in args.cpu_baseline_only.split(",")}), flush=True)
+        return
 
     from lagrangebench_amd import dist as lbdist
     rank, local_rank, world = lbdist.init()
+    cpu_jobs = None
     if world != args.gpus:
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
@@ -145,12 +154,18 @@ def main():
         eng.rollout(handle, traj, K)
     # warm-up: W steps of the same rollout
     eng.rollout(handle, traj, max(W, 1))
-    lbdist.barrier(device)
-    t0 = time.perf_counter()
-    pred, n_realloc = eng.rollout(handle, traj, K)  # host-synchronous at the end
-    lbdist.barrier(device)
-    dt = time.perf_counter() - t0
-    dt = lbdist.max_over_ranks(dt, device)
+    # timed region: EXACTLY K steps between barrier + synchronize on both sides, max over ranks; repeated
+    # `--repeats` times (same rollout, same inputs) - value / ms_per_step are the MEDIAN repeat, all repeats listed
+    dts, n_realloc = [], 0
+    for _ in range(max(1, args.repeats)):
+        lbdist.barrier(device)
+        t0 = time.perf_counter()
+        pred, nr = eng.rollout(handle, traj, K)  # host-synchronous at the end
+        lbdist.barrier(device)
+        dts.append(lbdist.max_over_ranks(time.perf_counter() - t0, device))
+        n_realloc += nr
+    dt = float(np.median(dts))
+    dist_info = lbdist.group_info(device)
     st = eng.stats()
     E_tot = st["n_edges_total"]
 
@@ -206,29 +221,20 @@ def main():
                 "unit": "TFLOP/s"}
     mfma["frac"] = mfma["achieved"] / mfma["peak"]
     mfma["fp32_equivalent_algorithmic_tflops"] = flop_algo / (us_edge * 1e-6) / 1e12
-    three = os.environ.get("LB_EDGE_WAVES", "3") == "3" and fused
-    ek = os.environ.get("LB_EDGE_KERNEL", "v0")
-    if math_mode == "f16x2" and fused and not ek.startswith("n"):
-        kern = {"v1": "k_edge16v<4 waves/SIMD, second read of the latents>", "v2": "k_edge16v<3 waves/SIMD, second read>",
-                "v3": "k_edge16p<2 waves/SIMD, software-pipelined>", "v4": "k_edge16l<2 waves/SIMD, late prefetch>",
-                "v5": "k_edge16v<2 waves/SIMD, resident latents>", "v6": "k_edge16v<3 waves/SIMD, resident latents>"}.get(
-                    ek, "k_edge16v<2 waves/SIMD, resident latents, GEMM-phase priority> (PROC, f16x2, fused segment_sum)")
-        pmc_key = "k_edge16p" if ek == "v3" else "k_edge16v"
-    else:
-        kern = ("k_edge16n (PROC, f16x2, 3 waves/SIMD)" if (math_mode == "f16x2" and three)
-                else "k_edge16<PROC," + ("f16x2>" if math_mode == "f16x2" else "f32>"))
-        pmc_key = "k_edge16n" if three else "k_edge16<true, true"
+    kern = eng.kernel_names()["edge"]  # the library names the kernel family it picked for this size / arithmetic
+    pmc_key = kern.split("<")[0].split(" ")[0]
     if math_mode == "f16x2":
         roof = {"kernel": kern, "bound": "hbm", "achieved": gbs_edge, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs_edge / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(pmc_key, args.workload, B),
                 "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured by this run)",
                 "us_per_launch": us_edge, "launches": int(n_edge), "bytes_per_launch": edge_bytes,
-                "bytes_incl_agg": edge_bytes_incl_agg, "mfma": mfma}
+                "bytes_incl_agg": edge_bytes_incl_agg, "mfma": mfma, "node_kernel": eng.kernel_names()["node"]}
     else:
         roof = {"kernel": kern, "bound": "mfma", "achieved": mfma["achieved"], "peak": mfma["peak"],
                 "unit": "TFLOP/s", "frac": mfma["frac"],
                 "traffic": pmc_traffic("k_edge16<true, false", args.workload, B),
+                "node_kernel": eng.kernel_names()["node"],
                 "us_per_launch": us_edge, "launches": int(n_edge), "flop_per_launch_executed": flop_prod,
                 "hbm": {"achieved": gbs_edge, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_edge / HBM_PEAK_GBS}}
     agg_bytes = E_tot * (D * 4 + 4) + BN * D * 4  # E*516 + N*512
@@ -243,6 +249,10 @@ def main():
         "steps": K,
         "warmup": W,
         "ms_per_step": 1e3 * dt / K,
+        "repeats": {"n": len(dts), "ms_per_step_all": [round(1e3 * x / K, 4) for x in dts],
+                    "ms_per_step_min": 1e3 * min(dts) / K, "ms_per_step_max": 1e3 * max(dts) / K,
+                    "note": "value / ms_per_step = the median repeat of the K-step timed region"},
+        "dist": dist_info,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -271,6 +281,30 @@ def main():
         "breakdown_ms_per_step": breakdown,
     }
 
+    if world == 1 and math_mode == "f16x2" and not args.no_f32:
+        # the same K steps in exact-fp32 MFMA arithmetic (what LB_MATH=f32 selects and what the range guard falls
+        # back to): recorded so that the driver's line carries both arithmetics
+        try:
+            eng.math_mode(0)
+            eng.rollout(handle, traj, K)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            eng.rollout(handle, traj, K)
+            torch.cuda.synchronize(device)
+            dt32 = time.perf_counter() - t0
+            out["f32_exact"] = {"ms_per_step": 1e3 * dt32 / K, "value": B * N * K / dt32, "unit": "particle-steps/s",
+                                "kernels": eng.kernel_names(), "note": "LB_MATH=f32 arithmetic, same inputs / weights"}
+        except Exception as exc:
+            out["f32_exact"] = {"error": repr(exc)[:200]}
+        finally:
+            eng.math_mode(1)
+    if world == 1 and not args.no_other_configs:
+        del pred, traj, handle, eng
+        out["other_configs"] = other_configs(device)
+    # Everything TIMED on the GPU is done.  The CPU-baseline legs now run as background processes on the host cores
+    # while the nested rocprofv3 passes (byte counters, nothing timed) re-run the GPU workload.
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_jobs = cpu_baseline_start(args)
     # roofline.traffic measured by THIS run: two nested rocprofv3 passes of the same command (FETCH_SIZE, WRITE_SIZE:
     # the counters do not fit one pass; --kernel-trace + --pmc only), after the timed region; any failure or a
     # missing rocprofv3 falls back to the committed table above
@@ -283,11 +317,8 @@ def main():
                     dst["traffic"] = hit[0]
                     dst["traffic_source"] = ("measured by this run: nested rocprofv3 --kernel-trace --pmc FETCH_SIZE / "
                                              "WRITE_SIZE passes (separate), (2*FETCH + WRITE) * 1 KiB per launch")
-    if world == 1 and not args.no_other_configs:
-        del pred, traj, handle, eng
-        out["other_configs"] = other_configs(device)
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(ds, params, L, args.cpu_steps)
+    if cpu_jobs is not None:
+        out["cpu_baseline"] = cpu_baseline_collect(cpu_jobs)
     print(json.dumps(out), flush=True)
 
 
@@ -375,9 +406,38 @@ def other_configs(device):
             torch.cuda.synchronize(device)
             dt = time.perf_counter() - t0
             N = pos.shape[1]
-            res.append({"workload": f"{workload} {'GNS-10-128' if kind == 'gns' else 'SEGNN-10-64'}", "n_particles": int(N),
-                        "batch": B, "steps": K, "ms_per_step": round(1e3 * dt / K, 4),
-                        "value": B * N * K / dt, "unit": "particle-steps/s"})
+            entry = {"workload": f"{workload} {'GNS-10-128' if kind == 'gns' else 'SEGNN-10-64'}", "n_particles": int(N),
+                     "batch": B, "steps": K, "ms_per_step": round(1e3 * dt / K, 4),
+                     "value": B * N * K / dt, "unit": "particle-steps/s"}
+            # this entry's own roofline: the processor edge (GNS) / message (SEGNN) kernel on the engine's HIP-event
+            # timers over min(K, 20) more steps
+            try:
+                Kt = min(K, 20)
+                E_tot = eng.stats()["n_edges_total"]
+                eng.timers_enable(True)
+                eng.timers_reset()
+                eng.rollout(handle, traj, Kt)
+                tm = eng.timers()
+                eng.timers_enable(False)
+                ms_e, n_e = tm["edge_mlp"]
+                us = 1e3 * ms_e / max(n_e, 1)
+                if kind == "gns":
+                    byts = E_tot * (2 * D * 4 + 8) + B * N * (2 * D * 4)
+                    entry["roofline"] = {"kernel": eng.kernel_names()["edge"], "node_kernel": eng.kernel_names()["node"],
+                                         "bound": "hbm", "us_per_launch": round(us, 2), "bytes_per_launch": int(byts),
+                                         "achieved": byts / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": byts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                         "note": "B = 1 graphs are launch-latency bound, not bandwidth bound"}
+                else:
+                    fl = E_tot * 2 * 3 * (128 * 64 + 64 * 32 + 3 * 64 * 32 + 64 * 64 + 32 * 32 + 3 * 32 * 32)
+                    entry["roofline"] = {"kernel": "k_sg_msg (gather + 2 gated TP blocks + segment_sum, f16x2)",
+                                         "bound": "mfma", "us_per_launch": round(us, 2),
+                                         "achieved": fl / (us * 1e-6) / 1e12, "peak": MFMA_F16_PEAK_TF,
+                                         "unit": "TFLOP/s", "frac": fl / (us * 1e-6) / 1e12 / MFMA_F16_PEAK_TF}
+                entry["breakdown_ms_per_step"] = {k: round(v[0] / Kt, 4) for k, v in tm.items() if v[1] > 0}
+            except Exception as exc:
+                entry["roofline"] = {"error": repr(exc)[:200]}
+            res.append(entry)
             del eng, traj, handle
         except Exception as exc:  # a sub-run must never take the headline line down
             res.append({"workload": workload, "batch": B, "error": repr(exc)[:200]})
@@ -463,41 +523,108 @@ def run_segnn(args, rank, world, device):
     print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(ds, params, L, n_steps):
-    """The CPU restatement in the reference's algorithmic shape (dense candidate matrix -> mask ->
-    compaction; MLPs over all E_cap padded rows; unfused gather/GEMM/LayerNorm/scatter-add; fp64
-    geometry, fp32 network; batch 1) on all host cores: torch-CPU for the network
+CPU_PLAN = {
+    # config 1 (TGV2D-2.5k, 20 steps) is mandatory; TGV3D-8k (the config the >= 5x target is quoted on)
+    # costs ~1.8 s per step on this host: a bounded sample.  One rollout of warm + steps steps, every step timed
+    # (the reference's step loop is host driven, rollout.py:125-169); the reported figure is the MEDIAN step.
+    "tgv2d": {"steps": 20, "warm": 2},
+    "tgv3d": {"steps": 3, "warm": 1},
+}
+
+
+def cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_leg(workload, L):
+    """One CPU-baseline leg (own process, `--cpu-baseline-only`): the CPU restatement in the reference's algorithmic
+    shape (dense candidate matrix -> mask -> compaction; MLPs over all E_cap padded rows; unfused
+    gather / GEMM / LayerNorm / scatter-add; fp64 geometry, fp32 network; batch 1): torch-CPU for the network
     (oracle/lb_oracle_torch.py), NumPy for the neighbor list / features / integrator."""
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
     from oracle import lb_oracle as O
     from oracle import lb_oracle_torch as OT
     from tests._common import oracle_case
-    # threads: torch-CPU on the MI355X host (256 hardware threads) is fastest at 32 threads and
-    # collapses when oversubscribed (measured with tools/cpu_threads_probe.py: 4/8/16/32/64/256
-    # threads -> 2.6/2.0/1.8/1.6/2.5/47 s per forward); "cores" reports the threads actually used
+    plan = CPU_PLAN[workload]
+    # threads: torch-CPU on the MI355X host (256 hardware threads) is fastest at 32 threads and collapses when
+    # oversubscribed (tools/cpu_threads_probe.py: 4/8/16/32/64/256 threads -> 2.6/2.0/1.8/1.6/2.5/47 s per TGV3D
+    # forward); "cores" reports the threads actually used
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
+    n_warm, n_steps = plan["warm"], plan["steps"]
+    ds = make_case(workload, n_trajs=1, extra_seq_length=n_warm + n_steps)
+    node_in, edge_in = gns_widths(ds)
+    params = GNS(len(ds.box), D, 2, L, 16).init_params(1234, node_in, edge_in, decoder_scale=0.01)
     ocase = oracle_case(ds)
     isl = ds.input_seq_length
     pos, pt = ds[0]
     pos = pos.astype(np.float64)
     pt_params = OT.params_to_torch(params)
+    stamps = []
 
     def apply(p, s, sample):
+        stamps.append(time.perf_counter())  # one call per rollout step, after that step's neighbor list / features
         return OT.gns_apply(pt_params, sample[0], sample[1], num_mp_steps=L), s
 
     _, nbrs = ocase.allocate_eval((pos[:, :isl], pt))
-    # 1 untimed step, then n_steps timed
-    O.eval_batched_rollout(apply, ocase, params, {}, (pos[None, :, :isl + 1], pt[None]), nbrs, 1, isl)
-    t0 = time.perf_counter()
-    O.eval_batched_rollout(apply, ocase, params, {}, (pos[None, :, :isl + n_steps], pt[None]), nbrs, n_steps, isl)
-    dt = time.perf_counter() - t0
+    t_begin = time.perf_counter()
+    O.eval_batched_rollout(apply, ocase, params, {}, (pos[None, :, :isl + n_warm + n_steps], pt[None]), nbrs,
+                           n_warm + n_steps, isl)
+    t_end = time.perf_counter()
+    # step i runs from (roughly) stamp[i] - its preprocessing to stamp[i+1] - the next one's: consecutive stamp
+    # differences are whole steps (network of step i + integrator + neighbor list / features of step i+1)
+    edges = stamps + [t_end]
+    steps = np.diff(np.asarray(edges))[n_warm:]
+    dt = float(np.median(steps))
     return {
-        "value": len(pt) * n_steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-        "sample": f"{n_steps} rollout steps of 1 {ds.name} trajectory (N={len(pt)}) after 1 warm-up step; "
-                  f"torch-CPU network + NumPy neighbor list in the reference's padded/unfused shape, "
-                  f"{1e3 * dt / n_steps:.0f} ms/step",
-        "note": "JAX is not installable here: this is the reference-shaped CPU restatement, not JAX-CPU",
+        "workload": workload, "value": len(pt) / dt, "unit": "particle-steps/s", "cores": cores,
+        "cpu_model": cpu_model_string(), "host_threads": os.cpu_count(), "kind": "port",
+        "ms_per_step": 1e3 * dt, "ms_per_step_all": [round(1e3 * float(t), 1) for t in steps],
+        "total_s": round(t_end - t_begin, 2),
+        "sample": f"median step of a {n_steps}-step rollout of 1 {ds.name} trajectory (N={len(pt)}) after {n_warm} warm-up "
+                  f"steps; torch-CPU network + NumPy neighbor list in the reference's padded/unfused shape",
     }
+
+
+def cpu_baseline_start(args):
+    """Start the CPU-baseline legs as ONE background process (host cores only; meanwhile the nested rocprofv3 passes -
+    byte counters, nothing timed - re-run the GPU workload)."""
+    import subprocess
+    legs = ["tgv2d"] + ([args.workload] if args.workload in CPU_PLAN and args.workload != "tgv2d" else ["tgv3d"])
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", ",".join(legs), "--mp-steps", str(args.mp_steps)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    return legs, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True,
+                                  start_new_session=True)
+
+
+def cpu_baseline_collect(job, timeout_s=240):
+    """cpu_baseline object of the bench line: the headline workload's leg on top, every leg under `configs`."""
+    import signal
+    names, p = job
+    try:
+        out, _ = p.communicate(timeout=timeout_s)
+        legs = json.loads(out.strip().splitlines()[-1])
+    except Exception as exc:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except Exception:
+            pass
+        legs = {w: {"workload": w, "error": repr(exc)[:200]} for w in names}
+    head = next((legs[w] for w in ("tgv3d", "ldc3d", "rpf2d", "tgv2d") if w in legs and "value" in legs[w]), None)
+    res = dict(head) if head else {"value": None, "unit": "particle-steps/s", "cores": None, "kind": "port", "sample": "failed"}
+    res["configs"] = legs
+    res["note"] = ("JAX is not installable here: this is the reference-shaped CPU restatement, not JAX-CPU; the legs "
+                   "run one after the other in a background process on the host cores while the nested rocprofv3 "
+                   "passes (byte counters only) re-run the GPU workload")
+    return res
 
 
 if __name__ == "__main__":

@@ -273,6 +273,12 @@ int lb_timer_get(lb_engine* eng, int32_t cls, double* ms_out, int64_t* launches_
 /* Current totals: real edges over all trajectories, E_cap, cell capacity (host-synchronous). */
 int lb_stats(lb_engine* eng, int64_t* n_edges_total, int32_t* e_cap, int32_t* cell_capacity);
 
+/* Which kernels a GNS forward of this engine runs on at its CURRENT size / arithmetic mode, as
+ * "edge=<kernel>;node=<kernel>" (NUL-terminated, truncated to cap): the network kernels are picked by graph size
+ * (M-split kernels for one small trajectory, wave-per-tile kernels for batches) - bench.py names the kernel its
+ * roofline line is about with this.  No reference counterpart (measurement aid). */
+int lb_kernel_names(lb_engine* eng, char* out, int32_t cap);
+
 /* Stand-alone jraph.segment_sum(messages, receivers, N) on the CURRENT list (gns.py:117-119):
  * msg (E_total,D) fp32 in engine edge order -> out (B*N,D) fp32.  Used by tests and by the
  * aggregation-roofline leg of bench.py. */

@@ -86,6 +86,7 @@ _SIGS = {
     "lb_timer_name": (C.c_char_p, [C.c_int32]),
     "lb_timer_get": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "lb_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "lb_kernel_names": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "lb_segment_sum": (C.c_int, [_P, _P, _P, C.c_int32]),
     "lb_segnn_create": (C.c_int, [_P, C.POINTER(SegnnDesc), _P, C.c_int64, C.POINTER(_P)]),
     "lb_segnn_destroy": (None, [_P]),

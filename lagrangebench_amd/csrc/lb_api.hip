@@ -139,8 +139,6 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   {
     const char* f = getenv("LB_FUSED_AGG");
     e->fused_agg = (f && f[0] == '0') ? 0 : 1;
-    const char* t = getenv("LB_EDGE_TILE");
-    e->edge_tile = (t && atoi(t) == 32) ? 32 : 16;
     const char* m = getenv("LB_MATH");
     e->f16x2 = (m && !strcmp(m, "f32")) ? 0 : 1;
     e->math_auto = m ? 0 : 1;  // LB_MATH given: that arithmetic, no guard-driven switch
@@ -804,26 +802,16 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
   g->enc_node_w1_h = g->blob + o_en_w1_h;
   g->enc_edge_w0_16h = g->blob + o_ee_w0_16h;
   g->enc_edge_w1_16h = g->blob + o_ee_w1_16h;
-  {  // LayerNorm width of this model (read by every network kernel through the control block)
-    const float lnc[2] = {1.0f / (float)dl, (float)(D - dl)};
-    LB_HIP(hipMemcpy(&e->ctrl->ln_inv_d, lnc, sizeof(lnc), hipMemcpyHostToDevice));
-  }
+  // LayerNorm width of this model (read by every network kernel through the control block: lb_gns_bind)
+  g->lnc[0] = 1.0f / (float)dl;
+  g->lnc[1] = (float)(D - dl);
   if (w_rms_min < 0.0078125 && e->f16x2 && e->math_auto) {
     fprintf(stderr, "[lbhip] a weight matrix has rms %.3g < 2^-7: its fp16 hi/lo split would fall short of the 1e-5 class - "
                     "this engine uses exact-fp32 MFMA arithmetic\n", w_rms_min);
     e->f16x2 = 0;
   }
-  // node-sized network scratch
-  e->g.kpad = kpad;
-  const int64_t BN = e->BN;
-  for (void* b : {(void*)e->xnode, (void*)e->nlat, (void*)e->agg, (void*)e->psr})
-    if (b) (void)hipFree(b);
-  e->xnode = e->nlat = e->agg = e->psr = nullptr;
-  int rc = LB_OK;
-  if (!rc) rc = lb_alloc(&e->xnode, (size_t)BN * kpad);
-  if (!rc) rc = lb_alloc(&e->nlat, (size_t)BN * D);
-  if (!rc) rc = lb_alloc(&e->agg, (size_t)BN * D);
-  if (!rc) rc = lb_alloc(&e->psr, (size_t)BN * 2 * D);
+  int rc = lb_ensure_node_scratch(e);
+  if (!rc) rc = lb_gns_bind(e, g);
   if (rc) {
     lb_gns_destroy(g);
     return rc;
@@ -832,8 +820,28 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
   return LB_OK;
 }
 
+int lb_ensure_node_scratch(lb_engine* e) {
+  const int64_t BN = e->BN;
+  if (!e->xnode) LB_TRY(lb_alloc(&e->xnode, (size_t)BN * LB_D));  // widest node input row
+  if (!e->nlat) LB_TRY(lb_alloc(&e->nlat, (size_t)BN * LB_D));
+  if (!e->agg) LB_TRY(lb_alloc(&e->agg, (size_t)BN * LB_D));
+  if (!e->psr) LB_TRY(lb_alloc(&e->psr, (size_t)BN * 2 * LB_D));
+  return LB_OK;
+}
+
+// Per-model constants that live in engine-wide state (the LayerNorm width in the control block, the node feature
+// row stride in the geometry): re-applied whenever another model of the same engine runs.
+int lb_gns_bind(lb_engine* e, lb_gns* g) {
+  if (e->bound_model == g) return LB_OK;
+  LB_HIP(hipMemcpyAsync(&e->ctrl->ln_inv_d, g->lnc, sizeof(g->lnc), hipMemcpyHostToDevice, e->stream));
+  e->g.kpad = g->kq_node * 8;
+  e->bound_model = g;
+  return LB_OK;
+}
+
 extern "C" void lb_gns_destroy(lb_gns* g) {
   if (!g) return;
+  if (g->eng && g->eng->bound_model == g) g->eng->bound_model = nullptr;
   if (g->blob) (void)hipFree(g->blob);
   for (float* b : g->gen_hn)
     if (b) (void)hipFree(b);

@@ -200,327 +200,6 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_edge16l: LATE prefetch.  Like k_edge16p every load of tile t+1 is issued by tile t, but only AFTER
-// its second GEMM, when the GEMM working set (first-layer activations, both fragment buffers) is dead:
-// the 96 prefetch registers never coexist with it, so two waves per SIMD keep ~90 VGPRs of slack for
-// the compiler's scheduling instead of running at the 256-register cap (k_edge16p: 341 us, spill-prone).
-// The loads still precede the tile's stores in program order, so the wait at the next tile's top does
-// not have to cover a store acknowledgement (gfx9's single in-order vmcnt).
-// (header of k_edge16p, the early-prefetch variant:)
-// k_edge16p: the same tile body, fully software-pipelined inside each wave.  While tile t is in the
-// GEMMs, ALL loads of tile t+1 (edge latents + gathered sender/receiver projections + CSR bounds) and
-// the indices of tile t+2 are in flight, so the bytes a CU has outstanding no longer depend on how
-// the phases of its waves happen to line up (fine-grained arbitration keeps equal waves in lock step:
-// they all load, then all compute).  The prefetch sets cost 96 VGPRs -> WPS = 2 (256 VGPRs).
-// The edge latents are touched once per layer (562 MB >> L2 + Infinity Cache): their loads and stores
-// are nontemporal so that the streams do not push the gathered psr table out of L2 / MALL
-// (tools/stream_bench: 257 -> 233 us for this access pattern).
-// The first tile is peeled: a waitcnt at the loop header serves the entry and the back edge with ONE
-// static count, and the entry's smaller count would drain the previous tile's stores on every trip.
-struct lb_e16l_state {
-  f32x4 ve[8], ps[8], pr[8];  // next tile, in flight
-  int s_n, r_n;               // indices of the tile after next
-  int r_pref, rb;             // receiver of the next tile's lanes + its boundary probe
-};
-
-template <int WPS, bool SKIP, int ABL = 0, bool PRIO = true>
-__global__ void __launch_bounds__(WPS * 256, WPS) k_edge16l(lb_edge16_args a) {
-  constexpr int THREADS = WPS * 256, WAVES = WPS * 4;
-  constexpr int NW0 = 4096;
-  __shared__ f32x4 sW[NW0 + 4096 + 96];
-  if (a.ctrl->overflow_step >= 0) return;
-  const int tid = threadIdx.x;
-  {
-    const f32x4* g0 = reinterpret_cast<const f32x4*>(a.w0p);
-    const f32x4* g1 = reinterpret_cast<const f32x4*>(a.w1p);
-    for (int i = tid; i < NW0; i += THREADS) sW[i] = g0[i];
-    for (int i = tid; i < 4096; i += THREADS) sW[NW0 + i] = g1[i];
-    if (tid < 96) {
-      const float* src = tid < 32 ? a.b1 : (tid < 64 ? a.ln_s : a.ln_o);
-      sW[NW0 + 4096 + tid] = reinterpret_cast<const f32x4*>(src)[tid & 31];
-    }
-  }
-  __syncthreads();
-  const int E = a.ctrl->n_edges_total;
-  const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
-  const int ntiles = (E + 15) >> 4;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, g = lane >> 4;
-  const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * WAVES + wave;
-  const int stride = (gridDim.x >> 3) * WAVES;
-  const int t_lo = (int)(((int64_t)ntiles * xcd) >> 3), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) >> 3);
-  int t = t_lo + slot;
-  if (t >= t_hi) return;
-  uint32_t off0 = (uint32_t)(uintptr_t)(lds_cptr)(sW + lane);
-  uint32_t off1 = (uint32_t)(uintptr_t)(lds_cptr)(sW + NW0 + lane);
-  uint32_t off2 = (uint32_t)(uintptr_t)(lds_cptr)(sW + NW0 + 4096 + g);
-  asm volatile("" : "+v"(off0), "+v"(off1), "+v"(off2));
-  const lds_cptr w0b = (lds_cptr)(uintptr_t)off0, w1b = (lds_cptr)(uintptr_t)off1, vecb = (lds_cptr)(uintptr_t)off2;
-  auto rowc_of = [&](int tt) -> int64_t {
-    const int row = tt * 16 + n;
-    return row < E ? row : E - 1;
-  };
-  const f32x4* psr4 = reinterpret_cast<const f32x4*>(a.psr);
-  const int n_iter = (t_hi - 1 - t) / stride + 1;
-  const int t_last = t + (n_iter - 1) * stride;
-
-  lb_e16l_state st;
-  // every load is unconditional (tile indices clamp to the wave's last tile): a load under a
-  // branch makes the compiler wait vmcnt(0) for the loop-carried registers
-  auto issue = [&](int tt, int s, int r) {
-    const f32x4* er = reinterpret_cast<const f32x4*>(a.elat) + (int64_t)tt * 512 + lane;
-    const f32x4* ps = psr4 + (int64_t)s * 64 + g;
-    const f32x4* pr = psr4 + (int64_t)r * 64 + 32 + g;
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-      st.ve[mb] = (ABL & 2) ? f32x4{1.f, 2.f, (float)tt, (float)mb} : __builtin_nontemporal_load(&er[64 * mb]);
-      st.ps[mb] = (ABL & 1) ? f32x4{.1f, .2f, (float)s, (float)mb} : ps[4 * mb];
-      st.pr[mb] = (ABL & 1) ? f32x4{.3f, .1f, (float)r, (float)mb} : pr[4 * mb];
-    }
-    st.r_pref = r;
-    st.rb = lb_edge_probe(a.receivers, tt, lane, E);
-  };
-  {
-    const int64_t rc = rowc_of(t);
-    int s0 = a.senders[rc], r0 = a.receivers[rc];
-    asm volatile("" : "+v"(s0), "+v"(r0));
-    issue(t, s0, r0);
-    const int64_t rn = rowc_of(min(t + stride, t_last));
-    st.s_n = a.senders[rn];
-    st.r_n = a.receivers[rn];
-  }
-
-  auto body = [&](int tc, bool first) {
-    // ---- take delivery of the prefetched tile
-    f32x4 acc[8], ve[8];
-    const int r_cur = st.r_pref;
-    int rb = st.rb;
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-      ve[mb] = st.ve[mb];
-      acc[mb] = lb_pk_add(st.ps[mb], st.pr[mb]);
-    }
-    asm volatile("" : "+v"(rb));
-    if (first) lb_range_probe(a.ctrl, ve, 8);
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
-    if constexpr (!(ABL & 8)) lb_gemm16v<false>(w0b, ve, acc);
-    if (first) lb_range_probe(a.ctrl, acc, 8);
-    f32x4 acc2[8];
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) acc2[mb] = vecb[4 * mb];
-    if constexpr (!(ABL & 8)) {
-      lb_gemm16v<true>(w1b, acc, acc2);
-    } else {
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc2[mb][j] += acc[mb][j] + ve[mb][j];
-    }
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-    // ---- late prefetch: the next tile's loads and the indices of the one after
-    {
-      int s = st.s_n, r = st.r_n;
-      asm volatile("" : "+v"(s), "+v"(r));
-      issue(min(tc + stride, t_last), s, r);
-      const int64_t rn = rowc_of(min(tc + 2 * stride, t_last));
-      st.s_n = a.senders[rn];
-      st.r_n = a.receivers[rn];
-    }
-    f32x4 y[8];
-    lb_layernorm16(acc2, vecb + 32, vecb + 64, y, ln_inv_d, ln_pad);
-    const int row = tc * 16 + n;
-    const bool valid = row < E;
-    if constexpr (!SKIP && !(ABL & 4)) {
-      f32x4* ew = reinterpret_cast<f32x4*>(a.elat_out ? a.elat_out : a.elat) + (int64_t)tc * 512 + lane;
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) __builtin_nontemporal_store(lb_pk_add(ve[mb], y[mb]), &ew[64 * mb]);
-    }
-    const int rr = valid ? r_cur : (-1 - n);
-    const int r_prev = __builtin_amdgcn_update_dpp(-2, rr, 0x111, 0xF, 0xF, false);
-    const bool head = (n == 0) || (rr != r_prev);
-    const unsigned H = (unsigned)(__ballot(head) & 0xffffull);
-    const unsigned below = H & ((2u << n) - 1u);
-    const int segstart = 31 - __clz(below);
-    const bool tail = (n == 15) || ((H >> (n + 1)) & 1u);
-    const float m1 = (n >= 1 && segstart <= n - 1) ? 1.f : 0.f, m2 = (n >= 2 && segstart <= n - 2) ? 1.f : 0.f;
-    const float m4 = (n >= 4 && segstart <= n - 4) ? 1.f : 0.f, m8 = (n >= 8 && segstart <= n - 8) ? 1.f : 0.f;
-    if (!valid) {
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) y[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int mb = 0; mb < 8; mb += 2) lb_scan8(y[mb], y[mb + 1], m1, m2, m4, m8);
-    if (tail && valid && !(ABL & 4)) {
-      int slot01;
-      const bool complete = lb_seg_complete(rb, rr, segstart, n, tc, E, slot01);
-      float* dst = complete ? a.agg + (int64_t)rr * 128 : a.part + ((int64_t)tc * 2 + slot01) * 128;
-      f32x4* d4 = reinterpret_cast<f32x4*>(dst) + g;
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) d4[4 * mb] = y[mb];
-    }
-  };
-  body(t, true);  // peeled (see the header comment)
-  t += stride;
-  for (int it = 1; it < n_iter; ++it, t += stride) body(t, false);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_edge16p: the same tile body, fully software-pipelined inside each wave.  While tile t is in the
-// GEMMs, ALL loads of tile t+1 (edge latents + gathered sender/receiver projections + CSR bounds) and
-// the indices of tile t+2 are in flight, so the bytes a CU has outstanding no longer depend on how
-// the phases of its waves happen to line up (fine-grained arbitration keeps equal waves in lock step:
-// they all load, then all compute).  The prefetch sets cost 96 VGPRs -> WPS = 2 (256 VGPRs).
-// The edge latents are touched once per layer (562 MB >> L2 + Infinity Cache): their loads and stores
-// are nontemporal so that the streams do not push the gathered psr table out of L2 / MALL
-// (tools/stream_bench: 257 -> 233 us for this access pattern).
-// The first tile is peeled: a waitcnt at the loop header serves the entry and the back edge with ONE
-// static count, and the entry's smaller count would drain the previous tile's stores on every trip.
-struct lb_e16p_state {
-  f32x4 ve[8], ps[8], pr[8];  // next tile, in flight
-  int s_n, r_n;               // indices of the tile after next
-  int r_pref, rb;             // receiver of the next tile's lanes + its boundary probe
-};
-
-template <int WPS, bool SKIP, int ABL = 0>
-__global__ void __launch_bounds__(WPS * 256, WPS) k_edge16p(lb_edge16_args a) {
-  constexpr int THREADS = WPS * 256, WAVES = WPS * 4;
-  constexpr int NW0 = 4096;
-  __shared__ f32x4 sW[NW0 + 4096 + 96];
-  if (a.ctrl->overflow_step >= 0) return;
-  const int tid = threadIdx.x;
-  {
-    const f32x4* g0 = reinterpret_cast<const f32x4*>(a.w0p);
-    const f32x4* g1 = reinterpret_cast<const f32x4*>(a.w1p);
-    for (int i = tid; i < NW0; i += THREADS) sW[i] = g0[i];
-    for (int i = tid; i < 4096; i += THREADS) sW[NW0 + i] = g1[i];
-    if (tid < 96) {
-      const float* src = tid < 32 ? a.b1 : (tid < 64 ? a.ln_s : a.ln_o);
-      sW[NW0 + 4096 + tid] = reinterpret_cast<const f32x4*>(src)[tid & 31];
-    }
-  }
-  __syncthreads();
-  const int E = a.ctrl->n_edges_total;
-  const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
-  const int ntiles = (E + 15) >> 4;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, g = lane >> 4;
-  const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * WAVES + wave;
-  const int stride = (gridDim.x >> 3) * WAVES;
-  const int t_lo = (int)(((int64_t)ntiles * xcd) >> 3), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) >> 3);
-  int t = t_lo + slot;
-  if (t >= t_hi) return;
-  uint32_t off0 = (uint32_t)(uintptr_t)(lds_cptr)(sW + lane);
-  uint32_t off1 = (uint32_t)(uintptr_t)(lds_cptr)(sW + NW0 + lane);
-  uint32_t off2 = (uint32_t)(uintptr_t)(lds_cptr)(sW + NW0 + 4096 + g);
-  asm volatile("" : "+v"(off0), "+v"(off1), "+v"(off2));
-  const lds_cptr w0b = (lds_cptr)(uintptr_t)off0, w1b = (lds_cptr)(uintptr_t)off1, vecb = (lds_cptr)(uintptr_t)off2;
-  auto rowc_of = [&](int tt) -> int64_t {
-    const int row = tt * 16 + n;
-    return row < E ? row : E - 1;
-  };
-  const f32x4* psr4 = reinterpret_cast<const f32x4*>(a.psr);
-  const int n_iter = (t_hi - 1 - t) / stride + 1;
-  const int t_last = t + (n_iter - 1) * stride;
-
-  lb_e16p_state st;
-  // every load is unconditional (tile indices clamp to the wave's last tile): a load under a
-  // branch makes the compiler wait vmcnt(0) for the loop-carried registers
-  auto issue = [&](int tt, int s, int r) {
-    const f32x4* er = reinterpret_cast<const f32x4*>(a.elat) + (int64_t)tt * 512 + lane;
-    const f32x4* ps = psr4 + (int64_t)s * 64 + g;
-    const f32x4* pr = psr4 + (int64_t)r * 64 + 32 + g;
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-      st.ve[mb] = (ABL & 2) ? f32x4{1.f, 2.f, (float)tt, (float)mb} : __builtin_nontemporal_load(&er[64 * mb]);
-      st.ps[mb] = (ABL & 1) ? f32x4{.1f, .2f, (float)s, (float)mb} : ps[4 * mb];
-      st.pr[mb] = (ABL & 1) ? f32x4{.3f, .1f, (float)r, (float)mb} : pr[4 * mb];
-    }
-    st.r_pref = r;
-    st.rb = lb_edge_probe(a.receivers, tt, lane, E);
-  };
-  {
-    const int64_t rc = rowc_of(t);
-    int s0 = a.senders[rc], r0 = a.receivers[rc];
-    asm volatile("" : "+v"(s0), "+v"(r0));
-    issue(t, s0, r0);
-    const int64_t rn = rowc_of(min(t + stride, t_last));
-    st.s_n = a.senders[rn];
-    st.r_n = a.receivers[rn];
-  }
-
-  auto body = [&](int tc, bool first) {
-    // ---- take delivery of the prefetched tile
-    f32x4 acc[8], ve[8];
-    const int r_cur = st.r_pref;
-    int rb = st.rb;
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-      ve[mb] = st.ve[mb];
-      acc[mb] = lb_pk_add(st.ps[mb], st.pr[mb]);
-    }
-    asm volatile("" : "+v"(rb));
-    // ---- put the next tile's loads and the indices of the one after in flight
-    {
-      int s = st.s_n, r = st.r_n;
-      asm volatile("" : "+v"(s), "+v"(r));
-      issue(min(tc + stride, t_last), s, r);
-      const int64_t rn = rowc_of(min(tc + 2 * stride, t_last));
-      st.s_n = a.senders[rn];
-      st.r_n = a.receivers[rn];
-    }
-    if (first) lb_range_probe(a.ctrl, ve, 8);
-    if constexpr (!(ABL & 8)) lb_gemm16v<false>(w0b, ve, acc);
-    if (first) lb_range_probe(a.ctrl, acc, 8);
-    f32x4 acc2[8];
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) acc2[mb] = vecb[4 * mb];
-    if constexpr (!(ABL & 8)) {
-      lb_gemm16v<true>(w1b, acc, acc2);
-    } else {
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc2[mb][j] += acc[mb][j] + ve[mb][j];
-    }
-    f32x4 y[8];
-    lb_layernorm16(acc2, vecb + 32, vecb + 64, y, ln_inv_d, ln_pad);
-    const int row = tc * 16 + n;
-    const bool valid = row < E;
-    if constexpr (!SKIP && !(ABL & 4)) {
-      f32x4* ew = reinterpret_cast<f32x4*>(a.elat_out ? a.elat_out : a.elat) + (int64_t)tc * 512 + lane;
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) __builtin_nontemporal_store(lb_pk_add(ve[mb], y[mb]), &ew[64 * mb]);
-    }
-    const int rr = valid ? r_cur : (-1 - n);
-    const int r_prev = __builtin_amdgcn_update_dpp(-2, rr, 0x111, 0xF, 0xF, false);
-    const bool head = (n == 0) || (rr != r_prev);
-    const unsigned H = (unsigned)(__ballot(head) & 0xffffull);
-    const unsigned below = H & ((2u << n) - 1u);
-    const int segstart = 31 - __clz(below);
-    const bool tail = (n == 15) || ((H >> (n + 1)) & 1u);
-    const float m1 = (n >= 1 && segstart <= n - 1) ? 1.f : 0.f, m2 = (n >= 2 && segstart <= n - 2) ? 1.f : 0.f;
-    const float m4 = (n >= 4 && segstart <= n - 4) ? 1.f : 0.f, m8 = (n >= 8 && segstart <= n - 8) ? 1.f : 0.f;
-    if (!valid) {
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) y[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int mb = 0; mb < 8; mb += 2) lb_scan8(y[mb], y[mb + 1], m1, m2, m4, m8);
-    if (tail && valid && !(ABL & 4)) {
-      int slot01;
-      const bool complete = lb_seg_complete(rb, rr, segstart, n, tc, E, slot01);
-      float* dst = complete ? a.agg + (int64_t)rr * 128 : a.part + ((int64_t)tc * 2 + slot01) * 128;
-      f32x4* d4 = reinterpret_cast<f32x4*>(dst) + g;
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) d4[4 * mb] = y[mb];
-    }
-  };
-  body(t, true);  // peeled (see the header comment)
-  t += stride;
-  for (int it = 1; it < n_iter; ++it, t += stride) body(t, false);
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_edge_enc16v: the ENCODER edge MLP (gns.py:73-84), e0 = LayerNorm(W1 relu(W0 f + b0) + b1) over the
 // edge features f = (rel_disp, rel_dist) the neighbor search wrote (8 floats per edge, zero padded).
 // Write-bound: 32 B read and 512 B written per edge.  Same tile walk, block loop, LayerNorm and
@@ -596,69 +275,37 @@ int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a) {
     g = (g + 7) / 8 * 8;
     return (int)(g < 8 ? 8 : (g > 256 ? 256 : g));
   };
-  static const int wps_env = getenv("LB_ENC_WPS") ? atoi(getenv("LB_ENC_WPS")) : 4;
   if (tiles_cap <= 256 * 8 * 2)
     hipLaunchKernelGGL((k_edge_enc16v<2>), dim3(grid_for(8)), dim3(512), 0, e->stream, a);
-  else if (wps_env == 2)
-    hipLaunchKernelGGL((k_edge_enc16v<2>), dim3(256), dim3(512), 0, e->stream, a);
-  else if (wps_env == 3)
-    hipLaunchKernelGGL((k_edge_enc16v<3>), dim3(256), dim3(768), 0, e->stream, a);
   else
     hipLaunchKernelGGL((k_edge_enc16v<4>), dim3(256), dim3(1024), 0, e->stream, a);
   LB_HIP(hipGetLastError());
   return LB_OK;
 }
 
-int lbk_edge16v(lb_engine* e, const lb_edge16_args& a, int variant) {
-#define LB_E16V(W, R, G)                                                                                \
+// Two waves per SIMD, GEMM-phase priority (round 2's measured best; the software-prefetching, second-read and
+// three- / four-wave variants live on in tools/museum/lb_edge16v_r02.hip for tools/edge16v_bench).
+int lbk_edge16v(lb_engine* e, const lb_edge16_args& a) {
+#define LB_E16V(NT, G)                                                                                  \
   do {                                                                                                  \
     if (a.skip_elat_store)                                                                              \
-      LB_LAUNCH_TIMED(e, (k_edge16v<W, R, true, 0, true>), dim3(G), dim3(W * 256), a);                  \
+      LB_LAUNCH_TIMED(e, (k_edge16v<2, false, true, 0, true, NT>), dim3(G), dim3(512), a);              \
     else                                                                                                \
-      LB_LAUNCH_TIMED(e, (k_edge16v<W, R, false, 0, true>), dim3(G), dim3(W * 256), a);                 \
+      LB_LAUNCH_TIMED(e, (k_edge16v<2, false, false, 0, true, NT>), dim3(G), dim3(512), a);             \
   } while (0)
-  // latents of the whole graph <= 96 MiB (LB_EDGE_NT_MIN_TILES tiles): cache-resident between layers, plain accesses
-  static const int64_t nt_min_tiles = getenv("LB_EDGE_NT_MIN_TILES") ? atoll(getenv("LB_EDGE_NT_MIN_TILES")) : 12288;
   // Small graphs (one 2.5 k-particle trajectory = ~1000 tiles): a launch is the latency chain
   // "stage 133 KiB of weights -> one tile per wave", so launch no more workgroups than there are tiles for.
   // The tile count is bounded on the host by the frozen capacity (the real count lives on the device).
   const int64_t tiles_cap = ((int64_t)e->e_cap * e->g.B + 15) / 16;
-  auto grid_for = [&](int waves_per_block) {
-    int64_t g = (tiles_cap + waves_per_block - 1) / waves_per_block;
-    g = (g + 7) / 8 * 8;  // the XCD-aware walk wants a multiple of 8
-    return (int)(g < 8 ? 8 : (g > 256 ? 256 : g));
-  };
-  if (variant == 0 && tiles_cap <= 256 * 8 * 2) {
-    // (one wave per SIMD, i.e. twice the workgroups, measures slower: 17 vs 13.8 us per launch on a 20 k-edge
-    // graph - every workgroup stages the 133 KiB of weights; three waves per SIMD: 15.4 us)
-    LB_E16V(2, false, grid_for(8));
-  } else if (variant == 0 && tiles_cap < nt_min_tiles) {
-    if (a.skip_elat_store)
-      LB_LAUNCH_TIMED(e, (k_edge16v<2, false, true, 0, true, false>), dim3(256), dim3(512), a);
-    else
-      LB_LAUNCH_TIMED(e, (k_edge16v<2, false, false, 0, true, false>), dim3(256), dim3(512), a);
-  } else {
-    switch (variant) {
-      case 0: LB_E16V(2, false, 256); break;   // default: two waves per SIMD measure faster than three
-      case 6: LB_E16V(3, false, 256); break;
-      case 1: LB_E16V(4, true, 256); break;
-      case 2: LB_E16V(3, true, 256); break;
-      case 4:
-        if (a.skip_elat_store)
-          hipLaunchKernelGGL((k_edge16l<2, true>), dim3(256), dim3(512), 0, e->stream, a);
-        else
-          hipLaunchKernelGGL((k_edge16l<2, false>), dim3(256), dim3(512), 0, e->stream, a);
-        break;
-      case 5: LB_E16V(2, false, 256); break;
-      case 3:
-        if (a.skip_elat_store)
-          hipLaunchKernelGGL((k_edge16p<2, true>), dim3(256), dim3(512), 0, e->stream, a);
-        else
-          hipLaunchKernelGGL((k_edge16p<2, false>), dim3(256), dim3(512), 0, e->stream, a);
-        break;
-      default: return lb_fail(LB_ERR_ARG, "k_edge16v variant %d", variant);
-    }
-  }
+  int64_t g = (tiles_cap + 7) / 8;
+  g = (g + 7) / 8 * 8;  // the XCD-aware walk wants a multiple of 8
+  const int grid = (int)(g < 8 ? 8 : (g > 256 ? 256 : g));
+  // latents of the whole graph <= 96 MiB (LB_EDGE_NT_MIN_TILES tiles): cache-resident between layers, plain accesses
+  static const int64_t nt_min_tiles = getenv("LB_EDGE_NT_MIN_TILES") ? atoll(getenv("LB_EDGE_NT_MIN_TILES")) : 12288;
+  if (tiles_cap < nt_min_tiles)
+    LB_E16V(false, grid);
+  else
+    LB_E16V(true, grid);
 #undef LB_E16V
   LB_HIP(hipGetLastError());
   return LB_OK;

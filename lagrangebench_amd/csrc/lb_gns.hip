@@ -23,6 +23,7 @@
 //   parts are projected once per NODE (fused into the tail of the node kernel) and gathered as
 //   the accumulator's initial value, which halves the dominant MFMA work.
 //   Aggregation is an atomic-free segmented sum over the receiver-sorted CSR (deterministic).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "lb_device.h"
@@ -139,170 +140,6 @@ __device__ __forceinline__ void lb_layernorm(const f32x16 (&acc)[4], f32x4 (&y)[
     }
 }
 
-// ============================================================================ edge kernels
-struct lb_edge_args {
-  const lb_ctrl* ctrl;
-  const int32_t* senders;
-  const int32_t* receivers;
-  const float* efeat;  // ENC input [E][8]
-  float* elat;         // [E][128] in/out
-  float* msg;          // [E][128] out (PROC)
-  const float* psr;    // [BN][256] = [n@Ws | n@Wr + b0]
-  const float* w0p;    // packed: PROC 128x128 (edge rows of W0), ENC 8x128
-  const float* b0;     // ENC only
-  const float* w1p;    // packed 128x128
-  const float* b1;
-  const float* ln_s;
-  const float* ln_o;
-  // fused aggregation (PROC): receiver-sorted CSR + outputs
-  int fused;
-  const int32_t* row_ptr;
-  float* agg;   // [BN][128] rows complete inside one tile
-  float* part;  // [ntiles][2][128] segments cut by a tile boundary
-};
-
-#define EDGE_THREADS 512
-#define EDGE_WAVES 8
-
-// ABL: ablation bits for tools/edge_bench.hip only (0 in the product): 1 no Ps/Pr gather, 2 no e
-// load, 4 no stores, 8 no LayerNorm, 16 no GEMM2, 32 no GEMM1.
-template <bool PROC, int ABL = 0>
-__global__ void __launch_bounds__(EDGE_THREADS, 2) k_edge_mlp(lb_edge_args a) {
-  // PROC: [0,4096) = W0 edge part, [4096,8192) = W1.  ENC: [0,256) = W0 (K=8), [256,4352) = W1.
-  constexpr int NW0 = PROC ? 4096 : 256;
-  __shared__ f32x4 sW[NW0 + 4096];
-  if (a.ctrl->overflow_step >= 0) return;
-  const int tid = threadIdx.x;
-  {
-    const f32x4* g0 = reinterpret_cast<const f32x4*>(a.w0p);
-    const f32x4* g1 = reinterpret_cast<const f32x4*>(a.w1p);
-    for (int i = tid; i < NW0; i += EDGE_THREADS) sW[i] = g0[i];
-    for (int i = tid; i < 4096; i += EDGE_THREADS) sW[NW0 + i] = g1[i];
-  }
-  __syncthreads();
-  const int E = a.ctrl->n_edges_total;
-  const int ntiles = (E + LB_TILE - 1) / LB_TILE;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int h = lane >> 5;
-  // XCD-aware tile walk: block b runs on XCD b % 8 (observed dispatch order); give every XCD one
-  // contiguous eighth of the receiver-sorted edge list so its L2 keeps that range's gathers.
-  const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * EDGE_WAVES + wave;
-  const int per_xcd = (gridDim.x >> 3) * EDGE_WAVES;
-  const int t_lo = (int)(((int64_t)ntiles * xcd) >> 3), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) >> 3);
-
-  auto ld0 = [&](int kq, int mb) -> f32x4 { return sW[(kq * 4 + mb) * 64 + lane]; };
-  auto ld1 = [&](int kq, int mb) -> f32x4 { return sW[NW0 + (kq * 4 + mb) * 64 + lane]; };
-
-  for (int tile = t_lo + slot; tile < t_hi; tile += per_xcd) {
-    const int row = tile * LB_TILE + (lane & 31);
-    const bool valid = row < E;
-    const int64_t rowc = valid ? row : (E - 1);
-    f32x16 acc[4];
-    f32x4 ve[16];
-    f32x4* erow = reinterpret_cast<f32x4*>(a.elat) + rowc * 32 + h;
-    if (PROC) {
-      const int s = a.senders[rowc], r = a.receivers[rowc];
-#pragma unroll
-      for (int kq = 0; kq < 16; ++kq) ve[kq] = (ABL & 2) ? f32x4{1.f, 2.f, 3.f, (float)lane} : erow[2 * kq];
-      const f32x4* ps = reinterpret_cast<const f32x4*>(a.psr) + (int64_t)s * 64 + h;
-      const f32x4* pr = reinterpret_cast<const f32x4*>(a.psr) + (int64_t)r * 64 + 32 + h;
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 t = (ABL & 1) ? f32x4{0.1f, 0.2f, (float)s, (float)r}
-                                    : ps[2 * (4 * mb + q)] + pr[2 * (4 * mb + q)];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[mb][4 * q + j] = t[j];
-        }
-      if constexpr (!(ABL & 32)) lb_gemm<16, 4>(ld0, ve, acc);
-    } else {
-      f32x4 vin[1];
-      vin[0] = reinterpret_cast<const f32x4*>(a.efeat)[rowc * 2 + h];
-      lb_acc_init(acc, a.b0, h);
-      lb_gemm<1, 4>(ld0, vin, acc);
-    }
-    f32x4 vh[16];
-    lb_acc_to_v(acc, vh, true);
-    f32x16 acc2[4];
-    lb_acc_init(acc2, a.b1, h);
-    if constexpr (!(ABL & 16)) lb_gemm<16, 4>(ld1, vh, acc2);
-    if constexpr ((ABL & 16) != 0) {
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) acc2[mb] = acc2[mb] + acc[mb];
-    }
-    f32x4 y[16];
-    if constexpr (ABL & 8)
-      lb_acc_to_v(acc2, y, false);
-    else
-      lb_layernorm(acc2, y, a.ln_s, a.ln_o, h, a.ctrl);
-    if (valid && !((ABL & 4) && a.senders[0] != -12345)) {
-      if (PROC) {
-        if (!a.fused) {
-          f32x4* mrow = reinterpret_cast<f32x4*>(a.msg) + rowc * 32 + h;
-#pragma unroll
-          for (int kq = 0; kq < 16; ++kq) mrow[2 * kq] = y[kq];  // e' for the stand-alone segment_sum
-        }
-        // residual (gns.py:120-122); e is re-read (L2-resident, fetched a few us ago by this CU)
-        // instead of being kept in 64 VGPRs across both GEMMs
-#pragma unroll
-        for (int kq = 0; kq < 16; ++kq) erow[2 * kq] = erow[2 * kq] + y[kq];
-      } else {
-#pragma unroll
-        for (int kq = 0; kq < 16; ++kq) erow[2 * kq] = y[kq];
-      }
-    }
-    if (PROC && a.fused) {
-      // ---- fused jraph.segment_sum(e', receivers): the tile's 32 edges are consecutive rows of
-      // the receiver-sorted list, so every receiver is a contiguous lane range.  Segmented
-      // Hillis-Steele scan across the 32 lanes of each half-wave with DPP row shifts (offsets
-      // 1,2,4,8 inside a 16-lane row, row_bcast15 across rows); the last lane of a segment ends up
-      // with the receiver's sum for its 64 features.  Rows lying entirely inside the tile are
-      // written to agg[r]; the (at most two) segments cut by a tile boundary go to the tile's
-      // partial slots and are combined, in tile order, by the node kernel.  No atomics.
-      const int p = lane & 31;
-      const int rr = valid ? a.receivers[rowc] : (-1 - p);
-      const int r_prev = __shfl_up(rr, 1, 32);
-      const bool head = (p == 0) || (rr != r_prev);
-      const unsigned H = (unsigned)(__ballot(head) & 0xffffffffull);  // both halves: same pattern
-      const unsigned below = H & (p == 31 ? 0xffffffffu : ((2u << p) - 1u));
-      const int segstart = 31 - __clz(below);
-      const bool tail = (p == 31) || ((H >> (p + 1)) & 1u);
-      const int pr16 = p & 15;
-      const bool m1 = pr16 >= 1 && segstart <= p - 1, m2 = pr16 >= 2 && segstart <= p - 2;
-      const bool m4 = pr16 >= 4 && segstart <= p - 4, m8 = pr16 >= 8 && segstart <= p - 8;
-      const bool mb15 = p >= 16 && segstart <= 15;
-#pragma unroll
-      for (int kq = 0; kq < 16; ++kq)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float x = y[kq][j];
-          float t;
-          t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xF, 0xF, true));
-          x += m1 ? t : 0.f;
-          t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xF, 0xF, true));
-          x += m2 ? t : 0.f;
-          t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xF, 0xF, true));
-          x += m4 ? t : 0.f;
-          t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xF, 0xF, true));
-          x += m8 ? t : 0.f;
-          t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xA, 0xF, false));
-          x += mb15 ? t : 0.f;
-          y[kq][j] = x;
-        }
-      if (tail && valid) {
-        const int k0 = a.row_ptr[rr], k1 = a.row_ptr[rr + 1];
-        const bool complete = (k0 >> 5) == ((k1 - 1) >> 5);
-        float* dst = complete ? a.agg + (int64_t)rr * 128
-                              : a.part + ((int64_t)tile * 2 + (k0 <= tile * LB_TILE ? 0 : 1)) * 128;
-        f32x4* d4 = reinterpret_cast<f32x4*>(dst) + h;
-#pragma unroll
-        for (int kq = 0; kq < 16; ++kq) d4[2 * kq] = y[kq];
-      }
-    }
-  }
-}
-
 // Gather a node's aggregated messages in the fused-aggregation scheme: one source when the
 // receiver's CSR row lies inside a single 32-edge tile (agg[g]), else the per-tile partial slots
 // in tile order.  Lane = node; v gets the lane's 64 features (half h).
@@ -408,59 +245,6 @@ __global__ void __launch_bounds__(64) k_node_mlp(lb_node_args a) {
   }
 }
 
-// ================================================================================= decoder
-struct lb_dec_args {
-  const lb_ctrl* ctrl;
-  int64_t n_rows;
-  const float* nlat;
-  const float* w0p;
-  const float* b0;
-  const float* w1p;  // packed 128 x 32 (out_dim padded)
-  const float* b1;   // [32]
-  float* acc_out;    // [rows][4]
-  int out_dim;
-};
-
-__global__ void __launch_bounds__(64) k_decoder(lb_dec_args a) {
-  if (a.ctrl->overflow_step >= 0) return;
-  const int lane = threadIdx.x & 63, h = lane >> 5;
-  const int64_t row = (int64_t)blockIdx.x * LB_TILE + (lane & 31);
-  const bool valid = row < a.n_rows;
-  const int64_t rowc = valid ? row : a.n_rows - 1;
-  const f32x4* w0 = reinterpret_cast<const f32x4*>(a.w0p);
-  const f32x4* w1 = reinterpret_cast<const f32x4*>(a.w1p);
-  f32x4 vn[16];
-  const f32x4* nr = reinterpret_cast<const f32x4*>(a.nlat) + rowc * 32 + h;
-#pragma unroll
-  for (int kq = 0; kq < 16; ++kq) vn[kq] = nr[2 * kq];
-  f32x16 acc[4];
-  lb_acc_init(acc, a.b0, h);
-  auto ld0 = [&](int kq, int mb) -> f32x4 { return w0[(kq * 4 + mb) * 64 + lane]; };
-  lb_gemm<16, 4>(ld0, vn, acc);
-  f32x4 vh[16];
-  lb_acc_to_v(acc, vh, true);
-  f32x16 acc2[1];
-  {
-    // rows of the C tile are output features j + 8q + 4h: outputs 0..3 live in lanes < 32, regs 0..3
-    const f32x4* b4 = reinterpret_cast<const f32x4*>(a.b1);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 t = b4[2 * q + h];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc2[0][4 * q + j] = t[j];
-    }
-  }
-  auto ld1 = [&](int kq, int mb) -> f32x4 { return w1[(kq * 1 + mb) * 64 + lane]; };
-  lb_gemm<16, 1>(ld1, vh, acc2);
-  if (valid && h == 0) {
-    f32x4 o = {acc2[0][0], acc2[0][1], acc2[0][2], acc2[0][3]};
-    reinterpret_cast<f32x4*>(a.acc_out)[rowc] = o;
-    bool bad = false;
-    for (int d = 0; d < a.out_dim; ++d) bad |= !(fabsf(o[d]) <= 3.0e38f);
-    if (bad) atomicOr(const_cast<int32_t*>(&a.ctrl->math_flags), LB_MATH_NONFINITE);
-  }
-}
-
 // ============================================================================= aggregation
 // jraph.segment_sum(e', receivers, N) on the receiver-sorted CSR: one half-wave per node row,
 // lane c owns the 16-byte column chunk c; the row's messages are one contiguous HBM range that
@@ -521,19 +305,31 @@ static int lb_msplit_env() {
 static bool lb_use_msplit_edge(const lb_engine* e) {
   static const int64_t max_tiles = getenv("LB_MS_MAX_TILES") ? atoll(getenv("LB_MS_MAX_TILES")) : 3072;
   const int env = lb_msplit_env();
-  if (!e->f16x2 || !e->fused_agg || e->edge_tile != 16 || env == 0) return false;
+  if (!e->f16x2 || !e->fused_agg || env == 0) return false;
   if (env == 1) return true;
   return ((int64_t)e->e_cap * e->g.B + 15) / 16 <= max_tiles;
 }
 static bool lb_use_msplit_node(const lb_engine* e) {
   static const int64_t max_nodes = getenv("LB_MS_MAX_NODES") ? atoll(getenv("LB_MS_MAX_NODES")) : 16384;
   const int env = lb_msplit_env();
-  if (!e->f16x2 || !e->fused_agg || e->edge_tile != 16 || env == 0) return false;
+  if (!e->f16x2 || env == 0) return false;
   if (env == 1) return true;
   return e->BN <= max_nodes;
 }
 
+extern "C" int lb_kernel_names(lb_engine* e, char* out, int32_t cap) {
+  if (!e || !out || cap < 1) return lb_fail(LB_ERR_ARG, "null argument");
+  const char* edge = !e->f16x2 ? "k_edge16<PROC,f32>"
+                     : !e->fused_agg ? "k_edge16<PROC,f16x2> + k_segment_sum"
+                     : lb_use_msplit_edge(e) ? "k_edge_ms (M-split, f16x2, fused segment_sum)"
+                                             : "k_edge16v<2 waves/SIMD, resident latents, GEMM-phase priority> (PROC, f16x2, fused segment_sum)";
+  const char* node = !e->f16x2 ? "k_node_mlp<f32>" : lb_use_msplit_node(e) ? "k_node_ms (M-split, f16x2)" : "k_node16s (f16x2)";
+  snprintf(out, (size_t)cap, "edge=%s;node=%s", edge, node);
+  return LB_OK;
+}
+
 int lbk_gns_forward(lb_engine* e, lb_gns* g) {
+  LB_TRY(lb_gns_bind(e, g));
   if (g->generic) return lbk_gns_forward_generic(e, g);
   // LB_MS_PARTS (debug / ablation): bit 0 encoder node, 1 encoder edge, 2 processor edge, 3 processor node
   static const int ms_parts = getenv("LB_MS_PARTS") ? atoi(getenv("LB_MS_PARTS")) : 15;
@@ -543,7 +339,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
   hipStream_t s = e->stream;
   const int64_t BN = e->BN;
   const int ntile_n = (int)((BN + LB_TILE - 1) / LB_TILE);
-  const int edge_blocks = 256;
+  const int L = g->desc.num_mp_steps;
   int rc;
 
   lb_tic(e, LB_T_NODEFEAT);
@@ -552,275 +348,161 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
   lb_toc(e);
   if (rc) return rc;
 
-  const int L = g->desc.num_mp_steps;
-  {
+  // Kernel families.  f16x2 (default): M-split kernels on small graphs, else k_edge16v / k_edge_enc16v (edges) and
+  // k_node16s (nodes).  Exact fp32 (LB_MATH=f32, or the range guard's fall-back): k_edge16<*, f32> and the 32-row
+  // k_node_mlp.  Stand-alone aggregation (lb_set_fused_aggregation(0)): k_edge16 writes the messages, k_segment_sum
+  // adds them up.
+  auto node_mlp = [&](const lb_mlp_w& w, const float* xin, int kq, bool with_agg, bool resid, int next,
+                      const float* ms_img, const float* w0h, const float* w1h, bool ms) -> int {
+    const bool proj = next < L;
     lb_node_args a{};
     a.ctrl = e->ctrl;
     a.n_rows = BN;
-    a.xin = e->xnode;
+    a.xin = xin;
+    a.agg = e->agg;
     a.nlat = e->nlat;
-    a.w0p = g->enc_node.w0;
-    a.b0 = g->enc_node.b0;
-    a.w1p = g->enc_node.w1;
-    a.b1 = g->enc_node.b1;
-    a.ln_s = g->enc_node.ln_s;
-    a.ln_o = g->enc_node.ln_o;
-    a.wpp = L > 0 ? g->proj_w[0] : nullptr;
-    a.bp = L > 0 ? g->proj_b[0] : nullptr;
+    a.w0p = w.w0;
+    a.b0 = w.b0;
+    a.w1p = w.w1;
+    a.b1 = w.b1;
+    a.ln_s = w.ln_s;
+    a.ln_o = w.ln_o;
+    a.wpp = proj ? g->proj_w[next] : nullptr;
+    a.bp = proj ? g->proj_b[next] : nullptr;
     a.psr = e->psr;
-    lb_tic(e, LB_T_ENC_NODE);
-    // LB_NODE_KERNEL=h selects the round-1 node kernel (lb_node16h.hip)
-    // and up to 16 k nodes (a launch is then a latency chain per workgroup: lb_node16h with its loader waves
-    // measures faster - TGV2D-2.5k 15 vs 24 us per launch; from 24 k nodes lb_node16s wins by 13 %)
-    static const bool node_s_env = !(getenv("LB_NODE_KERNEL") && getenv("LB_NODE_KERNEL")[0] == 'h');
-    static const int64_t node_s_min = getenv("LB_NODE_S_MIN") ? atoll(getenv("LB_NODE_S_MIN")) : 16385;
-    const bool node_s = node_s_env && BN >= node_s_min;
-    if (ms_en) {
+    a.fused = e->fused_agg;
+    a.tile_shift = 4;
+    a.row_ptr = e->row_ptr;
+    a.part = e->part;
+    if (ms) {
       lb_nms_args m{};
       m.ctrl = e->ctrl;
       m.n_rows = BN;
-      m.xin = e->xnode;
+      m.xin = xin;
+      m.agg = e->agg;
+      m.row_ptr = e->row_ptr;
+      m.part = e->part;
+      m.fused = e->fused_agg;
       m.nlat = e->nlat;
-      m.w = g->ms_enc_node;
+      m.w = ms_img;
       m.b0 = a.b0;
       m.b1 = a.b1;
       m.ln_s = a.ln_s;
       m.ln_o = a.ln_o;
       m.bp = a.bp;
       m.psr = e->psr;
-      rc = lbk_node_ms(e, m, g->kq_node / 4, false, false, L > 0);
-      if (rc) return rc;
-    } else if (e->f16x2 && node_s) {
-      rc = lbk_node16s(e, a, g->enc_node_w0_h, g->enc_node_w1_h, L > 0 ? g->proj_w_h2[0] : nullptr,
-                       g->kq_node / 4, 0, false);
-      if (rc) return rc;
-    } else if (e->f16x2) {
-      rc = lbk_node16h(e, a, g->enc_node_w0_h, g->enc_node_w1_h, L > 0 ? g->proj_w_h[0] : nullptr,
-                       g->kq_node / 4, 0, false);
-      if (rc) return rc;
-    } else if (g->kq_node == 4)
+      return lbk_node_ms(e, m, kq / 4, with_agg, resid, proj);
+    }
+    if (e->f16x2)
+      return lbk_node16s(e, a, w0h, w1h, proj ? g->proj_w_h2[next] : nullptr, kq / 4, with_agg ? 4 : 0, resid);
+    if (with_agg)
+      hipLaunchKernelGGL((k_node_mlp<16, 16, true>), dim3(ntile_n), dim3(64), 0, s, a);
+    else if (kq == 4)
       hipLaunchKernelGGL((k_node_mlp<4, 0, false>), dim3(ntile_n), dim3(64), 0, s, a);
-    else if (g->kq_node == 8)
+    else if (kq == 8)
       hipLaunchKernelGGL((k_node_mlp<8, 0, false>), dim3(ntile_n), dim3(64), 0, s, a);
-    else if (g->kq_node == 12)
+    else if (kq == 12)
       hipLaunchKernelGGL((k_node_mlp<12, 0, false>), dim3(ntile_n), dim3(64), 0, s, a);
     else
       hipLaunchKernelGGL((k_node_mlp<16, 0, false>), dim3(ntile_n), dim3(64), 0, s, a);
-    lb_toc(e);
+    return LB_OK;
+  };
+
+  lb_tic(e, LB_T_ENC_NODE);
+  rc = node_mlp(g->enc_node, e->xnode, g->kq_node, false, false, 0, g->ms_enc_node, g->enc_node_w0_h,
+                g->enc_node_w1_h, ms_en);
+  lb_toc(e);
+  if (rc) return rc;
+
+  lb_tic(e, LB_T_ENC_EDGE);
+  if (ms_ee) {
+    lb_ems_args m{};
+    m.ctrl = e->ctrl;
+    m.efeat = e->efeat;
+    m.elat = e->elat;
+    m.w = g->ms_enc_edge;
+    m.b0 = g->enc_edge.b0;
+    m.b1 = g->enc_edge.b1;
+    m.ln_s = g->enc_edge.ln_s;
+    m.ln_o = g->enc_edge.ln_o;
+    rc = lbk_edge_enc_ms(e, m);
+  } else {
+    lb_edge16_args b{};
+    b.ctrl = e->ctrl;
+    b.efeat = e->efeat;
+    b.elat = e->elat;
+    b.w0p = e->f16x2 ? g->enc_edge_w0_16h : g->enc_edge_w0_16;
+    b.b0 = g->enc_edge.b0;
+    b.w1p = e->f16x2 ? g->enc_edge_w1_16h : g->enc_edge_w1_16;
+    b.b1 = g->enc_edge.b1;
+    b.ln_s = g->enc_edge.ln_s;
+    b.ln_o = g->enc_edge.ln_o;
+    rc = e->f16x2 ? lbk_edge_enc16v(e, b) : lbk_edge16(e, b, false, false);
   }
-  {
-    lb_edge_args a{};
-    a.ctrl = e->ctrl;
-    a.efeat = e->efeat;
-    a.elat = e->elat;
-    a.w0p = g->enc_edge.w0;
-    a.b0 = g->enc_edge.b0;
-    a.w1p = g->enc_edge.w1;
-    a.b1 = g->enc_edge.b1;
-    a.ln_s = g->enc_edge.ln_s;
-    a.ln_o = g->enc_edge.ln_o;
-    lb_tic(e, LB_T_ENC_EDGE);
-    if (ms_ee) {
-      lb_ems_args m{};
-      m.ctrl = e->ctrl;
-      m.efeat = e->efeat;
-      m.elat = e->elat;
-      m.w = g->ms_enc_edge;
-      m.b0 = a.b0;
-      m.b1 = a.b1;
-      m.ln_s = a.ln_s;
-      m.ln_o = a.ln_o;
-      rc = lbk_edge_enc_ms(e, m);
-      if (rc) return rc;
-    } else if (e->edge_tile == 16) {
-      lb_edge16_args b{};
-      b.ctrl = a.ctrl;
-      b.efeat = a.efeat;
-      b.elat = a.elat;
-      b.w0p = e->f16x2 ? g->enc_edge_w0_16h : g->enc_edge_w0_16;
-      b.b0 = a.b0;
-      b.w1p = e->f16x2 ? g->enc_edge_w1_16h : g->enc_edge_w1_16;
-      b.b1 = a.b1;
-      b.ln_s = a.ln_s;
-      b.ln_o = a.ln_o;
-      // LB_ENC_KERNEL=h: the round-1 encoder kernel (k_edge16<ENC>)
-      static const bool enc_v = !(getenv("LB_ENC_KERNEL") && getenv("LB_ENC_KERNEL")[0] == 'h');
-      rc = (e->f16x2 && enc_v) ? lbk_edge_enc16v(e, b) : lbk_edge16(e, b, false, e->f16x2 != 0);
-      if (rc) return rc;
-    } else {
-      hipLaunchKernelGGL((k_edge_mlp<false>), dim3(edge_blocks), dim3(EDGE_THREADS), 0, s, a);
-    }
-    lb_toc(e);
-  }
+  lb_toc(e);
+  if (rc) return rc;
   if (g->tap) LB_HIP(hipMemcpyAsync(g->tap, e->nlat, sizeof(float) * BN * LB_D, hipMemcpyDeviceToDevice, s));
 
   for (int k = 0; k < L; ++k) {
-    {
-      lb_edge_args a{};
-      a.ctrl = e->ctrl;
-      a.senders = e->senders;
-      a.receivers = e->receivers;
-      a.elat = e->elat;
-      a.msg = e->msg;
-      a.psr = e->psr;
-      a.w0p = g->proc_edge[k].w0;
-      a.w1p = g->proc_edge[k].w1;
-      a.b1 = g->proc_edge[k].b1;
-      a.ln_s = g->proc_edge[k].ln_s;
-      a.ln_o = g->proc_edge[k].ln_o;
-      a.fused = e->fused_agg;
-      a.row_ptr = e->row_ptr;
-      a.agg = e->agg;
-      a.part = e->part;
-      lb_tic_single(e, LB_T_EDGE_MLP);
-      if (ms_pe) {
-        lb_ems_args m{};
-        m.ctrl = e->ctrl;
-        m.senders = e->senders;
-        m.receivers = e->receivers;
-        m.elat = e->elat;
-        m.psr = e->psr;
-        m.w = g->ms_proc_edge[k];
-        m.b1 = a.b1;
-        m.ln_s = a.ln_s;
-        m.ln_o = a.ln_o;
-        m.agg = e->agg;
-        m.part = e->part;
-        m.skip_elat_store = (k == L - 1) && !g->tap;
-        rc = lbk_edge_ms(e, m);
-        if (rc) return rc;
-      } else if (e->edge_tile == 16) {
-        lb_edge16_args b{};
-        b.ctrl = a.ctrl;
-        b.senders = a.senders;
-        b.receivers = a.receivers;
-        b.elat = a.elat;
-        b.msg = a.msg;
-        b.psr = a.psr;
-        b.w0p = e->f16x2 ? g->proc_edge_w0_16h[k] : g->proc_edge_w0_16[k];
-        b.w1p = e->f16x2 ? g->proc_edge_w1_16h[k] : g->proc_edge_w1_16[k];
-        b.b1 = a.b1;
-        b.ln_s = a.ln_s;
-        b.ln_o = a.ln_o;
-        b.fused = a.fused;
-        b.row_ptr = a.row_ptr;
-        b.agg = a.agg;
-        b.part = a.part;
-        b.skip_elat_store = (k == L - 1) && e->fused_agg && !g->tap;
-        // LB_EDGE_KERNEL: "n" = round-1 k_edge16n, "v0".."v3" = k_edge16v / k_edge16p variants
-        static const int ev = [] {
-          const char* s = getenv("LB_EDGE_KERNEL");
-          if (!s || !s[0]) return 0;
-          if (s[0] == 'n') return -1;
-          return (s[0] == 'v' && s[1] >= '0' && s[1] <= '6') ? s[1] - '0' : 0;
-        }();
-        if (e->f16x2 && e->fused_agg && ev >= 0) {
-          // LB_EDGE_PINGPONG=1: layer k reads one buffer and writes the other (the stand-alone message
-          // buffer is free in fused mode).  The bare stream measures ~4 % faster out of place
-          // (tools/stream_bench), the kernel does not (2.767 vs 2.766 ms per step): off by default
-          static const bool pingpong = getenv("LB_EDGE_PINGPONG") && getenv("LB_EDGE_PINGPONG")[0] == '1';
-          if (pingpong) {
-            b.elat = (k & 1) ? e->msg : e->elat;
-            b.elat_out = (k & 1) ? e->elat : e->msg;
-          }
-          rc = lbk_edge16v(e, b, ev);
-        } else {
-          rc = lbk_edge16(e, b, true, e->f16x2 != 0);
-        }
-        if (rc) return rc;
-      } else {
-        hipLaunchKernelGGL((k_edge_mlp<true>), dim3(edge_blocks), dim3(EDGE_THREADS), 0, s, a);
-      }
-      lb_toc(e);
+    const lb_mlp_w& pe = g->proc_edge[k];
+    const bool skip = (k == L - 1) && e->fused_agg && !g->tap;  // the last layer's edge latents have no reader
+    lb_tic_single(e, LB_T_EDGE_MLP);
+    if (ms_pe) {
+      lb_ems_args m{};
+      m.ctrl = e->ctrl;
+      m.senders = e->senders;
+      m.receivers = e->receivers;
+      m.elat = e->elat;
+      m.psr = e->psr;
+      m.w = g->ms_proc_edge[k];
+      m.b1 = pe.b1;
+      m.ln_s = pe.ln_s;
+      m.ln_o = pe.ln_o;
+      m.agg = e->agg;
+      m.part = e->part;
+      m.skip_elat_store = skip;
+      rc = lbk_edge_ms(e, m);
+    } else {
+      lb_edge16_args b{};
+      b.ctrl = e->ctrl;
+      b.senders = e->senders;
+      b.receivers = e->receivers;
+      b.elat = e->elat;
+      b.msg = e->msg;
+      b.psr = e->psr;
+      b.w0p = e->f16x2 ? g->proc_edge_w0_16h[k] : g->proc_edge_w0_16[k];
+      b.w1p = e->f16x2 ? g->proc_edge_w1_16h[k] : g->proc_edge_w1_16[k];
+      b.b1 = pe.b1;
+      b.ln_s = pe.ln_s;
+      b.ln_o = pe.ln_o;
+      b.fused = e->fused_agg;
+      b.row_ptr = e->row_ptr;
+      b.agg = e->agg;
+      b.part = e->part;
+      b.skip_elat_store = skip;
+      rc = (e->f16x2 && e->fused_agg) ? lbk_edge16v(e, b) : lbk_edge16(e, b, true, e->f16x2 != 0);
     }
+    lb_toc(e);
+    if (rc) return rc;
     if (!e->fused_agg) {
       lb_tic(e, LB_T_AGGREGATE);
       rc = lbk_segment_sum(e, e->msg, e->agg, LB_D);
       lb_toc(e);
       if (rc) return rc;
     }
-    {
-      lb_node_args a{};
-      a.ctrl = e->ctrl;
-      a.n_rows = BN;
-      a.xin = e->nlat;
-      a.agg = e->agg;
-      a.nlat = e->nlat;
-      a.w0p = g->proc_node[k].w0;
-      a.b0 = g->proc_node[k].b0;
-      a.w1p = g->proc_node[k].w1;
-      a.b1 = g->proc_node[k].b1;
-      a.ln_s = g->proc_node[k].ln_s;
-      a.ln_o = g->proc_node[k].ln_o;
-      a.wpp = (k + 1 < L) ? g->proj_w[k + 1] : nullptr;
-      a.bp = (k + 1 < L) ? g->proj_b[k + 1] : nullptr;
-      a.psr = e->psr;
-      a.fused = e->fused_agg;
-      a.tile_shift = e->edge_tile == 16 ? 4 : 5;
-      a.row_ptr = e->row_ptr;
-      a.part = e->part;
-      lb_tic_single(e, LB_T_NODE_MLP);
-      static const bool node_s_env = !(getenv("LB_NODE_KERNEL") && getenv("LB_NODE_KERNEL")[0] == 'h');
-      static const int64_t node_s_min = getenv("LB_NODE_S_MIN") ? atoll(getenv("LB_NODE_S_MIN")) : 16385;
-    const bool node_s = node_s_env && BN >= node_s_min;
-      if (ms_pn) {
-        lb_nms_args m{};
-        m.ctrl = e->ctrl;
-        m.n_rows = BN;
-        m.xin = e->nlat;
-        m.agg = e->agg;
-        m.row_ptr = e->row_ptr;
-        m.part = e->part;
-        m.fused = 1;
-        m.nlat = e->nlat;
-        m.w = g->ms_proc_node[k];
-        m.b0 = a.b0;
-        m.b1 = a.b1;
-        m.ln_s = a.ln_s;
-        m.ln_o = a.ln_o;
-        m.bp = a.bp;
-        m.psr = e->psr;
-        rc = lbk_node_ms(e, m, 4, true, true, k + 1 < L);
-        if (rc) return rc;
-      } else if (e->f16x2 && node_s) {
-        rc = lbk_node16s(e, a, g->proc_node_w0_h[k], g->proc_node_w1_h[k],
-                         (k + 1 < L) ? g->proj_w_h2[k + 1] : nullptr, 4, 4, true);
-        if (rc) return rc;
-      } else if (e->f16x2) {
-        rc = lbk_node16h(e, a, g->proc_node_w0_h[k], g->proc_node_w1_h[k],
-                         (k + 1 < L) ? g->proj_w_h[k + 1] : nullptr, 4, 4, true);
-        if (rc) return rc;
-      } else {
-        hipLaunchKernelGGL((k_node_mlp<16, 16, true>), dim3(ntile_n), dim3(64), 0, s, a);
-      }
-      lb_toc(e);
-    }
+    lb_tic_single(e, LB_T_NODE_MLP);
+    rc = node_mlp(g->proc_node[k], e->nlat, 16, true, true, k + 1, g->ms_proc_node[k], g->proc_node_w0_h[k],
+                  g->proc_node_w1_h[k], ms_pn);
+    lb_toc(e);
+    if (rc) return rc;
     if (g->tap)
       LB_HIP(hipMemcpyAsync(g->tap + (size_t)(k + 1) * BN * LB_D, e->nlat, sizeof(float) * BN * LB_D,
                             hipMemcpyDeviceToDevice, s));
   }
-  {
-    lb_dec_args a{};
-    a.ctrl = e->ctrl;
-    a.n_rows = BN;
-    a.nlat = e->nlat;
-    a.w0p = g->dec.w0;
-    a.b0 = g->dec.b0;
-    a.w1p = g->dec.w1;
-    a.b1 = g->dec.b1;
-    a.acc_out = e->acc;
-    a.out_dim = g->desc.out_dim;
-    lb_tic(e, LB_T_DECODER);
-    // LB_DEC_KERNEL=h: round 1's one-wave-per-tile fp32 kernel
-    static const bool dec16 = !(getenv("LB_DEC_KERNEL") && getenv("LB_DEC_KERNEL")[0] == 'h');
-    if (dec16 && e->edge_tile == 16) {
-      rc = lbk_decoder16(e, g);
-      if (rc) return rc;
-    } else {
-      hipLaunchKernelGGL(k_decoder, dim3(ntile_n), dim3(64), 0, s, a);
-    }
-    lb_toc(e);
-  }
+  lb_tic(e, LB_T_DECODER);
+  rc = lbk_decoder16(e, g);
+  lb_toc(e);
+  if (rc) return rc;
   LB_HIP(hipGetLastError());
   return LB_OK;
 }

@@ -469,28 +469,16 @@ int lb_gns_create_generic(lb_engine* e, const lb_gns_desc* d, const float* w, in
     g->g_proc_edge.push_back(mk(o_pe[k]));
     g->g_proc_node.push_back(mk(o_pn[k]));
   }
-  {
-    const float lnc[2] = {1.0f / (float)dl, (float)(D - dl)};
-    if (hipMemcpy(&e->ctrl->ln_inv_d, lnc, sizeof(lnc), hipMemcpyHostToDevice) != hipSuccess) {
-      lb_gns_destroy(g);
-      return lb_fail(LB_ERR_HIP, "control block upload failed");
-    }
-  }
+  g->lnc[0] = 1.0f / (float)dl;  // LayerNorm width of this model (lb_gns_bind)
+  g->lnc[1] = (float)(D - dl);
   if (w_rms_min < 0.0078125 && e->f16x2 && e->math_auto) {
     fprintf(stderr, "[lbhip] a weight matrix has rms %.3g < 2^-7: its fp16 hi/lo split would fall short of the 1e-5 class - "
                     "this engine uses exact-fp32 MFMA arithmetic\n", w_rms_min);
     e->f16x2 = 0;
   }
-  e->g.kpad = kpad;
   const int64_t BN = e->BN;
-  for (void* b : {(void*)e->xnode, (void*)e->nlat, (void*)e->agg, (void*)e->psr})
-    if (b) (void)hipFree(b);
-  e->xnode = e->nlat = e->agg = e->psr = nullptr;
-  int rc = LB_OK;
-  if (!rc) rc = lb_alloc(&e->xnode, (size_t)BN * kpad);
-  if (!rc) rc = lb_alloc(&e->nlat, (size_t)BN * D);
-  if (!rc) rc = lb_alloc(&e->agg, (size_t)BN * D);
-  if (!rc) rc = lb_alloc(&e->psr, (size_t)BN * 2 * D);
+  int rc = lb_ensure_node_scratch(e);
+  if (!rc) rc = lb_gns_bind(e, g);
   for (int i = 0; i < 3 && !rc; ++i) rc = lb_alloc(&g->gen_hn[i], (size_t)BN * D);
   if (rc) {
     lb_gns_destroy(g);

@@ -126,12 +126,13 @@ struct lb_engine {
   float* msg;          // [e_alloc][D]   (stand-alone segment_sum path only)
   float* part;         // [e_alloc/32+1][2][D] partial sums of receivers cut by a tile boundary
   int fused_agg;       // 1: aggregation fused into the edge kernel (default), 0: msg + k_segment_sum
-  int edge_tile;       // 16: k_edge16 (16x16x4 MFMA, software-pipelined, default); 32: k_edge_mlp
   int f16x2;           // 1: GEMMs in fp16 hi/lo split arithmetic on the fp16 MFMA (fp32-class accuracy)
   int math_auto;       // 1: f16x2 with the range guard - a raised lb_ctrl::math_flags makes the host repeat
                        //    the work in exact-fp32 MFMA arithmetic and stay there (LB_MATH unset);
                        // 0: the mode LB_MATH / lb_math_mode fixed
   float* acc;          // [BN][4] decoder output (dim padded to 4)
+  const void* bound_model = nullptr;  // the lb_gns whose per-model constants (LayerNorm width, node row stride) are
+                                      // currently in the control block / geometry: lb_gns_bind
 
   // timers
   bool timers_on;
@@ -157,8 +158,7 @@ struct lb_edge16_args {  // lb_edge16.hip
   const int32_t* receivers;
   const float* efeat;  // ENC input [E][8]
   float* elat;         // [E][128] in/out
-  float* elat_out;     // k_edge16v / k_edge16p only: where the updated latents go (null = in place); the
-                       // layers ping-pong between two buffers - an out-of-place stream measures ~4 % faster
+  float* elat_out;     // where the updated latents go (null = in place)
   float* msg;          // [E][128] out (PROC, !fused)
   const float* psr;    // [BN][256]
   const float* w0p;    // 16-packed: PROC 128x128 (edge rows of W0), ENC 16x128
@@ -226,6 +226,7 @@ struct lb_gns {
   std::vector<const float*> proc_node_w0_h, proc_node_w1_h, proj_w_h;
   std::vector<const float*> proj_w_h2;  // projection packed as two 128-wide halves [Ws | Wr] (lb_node16s.hip)
   int kq_node;         // node_in(+emb) padded to a multiple of 32, in units of 8
+  float lnc[2] = {1.0f / LB_D, 0.f};  // lb_ctrl::ln_inv_d, ln_pad of this model (latent width < 128: zero padded)
   float* tap;
   // decoder on the 16-row tile scheme (k_decoder16): W0 and the out_dim block of W1, both packings
   const float* dec_w0_h = nullptr;
@@ -337,6 +338,10 @@ int lb_sg_upd_image_floats(void);
 int lbk_sg_update(lb_engine* e, float* f, const float* agg, const float* nattr, const float* image,
                   bool combine_partials);
 
+// lb_api.hip: node-sized network scratch (allocated once per engine, xnode at the full 128-column width) and the
+// per-model constants that live in engine-wide state; several models may share one engine
+int lb_ensure_node_scratch(lb_engine* e);
+int lb_gns_bind(lb_engine* e, lb_gns* g);
 // lb_gns.hip
 int lbk_gns_forward(lb_engine* e, lb_gns* g);
 // lb_gns_generic.hip: num_mlp_layers != 2
@@ -350,16 +355,11 @@ void lb_pack_weight(const float* w, int K, int M, int Kpad, int Mpad, float* out
 void lb_pack_weight16(const float* w, int K, int M, int Kpad, float* out);
 void lb_pack_weight16h(const float* w, int K, int M, int Kpad, float* out, int Mpad = 128);
 
-// lb_node16h.hip
-int lbk_node16h(lb_engine* e, const lb_node_args& a, const float* w0h, const float* w1h,
-                const float* wph, int npa, int npb, bool resid);
 // lb_node16s.hip: round-2 node kernel (one weight pass per CU through a direct-to-LDS ring);
 // wph2 = projection packed as [Ws | Wr] halves, or null
 int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const float* w1h,
                 const float* wph2, int npa, int npb, bool resid);
 int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc, bool f16x2);
-// lb_edge16v.hip: round-2 processor edge kernel (f16x2, fused aggregation); variant 0 = three waves per
-// SIMD, resident latents (default), 1 = four waves + second read, 2 = three waves + second read,
-// 3 = two waves, fully software-pipelined
-int lbk_edge16v(lb_engine* e, const lb_edge16_args& a, int variant);
+// lb_edge16v.hip: processor edge kernel (f16x2, fused aggregation, two waves per SIMD)
+int lbk_edge16v(lb_engine* e, const lb_edge16_args& a);
 int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a);

@@ -305,26 +305,17 @@ int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const flo
   const f32x4* wp = reinterpret_cast<const f32x4*>(wph2);
   const bool proj = wph2 != nullptr;
   const int64_t tiles = (a.n_rows + 15) / 16;
-  // LB_NODE_NW=16: one 16-tile workgroup per CU (4-slot ring); default 8: two 8-tile workgroups per CU
-  // (2-slot rings); small launches use 4-tile workgroups so that more CUs take part
-  static const int want = getenv("LB_NODE_NW") ? atoi(getenv("LB_NODE_NW")) : 8;
-  const int nw = tiles < 8 * 256 ? 4 : (want == 16 ? 16 : 8);
+  // two 8-tile workgroups per CU (2-slot rings); small launches use 4-tile workgroups so that more CUs take part
+  // (16-wave workgroups and a deeper ring measured slower: round 2)
+  const int nw = tiles < 8 * 256 ? 4 : 8;
   const int nblk = (int)((tiles + nw - 1) / nw);
-  // few workgroups (at most one per CU): a launch is a latency chain of chunk steps - give each
-  // workgroup the deep ring (three chunks in flight) instead of a second co-resident workgroup
-  static const bool want_deep = getenv("LB_NODE_DEEP") && getenv("LB_NODE_DEEP")[0] == '1';
-  const bool deep = want_deep && nw == 4 && nblk <= 256;  // measured slower than the 2-slot ring: off
   dim3 grid(nblk), block(nw * 64);
 #define LB_NS(A, B, R, P, W, S) \
   LB_LAUNCH_TIMED(e, (k_node16s<A, B, R, P, W, S>), grid, block, a, w0, w1, wp)
 #define LB_NS_W(A, B, R, P)            \
   do {                                 \
-    if (nw == 16)                      \
-      LB_NS(A, B, R, P, 16, 4);        \
-    else if (nw == 8)                  \
+    if (nw == 8)                       \
       LB_NS(A, B, R, P, 8, 2);         \
-    else if (deep)                     \
-      LB_NS(A, B, R, P, 4, 4);         \
     else                               \
       LB_NS(A, B, R, P, 4, 2);         \
   } while (0)

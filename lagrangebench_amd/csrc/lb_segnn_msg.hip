@@ -558,20 +558,10 @@ int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg,
   a.agg = agg;
   a.part = e->part;
   a.dim = e->g.dim;
-  static const int dbg = getenv("LB_SGM_DBG") ? atoi(getenv("LB_SGM_DBG")) : 0;
-  static const int grid = getenv("LB_SGM_GRID") ? atoi(getenv("LB_SGM_GRID")) : 256;
   a.msg = e->msg;
-  static const int waves = getenv("LB_EDGE_WAVES") ? atoi(getenv("LB_EDGE_WAVES")) : 3;
-  if (dbg & 2) {
-    hipLaunchKernelGGL((k_sg_msg<2, 512>), dim3(grid), dim3(512), 0, e->stream, a);
-    return lbk_segment_sum(e, e->msg, agg, 128);
-  }
-  if (waves == 3)
-    hipLaunchKernelGGL((k_sg_msg<1, 768>), dim3(grid), dim3(768), 0, e->stream, a);
-  else if (dbg & 1)
-    hipLaunchKernelGGL((k_sg_msg<1, 512>), dim3(grid), dim3(512), 0, e->stream, a);
-  else
-    hipLaunchKernelGGL((k_sg_msg<0, 512>), dim3(grid), dim3(512), 0, e->stream, a);
+  // three waves per SIMD, no register prefetch (round 1's measured best; the two-wave software-pipelined schedule and
+  // the per-edge-message ablation are template modes 0 / 2 of the kernel, no longer instantiated in the product)
+  hipLaunchKernelGGL((k_sg_msg<1, 768>), dim3(256), dim3(768), 0, e->stream, a);
   if (finish) {  // consumers other than k_sg_upd want complete rows in agg
     const int nb = (int)((e->BN + 7) / 8);
     hipLaunchKernelGGL(k_sg_agg_finish, dim3(nb), dim3(256), 0, e->stream, e->ctrl, e->BN, e->row_ptr,

@@ -49,6 +49,19 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, local_rank, world
 
 
+def group_info(device: Optional[torch.device] = None) -> dict:
+    """What the LIVE process group looks like from this rank: backend, world size and the ranks an all_gather
+    actually returned (bench.py records it: "did RCCL see N ranks" must be readable from the bench line)."""
+    rank, _, world = env_world()
+    if not dist.is_initialized():
+        return {"initialized": False, "backend": None, "world_size": 1, "env_world_size": world, "ranks_seen": [0]}
+    t = torch.tensor([dist.get_rank()], dtype=torch.int64, device=_coll_device(device))
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return {"initialized": True, "backend": str(dist.get_backend()), "world_size": dist.get_world_size(),
+            "env_world_size": world, "ranks_seen": sorted(int(x.item()) for x in out)}
+
+
 def shard_trajectories(n_trajs: int, rank: int, world: int) -> List[int]:
     """Trajectory i -> rank i % world."""
     return [i for i in range(n_trajs) if i % world == rank]

@@ -206,6 +206,13 @@ class RolloutEngine:
         return {"n_edges_total": n.value, "e_cap": ec.value, "cell_capacity": cc.value}
 
     # ------------------------------------------------------------------ features
+
+    def kernel_names(self) -> dict:
+        """{"edge": ..., "node": ...}: the network kernels a GNS forward runs on at the current size."""
+        buf = C.create_string_buffer(256)
+        check(self.lib.lb_kernel_names(self._h, buf, 256), "lb_kernel_names")
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(";") if "=" in kv)
+
     def node_features(self) -> Dict[str, torch.Tensor]:
         f64 = dict(dtype=torch.float64, device=self.device)
         out = {"vel_hist": torch.empty((self.B, self.N, self.K * self.dim), **f64)}

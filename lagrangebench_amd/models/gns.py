@@ -120,12 +120,21 @@ class GNS(BaseModel):
                             float(flat[:: max(1, flat.size // 7)].astype(np.float64).sum())))
         return tuple(out)
 
+    _MAX_HANDLES = 4  # device copies kept per model object (LRU): a training loop that hands over a fresh
+    #                   parameter tree every step must not accumulate one packed weight blob per step
+
     def handle(self, engine, params):
         key = (id(engine), id(params))
         hit = self._handles.get(key)
         stamp = self._fingerprint(params)
-        if hit is not None and hit[1] is params and hit[2] == stamp:
+        if hit is not None and hit[1] is params and hit[2] == stamp and hit[0].engine is engine:
+            self._handles[key] = self._handles.pop(key)  # most recently used last
             return hit[0]
+        self._handles.pop(key, None)
+        while len(self._handles) >= self._MAX_HANDLES:
+            # drop OUR reference to the least recently used handle: GnsHandle.__del__ frees the device blob
+            # once no caller holds it any more
+            self._handles.pop(next(iter(self._handles)))
         d = GnsDesc()
         d.latent_size, d.blocks_per_step, d.num_mp_steps = self._latent_size, self._blocks_per_step, self._mp_steps
         d.embedding_size, d.num_particle_types = self._embedding_size, self._num_particle_types

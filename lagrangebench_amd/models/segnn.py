@@ -137,8 +137,12 @@ class SEGNN(BaseModel):
     def handle(self, engine, params):
         key = (id(engine), id(params))
         hit = self._handles.get(key)
-        if hit is not None and hit[1] is params:
+        if hit is not None and hit[1] is params and hit[0].engine is engine:
+            self._handles[key] = self._handles.pop(key)
             return hit[0]
+        self._handles.pop(key, None)
+        while len(self._handles) >= 4:  # LRU: at most four device copies per model object (models/gns.py)
+            self._handles.pop(next(iter(self._handles)))
         d = SegnnDesc()
         d.hidden, d.blocks_per_step, d.num_mp_steps = self._hidden, self._blocks_per_step, self._num_mp_steps
         d.homogeneous = int(bool(self._homogeneous_particles))

@@ -27,7 +27,7 @@ _RUN_DEFAULTS = {
     "train": dict(defaults.train),
     "eval": {"test": False, "n_rollout_steps": 20, "rollout_dir": None,
              "infer": dict(defaults.eval.infer), "train": dict(defaults.eval.train)},
-    "logging": dict(defaults.logging, ckp_dir=None),
+    "logging": dict(defaults.logging),
     "neighbors": dict(defaults.neighbors),
 }
 
@@ -38,7 +38,7 @@ def setup_data(cfg) -> Tuple[H5Dataset, H5Dataset, H5Dataset]:
     dataset_path = cfg.dataset.src
     if not osp.isabs(dataset_path):
         dataset_path = osp.join(os.getcwd(), dataset_path)
-    if cfg.logging.ckp_dir is not None:
+    if cfg.logging.ckp_dir is not None and cfg.mode in ("train", "all"):  # (inference writes no checkpoint)
         os.makedirs(cfg.logging.ckp_dir, exist_ok=True)
     if cfg.eval.rollout_dir is not None:
         os.makedirs(cfg.eval.rollout_dir, exist_ok=True)

@@ -122,7 +122,16 @@ class Trainer:
         leaves = [v for mod in sorted(params_t) for _, v in sorted(params_t[mod].items())]
         opt = torch.optim.AdamW(leaves, lr=self._lr(step), betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8)
         if isinstance(opt_state, dict) and "state" in opt_state:
-            opt.load_state_dict(opt_state)
+            # (a checkpoint stores the moments as numpy arrays: utils.save_haiku)
+            def _t(x):
+                if isinstance(x, np.ndarray):
+                    return torch.as_tensor(x)
+                if isinstance(x, dict):
+                    return {k: _t(v) for k, v in x.items()}
+                if isinstance(x, list):
+                    return [_t(v) for v in x]
+                return x
+            opt.load_state_dict(_t(opt_state))
         if store_ckp is not None:
             os.makedirs(os.path.join(store_ckp, "best"), exist_ok=True)
 
@@ -181,7 +190,7 @@ class Trainer:
                     metrics = averaged_metrics(eval_metrics)
                     if store_ckp is not None:
                         save_haiku(store_ckp, gns_params_to_haiku(params_np, model._mp_steps, model._blocks_per_step),
-                                   state, None, {"step": step, "loss": metrics.get("val/loss", None)})
+                                   state, opt.state_dict(), {"step": step, "loss": metrics.get("val/loss", None)})
                     print(metrics)
                     # the validation rollouts re-sized / re-used the engine: the training list is rebuilt
                     key, _, _, neighbors = case.allocate(key, raw_sample)

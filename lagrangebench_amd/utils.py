@@ -117,11 +117,32 @@ def load_pytree(model_dir: str, name: str):
     return tree
 
 
+def _opt_state_to_host(x):
+    """torch tensors -> numpy (recursively) so that opt_state.pkl loads without a device."""
+    try:
+        import torch
+        if isinstance(x, torch.Tensor):
+            return x.detach().cpu().numpy()
+    except ImportError:  # pragma: no cover
+        pass
+    if isinstance(x, dict):
+        return {k: _opt_state_to_host(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_opt_state_to_host(v) for v in x)
+    return x
+
+
 def save_haiku(ckp_dir: str, params, state, opt_state, metadata_ckp) -> None:
-    """utils.py:61-96 (opt_state is ignored: training is out of scope), incl. the best/ copy."""
+    """utils.py:61-96 incl. the best/ copy.  `opt_state.pkl` is always written (the reference's load_haiku opens
+    it unconditionally, utils.py:119-121): here it holds the AdamW state_dict of train/trainer.py (step counters
+    and both moments per leaf, in the key-sorted leaf order of the parameter tree) as numpy arrays, or None.  It
+    is NOT an optax state: a reference run can read params / state of these checkpoints, but restarts its
+    optimiser from scratch."""
     _os.makedirs(ckp_dir, exist_ok=True)
     save_pytree(ckp_dir, params, "params")
     save_pytree(ckp_dir, state if state is not None else {}, "state")
+    with open(_os.path.join(ckp_dir, "opt_state.pkl"), "wb") as f:
+        _pickle.dump(_opt_state_to_host(opt_state), f)
     with open(_os.path.join(ckp_dir, "metadata_ckp.json"), "w") as f:
         _json.dump(metadata_ckp, f)
     if "best" not in ckp_dir:
@@ -137,16 +158,26 @@ def save_haiku(ckp_dir: str, params, state, opt_state, metadata_ckp) -> None:
 
 
 def load_haiku(model_dir: str):
-    """utils.py:112-128: (params, state, opt_state, step); opt_state is returned as None."""
+    """utils.py:112-128: (params, state, opt_state, step).  opt_state is whatever opt_state.pkl holds when it
+    unpickles without JAX / optax (this package's AdamW state_dict, or None); an optax state written by the
+    reference needs cloudpickle + optax and is returned as None."""
     params = load_pytree(model_dir, "params")
     state = load_pytree(model_dir, "state") if _os.path.exists(_os.path.join(model_dir, "state_tree.pkl")) else {}
+    opt_state = None
+    opt_path = _os.path.join(model_dir, "opt_state.pkl")
+    if _os.path.exists(opt_path):
+        try:
+            with open(opt_path, "rb") as f:
+                opt_state = _pickle.load(f)
+        except Exception:  # an optax state of the reference: not loadable without JAX
+            opt_state = None
     step = 0
     meta = _os.path.join(model_dir, "metadata_ckp.json")
     if _os.path.exists(meta):
         with open(meta) as fp:
             step = _json.loads(fp.read()).get("step", 0)
     print(f"Loaded model from {model_dir} at step {step}")
-    return params, state, None, step
+    return params, state, opt_state, step
 
 
 _SCOPE_RANK = (("encoder", 0), ("processor", 1), ("decoder", 2))

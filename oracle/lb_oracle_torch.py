@@ -34,13 +34,17 @@ def _mlp(p, name, x, bps):
 
 @torch.no_grad()
 def gns_apply(params_t, features, particle_type, num_mp_steps=10, blocks_per_step=2,
-              skip_padding=False, return_intermediates=False):
+              skip_padding=False, return_intermediates=False, dtype=torch.float32):
     """GNS.__call__ in the reference's padded shape (padding id N gathers node N-1, is dropped by
     the scatter-add).  ``skip_padding`` evaluates the real edges only (same node outputs);
     ``return_intermediates`` also returns the node latents after the encoder and every layer
-    (same keys as lb_oracle.gns_apply), used by the full-size parity tests."""
+    (same keys as lb_oracle.gns_apply), used by the full-size parity tests.  ``dtype=torch.float64`` evaluates the
+    same fp32 inputs and weights in double precision: the yardstick the element-wise error tests measure both the
+    engine and an fp32 evaluation against."""
     nodes, edges = O.gns_transform(features)
-    nodes, edges = torch.from_numpy(nodes), torch.from_numpy(edges)
+    nodes, edges = torch.from_numpy(nodes).to(dtype), torch.from_numpy(edges).to(dtype)
+    if dtype != torch.float32:
+        params_t = {k: {kk: vv.to(dtype) for kk, vv in v.items()} for k, v in params_t.items()}
     n = nodes.shape[0]
     senders = torch.from_numpy(np.asarray(features["senders"]).astype(np.int64))
     receivers = torch.from_numpy(np.asarray(features["receivers"]).astype(np.int64))

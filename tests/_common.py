@@ -71,3 +71,35 @@ def oracle_model_apply(num_mp_steps):
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def elementwise_stats(a, b, floor_frac=1e-3):
+    """Element-wise relative error |a-b| / |b| over the entries that are not tiny (|b| > floor_frac * max|b|):
+    (99.9th percentile, maximum, number of entries looked at).  The max-norm `rel_err` lets an entry 100x below
+    the maximum be off by 1e-3 relative; `north_star` asks for 1e-5 relative PER acceleration."""
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    keep = np.abs(b) > floor_frac * np.max(np.abs(b))
+    r = np.abs(a[keep] - b[keep]) / np.abs(b[keep])
+    if r.size == 0:
+        return 0.0, 0.0, 0
+    return float(np.percentile(r, 99.9)), float(r.max()), int(r.size)
+
+
+def make_trained_like_params(ds, num_mp_steps=10, seed=77, decoder_scale=0.01):
+    """Weights with the statistics of a TRAINED checkpoint rather than of an initialiser: heavy-tailed matrices
+    (Student-t, 3 degrees of freedom, rescaled to the haiku variance), LayerNorm scales spread log-uniformly over
+    three decades (1e-2 .. 10) with signs, biases much larger than the weights' scale, offsets of order one."""
+    p = make_params(ds, num_mp_steps=num_mp_steps, seed=seed, decoder_scale=decoder_scale, random_affine=False)
+    r = np.random.default_rng(seed + 5)
+    for k, v in p.items():
+        if "w" in v and v["w"].ndim == 2 and not k.startswith("decoder/linear_1"):
+            w = r.standard_t(3, size=v["w"].shape)
+            w *= (1.0 / np.sqrt(v["w"].shape[0])) / np.sqrt(3.0)      # var of t(3) = 3
+            v["w"] = np.clip(w, -4.0, 4.0).astype(np.float32)
+        if "b" in v and k != "decoder/linear_1":
+            v["b"] = (1.5 * r.standard_normal(v["b"].shape)).astype(np.float32)
+        if "scale" in v:
+            mag = 10.0 ** r.uniform(-2.0, 1.0, size=v["scale"].shape)
+            v["scale"] = (mag * r.choice([-1.0, 1.0], size=mag.shape)).astype(np.float32)
+            v["offset"] = r.standard_normal(v["offset"].shape).astype(np.float32)
+    return p

@@ -21,7 +21,8 @@ torch = pytest.importorskip("torch")
 
 from oracle import lb_oracle as O  # noqa: E402
 from oracle import lb_oracle_torch as OT  # noqa: E402
-from tests._common import hip_case, make_params, oracle_case, rel_err  # noqa: E402
+from tests._common import (elementwise_stats, hip_case, make_params, make_trained_like_params, oracle_case,  # noqa: E402
+                           rel_err)
 
 
 def _np(t):
@@ -75,6 +76,17 @@ def test_full_size_gns_forward_and_rollout_vs_oracle(name, cfg_idx, n_steps):
     for k in range(L):
         assert rel_err(tap[k + 1][:N], inter[f"n{k}"]) < 1e-5, f"layer {k}"
     assert rel_err(acc, ref["acc"]) < 1e-5
+    # ---- element-wise: north_star asks for 1e-5 relative PER acceleration, the max-norm bar above lets small
+    # entries off.  Yardstick = the same network evaluated in fp64; the bar = what a plain fp32 evaluation (the
+    # torch-CPU oracle) itself achieves against it.  Entries below 1e-3 of the largest are left out (they are
+    # differences of O(1) terms: no fp32 evaluation keeps 1e-5 relative there).
+    truth = OT.gns_apply(OT.params_to_torch(params), of, pt, num_mp_steps=L, skip_padding=True, dtype=torch.float64)["acc"]
+    p999_h, max_h, n_h = elementwise_stats(acc, truth)
+    p999_o, max_o, _ = elementwise_stats(ref["acc"], truth)
+    print(f"[elementwise {name}] engine vs fp64: p99.9 {p999_h:.2e} max {max_h:.2e} | fp32 oracle vs fp64: "
+          f"p99.9 {p999_o:.2e} max {max_o:.2e} ({n_h} entries)")
+    assert p999_h <= max(3.0 * p999_o, 1e-5), (p999_h, p999_o)
+    assert max_h <= max(3.0 * max_o, 1e-4), (max_h, max_o)
 
     # ---- 20-step rollout (for RPF2D the first 20 of the 400 steps of configs[1])
     p2 = make_params(ds, num_mp_steps=L)
@@ -177,3 +189,48 @@ def test_batched_40k_nodes_forward_vs_oracle():
         for k in range(L):
             assert rel_err(tap[k + 1][b * N:(b + 1) * N], inter[f"n{k}"]) < 1e-5, (b, k)
         assert rel_err(acc[b], ref["acc"]) < 1e-5
+
+
+@pytest.mark.parametrize("name,batch", [("tgv2d", 1), ("small3d", 1), ("tgv3d", 3)], ids=["tgv2d", "small3d", "tgv3d_b3"])
+def test_trained_like_weight_statistics(name, batch):
+    """Random-init weights are the friendliest case for the fp16 hi/lo split (every operand O(1)).  A trained
+    checkpoint is not bound to that: heavy-tailed matrices, LayerNorm scales spread over three decades, biases much
+    larger than the weights' scale (tests/_common.py: make_trained_like_params).  The engine - whichever arithmetic its
+    range guard ends up in - must stay within 1e-5 of the oracle per layer and as accurate as an fp32 evaluation
+    element-wise; batch 3 of TGV3D runs the wave-per-tile kernels, one trajectory the M-split ones."""
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    L = 10
+    ds = make_case(name, n_trajs=batch, extra_seq_length=2)
+    dim, isl = len(ds.box), ds.input_seq_length
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    params = make_trained_like_params(ds, num_mp_steps=L, decoder_scale=1.0)
+    model = GNS(dim, 128, 2, L, 16)
+    pos = np.stack([ds[b][0] for b in range(batch)])
+    pt = np.stack([ds[b][1] for b in range(batch)])
+    N = pos.shape[1]
+    feats, nbrs = hcase.allocate_eval((pos[:, :, :isl], pt))
+    handle = model.handle(feats.engine, params)
+    tap = handle.set_tap(True)
+    acc = _np(model.apply(params, {}, (feats, pt))[0]["acc"])
+    tap = _np(tap).copy()
+    handle.set_tap(False)
+    mode, flags = feats.engine.math_mode()
+    print(f"[trained-like {name}] engine arithmetic after the forward: mode {mode} (0 = fp32, 1 = guarded f16x2), "
+          f"guard flags {flags}, kernels {feats.engine.kernel_names()}")
+    pt_t = OT.params_to_torch(params)
+    for b in range(batch):
+        of, _ = ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))
+        ref, inter = OT.gns_apply(pt_t, of, pt[b], num_mp_steps=L, skip_padding=True, return_intermediates=True)
+        truth = OT.gns_apply(pt_t, of, pt[b], num_mp_steps=L, skip_padding=True, dtype=torch.float64)["acc"]
+        sl = slice(b * N, (b + 1) * N)
+        assert rel_err(tap[0][sl], inter["enc_n"]) < 1e-5
+        for k in range(L):
+            assert rel_err(tap[k + 1][sl], inter[f"n{k}"]) < 1e-5, f"layer {k}"
+        assert rel_err(acc[b], ref["acc"]) < 1e-5
+        p999_h, max_h, n_h = elementwise_stats(acc[b], truth)
+        p999_o, max_o, _ = elementwise_stats(ref["acc"], truth)
+        print(f"[trained-like {name} b{b}] engine vs fp64: p99.9 {p999_h:.2e} max {max_h:.2e} | fp32 oracle vs fp64: "
+              f"p99.9 {p999_o:.2e} max {max_o:.2e} ({n_h} entries)")
+        assert p999_h <= max(3.0 * p999_o, 1e-5), (p999_h, p999_o)
+        assert max_h <= max(3.0 * max_o, 1e-4), (max_h, max_o)

@@ -431,14 +431,160 @@ __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
   }
 }
 
-// The fall-back launcher: exact fp32 (LB_MATH=f32 / the range guard's switch), the encoder in fp32, and the f16x2
-// processor with STAND-ALONE aggregation (messages written for k_segment_sum).  The fused f16x2 processor runs on
-// lb_edge16v.hip / lb_msplit.hip; round 1's three-wave k_edge16n is kept in tools/museum/lb_edge16_r01.hip.
+// ---------------------------------------------------------------------------------------------
+// k_edge16n: the processor edge MLP (f16x2, fused aggregation) WITHOUT the register prefetch of the
+// next tile.  Dropping the three 32-register prefetch sets brings the kernel under 168 VGPRs, i.e.
+// THREE waves per SIMD (12 per CU, one 768-thread workgroup around the same 133 KiB of LDS weights):
+// memory latency is then hidden by the two other waves of the SIMD instead of by a software
+// pipeline inside each wave.  Only the indices of the next tile are fetched ahead (2 registers).
+#define E16N_THREADS 768
+#define E16N_WAVES 12
+__global__ void __launch_bounds__(E16N_THREADS, 3) k_edge16n(lb_edge16_args a) {
+  constexpr int NW0 = 4096;
+  __shared__ f32x4 sW[NW0 + 4096 + 128];
+  if (a.ctrl->overflow_step >= 0) return;
+  const int tid = threadIdx.x;
+  {
+    const f32x4* g0 = reinterpret_cast<const f32x4*>(a.w0p);
+    const f32x4* g1 = reinterpret_cast<const f32x4*>(a.w1p);
+    for (int i = tid; i < NW0; i += E16N_THREADS) sW[i] = g0[i];
+    for (int i = tid; i < 4096; i += E16N_THREADS) sW[NW0 + i] = g1[i];
+    if (tid < 128) {
+      const float* src = tid < 32 ? a.b1 : (tid < 64 ? a.ln_s : (tid < 96 ? a.ln_o : a.b0));
+      sW[NW0 + 4096 + tid] = src ? reinterpret_cast<const f32x4*>(src)[tid & 31] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();
+  const int E = a.ctrl->n_edges_total;
+  const int ntiles = (E + 15) >> 4;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * E16N_WAVES + wave;
+  const int stride = (gridDim.x >> 3) * E16N_WAVES;
+  const int t_lo = (int)(((int64_t)ntiles * xcd) >> 3), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) >> 3);
+  int t = t_lo + slot;
+  if (t >= t_hi) return;
+  auto ldh0 = [&](int p, int mbo, int part) -> f32x4 { return sW[((p * 8 + mbo) * 2 + part) * 64 + lane]; };
+  auto ldh1 = [&](int p, int mbo, int part) -> f32x4 { return sW[NW0 + ((p * 8 + mbo) * 2 + part) * 64 + lane]; };
+  auto rowc_of = [&](int tt) -> int64_t {
+    const int row = tt * 16 + n;
+    return row < E ? row : E - 1;
+  };
+  const f32x4* psr4 = reinterpret_cast<const f32x4*>(a.psr);
+  const f32x4* b1_4 = &sW[NW0 + 4096];
+  const f32x4* lns4 = &sW[NW0 + 4096 + 32];
+  const f32x4* lno4 = &sW[NW0 + 4096 + 64];
+  const int n_iter = (t_hi - 1 - t) / stride + 1;
+  const int t_last = t + (n_iter - 1) * stride;
+  int s_c, r_c;
+  {
+    const int64_t rc = rowc_of(t);
+    s_c = a.senders[rc];
+    r_c = a.receivers[rc];
+  }
+  for (int it = 0; it < n_iter; ++it, t += stride) {
+    f32x4 acc[8], ve[8];
+    const int r_cur = r_c;
+    {
+      const f32x4* er = reinterpret_cast<const f32x4*>(a.elat) + (int64_t)t * 512 + lane;
+      const f32x4* ps = psr4 + (int64_t)s_c * 64 + g;
+      const f32x4* pr = psr4 + (int64_t)r_c * 64 + 32 + g;
+      f32x4 p0[8];
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) {
+        ve[mb] = er[64 * mb];
+        p0[mb] = ps[4 * mb];
+        acc[mb] = pr[4 * mb];
+      }
+      // indices of the next tile (branch-free: the last iteration re-reads its own)
+      const int64_t rn = rowc_of(min(t + stride, t_last));
+      s_c = a.senders[rn];
+      r_c = a.receivers[rn];
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) acc[mb] = acc[mb] + p0[mb];
+    }
+    lb_gemm16h<4>(ldh0, ve, acc);
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[mb][j] = fmaxf(acc[mb][j], 0.f);
+    f32x4 acc2[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc2[mb] = b1_4[4 * mb + g];
+    lb_gemm16h<4>(ldh1, acc, acc2);
+    float sm = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) sm += (acc2[mb][0] + acc2[mb][1]) + (acc2[mb][2] + acc2[mb][3]);
+    sm += __shfl_xor(sm, 16);
+    sm += __shfl_xor(sm, 32);
+    const float mean = sm * a.ctrl->ln_inv_d;
+    float vs = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = acc2[mb][j] - mean;
+        vs += d * d;
+      }
+    vs += __shfl_xor(vs, 16);
+    vs += __shfl_xor(vs, 32);
+    const float rs = 1.0f / sqrtf(fmaxf(vs - a.ctrl->ln_pad * (mean * mean), 0.f) * a.ctrl->ln_inv_d + 1e-5f);
+    f32x4 y[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const f32x4 sc = lns4[4 * mb + g], of = lno4[4 * mb + g];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[mb][j] = (sc[j] * rs) * (acc2[mb][j] - mean) + of[j];
+    }
+    const int row = t * 16 + n;
+    const bool valid = row < E;
+    if (!a.skip_elat_store) {
+      f32x4* er = reinterpret_cast<f32x4*>(a.elat) + (int64_t)t * 512 + lane;
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) er[64 * mb] = ve[mb] + y[mb];
+    }
+    const int rr = valid ? r_cur : (-1 - n);
+    const int r_prev = __builtin_amdgcn_update_dpp(-2, rr, 0x111, 0xF, 0xF, false);
+    const bool head = (n == 0) || (rr != r_prev);
+    const unsigned H = (unsigned)(__ballot(head) & 0xffffull);
+    const unsigned below = H & ((2u << n) - 1u);
+    const int segstart = 31 - __clz(below);
+    const bool tail = (n == 15) || ((H >> (n + 1)) & 1u);
+    const float m1 = (n >= 1 && segstart <= n - 1) ? 1.f : 0.f, m2 = (n >= 2 && segstart <= n - 2) ? 1.f : 0.f;
+    const float m4 = (n >= 4 && segstart <= n - 4) ? 1.f : 0.f, m8 = (n >= 8 && segstart <= n - 8) ? 1.f : 0.f;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = valid ? y[mb][j] : 0.f;
+        x = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xF, 0xF, true)), m1, x);
+        x = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xF, 0xF, true)), m2, x);
+        x = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xF, 0xF, true)), m4, x);
+        x = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xF, 0xF, true)), m8, x);
+        y[mb][j] = x;
+      }
+    if (tail && valid) {
+      const int k0 = a.row_ptr[rr], k1 = a.row_ptr[rr + 1];
+      const bool complete = (k0 >> 4) == ((k1 - 1) >> 4);
+      float* dst = complete ? a.agg + (int64_t)rr * 128
+                            : a.part + ((int64_t)t * 2 + (k0 <= t * 16 ? 0 : 1)) * 128;
+      f32x4* d4 = reinterpret_cast<f32x4*>(dst) + g;
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) d4[4 * mb] = y[mb];
+    }
+  }
+}
+
 int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc, bool f16x2) {
-  if (proc && f16x2)
+  static const int waves = getenv("LB_EDGE_WAVES") ? atoi(getenv("LB_EDGE_WAVES")) : 3;
+  if (proc && f16x2 && a.fused && waves == 3)
+    hipLaunchKernelGGL(k_edge16n, dim3(256), dim3(E16N_THREADS), 0, e->stream, a);
+  else if (proc && f16x2)
     hipLaunchKernelGGL((k_edge16<true, true>), dim3(256), dim3(E16_THREADS), 0, e->stream, a);
   else if (proc)
     hipLaunchKernelGGL((k_edge16<true, false>), dim3(256), dim3(E16_THREADS), 0, e->stream, a);
+  else if (f16x2)
+    hipLaunchKernelGGL((k_edge16<false, true>), dim3(256), dim3(E16_THREADS), 0, e->stream, a);
   else
     hipLaunchKernelGGL((k_edge16<false, false>), dim3(256), dim3(E16_THREADS), 0, e->stream, a);
   LB_HIP(hipGetLastError());
