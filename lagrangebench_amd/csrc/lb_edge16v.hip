@@ -299,7 +299,9 @@ int lbk_edge16v(lb_engine* e, const lb_edge16_args& a) {
   const int64_t tiles_cap = ((int64_t)e->e_cap * e->g.B + 15) / 16;
   int64_t g = (tiles_cap + 7) / 8;
   g = (g + 7) / 8 * 8;  // the XCD-aware walk wants a multiple of 8
-  const int grid = (int)(g < 8 ? 8 : (g > 256 ? 256 : g));
+  // LB_EDGE_GRID (measurement): cap on the workgroups (= CUs) the persistent kernel occupies
+  static const int grid_cap = getenv("LB_EDGE_GRID") ? atoi(getenv("LB_EDGE_GRID")) : 256;
+  const int grid = (int)(g < 8 ? 8 : (g > grid_cap ? grid_cap : g));
   // latents of the whole graph <= 96 MiB (LB_EDGE_NT_MIN_TILES tiles): cache-resident between layers, plain accesses
   static const int64_t nt_min_tiles = getenv("LB_EDGE_NT_MIN_TILES") ? atoll(getenv("LB_EDGE_NT_MIN_TILES")) : 12288;
   if (tiles_cap < nt_min_tiles)
