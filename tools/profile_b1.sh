@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
 for W in tgv2d rpf2d ldc3d tgv3d; do
-  B="python bench.py --no-cpu-baseline --no-other-configs --no-pmc --workload $W --batch 1 --steps 20 --warmup 20"
+  B="python bench.py --no-cpu-baseline --no-other-configs --no-pmc --workload $W --batch 1 --steps 20 --warmup 20 --no-f32 --repeats 3"
   $B > gpurun_out/$TAG/bench_${W}_b1.json 2> gpurun_out/$TAG/bench_${W}_b1.err
   rm -rf /tmp/p_$W
   timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_$W -- $B > gpurun_out/$TAG/kt_$W.log 2>&1
