@@ -196,6 +196,8 @@ def main():
         return
     value = world * B * N * K / dt
     ms_edge, n_edge = tm["edge_mlp"]
+    if n_edge == 0 and tm.get("processor", (0, 0))[1] > 0:   # all layers in one persistent launch: per-layer share
+        ms_edge, n_edge = tm["processor"][0], tm["processor"][1] * L
     ms_agg, n_agg = tm["aggregate"]
     us_edge = 1e3 * ms_edge / max(n_edge, 1)
     us_agg = 1e3 * ms_agg / max(n_agg, 1)
@@ -420,6 +422,8 @@ def other_configs(device):
                 tm = eng.timers()
                 eng.timers_enable(False)
                 ms_e, n_e = tm["edge_mlp"]
+                if n_e == 0 and tm.get("processor", (0, 0))[1] > 0:  # persistent launch: one layer's share (edge + node)
+                    ms_e, n_e = tm["processor"][0], tm["processor"][1] * 10
                 us = 1e3 * ms_e / max(n_e, 1)
                 if kind == "gns":
                     byts = E_tot * (2 * D * 4 + 8) + B * N * (2 * D * 4)

@@ -43,7 +43,7 @@ extern "C" int lb_version(void) { return 100; }
 // ---------------------------------------------------------------------------------- timers
 static const char* k_timer_names[LB_T_COUNT] = {
     "cells", "neighbors", "node_features", "enc_node", "enc_edge", "edge_mlp",
-    "aggregate", "node_mlp", "decoder", "integrate", "misc"};
+    "aggregate", "node_mlp", "decoder", "integrate", "misc", "processor"};
 
 static hipEvent_t lb_get_event(lb_engine* e) {
   if (!e->epool.empty()) {
@@ -263,7 +263,7 @@ extern "C" void lb_engine_destroy(lb_engine* e) {
                   e->cell_part, e->deg, e->row_ptr, e->scan_part, e->cpos, e->tmp_send, e->tmp_feat, e->tmp_feat64,
                   e->senders, e->receivers, e->efeat, e->efeat64,
                   e->overflow, e->nedges_b, e->xnode, e->nlat, e->agg, e->psr, e->elat, e->msg,
-                  e->part, e->acc, e->blocks_done};
+                  e->part, e->acc, e->blocks_done, e->persist_bar};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->ctrl_host) (void)hipHostFree(e->ctrl_host);
@@ -328,6 +328,12 @@ extern "C" int lb_read_window(lb_engine* e, double* out) {
 
 // --------------------------------------------------------------------------- neighbor list
 static int lb_check_density(lb_engine* e) {
+  if (e->ctrl_host->persist_error) {
+    e->persist_off = true;  // stay on the multi-launch path from now on
+    (void)hipMemsetAsync(&e->ctrl->persist_error, 0, sizeof(int32_t), e->stream);
+    return lb_fail(LB_ERR_STATE, "persistent processor launch: a grid-barrier spin timed out (workgroups not co-resident?); "
+                                 "results of this call are invalid, the engine now uses the multi-launch path");
+  }
   if (e->ctrl_host->density_error)
     return lb_fail(LB_ERR_DENSITY,
                    "neighbor search: %s (limits: %d stencil candidates, %d neighbors per particle)",
@@ -791,6 +797,27 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     g->ms_proc_edge.push_back(g->blob + o_ms_pe[k]);
     g->ms_proc_node.push_back(g->blob + o_ms_pn[k]);
   }
+  if (L > 0) {
+    std::vector<lb_persist_layer> tab(L);
+    for (int k = 0; k < L; ++k) {
+      lb_persist_layer& t = tab[k];
+      t.we = g->ms_proc_edge[k];
+      t.b1e = g->blob + o_pe[k].b1;
+      t.lnse = g->blob + o_pe[k].lns;
+      t.lnoe = g->blob + o_pe[k].lno;
+      t.wn = g->ms_proc_node[k];
+      t.b0n = g->blob + o_pn[k].b0;
+      t.b1n = g->blob + o_pn[k].b1;
+      t.lnsn = g->blob + o_pn[k].lns;
+      t.lnon = g->blob + o_pn[k].lno;
+      t.bp = (k + 1 < L) ? g->blob + o_pb[k + 1] : nullptr;
+    }
+    if (hipMalloc(&g->persist_layers, sizeof(lb_persist_layer) * L) != hipSuccess ||
+        hipMemcpy(g->persist_layers, tab.data(), sizeof(lb_persist_layer) * L, hipMemcpyHostToDevice) != hipSuccess) {
+      lb_gns_destroy(g);
+      return lb_fail(LB_ERR_HIP, "persistent-processor layer table upload failed");
+    }
+  }
   g->dec_unscale = dec_unscale;
   g->dec_w0_h = g->blob + o_dec_w0_h;
   g->dec_w0_f = g->blob + o_dec_w0_f;
@@ -842,6 +869,7 @@ int lb_gns_bind(lb_engine* e, lb_gns* g) {
 extern "C" void lb_gns_destroy(lb_gns* g) {
   if (!g) return;
   if (g->eng && g->eng->bound_model == g) g->eng->bound_model = nullptr;
+  if (g->persist_layers) (void)hipFree(g->persist_layers);
   if (g->blob) (void)hipFree(g->blob);
   for (float* b : g->gen_hn)
     if (b) (void)hipFree(b);

@@ -34,6 +34,7 @@ struct lb_ctrl {
                            // 4 = non-finite accelerations; checked by the host at its sync points
   float ln_inv_d;          // LayerNorm over a latent narrower than the 128-wide tiles (zero-padded weights):
   float ln_pad;            // mean = sum / d, var = (sum_128 (x-mean)^2 - pad * mean^2) / d, pad = 128 - d
+  int32_t persist_error;   // lb_persist.hip: a grid-barrier spin timed out (the launch gave up; results are invalid)
 };
 #define LB_MATH_LARGE 1
 #define LB_MATH_TINY 2
@@ -68,6 +69,7 @@ enum lb_timer_class {
   LB_T_DECODER,      // decoder MLP
   LB_T_INTEGRATE,    // integrator + kinematic select + window shift + prediction store
   LB_T_MISC,
+  LB_T_PROCESSOR,    // all message-passing layers as one persistent launch (lb_persist.hip)
   LB_T_COUNT
 };
 
@@ -131,6 +133,9 @@ struct lb_engine {
                        //    the work in exact-fp32 MFMA arithmetic and stay there (LB_MATH unset);
                        // 0: the mode LB_MATH / lb_math_mode fixed
   float* acc;          // [BN][4] decoder output (dim padded to 4)
+  unsigned* persist_bar = nullptr;    // grid-barrier words of the persistent processor launch (lb_persist.hip)
+  int persist_grid = 0;               // workgroups of that launch (= CUs, multiple of 8); 0 = not usable
+  bool persist_off = false;           // a barrier timed out once: the engine stays on the multi-launch path
   const void* bound_model = nullptr;  // the lb_gns whose per-model constants (LayerNorm width, node row stride) are
                                       // currently in the control block / geometry: lb_gns_bind
 
@@ -238,6 +243,7 @@ struct lb_gns {
   const float* ms_enc_node = nullptr;
   const float* ms_enc_edge = nullptr;
   std::vector<const float*> ms_proc_edge, ms_proc_node;
+  void* persist_layers = nullptr;  // device array of lb_persist_layer[L] (lb_persist.hip)
   // num_mlp_layers != 2 (lb_gns_generic.hip): one packed 128x128 Linear per input block, both packings
   bool generic = false;
   lb_gen_mlp g_enc_node, g_enc_edge, g_dec;

@@ -39,7 +39,38 @@ struct lb_nms_args {      // node kernel
   long long* dbg;         // LB_MS_DBG=1: shader-clock stamps of workgroup 0 (null in the product path)
 };
 
+struct lb_persist_layer {  // device pointers of one message-passing layer (lb_persist.hip)
+  const float* we;         // lb_pack_ms images [W0 edge rows | W1]
+  const float* b1e;
+  const float* lnse;
+  const float* lnoe;
+  const float* wn;         // [W0 (nlat | agg) | W1 | projection of layer k+1]
+  const float* b0n;
+  const float* b1n;
+  const float* lnsn;
+  const float* lnon;
+  const float* bp;         // [256] projection bias of layer k+1 (null on the last layer)
+};
+
+struct lb_persist_args {
+  lb_ctrl* ctrl;
+  const int32_t* senders;
+  const int32_t* receivers;
+  const int32_t* row_ptr;
+  float* elat;
+  float* psr;
+  float* agg;
+  float* part;
+  float* nlat;
+  int64_t n_rows;
+  int L;
+  const lb_persist_layer* layers;  // [L], device
+  unsigned* bar;                   // grid-barrier words (zeroed before every launch)
+  int grid;                        // workgroups = CUs used (multiple of 8)
+};
+
 void lb_pack_ms(const float* w, int K, int M, int nkb, int npw, bool perm, float* out);
 int lbk_edge_ms(lb_engine* e, const lb_ems_args& a);
 int lbk_edge_enc_ms(lb_engine* e, const lb_ems_args& a);
 int lbk_node_ms(lb_engine* e, const lb_nms_args& a, int nka, bool agg, bool resid, bool proj);
+int lbk_gns_persist(lb_engine* e, const lb_persist_args& a);

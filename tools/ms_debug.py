@@ -18,16 +18,22 @@ pos, pt = ds[0][0][None], ds[0][1][None]
 feats, nbrs = hcase.allocate_eval((pos[:, :, :isl], pt))
 eng = feats.engine
 handle = model.handle(eng, params)
-tap = handle.set_tap(True)
+NOTAP = os.environ.get("MS_DEBUG_NOTAP") == "1"   # the persistent processor launch only runs without a tap
+tap = None if NOTAP else handle.set_tap(True)
 pred, _ = model.apply(params, {}, (feats, pt))
-tap = tap.cpu().numpy()
+pred2, _ = model.apply(params, {}, (feats, pt))
+print("repeatable:", bool((pred["acc"] == pred2["acc"]).all()), eng.kernel_names())
+tap = None if NOTAP else tap.cpu().numpy()
 of, on = ocase.allocate_eval((pos[0][:, :isl].astype(np.float64), pt[0]))
 ref, inter = O.gns_apply(params, of, pt[0], num_mp_steps=L, skip_padding=True, return_intermediates=True)
 N = pos.shape[1]
 names = ["enc_n"] + [f"n{k}" for k in range(L)]
-for i, nm in enumerate(names):
+ONLY_LAST = os.environ.get("LB_PERSIST_TAP") == "1"
+for i, nm in enumerate([] if NOTAP else names):
+    if ONLY_LAST and i != L:
+        continue
     d = np.abs(tap[i][:N] - inter[nm])
     print(nm, "max err", d.max(), "ref max", np.abs(inter[nm]).max())
     print("  per 16-feature block:", np.round(d.reshape(N, 8, 16).max(axis=(0, 2)), 5))
     print("  per row%16:", np.round(d.reshape(-1, 16, 128)[: N // 16].max(axis=(0, 2)), 5))
-print("acc err", np.abs(pred["acc"].cpu().numpy()[0] - ref["acc"]).max())
+print("acc err", np.abs(pred["acc"].cpu().numpy()[0] - ref["acc"]).max(), "ref max", np.abs(ref["acc"]).max())
