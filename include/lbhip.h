@@ -191,6 +191,30 @@ int lb_rollout(lb_engine* eng, lb_gns* gns, const double* traj_dev, int32_t T, i
 
 /* ---- SEGNN (models/segnn.py:403-610), lmax_hidden = lmax_attributes = 1 --------------------- */
 
+/* ---- training step ----------------------------------------------------
+ * trainer.py:35-89: loss = _mse (weighted squared error of the normalised accelerations, summed over dim, masked
+ * to the non-kinematic particles, divided by their number), value_and_grad vmapped over the batch with the
+ * gradients SUMMED and the loss averaged, optax.adamw.  Forward (with saved activations), loss, backward and the
+ * optimiser step run on the device (csrc/lb_train.hip: rocBLAS sgemm for the dense contractions, hand-written HIP
+ * kernels for everything else); the graph, features and targets are the engine's (case.preprocess first). */
+typedef struct lb_gns_train lb_gns_train;
+/* weights_host: the flat blob of GNS.flatten (same layout as lb_gns_create); latent 128, two Linears per MLP. */
+int lb_gns_train_create(lb_engine* eng, const lb_gns_desc* desc, const float* weights_host, int64_t n_floats,
+                        lb_gns_train** out);
+void lb_gns_train_destroy(lb_gns_train* t);
+/* jax.value_and_grad(_mse) summed over the batch, on the engine's current window + neighbor list.
+ * target_dev (B*N, dim) fp32 normalised accelerations; gradients ACCUMULATE (lb_gns_train_zero_grad);
+ * *loss_out = mean of the per-trajectory losses; pred_out_dev (optional) receives the (B*N, dim) predictions. */
+int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, float loss_weight, double* loss_out,
+                           float* pred_out_dev);
+int lb_gns_train_zero_grad(lb_gns_train* t);
+/* optax.adamw(learning_rate, b1, b2, eps, weight_decay) on every parameter (trainer.py:183-193). */
+int lb_adamw_step(lb_gns_train* t, float lr, float b1, float b2, float eps, float weight_decay);
+/* which: 0 weights, 1 gradients, 2 / 3 first / second AdamW moment; flat blob in GNS.flatten order.
+ * write: step >= 0 also restores the optimiser's step counter (bias correction). */
+int lb_gns_train_read(lb_gns_train* t, int32_t which, float* out_host, int64_t n_floats);
+int lb_gns_train_write(lb_gns_train* t, int32_t which, const float* in_host, int64_t n_floats, int64_t step);
+
 typedef struct lb_segnn lb_segnn;
 
 /* SEGNN hyper-parameters (runner.py:217-237; configs: scalar_units 64 -> hidden irreps

@@ -87,6 +87,13 @@ _SIGS = {
     "lb_timer_get": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "lb_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lb_kernel_names": (C.c_int, [_P, C.c_char_p, C.c_int32]),
+    "lb_gns_train_create": (C.c_int, [_P, C.POINTER(GnsDesc), C.POINTER(C.c_float), C.c_int64, C.POINTER(_P)]),
+    "lb_gns_train_destroy": (None, [_P]),
+    "lb_gns_train_loss_grad": (C.c_int, [_P, _P, C.c_float, C.POINTER(C.c_double), _P]),
+    "lb_gns_train_zero_grad": (C.c_int, [_P]),
+    "lb_adamw_step": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "lb_gns_train_read": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.c_int64]),
+    "lb_gns_train_write": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.c_int64, C.c_int64]),
     "lb_segment_sum": (C.c_int, [_P, _P, _P, C.c_int32]),
     "lb_segnn_create": (C.c_int, [_P, C.POINTER(SegnnDesc), _P, C.c_int64, C.POINTER(_P)]),
     "lb_segnn_destroy": (None, [_P]),

@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liblbhip.so")
-SOURCES = ["lb_api.hip", "lb_neighbor.hip", "lb_state.hip", "lb_gns.hip", "lb_edge16.hip", "lb_segnn.hip", "lb_segnn_msg.hip", "lb_sinkhorn.hip", "lb_edge16v.hip", "lb_node16s.hip", "lb_gns_generic.hip", "lb_msplit.hip", "lb_persist.hip"]
+SOURCES = ["lb_api.hip", "lb_neighbor.hip", "lb_state.hip", "lb_gns.hip", "lb_edge16.hip", "lb_segnn.hip", "lb_segnn_msg.hip", "lb_sinkhorn.hip", "lb_edge16v.hip", "lb_node16s.hip", "lb_gns_generic.hip", "lb_msplit.hip", "lb_persist.hip", "lb_train.hip"]
 HEADERS = ["lb_internal.h", "lb_device.h", "lb_f16x2.h", "lb_msplit.h", "lb_msplit_dev.h", os.path.join("..", "..", "include", "lbhip.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
@@ -65,7 +65,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs)
+        # rocBLAS: the plain dense contractions of the TRAINING step (csrc/lb_train.hip); nothing on the rollout path
+        run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs +
+            ["-L/opt/rocm/lib", "-lrocblas", "-Wl,-rpath,/opt/rocm/lib"])
     return LIB
 
 

@@ -1,0 +1,600 @@
+// lb_train.hip - the GNS training step on the device: forward with saved activations, MSE loss, hand-written
+// backward, fused AdamW.
+//
+// Reference: lagrangebench/train/trainer.py:35-60 (_mse: weighted squared error of the predicted normalised
+// accelerations, summed over dim, masked to the non-kinematic particles, divided by their number) and :63-89
+// (_update: vmap(value_and_grad) over the batch, gradients SUMMED over the batch, loss averaged, optax.adamw);
+// the network is GNS.__call__ of models/gns.py:65-171 (haiku MLP / LayerNorm / Embed, jraph GraphNetwork).
+//
+// Design.  Training is the row next to the hot path, not the hot path: the step is built from plain dense
+// contractions - which go to rocBLAS sgemm (exact fp32; the prompt's rule: library GEMMs for plain GEMMs) - and
+// hand-written HIP kernels for everything that is not a GEMM: gather / concatenation of [n_s | n_r | e] and
+// [n | agg], bias + ReLU, LayerNorm forward and backward (two-pass statistics, one wave per 2 rows), ReLU masking,
+// column sums (bias / LayerNorm parameter gradients) with a two-level deterministic reduction, jraph.segment_sum
+// and its transpose on the receiver-sorted CSR, the sender-side scatter (fp32 atomics: the only non-deterministic
+// summation, as in the reference's XLA scatter), the embedding-table gradient, the masked MSE and its gradient,
+// AdamW over the flat parameter blob.  A batch of B trajectories is one disjoint graph: the per-trajectory losses
+// of _update (gradients summed, loss averaged) are obtained in one pass with a per-node weight 1 / n_nonkinematic(b).
+// The graph (receiver-sorted edge list), node / edge features and normalisation are the engine's: the caller runs
+// case.preprocess (noise, neighbor list, features, targets) first, exactly as for inference.
+// Weights live in fp32 in the layout of GNS.flatten (= lb_gns_create's blob): [embed] then per MLP w0 (in x 128),
+// b0, w1 (128 x out), b1 [, LayerNorm scale, offset]; gradients and both AdamW moments use the same layout.
+#include <math.h>
+#include <rocblas/rocblas.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "lb_device.h"
+
+#define TD 128  // latent width of the training path (GNS-*-128)
+
+struct lb_train_mlp {
+  int64_t w0, b0, w1, b1, lns, lno;  // float offsets into the blob
+  int in, out;
+  bool ln;
+};
+
+struct lb_gns_train {
+  lb_gns_desc desc;
+  lb_engine* eng;
+  rocblas_handle blas = nullptr;
+  int64_t n_floats = 0;
+  float *w = nullptr, *g = nullptr, *m = nullptr, *v = nullptr;  // weights, gradients, AdamW moments
+  int64_t off_embed = 0;
+  lb_train_mlp enc_node, enc_edge, dec;
+  std::vector<lb_train_mlp> pe, pn;
+  int nin = 0, kpad = 0;
+  int64_t step = 0;
+  // activations (sized for cap_n nodes / cap_e edges)
+  int64_t cap_n = 0, cap_e = 0;
+  float *xnode = nullptr, *a_en = nullptr, *z_en = nullptr, *a_ee = nullptr, *z_ee = nullptr;
+  std::vector<float*> nlat, elat;            // [L+1] node / edge latents entering layer k
+  std::vector<float*> xe, ae, ze, xn, an, zn;  // per layer: concat input, post-ReLU hidden, pre-LayerNorm output
+  float *a_d = nullptr, *pred = nullptr;
+  float *dn = nullptr, *de = nullptr, *dy = nullptr, *dz = nullptr, *da = nullptr, *dx = nullptr, *dagg = nullptr;
+  float* agg = nullptr;
+  float* colsum = nullptr;   // partial column sums [blocks][<=128]
+  float* node_w = nullptr;   // per node loss weight (0 for kinematic particles)
+  double* loss_dev = nullptr;
+  int32_t* cnt_dev = nullptr;  // non-kinematic particles per trajectory
+};
+
+static const char* blas_err(rocblas_status s) { return rocblas_status_to_string(s); }
+#define LB_BLAS(call)                                                                            \
+  do {                                                                                           \
+    rocblas_status _s = (call);                                                                  \
+    if (_s != rocblas_status_success) return lb_fail(LB_ERR_HIP, "%s: %s", #call, blas_err(_s)); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------- kernels
+// y[r][c] = relu?(y[r][c] + b[c])
+__global__ void k_bias_act(float* __restrict__ y, const float* __restrict__ b, int64_t rows, int cols, int relu) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  float x = y[i] + b[i % cols];
+  y[i] = relu ? fmaxf(x, 0.f) : x;
+}
+// LayerNorm forward over 128 columns: z (pre, bias already added) -> y = scale * zhat + offset [+ resid]; 64 lanes
+// own one row, 2 columns each
+__global__ void k_ln_fwd(const float* __restrict__ z, const float* __restrict__ sc, const float* __restrict__ of,
+                         const float* __restrict__ resid, float* __restrict__ y, int64_t rows) {
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int l = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float x0 = z[r * TD + l], x1 = z[r * TD + 64 + l];
+  float s = x0 + x1;
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.f / TD);
+  const float d0 = x0 - mean, d1 = x1 - mean;
+  float q = d0 * d0 + d1 * d1;
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rs = 1.0f / sqrtf(q * (1.f / TD) + 1e-5f);
+  float y0 = sc[l] * (d0 * rs) + of[l], y1 = sc[64 + l] * (d1 * rs) + of[64 + l];
+  if (resid) {
+    y0 += resid[r * TD + l];
+    y1 += resid[r * TD + 64 + l];
+  }
+  y[r * TD + l] = y0;
+  y[r * TD + 64 + l] = y1;
+}
+// LayerNorm backward: dy, z -> dz; also writes dy * zhat into t (for d scale), d offset = column sum of dy
+__global__ void k_ln_bwd(const float* __restrict__ z, const float* __restrict__ sc, const float* __restrict__ dy,
+                         float* __restrict__ dz, float* __restrict__ t, int64_t rows) {
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int l = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float x0 = z[r * TD + l], x1 = z[r * TD + 64 + l];
+  float s = x0 + x1;
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.f / TD);
+  const float d0 = x0 - mean, d1 = x1 - mean;
+  float q = d0 * d0 + d1 * d1;
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rs = 1.0f / sqrtf(q * (1.f / TD) + 1e-5f);
+  const float h0 = d0 * rs, h1 = d1 * rs;
+  const float g0 = dy[r * TD + l], g1 = dy[r * TD + 64 + l];
+  const float u0 = g0 * sc[l], u1 = g1 * sc[64 + l];
+  float a = u0 + u1, b = u0 * h0 + u1 * h1;
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
+  }
+  a *= (1.f / TD);
+  b *= (1.f / TD);
+  dz[r * TD + l] = rs * (u0 - a - h0 * b);
+  dz[r * TD + 64 + l] = rs * (u1 - a - h1 * b);
+  t[r * TD + l] = g0 * h0;
+  t[r * TD + 64 + l] = g1 * h1;
+}
+// da *= (a > 0)
+__global__ void k_relu_bwd(float* __restrict__ da, const float* __restrict__ a, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !(a[i] > 0.f)) da[i] = 0.f;
+}
+// column sums of x (rows x cols, cols <= 128): deterministic two-level reduction (fixed row blocks of 1024 rows)
+__global__ void k_colsum_part(const float* __restrict__ x, int64_t rows, int cols, int ld, float* __restrict__ part) {
+  const int c = threadIdx.x;
+  if (c >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.x * 1024, r1 = r0 + 1024 < rows ? r0 + 1024 : rows;
+  float s = 0.f;
+  for (int64_t r = r0; r < r1; ++r) s += x[r * ld + c];
+  part[(int64_t)blockIdx.x * 128 + c] = s;
+}
+__global__ void k_colsum_fin(const float* __restrict__ part, int nblocks, int cols, float* __restrict__ out) {
+  const int c = threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * 128 + c];
+  out[c] += s;
+}
+// xe[e] = [n[snd] | n[rcv] | el[e]]  (gns.py:97-100)
+__global__ void k_gather_edge_in(const float* __restrict__ n, const float* __restrict__ el,
+                                 const int32_t* __restrict__ snd, const int32_t* __restrict__ rcv,
+                                 float* __restrict__ xe, int64_t E) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E * 96) return;
+  const int64_t e = i / 96;
+  const int q = (int)(i % 96);  // f32x4 chunk of the 384-wide row
+  const f32x4* src = q < 32 ? reinterpret_cast<const f32x4*>(n) + (int64_t)snd[e] * 32 + q
+                   : q < 64 ? reinterpret_cast<const f32x4*>(n) + (int64_t)rcv[e] * 32 + (q - 32)
+                            : reinterpret_cast<const f32x4*>(el) + e * 32 + (q - 64);
+  reinterpret_cast<f32x4*>(xe)[i] = *src;
+}
+// transpose of the gather: dn[snd] += dxe[:, :128] (atomics), dn[rcv] += dxe[:, 128:256] (atomics), de += dxe[:, 256:]
+__global__ void k_scatter_edge_in(const float* __restrict__ dxe, const int32_t* __restrict__ snd,
+                                  const int32_t* __restrict__ rcv, float* __restrict__ dn, float* __restrict__ de,
+                                  int64_t E) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E * 384) return;
+  const int64_t e = i / 384;
+  const int c = (int)(i % 384);
+  const float x = dxe[i];
+  if (c < 128)
+    atomicAdd(&dn[(int64_t)snd[e] * TD + c], x);
+  else if (c < 256)
+    atomicAdd(&dn[(int64_t)rcv[e] * TD + (c - 128)], x);
+  else
+    de[e * TD + (c - 256)] += x;
+}
+// xn[i] = [n[i] | agg[i]]
+__global__ void k_concat_node_in(const float* __restrict__ n, const float* __restrict__ agg, float* __restrict__ xn,
+                                 int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * 64) return;
+  const int64_t r = i / 64;
+  const int q = (int)(i % 64);
+  reinterpret_cast<f32x4*>(xn)[i] = q < 32 ? reinterpret_cast<const f32x4*>(n)[r * 32 + q]
+                                           : reinterpret_cast<const f32x4*>(agg)[r * 32 + (q - 32)];
+}
+// dn += dxn[:, :128]; dagg = dxn[:, 128:]
+__global__ void k_split_node_in(const float* __restrict__ dxn, float* __restrict__ dn, float* __restrict__ dagg,
+                                int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * 256) return;
+  const int64_t r = i / 256;
+  const int c = (int)(i % 256);
+  if (c < 128)
+    dn[r * TD + c] += dxn[i];
+  else
+    dagg[r * TD + (c - 128)] = dxn[i];
+}
+// jraph.segment_sum on the receiver-sorted CSR (rows are contiguous edge ranges): agg[r] = sum_e msg[e]
+__global__ void k_seg_sum(const int32_t* __restrict__ row_ptr, const float* __restrict__ msg, float* __restrict__ agg,
+                          int64_t N, int64_t E) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * 32) return;
+  const int64_t r = i / 32;
+  const int q = (int)(i % 32);
+  int64_t k0 = row_ptr[r], k1 = row_ptr[r + 1];
+  k0 = k0 < E ? k0 : E;
+  k1 = k1 < E ? k1 : E;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t k = k0; k < k1; ++k) s = s + reinterpret_cast<const f32x4*>(msg)[k * 32 + q];
+  reinterpret_cast<f32x4*>(agg)[i] = s;
+}
+// its transpose: dmsg[e] = base[e] + dagg[rcv[e]]
+__global__ void k_seg_sum_bwd(const float* __restrict__ base, const float* __restrict__ dagg,
+                              const int32_t* __restrict__ rcv, float* __restrict__ out, int64_t E) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E * 32) return;
+  const int64_t e = i / 32;
+  const int q = (int)(i % 32);
+  f32x4 v = reinterpret_cast<const f32x4*>(dagg)[(int64_t)rcv[e] * 32 + q];
+  if (base) v = v + reinterpret_cast<const f32x4*>(base)[i];
+  reinterpret_cast<f32x4*>(out)[i] = v;
+}
+// y += x (n floats)
+__global__ void k_axpy1(float* __restrict__ y, const float* __restrict__ x, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += x[i];
+}
+// non-kinematic particle count per trajectory (utils.py:28-35) and the per-node loss weight 1 / count
+__global__ void k_count_nonkin(const int32_t* __restrict__ ptype, int64_t BN, int N, int32_t* __restrict__ cnt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BN) return;
+  const int pt = ptype[i];
+  if (!(pt == 1 || pt == 2 || pt == -1)) atomicAdd(&cnt[i / N], 1);
+}
+__global__ void k_node_weight(const int32_t* __restrict__ ptype, const int32_t* __restrict__ cnt, int64_t BN, int N,
+                              float* __restrict__ w) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BN) return;
+  const int pt = ptype[i];
+  const bool kin = pt == 1 || pt == 2 || pt == -1;
+  const int c = cnt[i / N];
+  w[i] = (kin || c <= 0) ? 0.f : 1.0f / (float)c;
+}
+// loss = (1/B) sum_i w_i * lw * sum_d (pred - target)^2 ; dpred = 2 lw w_i (pred - target)   (gradients SUMMED over b)
+__global__ void k_mse_grad(const float* __restrict__ pred, const float* __restrict__ target,
+                           const float* __restrict__ nw, int64_t BN, int dim, float lw, float inv_b,
+                           float* __restrict__ dpred, double* __restrict__ loss) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double l = 0.0;
+  if (i < BN) {
+    const float w = nw[i];
+    for (int d = 0; d < dim; ++d) {
+      const float diff = pred[i * dim + d] - target[i * dim + d];
+      l += (double)(w * lw * diff * diff);
+      dpred[i * dim + d] = 2.f * lw * w * diff;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+  if ((threadIdx.x & 63) == 0 && l != 0.0) atomicAdd(loss, l * (double)inv_b);
+}
+// d embed[type] += sum over nodes of that type of dxnode[:, col0 : col0 + emb]
+__global__ void k_embed_grad(const float* __restrict__ dx, int ld, int col0, int emb, const int32_t* __restrict__ ptype,
+                             int ntypes, int64_t BN, float* __restrict__ gembed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BN * emb) return;
+  const int64_t r = i / emb;
+  const int c = (int)(i % emb);
+  int pt = ptype[r];
+  if (pt < 0) pt += ntypes;  // hk.Embed wraps negative ids (padding type -1 -> row 8)
+  atomicAdd(&gembed[(int64_t)pt * emb + c], dx[r * ld + col0 + c]);
+}
+// optax.adamw(lr, b1, b2, eps, weight_decay): m, v moments, bias correction, decoupled decay (trainer.py:189-193)
+__global__ void k_adamw(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                        float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                        float c1, float c2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float mh = mi / c1, vh = vi / c2;
+  w[i] -= lr * (mh / (sqrtf(vh) + eps) + wd * w[i]);
+}
+
+// ------------------------------------------------------------------------------------------- host helpers
+#define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
+
+// row-major Y[rows x M] (ldy) = X[rows x K] (ldx) * W[K x M] (+ beta * Y)
+static int gemm_nn(lb_gns_train* t, int64_t rows, int M, int K, const float* X, int ldx, const float* W, float* Y,
+                   int ldy, float beta = 0.f) {
+  const float alpha = 1.f;
+  if (rows == 0) return LB_OK;
+  LB_BLAS(rocblas_sgemm(t->blas, rocblas_operation_none, rocblas_operation_none, M, (int)rows, K, &alpha, W, M, X, ldx,
+                        &beta, Y, ldy));
+  return LB_OK;
+}
+// dX[rows x K] (ldx) = dY[rows x M] * W^T
+static int gemm_nt(lb_gns_train* t, int64_t rows, int M, int K, const float* dY, const float* W, float* dX, int ldx) {
+  const float alpha = 1.f, beta = 0.f;
+  if (rows == 0) return LB_OK;
+  LB_BLAS(rocblas_sgemm(t->blas, rocblas_operation_transpose, rocblas_operation_none, K, (int)rows, M, &alpha, W, M, dY, M,
+                        &beta, dX, ldx));
+  return LB_OK;
+}
+// dW[K x M] += X^T[K x rows] * dY[rows x M]
+static int gemm_tn(lb_gns_train* t, int64_t rows, int M, int K, const float* X, int ldx, const float* dY, float* dW) {
+  const float alpha = 1.f, beta = 1.f;
+  if (rows == 0) return LB_OK;
+  LB_BLAS(rocblas_sgemm(t->blas, rocblas_operation_none, rocblas_operation_transpose, M, K, (int)rows, &alpha, dY, M, X, ldx,
+                        &beta, dW, M));
+  return LB_OK;
+}
+static int colsum_add(lb_gns_train* t, const float* x, int64_t rows, int cols, int ld, float* out) {
+  if (rows == 0) return LB_OK;
+  const int nb = (int)((rows + 1023) / 1024);
+  hipStream_t s = t->eng->stream;
+  hipLaunchKernelGGL(k_colsum_part, dim3(nb), dim3(128), 0, s, x, rows, cols, ld, t->colsum);
+  hipLaunchKernelGGL(k_colsum_fin, dim3(1), dim3(128), 0, s, t->colsum, nb, cols, out);
+  return LB_OK;
+}
+
+// forward of one MLP block: X (rows x in, ldx) -> a = relu(X W0 + b0) -> z = a W1 + b1 -> [LayerNorm (+ resid)] -> y
+static int mlp_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* X, int ldx, float* a, float* z,
+                   const float* resid, float* y) {
+  hipStream_t s = t->eng->stream;
+  LB_TRY(gemm_nn(t, rows, TD, p.in, X, ldx, t->w + p.w0, a, TD));
+  if (rows) hipLaunchKernelGGL(k_bias_act, GRID1(rows * TD), 0, s, a, t->w + p.b0, rows, TD, 1);
+  float* zz = p.ln ? z : y;
+  LB_TRY(gemm_nn(t, rows, p.out, TD, a, TD, t->w + p.w1, zz, p.out));
+  if (rows) hipLaunchKernelGGL(k_bias_act, GRID1(rows * p.out), 0, s, zz, t->w + p.b1, rows, p.out, 0);
+  if (p.ln && rows)
+    hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, z, t->w + p.lns, t->w + p.lno, resid, y, rows);
+  return LB_OK;
+}
+// backward of one MLP block.  dy: gradient w.r.t. the block's output BEFORE the residual add (rows x out);
+// produces parameter gradients (accumulated) and, if dX != null, dX (rows x in, ld = ldx).  Scratch: t->dz, t->da.
+static int mlp_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* X, int ldx, const float* a,
+                   const float* z, const float* dy, float* dX) {
+  hipStream_t s = t->eng->stream;
+  if (rows == 0) return LB_OK;
+  const float* dzz = dy;
+  if (p.ln) {
+    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, z, t->w + p.lns, dy, t->dz, t->da, rows);
+    LB_TRY(colsum_add(t, t->da, rows, TD, TD, t->g + p.lns));  // d scale = sum dy * zhat
+    LB_TRY(colsum_add(t, dy, rows, TD, TD, t->g + p.lno));     // d offset = sum dy
+    dzz = t->dz;
+  }
+  LB_TRY(gemm_tn(t, rows, p.out, TD, a, TD, dzz, t->g + p.w1));
+  LB_TRY(colsum_add(t, dzz, rows, p.out, p.out, t->g + p.b1));
+  LB_TRY(gemm_nt(t, rows, p.out, TD, dzz, t->w + p.w1, t->da, TD));
+  hipLaunchKernelGGL(k_relu_bwd, GRID1(rows * TD), 0, s, t->da, a, rows * TD);
+  LB_TRY(gemm_tn(t, rows, TD, p.in, X, ldx, t->da, t->g + p.w0));
+  LB_TRY(colsum_add(t, t->da, rows, TD, TD, t->g + p.b0));
+  if (dX) LB_TRY(gemm_nt(t, rows, TD, p.in, t->da, t->w + p.w0, dX, ldx));
+  return LB_OK;
+}
+
+template <typename T>
+static int tr_alloc(T** p, size_t n) {
+  if (*p) (void)hipFree(*p);
+  return lb_alloc(p, n);
+}
+
+static int train_ensure(lb_gns_train* t, int64_t BN, int64_t E) {
+  const int L = t->desc.num_mp_steps;
+  if (BN <= t->cap_n && E <= t->cap_e && t->xnode) return LB_OK;
+  LB_HIP(hipStreamSynchronize(t->eng->stream));
+  const int64_t cn = std::max(BN, t->cap_n), ce = std::max(E + E / 8 + 1024, t->cap_e);
+  LB_TRY(tr_alloc(&t->xnode, (size_t)cn * t->kpad));
+  LB_TRY(tr_alloc(&t->a_en, (size_t)cn * TD));
+  LB_TRY(tr_alloc(&t->z_en, (size_t)cn * TD));
+  LB_TRY(tr_alloc(&t->a_ee, (size_t)ce * TD));
+  LB_TRY(tr_alloc(&t->z_ee, (size_t)ce * TD));
+  for (int k = 0; k <= L; ++k) {
+    LB_TRY(tr_alloc(&t->nlat[k], (size_t)cn * TD));
+    LB_TRY(tr_alloc(&t->elat[k], (size_t)ce * TD));
+  }
+  for (int k = 0; k < L; ++k) {
+    LB_TRY(tr_alloc(&t->xe[k], (size_t)ce * 3 * TD));
+    LB_TRY(tr_alloc(&t->ae[k], (size_t)ce * TD));
+    LB_TRY(tr_alloc(&t->ze[k], (size_t)ce * TD));
+    LB_TRY(tr_alloc(&t->xn[k], (size_t)cn * 2 * TD));
+    LB_TRY(tr_alloc(&t->an[k], (size_t)cn * TD));
+    LB_TRY(tr_alloc(&t->zn[k], (size_t)cn * TD));
+  }
+  const int64_t cm = std::max(cn, ce);
+  LB_TRY(tr_alloc(&t->a_d, (size_t)cn * TD));
+  LB_TRY(tr_alloc(&t->pred, (size_t)cn * 4));
+  LB_TRY(tr_alloc(&t->dn, (size_t)cn * TD));
+  LB_TRY(tr_alloc(&t->de, (size_t)ce * TD));
+  LB_TRY(tr_alloc(&t->dy, (size_t)cm * TD));
+  LB_TRY(tr_alloc(&t->dz, (size_t)cm * TD));
+  LB_TRY(tr_alloc(&t->da, (size_t)cm * TD));
+  LB_TRY(tr_alloc(&t->dx, (size_t)cm * 3 * TD));
+  LB_TRY(tr_alloc(&t->dagg, (size_t)cn * TD));
+  LB_TRY(tr_alloc(&t->agg, (size_t)cn * TD));
+  LB_TRY(tr_alloc(&t->colsum, (size_t)(cm / 1024 + 2) * 128));
+  LB_TRY(tr_alloc(&t->node_w, (size_t)cn));
+  t->cap_n = cn;
+  t->cap_e = ce;
+  return LB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const float* w, int64_t n_floats,
+                                   lb_gns_train** out) {
+  if (!e || !d || !w || !out) return lb_fail(LB_ERR_ARG, "null argument");
+  if (d->latent_size != TD || d->blocks_per_step != 2)
+    return lb_fail(LB_ERR_UNSUPPORTED, "training path: latent_size 128 and num_mlp_layers 2 are built");
+  if (d->out_dim != e->g.dim || d->node_in != e->g.node_in || d->edge_in != e->g.dim + 1)
+    return lb_fail(LB_ERR_ARG, "model widths do not match the case");
+  const int L = d->num_mp_steps;
+  const bool has_emb = d->num_particle_types > 1;
+  const int emb = has_emb ? d->embedding_size : 0;
+  lb_gns_train* t = new lb_gns_train();
+  t->desc = *d;
+  t->eng = e;
+  t->nin = d->node_in + emb;
+  t->kpad = (t->nin + 31) / 32 * 32;
+  int64_t o = 0;
+  t->off_embed = 0;
+  if (has_emb) o += (int64_t)d->num_particle_types * emb;
+  auto mlp = [&](int in, int outw, bool ln) {
+    lb_train_mlp p{};
+    p.in = in;
+    p.out = outw;
+    p.ln = ln;
+    p.w0 = o; o += (int64_t)in * TD;
+    p.b0 = o; o += TD;
+    p.w1 = o; o += (int64_t)TD * outw;
+    p.b1 = o; o += outw;
+    if (ln) {
+      p.lns = o; o += outw;
+      p.lno = o; o += outw;
+    }
+    return p;
+  };
+  t->enc_node = mlp(t->nin, TD, true);
+  t->enc_edge = mlp(d->edge_in, TD, true);
+  for (int k = 0; k < L; ++k) {
+    t->pe.push_back(mlp(3 * TD, TD, true));
+    t->pn.push_back(mlp(2 * TD, TD, true));
+  }
+  t->dec = mlp(TD, d->out_dim, false);
+  if (o != n_floats) {
+    delete t;
+    return lb_fail(LB_ERR_ARG, "weight blob has %lld floats, expected %lld", (long long)n_floats, (long long)o);
+  }
+  t->n_floats = o;
+  t->nlat.assign(L + 1, nullptr);
+  t->elat.assign(L + 1, nullptr);
+  t->xe.assign(L, nullptr); t->ae.assign(L, nullptr); t->ze.assign(L, nullptr);
+  t->xn.assign(L, nullptr); t->an.assign(L, nullptr); t->zn.assign(L, nullptr);
+  int rc = LB_OK;
+  for (float** p : {&t->w, &t->g, &t->m, &t->v})
+    if (!rc) rc = lb_alloc(p, (size_t)o);
+  if (!rc) rc = lb_alloc(&t->loss_dev, 1);
+  if (!rc) rc = lb_alloc(&t->cnt_dev, (size_t)e->g.B);
+  if (!rc && rocblas_create_handle(&t->blas) != rocblas_status_success) rc = lb_fail(LB_ERR_HIP, "rocblas_create_handle failed");
+  if (!rc && (hipMemcpy(t->w, w, sizeof(float) * o, hipMemcpyHostToDevice) != hipSuccess ||
+              hipMemset(t->g, 0, sizeof(float) * o) != hipSuccess || hipMemset(t->m, 0, sizeof(float) * o) != hipSuccess ||
+              hipMemset(t->v, 0, sizeof(float) * o) != hipSuccess))
+    rc = lb_fail(LB_ERR_HIP, "weight upload failed");
+  if (rc) {
+    lb_gns_train_destroy(t);
+    return rc;
+  }
+  *out = t;
+  return LB_OK;
+}
+
+extern "C" void lb_gns_train_destroy(lb_gns_train* t) {
+  if (!t) return;
+  if (t->blas) (void)rocblas_destroy_handle(t->blas);
+  std::vector<void*> bufs = {t->w, t->g, t->m, t->v, t->xnode, t->a_en, t->z_en, t->a_ee, t->z_ee, t->a_d, t->pred,
+                             t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->colsum, t->node_w,
+                             t->loss_dev, t->cnt_dev};
+  for (auto* v : {&t->nlat, &t->elat, &t->xe, &t->ae, &t->ze, &t->xn, &t->an, &t->zn})
+    for (float* p : *v) bufs.push_back(p);
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  delete t;
+}
+
+// value_and_grad of _mse, summed over the batch (trainer.py:63-89), on the engine's CURRENT window / neighbor list.
+// target_dev: (B*N, dim) fp32 normalised accelerations.  Gradients ACCUMULATE into the gradient blob (zero it with
+// lb_gns_train_zero_grad); *loss_out = mean over the batch of the per-trajectory losses (host-synchronous).
+extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, float loss_weight, double* loss_out,
+                                      float* pred_out_dev) {
+  if (!t || !target_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  lb_engine* e = t->eng;
+  if (e->e_cap <= 0) return lb_fail(LB_ERR_STATE, "lb_gns_train_loss_grad before lb_nl_allocate");
+  hipStream_t s = e->stream;
+  LB_BLAS(rocblas_set_stream(t->blas, s));
+  LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, s));
+  LB_HIP(hipStreamSynchronize(s));
+  if (e->ctrl_host->overflow_step >= 0) return lb_fail(LB_ERR_STATE, "neighbor list overflowed: re-allocate first");
+  const int64_t E = e->ctrl_host->n_edges_total, BN = e->BN;
+  const int L = t->desc.num_mp_steps, dim = t->desc.out_dim;
+  LB_TRY(train_ensure(t, BN, E));
+  const bool has_emb = t->desc.num_particle_types > 1;
+  const int emb = has_emb ? t->desc.embedding_size : 0;
+  // ---- features (engine kernels): node row [features | embedding | 0-pad], edge features from the neighbor build
+  const int kpad_saved = e->g.kpad;
+  e->g.kpad = t->kpad;
+  int rc = lbk_node_features(e, t->xnode, has_emb ? t->w + t->off_embed : nullptr, emb, t->desc.num_particle_types, nullptr,
+                             nullptr, nullptr, nullptr);
+  e->g.kpad = kpad_saved;
+  if (rc) return rc;
+  // ---- forward
+  LB_TRY(mlp_fwd(t, t->enc_node, BN, t->xnode, t->kpad, t->a_en, t->z_en, nullptr, t->nlat[0]));
+  LB_TRY(mlp_fwd(t, t->enc_edge, E, e->efeat, 8, t->a_ee, t->z_ee, nullptr, t->elat[0]));
+  for (int k = 0; k < L; ++k) {
+    if (E) hipLaunchKernelGGL(k_gather_edge_in, GRID1(E * 96), 0, s, t->nlat[k], t->elat[k], e->senders, e->receivers, t->xe[k], E);
+    // e' = LN(MLP(xe)) is both the message and (plus e) the next edge latent: keep e' in dy, then residual
+    LB_TRY(mlp_fwd(t, t->pe[k], E, t->xe[k], 3 * TD, t->ae[k], t->ze[k], nullptr, t->dy));
+    hipLaunchKernelGGL(k_seg_sum, GRID1(BN * 32), 0, s, e->row_ptr, t->dy, t->agg, BN, E);
+    if (E) {
+      LB_HIP(hipMemcpyAsync(t->elat[k + 1], t->elat[k], sizeof(float) * E * TD, hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(k_axpy1, GRID1(E * TD), 0, s, t->elat[k + 1], t->dy, E * TD);
+    }
+    hipLaunchKernelGGL(k_concat_node_in, GRID1(BN * 64), 0, s, t->nlat[k], t->agg, t->xn[k], BN);
+    LB_TRY(mlp_fwd(t, t->pn[k], BN, t->xn[k], 2 * TD, t->an[k], t->zn[k], t->nlat[k], t->nlat[k + 1]));
+  }
+  LB_TRY(mlp_fwd(t, t->dec, BN, t->nlat[L], TD, t->a_d, nullptr, nullptr, t->pred));
+  if (pred_out_dev) LB_HIP(hipMemcpyAsync(pred_out_dev, t->pred, sizeof(float) * BN * dim, hipMemcpyDeviceToDevice, s));
+  // ---- loss and d loss / d pred
+  LB_HIP(hipMemsetAsync(t->cnt_dev, 0, sizeof(int32_t) * e->g.B, s));
+  LB_HIP(hipMemsetAsync(t->loss_dev, 0, sizeof(double), s));
+  hipLaunchKernelGGL(k_count_nonkin, GRID1(BN), 0, s, e->ptype, BN, e->g.N, t->cnt_dev);
+  hipLaunchKernelGGL(k_node_weight, GRID1(BN), 0, s, e->ptype, t->cnt_dev, BN, e->g.N, t->node_w);
+  hipLaunchKernelGGL(k_mse_grad, GRID1(BN), 0, s, t->pred, target_dev, t->node_w, BN, dim, loss_weight, 1.0f / (float)e->g.B,
+                     t->dy, t->loss_dev);
+  // ---- backward
+  LB_TRY(mlp_bwd(t, t->dec, BN, t->nlat[L], TD, t->a_d, nullptr, t->dy, t->dn));  // dn = d loss / d n_L
+  LB_HIP(hipMemsetAsync(t->de, 0, sizeof(float) * std::max<int64_t>(E, 1) * TD, s));  // e_L has no reader
+  for (int k = L - 1; k >= 0; --k) {
+    // node block: n_{k+1} = n_k + LN(MLP([n_k | agg_k])): dy = dn (also flows to n_k through the residual)
+    LB_TRY(mlp_bwd(t, t->pn[k], BN, t->xn[k], 2 * TD, t->an[k], t->zn[k], t->dn, t->dx));
+    hipLaunchKernelGGL(k_split_node_in, GRID1(BN * 256), 0, s, t->dx, t->dn, t->dagg, BN);
+    // edge block: e' feeds agg (gather of dagg over receivers) and e_{k+1} = e_k + e' (de)
+    if (E) hipLaunchKernelGGL(k_seg_sum_bwd, GRID1(E * 32), 0, s, t->de, t->dagg, e->receivers, t->dy, E);
+    LB_TRY(mlp_bwd(t, t->pe[k], E, t->xe[k], 3 * TD, t->ae[k], t->ze[k], t->dy, t->dx));
+    if (E) hipLaunchKernelGGL(k_scatter_edge_in, GRID1(E * 384), 0, s, t->dx, e->senders, e->receivers, t->dn, t->de, E);
+  }
+  LB_TRY(mlp_bwd(t, t->enc_edge, E, e->efeat, 8, t->a_ee, t->z_ee, t->de, nullptr));
+  LB_TRY(mlp_bwd(t, t->enc_node, BN, t->xnode, t->kpad, t->a_en, t->z_en, t->dn, has_emb ? t->dx : nullptr));
+  if (has_emb)
+    hipLaunchKernelGGL(k_embed_grad, GRID1(BN * emb), 0, s, t->dx, t->kpad, t->desc.node_in, emb, e->ptype,
+                       t->desc.num_particle_types, BN, t->g + t->off_embed);
+  LB_HIP(hipGetLastError());
+  if (loss_out) {
+    LB_HIP(hipMemcpyAsync(loss_out, t->loss_dev, sizeof(double), hipMemcpyDeviceToHost, s));
+    LB_HIP(hipStreamSynchronize(s));
+  }
+  return LB_OK;
+}
+
+extern "C" int lb_gns_train_zero_grad(lb_gns_train* t) {
+  if (!t) return lb_fail(LB_ERR_ARG, "null argument");
+  LB_HIP(hipMemsetAsync(t->g, 0, sizeof(float) * t->n_floats, t->eng->stream));
+  return LB_OK;
+}
+
+// optax.adamw step on every parameter (trainer.py:189-193, :86-87); the step counter of the bias correction lives
+// in the handle (set_step restores it from a checkpoint)
+extern "C" int lb_adamw_step(lb_gns_train* t, float lr, float b1, float b2, float eps, float weight_decay) {
+  if (!t) return lb_fail(LB_ERR_ARG, "null argument");
+  t->step += 1;
+  const float c1 = 1.f - powf(b1, (float)t->step), c2 = 1.f - powf(b2, (float)t->step);
+  hipLaunchKernelGGL(k_adamw, GRID1(t->n_floats), 0, t->eng->stream, t->w, t->g, t->m, t->v, t->n_floats, lr, b1, b2, eps,
+                     weight_decay, c1, c2);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
+// which: 0 weights, 1 gradients, 2 first moment, 3 second moment (flat blob, GNS.flatten order)
+extern "C" int lb_gns_train_read(lb_gns_train* t, int32_t which, float* out_host, int64_t n_floats) {
+  if (!t || !out_host || n_floats != t->n_floats || which < 0 || which > 3) return lb_fail(LB_ERR_ARG, "bad argument");
+  const float* src = which == 0 ? t->w : which == 1 ? t->g : which == 2 ? t->m : t->v;
+  LB_HIP(hipStreamSynchronize(t->eng->stream));
+  LB_HIP(hipMemcpy(out_host, src, sizeof(float) * n_floats, hipMemcpyDeviceToHost));
+  return LB_OK;
+}
+extern "C" int lb_gns_train_write(lb_gns_train* t, int32_t which, const float* in_host, int64_t n_floats, int64_t step) {
+  if (!t || !in_host || n_floats != t->n_floats || which < 0 || which > 3) return lb_fail(LB_ERR_ARG, "bad argument");
+  float* dst = which == 0 ? t->w : which == 1 ? t->g : which == 2 ? t->m : t->v;
+  LB_HIP(hipStreamSynchronize(t->eng->stream));
+  LB_HIP(hipMemcpy(dst, in_host, sizeof(float) * n_floats, hipMemcpyHostToDevice));
+  if (step >= 0) t->step = step;
+  return LB_OK;
+}

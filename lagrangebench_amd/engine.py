@@ -242,6 +242,14 @@ class RolloutEngine:
                                      C.c_int64(blob.size), C.byref(h)), "lb_gns_create")
         return GnsHandle(self, h, desc)
 
+    def gns_train_create(self, desc: GnsDesc, blob: np.ndarray) -> "GnsTrainHandle":
+        """Device-resident training state (weights, gradients, AdamW moments) of one GNS: csrc/lb_train.hip."""
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        h = C.c_void_p()
+        check(self.lib.lb_gns_train_create(self._h, C.byref(desc), blob.ctypes.data_as(C.POINTER(C.c_float)),
+                                           C.c_int64(blob.size), C.byref(h)), "lb_gns_train_create")
+        return GnsTrainHandle(self, h, desc, blob.size)
+
     def gns_forward(self, gns: "GnsHandle", out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
             out = torch.empty((self.B, self.N, self.dim), dtype=torch.float32, device=self.device)
@@ -387,6 +395,56 @@ class GnsHandle:
             if self.engine._h:
                 torch.cuda.synchronize(self.engine.device)
             self.engine.lib.lb_gns_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GnsTrainHandle:
+    """trainer.py:35-89 on the device: value_and_grad of _mse summed over the batch + optax.adamw."""
+
+    def __init__(self, engine: RolloutEngine, h, desc: GnsDesc, n_floats: int):
+        self.engine, self._h, self.desc, self.n_floats = engine, h, desc, int(n_floats)
+
+    def loss_grad(self, target: torch.Tensor, loss_weight: float = 1.0, want_pred: bool = False):
+        """target (B, N, dim) normalised accelerations -> mean per-trajectory loss (float); gradients accumulate."""
+        e = self.engine
+        tgt = target.to(device=e.device, dtype=torch.float32).reshape(e.B * e.N, e.dim).contiguous()
+        loss = C.c_double()
+        pred = torch.empty((e.B, e.N, e.dim), dtype=torch.float32, device=e.device) if want_pred else None
+        check(e.lib.lb_gns_train_loss_grad(self._h, ptr(tgt), C.c_float(float(loss_weight)), C.byref(loss),
+                                           ptr(pred) if want_pred else None), "lb_gns_train_loss_grad")
+        return (loss.value, pred) if want_pred else loss.value
+
+    def zero_grad(self) -> None:
+        check(self.engine.lib.lb_gns_train_zero_grad(self._h), "lb_gns_train_zero_grad")
+
+    def adamw_step(self, lr: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8, weight_decay: float = 1e-8) -> None:
+        check(self.engine.lib.lb_adamw_step(self._h, C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps),
+                                            C.c_float(weight_decay)), "lb_adamw_step")
+
+    def read(self, which: str = "weights") -> np.ndarray:
+        idx = {"weights": 0, "grads": 1, "m": 2, "v": 3}[which]
+        out = np.empty(self.n_floats, np.float32)
+        check(self.engine.lib.lb_gns_train_read(self._h, idx, out.ctypes.data_as(C.POINTER(C.c_float)),
+                                                C.c_int64(out.size)), "lb_gns_train_read")
+        return out
+
+    def write(self, which: str, blob: np.ndarray, step: int = -1) -> None:
+        idx = {"weights": 0, "grads": 1, "m": 2, "v": 3}[which]
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        check(self.engine.lib.lb_gns_train_write(self._h, idx, blob.ctypes.data_as(C.POINTER(C.c_float)),
+                                                 C.c_int64(blob.size), C.c_int64(step)), "lb_gns_train_write")
+
+    def close(self):
+        if self._h:
+            if self.engine._h:
+                torch.cuda.synchronize(self.engine.device)
+            self.engine.lib.lb_gns_train_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -105,6 +105,38 @@ class GNS(BaseModel):
                 out += [np.asarray(ln["scale"], np.float32).ravel(), np.asarray(ln["offset"], np.float32).ravel()]
         return np.concatenate(out)
 
+    def unflatten(self, blob, like) -> Dict:
+        """Inverse of flatten: the flat blob (weights, gradients or optimiser moments of the training handle) back
+        into a parameter tree shaped like `like`."""
+        blob = np.asarray(blob, np.float32)
+        out, o = {}, 0
+
+        def take(mod, leaf):
+            nonlocal o
+            shape = np.asarray(like[mod][leaf]).shape
+            n = int(np.prod(shape))
+            out.setdefault(mod, {})[leaf] = blob[o:o + n].reshape(shape).copy()
+            o += n
+        if self._num_particle_types > 1:
+            take("embed", "embeddings")
+        for name in layer_names(self._mp_steps):
+            for li in range(self._blocks_per_step):
+                take(f"{name}/linear_{li}", "w")
+                take(f"{name}/linear_{li}", "b")
+            if f"{name}/layer_norm" in like:
+                take(f"{name}/layer_norm", "scale")
+                take(f"{name}/layer_norm", "offset")
+        assert o == blob.size, (o, blob.size)
+        return out
+
+    def train_handle(self, engine, params):
+        """Device-resident training state for `params` on `engine` (csrc/lb_train.hip)."""
+        d = GnsDesc()
+        d.latent_size, d.blocks_per_step, d.num_mp_steps = self._latent_size, self._blocks_per_step, self._mp_steps
+        d.embedding_size, d.num_particle_types = self._embedding_size, self._num_particle_types
+        d.node_in, d.edge_in, d.out_dim = engine.node_in, engine.dim + 1, self._output_size
+        return engine.gns_train_create(d, self.flatten(params))
+
     # ------------------------------------------------------------------ engine binding
     @staticmethod
     def _fingerprint(params) -> tuple:

@@ -151,6 +151,76 @@ def test_torch_forward_on_engine_graph_equals_hip_forward():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,scale,L,B", [("small2d", 1.0, 3, 2), ("small3d", 1.0, 2, 1), ("tgv2d", 0.6, 10, 2),
+                                            ("ldc3d", 0.4, 2, 2)])
+def test_hip_gradients_match_torch_autograd(name, scale, L, B):
+    """the hand-written backward (csrc/lb_train.hip: lb_gns_train_loss_grad) against torch
+    autograd of the checker network (models/gns_torch.py, itself checked against the oracle and finite differences
+    above) on engine-built graphs: loss and every parameter gradient of _mse (trainer.py:35-60), gradients summed and
+    loss averaged over the batch (trainer.py:63-89), within 1e-4 relative per leaf; then one AdamW step against
+    torch.optim.AdamW."""
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    from lagrangebench_amd.models.gns_torch import gns_apply_torch, gns_inputs_from_features, params_to_torch
+    from lagrangebench_amd.utils import get_kinematic_mask
+    from tests._common import hip_case
+    ds = make_case(name, n_trajs=B, extra_seq_length=3, scale=scale)
+    hcase = hip_case(ds)
+    isl, dim = ds.input_seq_length, len(ds.box)
+    pos = np.stack([ds[b][0] for b in range(B)])
+    pt = np.stack([ds[b][1] for b in range(B)])
+    params = make_params(ds, num_mp_steps=L, decoder_scale=1.0)
+    model = GNS(dim, 128, 2, L, 16)
+    feats, _ = hcase.allocate_eval((pos[:, :, :isl], pt))
+    eng = feats.engine
+    target = torch.randn((B, pos.shape[1], dim), generator=torch.Generator().manual_seed(5))
+    th = model.train_handle(eng, params)
+    th.zero_grad()
+    loss_h, pred_h = th.loss_grad(target, 1.0, want_pred=True)
+    g_h = model.unflatten(th.read("grads"), params)
+
+    feats.materialize()
+    dev = eng.device
+    pt_t = params_to_torch(params, device=dev, requires_grad=True)
+    losses = []
+    for b in range(B):
+        node, edge, snd, rcv, ptt = gns_inputs_from_features(feats, torch.as_tensor(pt), b)
+        pred = gns_apply_torch(pt_t, node, edge, snd, rcv, ptt, L)
+        assert float((pred - pred_h[b]).abs().max() / pred.abs().max()) < 1e-5
+        nk = ~get_kinematic_mask(ptt)
+        tot = ((pred - target[b].to(dev)) ** 2).sum(dim=-1)
+        lb = torch.where(nk, tot, torch.zeros_like(tot)).sum() / nk.sum()
+        lb.backward()
+        losses.append(float(lb))
+    assert abs(loss_h - np.mean(losses)) <= 1e-5 * abs(np.mean(losses)), (loss_h, losses)
+    worst = 0.0
+    for mod, leaves in pt_t.items():
+        for leaf, v in leaves.items():
+            ref = v.grad.detach().cpu().numpy()
+            err = np.abs(g_h[mod][leaf] - ref).max() / max(np.abs(ref).max(), 1e-30)
+            worst = max(worst, err)
+            assert err < 1e-4, (mod, leaf, err)
+    print(f"[grad {name}] loss {loss_h:.6f}, worst relative gradient error over the leaves {worst:.2e}")
+
+    # one optimiser step: optax.adamw == torch AdamW (decoupled decay).  Both get the SAME gradients (the engine's):
+    # the first Adam step is sign(g) * lr for |g| >> eps, so rounding-level differences of near-zero gradients
+    # (dead ReLU units) would otherwise show up as 1e-5-sized differences of the update
+    for mod, lv in pt_t.items():
+        for leaf, v in lv.items():
+            v.grad = torch.as_tensor(g_h[mod][leaf], device=dev)
+    leaves = [v for mod in sorted(pt_t) for _, v in sorted(pt_t[mod].items())]
+    opt = torch.optim.AdamW(leaves, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    opt.step()
+    th.adamw_step(1e-3, 0.9, 0.999, 1e-8, 1e-2)
+    w_h = model.unflatten(th.read("weights"), params)
+    for mod, lv in pt_t.items():
+        for leaf, v in lv.items():
+            ref = v.detach().cpu().numpy()
+            assert np.abs(w_h[mod][leaf] - ref).max() <= 2e-6 * max(np.abs(ref).max(), 1.0) + 1e-7, (mod, leaf)
+    th.close()
+
+
+@pytest.mark.gpu
 def test_trainer_lowers_the_loss_and_runner_mode_all(tmp_path):
     """tests/runner_test.py:14-57 runs train_or_infer end to end on the LJ dataset and expects 0."""
     from lagrangebench_amd.case_setup import case_builder
