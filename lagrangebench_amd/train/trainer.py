@@ -7,11 +7,12 @@ normalised acceleration target) -> optional no-grad unroll steps -> MSE over the
 exponentially decaying learning rate (:183-193) -> every ``eval_steps``: validation rollouts through
 ``eval_rollout`` (the fused HIP loop) + checkpoint in the reference's on-disk format (:385-407).
 
-What runs where: neighbor list, feature assembly, integrator and every evaluation rollout are the HIP
-engine; the loss step differentiates ``models/gns_torch.py`` (a torch restatement of the GNS forward, fp32
-on the same GPU) with torch.autograd and steps ``torch.optim.AdamW`` - there are no hand-written backward
-kernels yet, which is why DESIGN.md lists this row as partial.  Only GNS is trainable; wandb logging is
-not wired (stdout, as the reference's default).
+What runs where: neighbor list, feature assembly, integrator, every evaluation rollout AND the loss step are the
+HIP engine: ``lb_gns_train_loss_grad`` (csrc/lb_train.hip: forward with saved activations, masked MSE, hand-written
+backward kernels + rocBLAS sgemm for the dense contractions) accumulates the gradients of the whole batch,
+``lb_adamw_step`` applies optax.adamw on the device; weights, gradients and both moments stay in HBM (exact fp32).
+torch is used for the noise / sampling random streams and as the tensor container only.  Only GNS (latent 128, two
+Linears per MLP) is trainable; wandb logging is not wired (stdout, as the reference's default).
 """
 from __future__ import annotations
 
@@ -25,7 +26,6 @@ from ..defaults import defaults, merge
 from ..evaluate import MetricsComputer, averaged_metrics, eval_rollout
 from ..evaluate.rollout import _Loader
 from ..models.gns import GNS
-from ..models.gns_torch import gns_apply_torch, gns_inputs_from_features, params_to_numpy, params_to_torch
 from ..utils import (broadcast_from_batch, get_kinematic_mask, gns_params_from_haiku, gns_params_to_haiku,
                      load_haiku, save_haiku)
 from .strats import push_forward_build, push_forward_sample_steps
@@ -37,17 +37,6 @@ def exponential_decay(step: int, init_value: float, transition_steps: float, dec
     init * rate ** (step / transition_steps), clipped at end_value."""
     v = init_value * decay_rate ** (step / transition_steps)
     return max(v, end_value) if decay_rate < 1 else min(v, end_value)
-
-
-def _mse(params_t, features, particle_type, target, model: GNS, loss_weight: Dict[str, float]):
-    """trainer.py:35-60 for one trajectory of the batch: weighted squared error of every predicted
-    quantity, summed over dim, averaged over the non-kinematic particles."""
-    node, edge, snd, rcv, pt = gns_inputs_from_features(features, particle_type)
-    pred = {"acc": gns_apply_torch(params_t, node, edge, snd, rcv, pt, model._mp_steps, model._blocks_per_step)}
-    non_kin = ~get_kinematic_mask(pt)
-    total = sum(float(loss_weight[k]) * ((pred[k] - target[k].to(pred[k].dtype)) ** 2).sum(dim=-1) for k in pred)
-    total = torch.where(non_kin, total, torch.zeros_like(total))
-    return total.sum() / non_kin.sum()
 
 
 class _ShuffledLoader:
@@ -68,7 +57,7 @@ class Trainer:
     def __init__(self, model: GNS, case, data_train, data_valid, cfg_train=None, cfg_eval=None, cfg_logging=None,
                  input_seq_length: int = defaults.model.input_seq_length, seed: int = defaults.seed):
         if not isinstance(model, GNS):
-            raise NotImplementedError("Trainer: only GNS has a differentiable forward (models/gns_torch.py)")
+            raise NotImplementedError("Trainer: only GNS has a device training step (csrc/lb_train.hip)")
         self.model, self.case, self.input_seq_length = model, case, input_seq_length
         self.cfg_train = merge(defaults.train, cfg_train)
         self.cfg_eval = merge(defaults.eval, cfg_eval)
@@ -99,7 +88,7 @@ class Trainer:
     def train(self, step_max: int = defaults.train.step_max, params=None, state=None, opt_state=None,
               store_ckp: Optional[str] = None, load_ckp: Optional[str] = None, wandb_config=None
               ) -> Tuple[Dict, Dict, Dict]:
-        """trainer.py:209-421.  Returns (params as numpy, state, opt_state = torch AdamW state_dict)."""
+        """trainer.py:209-421.  Returns (params as numpy, state, opt_state = {"m", "v", "step"} flat AdamW moments)."""
         model, case, cfg_train, cfg_eval, cfg_logging = self.model, self.case, self.cfg_train, self.cfg_eval, self.cfg_logging
         noise_std, pushforward = cfg_train.noise_std, cfg_train.pushforward
         isl = self.input_seq_length
@@ -118,25 +107,24 @@ class Trainer:
                 params = gns_params_from_haiku(params, model._mp_steps, model._blocks_per_step)
         else:
             params, state = model.init(torch.randint(0, 2**31 - 1, (1,), generator=key).numpy(), (features, raw_sample[1]))
-        params_t = params_to_torch(params, device=device, requires_grad=True)
-        leaves = [v for mod in sorted(params_t) for _, v in sorted(params_t[mod].items())]
-        opt = torch.optim.AdamW(leaves, lr=self._lr(step), betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8)
-        if isinstance(opt_state, dict) and "state" in opt_state:
-            # (a checkpoint stores the moments as numpy arrays: utils.save_haiku)
-            def _t(x):
-                if isinstance(x, np.ndarray):
-                    return torch.as_tensor(x)
-                if isinstance(x, dict):
-                    return {k: _t(v) for k, v in x.items()}
-                if isinstance(x, list):
-                    return [_t(v) for v in x]
-                return x
-            opt.load_state_dict(_t(opt_state))
+        B = self.loader_train.batch_size
+        th = model.train_handle(case.engine(B), params)   # weights, gradients, AdamW moments: device resident
+        if isinstance(opt_state, dict) and "m" in opt_state and "v" in opt_state:
+            th.write("m", np.asarray(opt_state["m"], np.float32))
+            th.write("v", np.asarray(opt_state["v"], np.float32), step=int(opt_state.get("step", step)))
+        o = cfg_train.optimizer
+        lw = float(self.loss_weight.get("acc", 1.0))
+
+        def current_params():
+            return model.unflatten(th.read("weights"), params)
+
+        def opt_state_dict():
+            return {"kind": "lagrangebench_amd adamw (flat blobs in GNS.flatten order)", "m": th.read("m"),
+                    "v": th.read("v"), "step": int(step)}
         if store_ckp is not None:
             os.makedirs(os.path.join(store_ckp, "best"), exist_ok=True)
 
         push_forward = push_forward_build(model.apply, case)
-        B = self.loader_train.batch_size
         log = []
         while step < step_max + 1:
             for raw_batch in self.loader_train:
@@ -145,7 +133,7 @@ class Trainer:
                 key, features_batch, target_batch, neighbors = case.preprocess(key, sample, noise_std, neighbors,
                                                                                unroll_steps)
                 if unroll_steps > 0 and not bool(neighbors.did_buffer_overflow.sum() > 0):
-                    params_np = params_to_numpy(params_t)
+                    params_np = current_params()
                     # the noisy positions the features were computed from ARE the engine's window
                     cur = case.engine(B).read_window()
                     tshift = unroll_steps
@@ -162,26 +150,18 @@ class Trainer:
                     _, _, _, neighbors = case.allocate(key, (raw_batch[0][ind], raw_batch[1][ind]), noise_std)
                     print(f"From (2, {old}) to (2, {neighbors.max_occupancy})")
                     continue
-                features_batch.materialize()
-                for g in opt.param_groups:
-                    g["lr"] = self._lr(step)
-                opt.zero_grad(set_to_none=True)
-                losses = []
-                for b in range(B):
-                    fb = {k: features_batch[k][b] for k in features_batch.keys()}
-                    tb = {"acc": target_batch["acc"][b]}
-                    lb = _mse(params_t, fb, torch.as_tensor(raw_batch[1][b]), tb, model, self.loss_weight)
-                    lb.backward()                      # gradients summed over the batch (trainer.py:82)
-                    losses.append(lb.detach())
-                opt.step()
-                loss = torch.stack(losses).mean()      # loss averaged over the batch (trainer.py:84)
+                # value_and_grad of _mse vmapped over the batch, gradients summed, loss averaged (trainer.py:63-89) +
+                # optax.adamw(lr(step), weight_decay 1e-8): on the engine's current window / neighbor list
+                th.zero_grad()
+                loss = th.loss_grad(target_batch["acc"], lw)
+                th.adamw_step(self._lr(step), 0.9, 0.999, 1e-8, float(getattr(o, "weight_decay", 1e-8)))
 
                 if step % cfg_logging.log_steps == 0:
                     step_str = str(step).zfill(len(str(int(step_max))))
                     print(f"{step_str}, train/loss: {float(loss):.5f}.")
                     log.append((step, float(loss)))
                 if step % cfg_logging.eval_steps == 0 and step > 0:
-                    params_np = params_to_numpy(params_t)
+                    params_np = current_params()
                     eval_metrics = eval_rollout(model_apply=model.apply, case=case, params=params_np, state=state,
                                                 loader_eval=self.loader_valid, neighbors=broadcast_from_batch(neighbors, 0),
                                                 metrics_computer=self.metrics_computer,
@@ -190,7 +170,7 @@ class Trainer:
                     metrics = averaged_metrics(eval_metrics)
                     if store_ckp is not None:
                         save_haiku(store_ckp, gns_params_to_haiku(params_np, model._mp_steps, model._blocks_per_step),
-                                   state, opt.state_dict(), {"step": step, "loss": metrics.get("val/loss", None)})
+                                   state, opt_state_dict(), {"step": step, "loss": metrics.get("val/loss", None)})
                     print(metrics)
                     # the validation rollouts re-sized / re-used the engine: the training list is rebuilt
                     key, _, _, neighbors = case.allocate(key, raw_sample)
@@ -198,4 +178,6 @@ class Trainer:
                 if step == step_max + 1:
                     break
         self.loss_log = log
-        return params_to_numpy(params_t), state, opt.state_dict()
+        out = (current_params(), state, opt_state_dict())
+        th.close()
+        return out

@@ -1,8 +1,9 @@
-"""Differentiable GNS forward in torch (models/gns.py:65-171 through haiku / jraph), used by the trainer
-(SURVEY.md section 8f, N4): the inference path runs the hand-written HIP kernels, the TRAINING step
-differentiates this restatement with torch.autograd on the same device, on the graph (receiver-sorted
-edge list) and the features the HIP engine built.  Same arithmetic as the CPU checker of the test suite -
-`tests/test_train.py` checks the two against each other and the gradients against finite differences.
+"""Differentiable GNS forward in torch (models/gns.py:65-171 through haiku / jraph): TEST INFRASTRUCTURE - the
+checker of the device training step (csrc/lb_train.hip: lb_gns_train_loss_grad).  torch.autograd over this
+restatement, on the graph (receiver-sorted edge list) and the features the HIP engine built, gives the reference
+gradients of trainer.py:35-60's _mse; `tests/test_train.py` checks this file against the NumPy oracle and its
+gradients against finite differences, then the engine's gradients against it.  Only tests import it (round 2 had
+the Trainer differentiate it; round 3's Trainer steps through the C ABI).
 """
 from __future__ import annotations
 
@@ -11,7 +12,7 @@ from typing import Dict
 import numpy as np
 import torch
 
-from .gns import layer_names
+from lagrangebench_amd.models.gns import layer_names
 
 
 def params_to_torch(params, device=None, requires_grad: bool = False) -> Dict[str, Dict[str, torch.Tensor]]:

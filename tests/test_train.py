@@ -88,7 +88,7 @@ def _oracle_inputs(name="small2d", L=2):
 
 
 def test_torch_gns_matches_the_oracle_and_its_gradients_match_finite_differences():
-    from lagrangebench_amd.models.gns_torch import gns_apply_torch, gns_inputs_from_features, params_to_torch
+    from oracle.gns_torch import gns_apply_torch, gns_inputs_from_features, params_to_torch
     L = 2
     ds, feats, pt, params = _oracle_inputs(L=L)
     ref = O.gns_apply(params, feats, pt, num_mp_steps=L, skip_padding=True)["acc"]
@@ -129,7 +129,7 @@ def test_torch_gns_matches_the_oracle_and_its_gradients_match_finite_differences
 def test_torch_forward_on_engine_graph_equals_hip_forward():
     from lagrangebench_amd.data import make_case
     from lagrangebench_amd.models import GNS
-    from lagrangebench_amd.models.gns_torch import gns_apply_torch, gns_inputs_from_features, params_to_torch
+    from oracle.gns_torch import gns_apply_torch, gns_inputs_from_features, params_to_torch
     from tests._common import hip_case
     L = 3
     ds = make_case("small3d", n_trajs=2, extra_seq_length=3)
@@ -155,13 +155,13 @@ def test_torch_forward_on_engine_graph_equals_hip_forward():
                                             ("ldc3d", 0.4, 2, 2)])
 def test_hip_gradients_match_torch_autograd(name, scale, L, B):
     """the hand-written backward (csrc/lb_train.hip: lb_gns_train_loss_grad) against torch
-    autograd of the checker network (models/gns_torch.py, itself checked against the oracle and finite differences
+    autograd of the checker network (oracle/gns_torch.py, itself checked against the oracle and finite differences
     above) on engine-built graphs: loss and every parameter gradient of _mse (trainer.py:35-60), gradients summed and
     loss averaged over the batch (trainer.py:63-89), within 1e-4 relative per leaf; then one AdamW step against
     torch.optim.AdamW."""
     from lagrangebench_amd.data import make_case
     from lagrangebench_amd.models import GNS
-    from lagrangebench_amd.models.gns_torch import gns_apply_torch, gns_inputs_from_features, params_to_torch
+    from oracle.gns_torch import gns_apply_torch, gns_inputs_from_features, params_to_torch
     from lagrangebench_amd.utils import get_kinematic_mask
     from tests._common import hip_case
     ds = make_case(name, n_trajs=B, extra_seq_length=3, scale=scale)
@@ -186,7 +186,7 @@ def test_hip_gradients_match_torch_autograd(name, scale, L, B):
     for b in range(B):
         node, edge, snd, rcv, ptt = gns_inputs_from_features(feats, torch.as_tensor(pt), b)
         pred = gns_apply_torch(pt_t, node, edge, snd, rcv, ptt, L)
-        assert float((pred - pred_h[b]).abs().max() / pred.abs().max()) < 1e-5
+        assert float((pred.detach() - pred_h[b]).abs().max() / pred.detach().abs().max()) < 1e-5
         nk = ~get_kinematic_mask(ptt)
         tot = ((pred - target[b].to(dev)) ** 2).sum(dim=-1)
         lb = torch.where(nk, tot, torch.zeros_like(tot)).sum() / nk.sum()
@@ -251,8 +251,11 @@ def test_trainer_lowers_the_loss_and_runner_mode_all(tmp_path):
     losses = [l for _, l in trainer.loss_log]
     assert np.isfinite(losses).all() and np.mean(losses[-4:]) < 0.7 * np.mean(losses[:3]), losses
     assert os.path.exists(os.path.join(ckp, "params_tree.pkl")) and os.path.exists(os.path.join(ckp, "best", "params_array.npy"))
-    loaded, _, _, step = load_haiku(ckp)
+    loaded, _, opt_loaded, step = load_haiku(ckp)
     assert step in (30, 60) and any("MLP" in k for k in loaded)
+    # the optimiser state travels with the checkpoint (opt_state.pkl: both AdamW moments + the step counter)
+    assert os.path.exists(os.path.join(ckp, "opt_state.pkl")) and set(opt_loaded) >= {"m", "v", "step"}
+    assert opt_loaded["m"].shape == opt_loaded["v"].shape and np.abs(opt_loaded["v"]).max() > 0
     # resume from the checkpoint for a few more steps (trainer.py:267-269)
     p2, _, _ = trainer.train(step_max=step + 3, load_ckp=ckp)
     assert set(p2) == set(params)
