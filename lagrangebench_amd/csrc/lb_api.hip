@@ -142,6 +142,8 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
     const char* m = getenv("LB_MATH");
     e->f16x2 = (m && !strcmp(m, "f32")) ? 0 : 1;
     e->math_auto = m ? 0 : 1;  // LB_MATH given: that arithmetic, no guard-driven switch
+    const char* gf = getenv("LB_GUARD");
+    e->guard_full = (gf && !strcmp(gf, "full")) ? 1 : 0;
   }
   lb_geom& g = e->g;
   memset(&g, 0, sizeof(g));
@@ -243,6 +245,7 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   lb_ctrl c0;
   memset(&c0, 0, sizeof(c0));
   c0.overflow_step = -1;
+  c0.math_step = LB_MATH_NO_STEP;
   c0.ln_inv_d = 1.0f / LB_D;
   if (hipMemcpy(e->ctrl, &c0, sizeof(c0), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemset(e->blocks_done, 0, sizeof(int32_t)) != hipSuccess ||
@@ -899,16 +902,22 @@ __global__ void k_acc_export(int64_t BN, int dim, const float* __restrict__ acc4
 // f16x2 range guard, host side: read (and clear) the flags the kernels raised since the last check.
 // Returns 1 when the engine was in guarded f16x2 mode and has just been switched to exact fp32 - the
 // caller then repeats its work; the switch is sticky for the engine.
-static int lb_math_check(lb_engine* e, int* switched) {
+static int lb_math_check(lb_engine* e, int* switched, int* flagged_step = nullptr) {
   *switched = 0;
   LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, e->stream));
   LB_HIP(hipStreamSynchronize(e->stream));
   const int flags = e->ctrl_host->math_flags;
   if (!flags) return LB_OK;
-  LB_HIP(hipMemsetAsync(&e->ctrl->math_flags, 0, sizeof(int32_t), e->stream));
+  if (flagged_step) *flagged_step = e->ctrl_host->math_step;
+  {
+    const int32_t reset[1] = {LB_MATH_NO_STEP};
+    LB_HIP(hipMemsetAsync(&e->ctrl->math_flags, 0, sizeof(int32_t), e->stream));
+    LB_HIP(hipMemcpyAsync(&e->ctrl->math_step, reset, sizeof(reset), hipMemcpyHostToDevice, e->stream));
+    LB_HIP(hipStreamSynchronize(e->stream));
+  }
   if (e->f16x2 && e->math_auto) {
     fprintf(stderr,
-            "[lbhip] f16x2 range guard raised (%s%s%s): repeating in exact-fp32 MFMA arithmetic and staying there\n",
+            "[lbhip] f16x2 range guard raised (%s%s%s): continuing in exact-fp32 MFMA arithmetic from the flagged step\n",
             flags & LB_MATH_LARGE ? "operand >= 2^15 " : "", flags & LB_MATH_TINY ? "operand tile < 2^-10 " : "",
             flags & LB_MATH_NONFINITE ? "non-finite acceleration" : "");
     e->f16x2 = 0;
@@ -919,14 +928,17 @@ static int lb_math_check(lb_engine* e, int* switched) {
 
 extern "C" int lb_math_mode(lb_engine* e, int32_t set_mode, int32_t* mode_out, int32_t* flags_out) {
   if (!e) return lb_fail(LB_ERR_ARG, "null engine");
-  if (set_mode < -1 || set_mode > 2) return lb_fail(LB_ERR_ARG, "set_mode must be -1 (query), 0 (f32), 1 (f16x2, guarded) or 2 (f16x2, unguarded)");
+  if (set_mode < -1 || set_mode > 3)
+    return lb_fail(LB_ERR_ARG, "set_mode must be -1 (query), 0 (f32), 1 (f16x2, guarded), 2 (f16x2, unguarded) or 3 (f16x2, "
+                               "guarded, every tile of the batch kernels tested)");
   if (set_mode >= 0) {
     e->f16x2 = set_mode != 0;
-    e->math_auto = set_mode == 1;
+    e->math_auto = set_mode == 1 || set_mode == 3;
+    e->guard_full = set_mode == 3;
   }
   LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, e->stream));
   LB_HIP(hipStreamSynchronize(e->stream));
-  if (mode_out) *mode_out = e->f16x2 ? (e->math_auto ? 1 : 2) : 0;
+  if (mode_out) *mode_out = e->f16x2 ? (e->math_auto ? (e->guard_full ? 3 : 1) : 2) : 0;
   if (flags_out) *flags_out = e->ctrl_host->math_flags;
   return LB_OK;
 }
@@ -977,13 +989,24 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
   if (g->eng != e) return lb_fail(LB_ERR_ARG, "model was created for another engine");
   LB_TRY(lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, n_realloc_out));
   if (e->f16x2 && e->math_auto) {
-    // the guard is sampled on every launch; a raised flag anywhere in the rollout repeats ALL of it in
-    // fp32 (the step it was raised in is not recorded: a checkpoint either fits fp16's range or not)
-    int switched = 0;
-    LB_TRY(lb_math_check(e, &switched));
+    // The guard records the FIRST step at which a flag was raised (lb_ctrl::math_step): every step before it is
+    // valid f16x2 work, so the rollout RESUMES there in exact fp32 - window rebuilt from the input frames and the
+    // predictions already made - instead of being repeated from step 0 (round 2).  The engine then stays in fp32: a
+    // checkpoint that left fp16's range once is expected to do so again.
+    int switched = 0, s0 = 0;
+    // LB_TEST_RESUME_AT=k (tests only): behave as if the guard had fired at step k of this rollout
+    static const int force_at = getenv("LB_TEST_RESUME_AT") ? atoi(getenv("LB_TEST_RESUME_AT")) : -1;
+    if (force_at >= 0 && force_at < n_steps) {
+      const int32_t inj[2] = {LB_MATH_TINY, force_at};
+      LB_HIP(hipMemcpyAsync(&e->ctrl->math_flags, &inj[0], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+      LB_HIP(hipMemcpyAsync(&e->ctrl->math_step, &inj[1], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+      LB_HIP(hipStreamSynchronize(e->stream));
+    }
+    LB_TRY(lb_math_check(e, &switched, &s0));
     if (switched) {
+      s0 = std::max(0, std::min(s0, n_steps - 1));
       int32_t n2 = 0;
-      LB_TRY(lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, &n2));
+      LB_TRY(lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, &n2, s0));
       if (n_realloc_out) *n_realloc_out += n2;
     }
   }
@@ -1000,7 +1023,7 @@ static int lb_enqueue_step(lb_engine* e, int (*forward)(lb_engine*, void*), void
 
 int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* model,
                        const double* traj_dev, int32_t T, int32_t n_steps, double* pred_out_dev,
-                       int32_t* n_realloc_out) {
+                       int32_t* n_realloc_out, int32_t start_step) {
   if (T < e->g.isl) return lb_fail(LB_ERR_ARG, "trajectory shorter than input_seq_length");
   if (e->g.force_kind == LB_FORCE_BUFFER)
     return lb_fail(LB_ERR_UNSUPPORTED, "lb_rollout with LB_FORCE_BUFFER: drive the steps from the host");
@@ -1029,9 +1052,12 @@ int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* mo
     e->stream = e->gstream;
   }
   int n_realloc = 0;
-  LB_TRY(lbk_load_window(e, traj_dev, T, 0, 0));
+  if (start_step > 0)   // resume: window of step start_step from the input frames + the predictions made so far
+    LB_TRY(lbk_load_window_resume(e, traj_dev, T, pred_out_dev, n_steps, start_step));
+  else
+    LB_TRY(lbk_load_window(e, traj_dev, T, 0, 0));
   if (e->e_cap <= 0) LB_TRY(lb_nl_allocate(e, nullptr, nullptr, nullptr));
-  int step = 0;
+  int step = start_step;
   const int RA = 3;  // steps the host may run ahead of the device
   while (step < n_steps) {
     bool warm = false;  // the first step after a (re-)allocation runs uncaptured: lazy buffer growth

@@ -44,3 +44,10 @@ __device__ __forceinline__ double lb_pos(const double* __restrict__ win, const l
 }
 
 __device__ __forceinline__ int lb_lane() { return threadIdx.x & 63; }
+
+// range guard: raise flag bits and remember the first rollout step they were raised in
+__device__ __forceinline__ void lb_raise_math(const lb_ctrl* ctrl, int flags) {
+  lb_ctrl* c = const_cast<lb_ctrl*>(ctrl);
+  atomicOr(&c->math_flags, flags);
+  atomicMin(&c->math_step, c->step);
+}

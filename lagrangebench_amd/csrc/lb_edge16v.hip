@@ -33,7 +33,9 @@
 // NT: the edge latents are streamed with nontemporal loads / stores (batches whose latents exceed the 256 MiB
 // Infinity Cache); a single trajectory's latents (tens of MB) are read back from the cache by the next layer, so
 // small graphs use plain accesses.
-template <int WPS, bool RELOAD, bool SKIP, int ABL = 0, bool PRIO = false, bool NT = true>
+// GUARD: exhaustive TINY test of the f16x2 range guard on every tile (lb_tile_tiny; +8 % kernel time: lb_math_mode 3 /
+// LB_GUARD=full), else the sampled probe (first tile of every wave).
+template <int WPS, bool RELOAD, bool SKIP, int ABL = 0, bool PRIO = false, bool NT = true, bool GUARD = false>
 __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
   constexpr int THREADS = WPS * 256, WAVES = WPS * 4;
   constexpr int NW0 = 4096;
@@ -103,6 +105,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
   // (the first tile's indices were waited for above, by the barrier: a wait at the loop header would also be
   // executed on the back edge, where it drains the previous tile's stores)
   asm volatile("" : "+v"(s_c), "+v"(r_c));
+  int guard_tiny = 0;  // exhaustive TINY guard: every tile's two GEMM operands (lb_tile_tiny)
   for (int it = 0; it < n_iter; ++it, t += stride) {
     f32x4 acc[8], ve[8];
     const int r_cur = r_c;
@@ -134,14 +137,16 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
     // MFMAs then issue back to back and the others fill the issue slots in between (VALU beside a busy
     // matrix pipe still runs at ~1 instruction per 7 cycles, tools/simd_overlap_bench)
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
-    if constexpr (!(ABL & 8)) lb_gemm16v<false>(w0b, ve, acc);
+    uint32_t or_e = 0, or_h = 0;
+    if constexpr (!(ABL & 8)) lb_gemm16v<false, 4, GUARD>(w0b, ve, acc, &or_e);
     if (it == 0) lb_range_probe(a.ctrl, acc, 8);
     f32x4 acc2[8];
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) acc2[mb] = vecb[4 * mb];
     if constexpr (!(ABL & 8)) {
-      lb_gemm16v<true>(w1b, acc, acc2);
+      lb_gemm16v<true, 4, GUARD>(w1b, acc, acc2, &or_h);
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+      if constexpr (GUARD) guard_tiny |= (int)lb_tile_tiny(or_e) | (int)lb_tile_tiny(or_h);
     } else {
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb)
@@ -197,6 +202,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
       for (int mb = 0; mb < 8; ++mb) d4[4 * mb] = y[mb];
     }
   }
+  if (guard_tiny && lane == 0) lb_raise_math(a.ctrl, LB_MATH_TINY);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -286,12 +292,19 @@ int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a) {
 // Two waves per SIMD, GEMM-phase priority (round 2's measured best; the software-prefetching, second-read and
 // three- / four-wave variants live on in tools/museum/lb_edge16v_r02.hip for tools/edge16v_bench).
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a) {
-#define LB_E16V(NT, G)                                                                                  \
+#define LB_E16V_(NT, G, GU)                                                                             \
   do {                                                                                                  \
     if (a.skip_elat_store)                                                                              \
-      LB_LAUNCH_TIMED(e, (k_edge16v<2, false, true, 0, true, NT>), dim3(G), dim3(512), a);              \
+      LB_LAUNCH_TIMED(e, (k_edge16v<2, false, true, 0, true, NT, GU>), dim3(G), dim3(512), a);          \
     else                                                                                                \
-      LB_LAUNCH_TIMED(e, (k_edge16v<2, false, false, 0, true, NT>), dim3(G), dim3(512), a);             \
+      LB_LAUNCH_TIMED(e, (k_edge16v<2, false, false, 0, true, NT, GU>), dim3(G), dim3(512), a);         \
+  } while (0)
+#define LB_E16V(NT, G)        \
+  do {                        \
+    if (e->guard_full)        \
+      LB_E16V_(NT, G, true);  \
+    else                      \
+      LB_E16V_(NT, G, false); \
   } while (0)
   // Small graphs (one 2.5 k-particle trajectory = ~1000 tiles): a launch is the latency chain
   // "stage 133 KiB of weights -> one tile per wave", so launch no more workgroups than there are tiles for.
@@ -309,6 +322,7 @@ int lbk_edge16v(lb_engine* e, const lb_edge16_args& a) {
   else
     LB_E16V(true, grid);
 #undef LB_E16V
+#undef LB_E16V_
   LB_HIP(hipGetLastError());
   return LB_OK;
 }

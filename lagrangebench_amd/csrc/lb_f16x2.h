@@ -39,8 +39,17 @@ __device__ __forceinline__ void lb_range_probe(const lb_ctrl* ctrl, const f32x4*
     int f = 0;
     if (any_bad || m >= 32768.f) f |= LB_MATH_LARGE;
     if (m > 0.f && m < 0.0009765625f) f |= LB_MATH_TINY;
-    if (f) atomicOr(const_cast<int32_t*>(&ctrl->math_flags), f);
+    if (f) lb_raise_math(ctrl, f);
   }
+}
+
+// Exhaustive TINY test of the range guard.  `orv` = OR of the fp16 `hi` bit patterns of every B-operand element a
+// lane fed into one GEMM of one tile.  Exponent bits 14:12 of a half are clear iff |hi| < 2^-11; if that holds for
+// EVERY element of the tile (all lanes) and the operand is not identically zero, the `lo` halves of the whole tile
+// are subnormal (absolute 2^-25 floor instead of a relative 2^-22): raise LB_MATH_TINY.  (LARGE needs no exhaustive
+// test: an overflowing `hi` is inf, travels through every later layer and is caught by the decoder's check.)
+__device__ __forceinline__ bool lb_tile_tiny(uint32_t orv) {
+  return !__any((orv & 0x70007000u) != 0u) && __any((orv & 0x7fff7fffu) != 0u);
 }
 
 // hi = fp16(x) (RNE), lo = fp16(x - hi) for 8 values: 4 v_cvt_pk_f16_f32 + 8 v_fma_mix{lo,hi}_f16
@@ -75,8 +84,17 @@ __device__ __forceinline__ void lb_split8v(const f32x4& x0, const f32x4& x1, h8&
 // acc[0..7] += W^T * v over NP k-steps of 32 (f16x2: lo*hi + hi*lo + hi*hi), phase-pipelined LDS reads.
 // wbase: this lane's LDS pointer to fragment (p 0, mbo 0, part 0); fragment (p, mbo, part) sits
 // ((p*8 + mbo)*2 + part)*64 f32x4 further.  RELU applies max(x, 0) to v while it is split.
-template <bool RELU, int NP = 4>
-__device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[2 * NP], f32x4 (&acc)[8]) {
+// GUARD: the fp16 `hi` halves of the B operand are OR-ed into `orv` while they are split (two v_or3 per k-step): the
+// exhaustive TINY test of the range guard (lb_tile_tiny below).
+template <bool RELU, int NP = 4, bool GUARD = false>
+__device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[2 * NP], f32x4 (&acc)[8], uint32_t* orv = nullptr) {
+  auto note = [&](const h8& h) {
+    if constexpr (GUARD) {
+      typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
+      const u32x4g u = __builtin_bit_cast(u32x4g, h);
+      *orv |= (u[0] | u[1]) | (u[2] | u[3]);
+    }
+  };
   auto frag = [&](int p, int mbo, int part) -> h8 {
     return __builtin_bit_cast(h8, wbase[((p * 8 + mbo) * 2 + part) * 64]);
   };
@@ -97,6 +115,7 @@ __device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[2 * 
 #pragma unroll
   for (int c = 0; c < 4; ++c) Y[c] = frag(0, c, 0);
   lb_split8v(relu4(v[0]), relu4(v[1]), bh, bl);
+  note(bh);
   SB();
 #pragma unroll
   for (int blk = 0; blk < 2 * NP; ++blk) {
@@ -115,7 +134,10 @@ __device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[2 * 
       for (int c = 0; c < 4; ++c) X[c] = frag(np, 4 * nq + c, 1);
     }
     // the next k-step's operand is split while this block's MFMAs run
-    if (q == 1 && p < NP - 1) lb_split8v(relu4(v[2 * p + 2]), relu4(v[2 * p + 3]), nbh, nbl);
+    if (q == 1 && p < NP - 1) {
+      lb_split8v(relu4(v[2 * p + 2]), relu4(v[2 * p + 3]), nbh, nbl);
+      note(nbh);
+    }
     // phase 2: hi * lo, hi * hi (wait for the `hi` fragments; the next block's `lo` reads stay in flight)
     if (blk < 2 * NP - 1)
       __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(4));

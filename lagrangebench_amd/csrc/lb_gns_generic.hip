@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(GD_THREADS, 2) k_dense16(lb_dense_args a) {
       reinterpret_cast<f32x4*>(a.acc_out)[row] = o;
       bool bad = false;
       for (int d = 0; d < a.out_dim; ++d) bad |= !(fabsf(o[d]) <= 3.0e38f);
-      if (bad) atomicOr(const_cast<int32_t*>(&a.ctrl->math_flags), LB_MATH_NONFINITE);
+      if (bad) lb_raise_math(a.ctrl, LB_MATH_NONFINITE);
     }
   }
 }
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(GD_THREADS, 2) k_decoder16(lb_dec16_args a) {
       reinterpret_cast<f32x4*>(a.acc_out)[row] = o;
       bool bad = false;
       for (int d = 0; d < a.out_dim; ++d) bad |= !(fabsf(o[d]) <= 3.0e38f);
-      if (bad) atomicOr(const_cast<int32_t*>(&a.ctrl->math_flags), LB_MATH_NONFINITE);
+      if (bad) lb_raise_math(a.ctrl, LB_MATH_NONFINITE);
     }
   }
 }

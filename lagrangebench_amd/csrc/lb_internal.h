@@ -35,7 +35,10 @@ struct lb_ctrl {
   float ln_inv_d;          // LayerNorm over a latent narrower than the 128-wide tiles (zero-padded weights):
   float ln_pad;            // mean = sum / d, var = (sum_128 (x-mean)^2 - pad * mean^2) / d, pad = 128 - d
   int32_t persist_error;   // lb_persist.hip: a grid-barrier spin timed out (the launch gave up; results are invalid)
+  int32_t math_step;       // first rollout step at which a range-guard flag was raised (0x7fffffff = none): lb_rollout
+                           // resumes THERE in exact fp32 instead of repeating the rollout
 };
+#define LB_MATH_NO_STEP 0x7fffffff
 #define LB_MATH_LARGE 1
 #define LB_MATH_TINY 2
 #define LB_MATH_NONFINITE 4
@@ -132,6 +135,8 @@ struct lb_engine {
   int math_auto;       // 1: f16x2 with the range guard - a raised lb_ctrl::math_flags makes the host repeat
                        //    the work in exact-fp32 MFMA arithmetic and stay there (LB_MATH unset);
                        // 0: the mode LB_MATH / lb_math_mode fixed
+  int guard_full;      // 1: the wave-per-tile edge kernel tests EVERY tile for the TINY condition (lb_math_mode 3 /
+                       //    LB_GUARD=full; +8 % on that kernel); 0: sampled probe.  The M-split kernels always test all.
   float* acc;          // [BN][4] decoder output (dim padded to 4)
   unsigned* persist_bar = nullptr;    // grid-barrier words of the persistent processor launch (lb_persist.hip)
   int persist_grid = 0;               // workgroups of that launch (= CUs, multiple of 8); 0 = not usable
@@ -306,6 +311,7 @@ int lbk_edge_features_export(lb_engine* e, double* rel_disp, double* rel_dist);
 
 // lb_state.hip
 int lbk_load_window(lb_engine* e, const double* traj, int T, int t0, int step);
+int lbk_load_window_resume(lb_engine* e, const double* traj, int T, const double* pred, int pred_T, int step);
 int lbk_read_window(lb_engine* e, double* out);
 int lbk_node_features(lb_engine* e, float* xnode, const float* embed, int emb, int ntypes,
                       double* vel_hist, double* vel_mag, double* bound, double* force);
@@ -327,7 +333,7 @@ int lbk_node_features_raw(lb_engine* e, float* xnode, int kpad);
 // lb_api.hip: the device-resident step loop shared by the models
 int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* model,
                        const double* traj_dev, int32_t T, int32_t n_steps, double* pred_out_dev,
-                       int32_t* n_realloc_out);
+                       int32_t* n_realloc_out, int32_t start_step = 0);
 
 // lb_segnn.hip
 struct lb_segnn;

@@ -164,7 +164,7 @@ struct ms_guard {
     if (!(m < 32768.f)) f |= LB_MATH_LARGE;  // close to the fp16 range, inf
     const bool any_nan = __any(f & LB_MATH_LARGE), any_tiny = __any(f & LB_MATH_TINY);
     f = (any_nan ? LB_MATH_LARGE : 0) | (any_tiny ? LB_MATH_TINY : 0);
-    if (lane == 0 && f) atomicOr(const_cast<int32_t*>(&ctrl->math_flags), f);
+    if (lane == 0 && f) lb_raise_math(ctrl, f);
   }
 };
 

@@ -26,6 +26,31 @@ __global__ void k_load_window(lb_geom g, int64_t BN, const double* __restrict__ 
   }
 }
 
+// Window of rollout step `step` rebuilt from the input frames and the predictions made so far: frame f of the sequence
+// [traj[:, :isl] | pred[:, 0], pred[:, 1], ...] (pred is (B, pred_T, N, dim), the layout k_integrate writes).
+__global__ void k_load_window_resume(lb_geom g, int64_t BN, const double* __restrict__ traj, int T,
+                                     const double* __restrict__ pred, int pred_T, int step, double* __restrict__ win,
+                                     lb_ctrl* __restrict__ ctrl) {
+  int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi == 0) ctrl->step = step;
+  if (gi >= BN) return;
+  const int b = (int)(gi / g.N), i = (int)(gi % g.N);
+  for (int f = 0; f < g.isl; ++f) {
+    const int slot = (step + f) % g.isl, frame = step + f;
+    for (int d = 0; d < g.dim; ++d)
+      win[((int64_t)slot * g.dim + d) * BN + gi] =
+          frame < g.isl ? traj[(gi * T + frame) * g.dim + d]
+                        : pred[(((int64_t)b * pred_T + (frame - g.isl)) * g.N + i) * g.dim + d];
+  }
+}
+int lbk_load_window_resume(lb_engine* e, const double* traj, int T, const double* pred, int pred_T, int step) {
+  const int nb = (int)((e->BN + 255) / 256);
+  hipLaunchKernelGGL(k_load_window_resume, dim3(nb), dim3(256), 0, e->stream, e->g, e->BN, traj, T, pred, pred_T, step,
+                     e->win, e->ctrl);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
 int lbk_load_window(lb_engine* e, const double* traj, int T, int t0, int step) {
   const int nb = (int)((e->BN + 255) / 256);
   hipLaunchKernelGGL(k_load_window, dim3(nb), dim3(256), 0, e->stream, e->g, e->BN, traj, T, t0,
