@@ -54,7 +54,8 @@ typedef struct lb_case_desc {
   int32_t has_vel_mag;  /* cfg_model.magnitude_features - features.py:80-85 */
   int32_t force_kind;   /* LB_FORCE_* : external_force_fn - features.py:105-107 */
   int32_t force_axis;
-  int32_t reserved0;
+  int32_t geometry_f32; /* dtype of case_builder (case.py:169): 0 float64 (default), 1 float32 - buffers stay fp64, every
+                         * value is float-representable and every arithmetic result is rounded to float */
   double box[3];
   double r_cutoff;      /* metadata["default_connectivity_radius"] */
   double capacity_multiplier; /* cfg_neighbors.multiplier */

@@ -21,7 +21,7 @@ class CaseDesc(C.Structure):
     _fields_ = [
         ("dim", C.c_int32), ("n_particles", C.c_int32), ("batch", C.c_int32), ("isl", C.c_int32),
         ("periodic", C.c_int32), ("has_bound", C.c_int32), ("has_vel_mag", C.c_int32),
-        ("force_kind", C.c_int32), ("force_axis", C.c_int32), ("reserved0", C.c_int32),
+        ("force_kind", C.c_int32), ("force_axis", C.c_int32), ("geometry_f32", C.c_int32),
         ("box", D3), ("r_cutoff", C.c_double), ("capacity_multiplier", C.c_double),
         ("vel_mean", D3), ("vel_std", D3), ("acc_mean", D3), ("acc_std", D3),
         ("bound_lo", D3), ("bound_hi", D3),

@@ -63,12 +63,14 @@ class CaseSetupFn:
         self.cfg_neighbors = cfg_neighbors
         self.cfg_model = cfg_model
         self.dtype = dtype
+        self.f32 = _is_f32(dtype)
         self.device = device
         self.force = force
         self.dim = int(len(self.box))
         self.N = int(metadata["num_particles_max"])
         self.periodic = bool(np.array(metadata["periodic_boundary_conditions"]).any())
-        self.normalization_stats = get_dataset_stats(metadata, cfg_model["isotropic_norm"], noise_std)
+        self.normalization_stats = get_dataset_stats(metadata, cfg_model["isotropic_norm"], noise_std,
+                                                     dtype=np.float32 if self.f32 else np.float64)
         self.displacement, self.shift = make_displacement(self.box, self.periodic)
         self._engines: Dict[int, RolloutEngine] = {}
 
@@ -87,7 +89,7 @@ class CaseSetupFn:
                 bounds=md["bounds"],
                 has_bound=not any(md["periodic_boundary_conditions"]),
                 has_vel_mag=bool(self.cfg_model["magnitude_features"]),
-                force=self.force, device=self.device,
+                force=self.force, device=self.device, geometry_f32=self.f32,
             )
             self._engines[batch] = eng
         return eng
@@ -106,11 +108,15 @@ class CaseSetupFn:
                     unroll_steps: int = 0, noise_std: float = 0.0, key=None):
         pos, ptype, batched = self._split(sample)
         isl = self.input_seq_length
+        if self.f32:  # case.py:169: pos_input = jnp.asarray(sample[0], dtype=dtype)
+            pos = pos.to(torch.float32)
         if mode == "train" and noise_std not in (0, 0.0) and pos.shape[2] > 1:
             # case.py:172-178: random-walk noise on the input window, targets shifted consistently
             from ..train.strats import add_gns_noise
             key, pos = add_gns_noise(key, pos.to(torch.float64), ptype, isl, float(noise_std),
                                      lambda r, dr: self.shift(r, dr))
+            if self.f32:
+                pos = pos.to(torch.float32)
         B = pos.shape[0]
         eng = self.engine(B)
         eng.set_particle_type(ptype)
@@ -135,6 +141,8 @@ class CaseSetupFn:
     def _compute_target(self, p3: torch.Tensor, batched: bool):
         """case.py:142-160 (training targets; plain torch - not on the inference hot path)."""
         s = self.normalization_stats
+        if self.f32:  # the window holds float-representable values: the targets are float arithmetic on them
+            p3 = p3.to(torch.float32)
         t = lambda a: torch.as_tensor(a, dtype=p3.dtype, device=p3.device)
         cur_v = self.displacement(p3[:, :, 1], p3[:, :, 0])
         nxt_v = self.displacement(p3[:, :, 2], p3[:, :, 1])
@@ -165,6 +173,8 @@ class CaseSetupFn:
         if "pos" in normalized_in:
             return normalized_in["pos"]
         ps = _as_tensor(position_sequence)
+        if self.f32:
+            ps = ps.to(torch.float32)
         batched = ps.dim() == 4
         if not batched:
             ps = ps[None]
@@ -204,6 +214,10 @@ def _force_spec(external_force_fn, bounds=None) -> Optional[ForceSpec]:
     raise TypeError("external_force_fn must be None, a ForceSpec, a dict or a callable")
 
 
+def _is_f32(dtype) -> bool:
+    return str(dtype) in ("float32", "torch.float32", "<class 'numpy.float32'>") or dtype in (np.float32, torch.float32)
+
+
 def case_builder(
     box,
     metadata: Dict,
@@ -219,13 +233,18 @@ def case_builder(
 
     ``external_force_fn``: a ForceSpec (device-evaluated), a dict describing a piecewise-constant
     force, or a callable ``pos (n,dim) torch tensor -> (n,dim)`` evaluated with torch each step.
-    ``dtype``: only "float64" (the reference default, defaults.py:22) is built.
+    ``dtype``: "float64" (the reference default, defaults.py:22) or "float32" (what the reference's own
+    tests/case_test.py runs in): in float32 mode the positions are cast to f32 on entry (case.py:169) and every
+    geometry result (neighbor predicate, features, targets, integrator) is the float result bit for bit; the
+    buffers and the returned tensors stay float64 holding float-representable values.
     """
     cfg_neighbors = merge(defaults.neighbors, cfg_neighbors)
     cfg_model = merge(defaults.model, cfg_model)
-    if str(dtype) not in ("float64", "torch.float64", "<class 'numpy.float64'>") and dtype not in (
-            np.float64, torch.float64):
-        raise NotImplementedError("case_builder: only dtype=float64 is built")
+    if not (_is_f32(dtype) or str(dtype) in ("float64", "torch.float64", "<class 'numpy.float64'>") or dtype in (
+            np.float64, torch.float64)):
+        raise NotImplementedError(f"case_builder: dtype {dtype!r} (float64 and float32 are built)")
+    if _is_f32(dtype) and _force_spec(external_force_fn, metadata.get("bounds")) is not None:
+        raise NotImplementedError("case_builder: dtype=float32 with an external force is not built")
     if cfg_neighbors.multiplier < 1.25:
         warnings.warn(f"cfg_neighbors.multiplier={cfg_neighbors.multiplier} < 1.25 is very low.")
     if cfg_neighbors.backend not in ("jaxmd_vmap", "jaxmd_scan", "hip"):

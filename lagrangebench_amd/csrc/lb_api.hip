@@ -156,8 +156,12 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   g.has_vel_mag = d->has_vel_mag != 0;
   g.force_kind = d->force_kind;
   g.force_axis = d->force_axis;
-  g.rc = d->r_cutoff;
-  g.rc2 = d->r_cutoff * d->r_cutoff;
+  g.f32 = d->geometry_f32 != 0;
+  // dtype=float32: every constant is the float the reference would hold (cutoff^2 is squared in Python floats and
+  // THEN cast: jax-md prunes with position.dtype.type(cutoff_sq))
+  auto R = [&](double x) { return g.f32 ? (double)(float)x : x; };
+  g.rc = R(d->r_cutoff);
+  g.rc2 = R(d->r_cutoff * d->r_cutoff);
   // jax-md partition.py: box and cell_size are float32; cell list only if cutoff < box/3.
   bool use_cells = true;
   for (int k = 0; k < d->dim; ++k) {
@@ -169,14 +173,14 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   for (int k = 0; k < 3; ++k) {
     g.ncell[k] = 1;
     g.cell_size[k] = 1.0;
-    g.box[k] = k < d->dim ? d->box[k] : 1.0;
+    g.box[k] = k < d->dim ? R(d->box[k]) : 1.0;
     g.half_box[k] = g.box[k] * 0.5;
-    g.vel_mean[k] = d->vel_mean[k];
-    g.vel_std[k] = d->vel_std[k];
-    g.acc_mean[k] = d->acc_mean[k];
-    g.acc_std[k] = d->acc_std[k];
-    g.bound_lo[k] = d->bound_lo[k];
-    g.bound_hi[k] = d->bound_hi[k];
+    g.vel_mean[k] = R(d->vel_mean[k]);
+    g.vel_std[k] = R(d->vel_std[k]);
+    g.acc_mean[k] = R(d->acc_mean[k]);
+    g.acc_std[k] = R(d->acc_std[k]);
+    g.bound_lo[k] = R(d->bound_lo[k]);
+    g.bound_hi[k] = R(d->bound_hi[k]);
     g.force_lo[k] = d->force_lo[k];
     g.force_hi[k] = d->force_hi[k];
   }

@@ -52,6 +52,7 @@ struct lb_geom {
   int32_t nstencil;        // 3^dim, or 1 when !use_cell_list
   int32_t node_in;         // feature columns without embedding
   int32_t kpad;            // node feature row stride (multiple of 32)
+  int32_t f32;             // dtype=float32 geometry: every arithmetic result rounded to float (lb_device.h: lb_r)
   double cell_size[3];     // f32-rounded like jax-md, widened
   double box[3], half_box[3];
   double rc, rc2;

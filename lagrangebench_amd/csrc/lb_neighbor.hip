@@ -55,7 +55,7 @@ __global__ void k_cell_count(lb_geom g, int64_t BN, const double* __restrict__ w
   int h = 0, mult = 1;
   for (int d = 0; d < g.dim; ++d) {
     double p = lb_pos(win, g, BN, step, g.isl - 1, d, gi);
-    int c = __double2int_rz(p / g.cell_size[d]);  // jnp.array(position / cell_size, dtype=i32)
+    int c = __double2int_rz(lb_r(p / g.cell_size[d], g.f32));  // jnp.array(position / cell_size, dtype=i32)
     c = c < 0 ? 0 : (c >= g.ncell[d] ? g.ncell[d] - 1 : c);
     h += c * mult;
     mult *= g.ncell[d];
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(LB_SMALL_T)
       int h = 0, mult = 1;
       for (int d = 0; d < g.dim; ++d) {
         double p = lb_pos(win, g, BN, step, g.isl - 1, d, gi);
-        int c = __double2int_rz(p / g.cell_size[d]);  // jnp.array(position / cell_size, dtype=i32)
+        int c = __double2int_rz(lb_r(p / g.cell_size[d], g.f32));  // jnp.array(position / cell_size, dtype=i32)
         c = c < 0 ? 0 : (c >= g.ncell[d] ? g.ncell[d] - 1 : c);
         h += c * mult;
         mult *= g.ncell[d];
@@ -259,7 +259,7 @@ struct lb_nl_args {
   int32_t maxd;
 };
 
-template <int MODE, int NL_THREADS, int MAXC>
+template <int MODE, int NL_THREADS, int MAXC, bool F32 = false>
 __global__ void __launch_bounds__(NL_THREADS)
     k_nl(lb_geom g, int64_t BN, lb_ctrl* __restrict__ ctrl, lb_nl_args a) {
   constexpr int NL_WAVES = NL_THREADS / 64;
@@ -343,11 +343,11 @@ __global__ void __launch_bounds__(NL_THREADS)
       if (j < M) {
         // metric_sq(position[sender], position[receiver]): sender = staged candidate,
         // receiver = row owner; sum of squares in x,y,z order, no FMA contraction.
-        double dd = lb_disp1(s_p[0][j], pr[0], g.box[0], g.half_box[0], g.periodic);
-        double d2 = dd * dd;
+        double dd = lb_disp1(s_p[0][j], pr[0], g.box[0], g.half_box[0], g.periodic, F32);
+        double d2 = lb_r(dd * dd, F32);
         for (int d = 1; d < g.dim; ++d) {
-          dd = lb_disp1(s_p[d][j], pr[d], g.box[d], g.half_box[d], g.periodic);
-          d2 = d2 + dd * dd;
+          dd = lb_disp1(s_p[d][j], pr[d], g.box[d], g.half_box[d], g.periodic, F32);
+          d2 = lb_r(d2 + lb_r(dd * dd, F32), F32);
         }
         ok = d2 < g.rc2;  // strict <
       }
@@ -395,10 +395,10 @@ __global__ void __launch_bounds__(NL_THREADS)
         double rd[3] = {0, 0, 0};
         double s2 = 0.0;
         for (int d = 0; d < g.dim; ++d) {
-          rd[d] = lb_disp1(pr[d], s_p[d][j], g.box[d], g.half_box[d], g.periodic) / g.rc;
-          s2 = (d == 0) ? rd[d] * rd[d] : s2 + rd[d] * rd[d];
+          rd[d] = lb_r(lb_disp1(pr[d], s_p[d][j], g.box[d], g.half_box[d], g.periodic, F32) / g.rc, F32);
+          s2 = (d == 0) ? lb_r(rd[d] * rd[d], F32) : lb_r(s2 + lb_r(rd[d] * rd[d], F32), F32);
         }
-        const double dist = s2 > 0.0 ? sqrt(s2) : 0.0;
+        const double dist = s2 > 0.0 ? lb_r(sqrt(s2), F32) : 0.0;
         const f32x4 lo = (g.dim == 2) ? f32x4{(float)rd[0], (float)rd[1], (float)dist, 0.f}
                                       : f32x4{(float)rd[0], (float)rd[1], (float)rd[2], (float)dist};
         if (MODE == NL_ROWS) {
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(NL_THREADS)
 // per receiver), and with one workgroup per CELL the staged stencil (28 B x cell_capacity x 3^dim of
 // LDS) capped the occupancy at a handful of waves per CU.  Same predicate, same operand order.
 #define NLW_WAVES 4
-template <int MODE>
+template <int MODE, bool F32 = false>
 __global__ void __launch_bounds__(64 * NLW_WAVES)
     k_nlw(lb_geom g, int64_t BN, lb_ctrl* __restrict__ ctrl, lb_nl_args a) {
   __shared__ int s_row[NLW_WAVES][LB_MAX_ROW];
@@ -493,11 +493,11 @@ __global__ void __launch_bounds__(64 * NLW_WAVES)
     if (j < M) {
       src = slot_of(j);
       // metric_sq(position[sender], position[receiver]): sum of squares in x,y,z order, no FMA
-      double dd = lb_disp1(a.cpos[src], pr[0], g.box[0], g.half_box[0], g.periodic);
-      double d2 = dd * dd;
+      double dd = lb_disp1(a.cpos[src], pr[0], g.box[0], g.half_box[0], g.periodic, F32);
+      double d2 = lb_r(dd * dd, F32);
       for (int d = 1; d < g.dim; ++d) {
-        dd = lb_disp1(a.cpos[(int64_t)d * BN + src], pr[d], g.box[d], g.half_box[d], g.periodic);
-        d2 = d2 + dd * dd;
+        dd = lb_disp1(a.cpos[(int64_t)d * BN + src], pr[d], g.box[d], g.half_box[d], g.periodic, F32);
+        d2 = lb_r(d2 + lb_r(dd * dd, F32), F32);
       }
       ok = d2 < g.rc2;  // strict <
     }
@@ -543,10 +543,10 @@ __global__ void __launch_bounds__(64 * NLW_WAVES)
       double rd[3] = {0, 0, 0};
       double s2 = 0.0;
       for (int d = 0; d < g.dim; ++d) {
-        rd[d] = lb_disp1(pr[d], a.cpos[(int64_t)d * BN + src], g.box[d], g.half_box[d], g.periodic) / g.rc;
-        s2 = (d == 0) ? rd[d] * rd[d] : s2 + rd[d] * rd[d];
+        rd[d] = lb_r(lb_disp1(pr[d], a.cpos[(int64_t)d * BN + src], g.box[d], g.half_box[d], g.periodic, F32) / g.rc, F32);
+        s2 = (d == 0) ? lb_r(rd[d] * rd[d], F32) : lb_r(s2 + lb_r(rd[d] * rd[d], F32), F32);
       }
-      const double dist = s2 > 0.0 ? sqrt(s2) : 0.0;
+      const double dist = s2 > 0.0 ? lb_r(sqrt(s2), F32) : 0.0;
       const f32x4 lo = (g.dim == 2) ? f32x4{(float)rd[0], (float)rd[1], (float)dist, 0.f}
                                     : f32x4{(float)rd[0], (float)rd[1], (float)rd[2], (float)dist};
       if (MODE == NL_ROWS) {
@@ -693,6 +693,11 @@ static void lb_launch_nl(lb_engine* e, int small, const lb_nl_args& a) {
   // 0.18 ms per step), 3^2-cell stencils the staged per-cell kernel (DAM2D 0.11 vs 0.15 ms)
   static const char* force = getenv("LB_NL_KERNEL");  // "cell" | "wave": ablation override
   const bool per_wave = force ? force[0] == 'w' : e->g.nstencil == 27;
+  if (e->g.f32) {  // dtype=float32 geometry: the wave-per-receiver kernel with every result rounded to float
+    const int nb = (int)((e->BN + NLW_WAVES - 1) / NLW_WAVES);
+    hipLaunchKernelGGL((k_nlw<MODE, true>), dim3(nb), dim3(64 * NLW_WAVES), 0, e->stream, e->g, e->BN, e->ctrl, a);
+    return;
+  }
   if (per_wave) {
     const int nb = (int)((e->BN + NLW_WAVES - 1) / NLW_WAVES);
     hipLaunchKernelGGL((k_nlw<MODE>), dim3(nb), dim3(64 * NLW_WAVES), 0, e->stream, e->g, e->BN, e->ctrl, a);

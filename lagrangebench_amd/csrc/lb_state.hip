@@ -100,15 +100,15 @@ __global__ void k_node_features(lb_geom g, int64_t BN, const double* __restrict_
     double s2 = 0.0;
     for (int d = 0; d < dim; ++d) {
       pcur[d] = lb_pos(win, g, BN, step, t + 1, d, gi);
-      const double v = lb_disp1(pcur[d], pprev[d], g.box[d], g.half_box[d], g.periodic);
-      const double nv = (v - g.vel_mean[d]) / g.vel_std[d];
+      const double v = lb_disp1(pcur[d], pprev[d], g.box[d], g.half_box[d], g.periodic, g.f32);
+      const double nv = lb_r(lb_r(v - g.vel_mean[d], g.f32) / g.vel_std[d], g.f32);
       if (x) x[t * dim + d] = (float)nv;
       if (vel_hist) vel_hist[gi * (K * dim) + t * dim + d] = nv;
-      s2 = (d == 0) ? nv * nv : s2 + nv * nv;
+      s2 = (d == 0) ? lb_r(nv * nv, g.f32) : lb_r(s2 + lb_r(nv * nv, g.f32), g.f32);
       pprev[d] = pcur[d];
     }
     if (g.has_vel_mag) {
-      const double m = sqrt(s2);
+      const double m = lb_r(sqrt(s2), g.f32);
       if (x) x[K * dim + t] = (float)m;
       if (vel_mag) vel_mag[gi * K + t] = m;
     }
@@ -118,8 +118,8 @@ __global__ void k_node_features(lb_geom g, int64_t BN, const double* __restrict_
     for (int d = 0; d < dim; ++d) pcur[d] = lb_pos(win, g, BN, step, 0, d, gi);
   if (g.has_bound) {
     for (int d = 0; d < dim; ++d) {
-      double lo = (pcur[d] - g.bound_lo[d]) / g.rc;
-      double hi = (g.bound_hi[d] - pcur[d]) / g.rc;
+      double lo = lb_r(lb_r(pcur[d] - g.bound_lo[d], g.f32) / g.rc, g.f32);
+      double hi = lb_r(lb_r(g.bound_hi[d] - pcur[d], g.f32) / g.rc, g.f32);
       lo = fmin(fmax(lo, -1.0), 1.0);
       hi = fmin(fmax(hi, -1.0), 1.0);
       if (x) {
@@ -212,9 +212,9 @@ __global__ void k_integrate(lb_geom g, int64_t BN, double* __restrict__ win,
     } else {
       const double p1 = lb_pos(win, g, BN, step, g.isl - 1, d, gi);
       const double p0 = lb_pos(win, g, BN, step, g.isl - 2, d, gi);
-      const double a = g.acc_mean[d] + (double)acc[gi * acc_stride + d] * g.acc_std[d];
-      const double v = lb_disp1(p1, p0, g.box[d], g.half_box[d], g.periodic);
-      out = lb_shift1(p1, v + a, g.box[d], g.periodic);
+      const double a = lb_r(g.acc_mean[d] + lb_r((double)acc[gi * acc_stride + d] * g.acc_std[d], g.f32), g.f32);
+      const double v = lb_disp1(p1, p0, g.box[d], g.half_box[d], g.periodic, g.f32);
+      out = lb_shift1(p1, lb_r(v + a, g.f32), g.box[d], g.periodic, g.f32);
     }
     win[((int64_t)slot_new * g.dim + d) * BN + gi] = out;
     if (pred && step < pred_T) pred[(((int64_t)b * pred_T + step) * g.N + i) * g.dim + d] = out;
@@ -231,13 +231,13 @@ __global__ void k_case_integrate(lb_geom g, int64_t BN, int mode, const float* _
     const double p1 = pos_seq[(gi * T + (T - 1)) * g.dim + d];
     double nv;
     if (mode == 1) {
-      nv = g.vel_mean[d] + (double)pred[gi * g.dim + d] * g.vel_std[d];
+      nv = lb_r(g.vel_mean[d] + lb_r((double)pred[gi * g.dim + d] * g.vel_std[d], g.f32), g.f32);
     } else {
       const double p0 = pos_seq[(gi * T + (T - 2)) * g.dim + d];
-      const double a = g.acc_mean[d] + (double)pred[gi * g.dim + d] * g.acc_std[d];
-      nv = lb_disp1(p1, p0, g.box[d], g.half_box[d], g.periodic) + a;
+      const double a = lb_r(g.acc_mean[d] + lb_r((double)pred[gi * g.dim + d] * g.acc_std[d], g.f32), g.f32);
+      nv = lb_r(lb_disp1(p1, p0, g.box[d], g.half_box[d], g.periodic, g.f32) + a, g.f32);
     }
-    out[gi * g.dim + d] = lb_shift1(p1, nv, g.box[d], g.periodic);
+    out[gi * g.dim + d] = lb_shift1(p1, nv, g.box[d], g.periodic, g.f32);
   }
 }
 

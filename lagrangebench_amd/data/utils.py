@@ -7,12 +7,12 @@ import numpy as np
 
 
 def get_dataset_stats(metadata: Dict[str, List[float]], is_isotropic_norm: bool,
-                      noise_std: float) -> Dict[str, Dict[str, np.ndarray]]:
-    """lagrangebench/data/utils.py:9-45 (host-side, a handful of fp64 scalars)."""
-    acc_mean = np.array(metadata["acc_mean"], dtype=np.float64)
-    acc_std = np.array(metadata["acc_std"], dtype=np.float64)
-    vel_mean = np.array(metadata["vel_mean"], dtype=np.float64)
-    vel_std = np.array(metadata["vel_std"], dtype=np.float64)
+                      noise_std: float, dtype=np.float64) -> Dict[str, Dict[str, np.ndarray]]:
+    """lagrangebench/data/utils.py:9-45 (host-side, a handful of scalars in the case's dtype)."""
+    acc_mean = np.array(metadata["acc_mean"], dtype=dtype)
+    acc_std = np.array(metadata["acc_std"], dtype=dtype)
+    vel_mean = np.array(metadata["vel_mean"], dtype=dtype)
+    vel_std = np.array(metadata["vel_std"], dtype=dtype)
     if is_isotropic_norm:
         acc_mean = np.mean(acc_mean) * np.ones_like(acc_mean)
         acc_std = np.sqrt(np.mean(acc_std**2)) * np.ones_like(acc_std)

@@ -72,6 +72,7 @@ class RolloutEngine:
         has_vel_mag: bool = False,
         force: Optional[ForceSpec] = None,
         device: Optional[torch.device] = None,
+        geometry_f32: bool = False,
     ):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -83,6 +84,8 @@ class RolloutEngine:
         d = CaseDesc()
         d.dim, d.n_particles, d.batch, d.isl = dim, n_particles, batch, isl
         d.periodic = int(bool(periodic))
+        d.geometry_f32 = int(bool(geometry_f32))
+        self.geometry_f32 = bool(geometry_f32)
         d.has_bound = int(bool(has_bound))
         d.has_vel_mag = int(bool(has_vel_mag))
         d.force_kind = force.kind if force is not None else _lib.LB_FORCE_NONE

@@ -84,8 +84,8 @@ def train_or_infer(cfg):
     mode = cfg.mode
     if mode not in ("train", "infer", "all"):
         raise ValueError("mode must be one of 'train', 'infer', 'all'")
-    if cfg.dtype != "float64":
-        raise NotImplementedError("only dtype=float64 is built")
+    if cfg.dtype not in ("float64", "float32"):
+        raise NotImplementedError("dtype must be float64 (the reference default) or float32")
     data_train, data_valid, data_test = setup_data(cfg)
     metadata = data_train.metadata
     bounds = np.array(metadata["bounds"])

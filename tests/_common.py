@@ -15,14 +15,14 @@ def oracle_case(ds, isl=None, dtype=np.float64):
         noise_std=ds.noise_std, external_force_fn=ds.external_force_fn, dtype=dtype)
 
 
-def hip_case(ds, isl=None):
+def hip_case(ds, isl=None, dtype="float64"):
     from lagrangebench_amd.case_setup import case_builder
     isl = isl or ds.input_seq_length
     return case_builder(
         ds.box, ds.metadata, isl,
         cfg_neighbors={"multiplier": ds.multiplier},
         cfg_model={"isotropic_norm": ds.isotropic_norm, "magnitude_features": getattr(ds, "magnitude_features", False)},
-        noise_std=ds.noise_std, external_force_fn=ds.force)
+        noise_std=ds.noise_std, external_force_fn=ds.force, dtype=dtype)
 
 
 def feature_widths(ds, isl=None):

@@ -73,6 +73,69 @@ def test_case_test_goldens_on_engine(golden_dir):
     assert np.isclose(_np(new_pos), pos[:, 3]).all()
 
 
+def test_case_test_goldens_on_engine_float32(golden_dir):
+    """The reference's tests/case_test.py runs in float32 (x64 is not enabled there): the same hand-computed goldens
+    through case_builder(dtype="float32") - every returned value must be a float32 value."""
+    _need_gpu()
+    from lagrangebench_amd.case_setup import case_builder
+    with open(os.path.join(golden_dir, "case_test_vectors.json")) as f:
+        vec = json.load(f)
+    md = vec["metadata"]
+    bounds = np.array(md["bounds"])
+    case = case_builder(bounds[:, 1] - bounds[:, 0], md, vec["input_seq_length"], vec["cfg_neighbors"], vec["cfg_model"],
+                        noise_std=vec["noise_std"], dtype="float32")
+    pos, pt, exp = np.array(vec["position_data"]), np.array(vec["particle_types"]), vec["expected"]
+    key, features, target, nbrs = case.allocate(None, (pos, pt))
+    idx = _np(nbrs.idx)
+    assert idx.shape == (2, 6) and (O.canonical_edges(idx, 3) == O.canonical_edges(np.array(exp["neighbors_idx"]), 3)).all()
+    assert np.isclose(_np(target["vel"]), np.array(exp["target_vel"])).all()
+    assert np.isclose(_np(target["acc"]), np.array(exp["target_acc"]), atol=1e-6).all()
+    vh = _np(features["vel_hist"])
+    assert np.isclose(vh, np.array(exp["vel_hist"]), atol=1e-6).all()
+    for k in ("vel_hist", "rel_disp", "rel_dist"):
+        v = _np(features[k])
+        assert np.array_equal(v, v.astype(np.float32).astype(v.dtype)), k   # float32 values in fp64 containers
+    new_pos = case.integrate({"acc": torch.tensor(exp["integrate_acc"], dtype=torch.float32)}, pos[:, :3])
+    assert np.isclose(_np(new_pos), pos[:, 3]).all()
+    assert np.array_equal(_np(new_pos), _np(new_pos).astype(np.float32).astype(np.float64))
+
+
+@pytest.mark.parametrize("name,scale", [("small2d", 1.0), ("small3d", 1.0), ("tgv2d", 0.6), ("ldc3d", 0.4), ("tgv3d", 0.6)])
+def test_float32_geometry_bitexact_vs_float32_oracle(name, scale):
+    """dtype=float32 (case.py:169): edge list, features and the integrator against the oracle run in float32 -
+    bit for bit (the engine rounds every fp64 result to float: for + - * / sqrt that IS the float operation)."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    ds = make_case(name, n_trajs=1, extra_seq_length=3, scale=scale)
+    if ds.external_force_fn is not None:
+        pytest.skip("float32 geometry with an external force is not built")
+    ocase, hcase = oracle_case(ds, dtype=np.float32), hip_case(ds, dtype="float32")
+    isl = ds.input_seq_length
+    pos, pt = ds[0]
+    N = len(pt)
+    feats, nbrs = hcase.allocate_eval((pos[:, :isl], pt))
+    of, on = ocase.allocate_eval((pos[:, :isl].astype(np.float32), pt))
+    idx = _np(nbrs.idx)
+    want = O.canonical_edges(on.idx, N)
+    ne = want.shape[1]
+    assert int(_np(nbrs.n_edges)) == ne and (idx[:, :ne] == want).all()
+    assert of["vel_hist"].dtype == np.float32
+    assert np.array_equal(_np(feats["vel_hist"]).astype(np.float32), of["vel_hist"])
+    real = on.idx[0] < N
+    order = np.lexsort((on.idx[1][real], on.idx[0][real]))
+    assert np.array_equal(_np(feats["rel_disp"])[:ne].astype(np.float32), of["rel_disp"][real][order])
+    assert np.array_equal(_np(feats["rel_dist"])[:ne].astype(np.float32), of["rel_dist"][real][order])
+    for k in ("bound", "vel_mag"):
+        if k in of:
+            assert np.array_equal(_np(feats[k]).astype(np.float32), of[k]), k
+    # integrator (case.py:230-259) on random normalised accelerations
+    acc = np.random.default_rng(2).standard_normal((N, len(ds.box))).astype(np.float32)
+    want_pos = ocase.integrate({"acc": acc}, pos[:, :isl].astype(np.float32))
+    got_pos = _np(hcase.integrate({"acc": torch.as_tensor(acc)}, pos[:, :isl]))
+    assert want_pos.dtype == np.float32 and np.array_equal(got_pos.astype(np.float32), want_pos)
+    assert np.array_equal(got_pos, got_pos.astype(np.float32).astype(np.float64))
+
+
 # ------------------------------------------------------------------ neighbor list + features
 CASES = [("small2d", 1.0), ("small3d", 1.0), ("tgv2d", 0.6), ("rpf2d", 0.5), ("tgv3d", 0.6),
          ("ldc3d", 0.5), ("dam2d", 0.3)]
