@@ -196,13 +196,9 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
     g.nstencil = d->dim == 2 ? 9 : 27;
   } else {
     g.nstencil = 1;
-    // all-pairs candidates: one "cell" per trajectory, staged whole in LDS
-    if (d->n_particles > LB_MAX_STENCIL_CAND) {
-      delete e;
-      return lb_fail(LB_ERR_UNSUPPORTED,
-                     "box < 3*r_cutoff (no cell list) supports at most %d particles",
-                     LB_MAX_STENCIL_CAND);
-    }
+    // all-pairs candidates: one "cell" per trajectory - staged whole in LDS up to LB_MAX_STENCIL_CAND particles, beyond
+    // that the wave-per-receiver kernel walks it from global memory (dense fall-back)
+    if (d->n_particles > LB_MAX_STENCIL_CAND) e->nl_dense = true;
     for (int k = 0; k < d->dim; ++k) g.cell_size[k] = 1e300;  // every particle -> cell 0
   }
   const int K = d->isl - 1;
@@ -343,10 +339,10 @@ static int lb_check_density(lb_engine* e) {
   }
   if (e->ctrl_host->density_error)
     return lb_fail(LB_ERR_DENSITY,
-                   "neighbor search: %s (limits: %d stencil candidates, %d neighbors per particle)",
+                   "neighbor search: %s (limits of the dense fall-back: %d neighbors per particle)",
                    e->ctrl_host->density_error == 1 ? "3^dim-cell stencil too populated"
                                                     : "a particle has too many neighbors",
-                   LB_MAX_STENCIL_CAND, LB_MAX_ROW);
+                   LB_MAX_ROW_DENSE);
   return LB_OK;
 }
 
@@ -387,7 +383,8 @@ extern "C" int lb_nl_allocate(lb_engine* e, int32_t* cell_capacity_out, int32_t*
   // per-node slots of the single-sweep update path: twice the current max degree
   {
     int32_t want = std::max(16, ((2 * h->max_deg + 7) / 8) * 8);
-    want = std::min<int32_t>(want, LB_MAX_ROW);
+    want = std::min<int32_t>(want, e->nl_dense ? LB_MAX_ROW_DENSE : LB_MAX_ROW);
+    if (e->nl_dense) e->row_cap = std::max(e->row_cap, std::min<int32_t>((want + 63) / 64 * 64, LB_MAX_ROW_DENSE));
     if (want > e->maxd || !e->tmp_send) {
       LB_HIP(hipStreamSynchronize(e->stream));
       for (void* b : {(void*)e->tmp_send, (void*)e->tmp_feat, (void*)e->tmp_feat64})

@@ -11,7 +11,8 @@
 #include "../../include/lbhip.h"
 
 #define LB_MAX_STENCIL_CAND 2048  // candidates staged in LDS per cell block (27*cap must fit)
-#define LB_MAX_ROW 256            // max degree of one receiver row
+#define LB_MAX_ROW 256            // row buffer of the default neighbor kernels (neighbors per particle)
+#define LB_MAX_ROW_DENSE 4096     // ... of the dense fall-back (wave-per-receiver kernel, dynamic LDS)
 #define LB_TILE 32                // rows (edges / nodes) per wave tile: the N of the 32x32x2 MFMA
 #define LB_D 128                  // latent width built so far
 
@@ -112,6 +113,8 @@ struct lb_engine {
   int32_t* row_ptr;    // [BN+1]
   int32_t* scan_part;  // partial sums of the two-level scans
   double* cpos;        // [dim][BN] newest-frame positions in cell-sorted order
+  bool nl_dense = false;  // sticky: the density exceeded the staged kernel's limits once -> wave-per-receiver kernel
+  int32_t row_cap = 0;    // its LDS row buffer (entries per wave), sized from the largest degree seen
   int32_t maxd;        // per-node slot count of the single-sweep update path (0 = not sized)
   int32_t* tmp_send;   // [BN][maxd] sorted sender rows before compaction
   float* tmp_feat;     // [BN][maxd][4]

@@ -257,6 +257,7 @@ struct lb_nl_args {
   double* efeat64;          // optional fp64 copy, same indexing with 4 doubles per edge
   int64_t e_alloc;
   int32_t maxd;
+  int32_t row_cap;          // k_nlw: LDS row-buffer entries per wave (>= LB_MAX_ROW)
 };
 
 template <int MODE, int NL_THREADS, int MAXC, bool F32 = false>
@@ -310,7 +311,14 @@ __global__ void __launch_bounds__(NL_THREADS)
   __syncthreads();
   int M = s_coff[g.nstencil];
   if (M > MAXC) {
-    if (tid == 0) atomicExch(&ctrl->density_error, 1);
+    // too many stencil candidates for the staged kernel.  Update path: ask for a re-allocation (which detects the
+    // density in its counting pass and switches the engine to the dense fall-back); allocation: flag it
+    if (tid == 0) {
+      if (MODE == NL_ROWS)
+        atomicExch(&ctrl->row_overflow, 1);
+      else
+        atomicExch(&ctrl->density_error, 1);
+    }
     M = MAXC;
   }
   // stage the stencil's particles (ids + fp64 positions, contiguous per cell in the sorted arrays)
@@ -364,8 +372,13 @@ __global__ void __launch_bounds__(NL_THREADS)
       // serialises at its L2 channel - it was 150 of the 165 us of this kernel on 64 k receivers)
     }
     if (MODE == NL_COUNT) continue;
-    if (count > LB_MAX_ROW) {
-      if (lane == 0) atomicExch(&ctrl->density_error, 2);
+    if (count > LB_MAX_ROW) {  // (update path: re-allocate - the allocation sizes the dense fall-back's row buffer)
+      if (lane == 0) {
+        if (MODE == NL_ROWS)
+          atomicExch(&ctrl->row_overflow, 1);
+        else
+          atomicExch(&ctrl->density_error, 2);
+      }
       count = LB_MAX_ROW;
     }
     if (MODE == NL_ROWS && count > a.maxd) {
@@ -433,10 +446,15 @@ __global__ void __launch_bounds__(NL_THREADS)
 template <int MODE, bool F32 = false>
 __global__ void __launch_bounds__(64 * NLW_WAVES)
     k_nlw(lb_geom g, int64_t BN, lb_ctrl* __restrict__ ctrl, lb_nl_args a) {
-  __shared__ int s_row[NLW_WAVES][LB_MAX_ROW];
+  // row buffers in DYNAMIC LDS: per wave row_cap candidate slots + row_cap sender ids (a.row_cap >= LB_MAX_ROW: the
+  // dense fall-back sizes it from the largest degree seen - the reference re-allocates for any occupancy)
+  extern __shared__ int s_dyn[];
+  const int row_cap = a.row_cap;
   __shared__ int s_cstart[NLW_WAVES][28], s_coff[NLW_WAVES][29];
   if (ctrl->overflow_step >= 0) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int* const s_row = s_dyn + (size_t)wave * 2 * row_cap;
+  int* const s_id = s_row + row_cap;
   const int64_t r = (int64_t)blockIdx.x * NLW_WAVES + wave;  // receiver slot in cell-sorted order
   if (r >= BN) return;
   const int gr = a.cell_part[r];
@@ -504,7 +522,7 @@ __global__ void __launch_bounds__(64 * NLW_WAVES)
     const unsigned long long mask = __ballot(ok);
     if (MODE != NL_COUNT && ok) {
       const int pos = count + __popcll(mask & lt_mask);
-      if (pos < LB_MAX_ROW) s_row[wave][pos] = src;
+      if (pos < row_cap) s_row[pos] = src;
     }
     count += __popcll(mask);
   }
@@ -513,9 +531,14 @@ __global__ void __launch_bounds__(64 * NLW_WAVES)
     // (ctrl->max_deg is reduced by the degree scan that follows, see k_nl)
   }
   if (MODE == NL_COUNT) return;
-  if (count > LB_MAX_ROW) {
-    if (lane == 0) atomicExch(&ctrl->density_error, 2);
-    count = LB_MAX_ROW;
+  if (count > row_cap) {
+    if (lane == 0) {
+      if (MODE == NL_ROWS && row_cap < LB_MAX_ROW_DENSE)
+        atomicExch(&ctrl->row_overflow, 1);  // re-allocate with a longer row buffer
+      else
+        atomicExch(&ctrl->density_error, 2);
+    }
+    count = row_cap;
   }
   if (MODE == NL_ROWS && count > a.maxd) {
     if (lane == 0) atomicExch(&ctrl->row_overflow, 1);  // per-node slots too small: re-allocate
@@ -523,17 +546,21 @@ __global__ void __launch_bounds__(64 * NLW_WAVES)
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   const int64_t base = (MODE == NL_ROWS) ? (int64_t)gr * a.maxd : (int64_t)a.row_ptr[gr];
+  if (count > 64) {  // long rows: the sender ids go to LDS once, the rank loop reads them as broadcasts
+    for (int t = lane; t < count; t += 64) s_id[t] = a.cell_part[s_row[t]];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
   for (int t0 = 0; t0 < count; t0 += 64) {
     const int t = t0 + lane;
     const bool act = t < count;
-    const int src = act ? s_row[wave][t] : 0;
+    const int src = act ? s_row[t] : 0;
     const int my = act ? a.cell_part[src] : 0x7fffffff;
     // rank of this sender id inside the row (ids are unique): lane broadcasts for rows <= 64
     int rank = 0;
     if (count <= 64) {
       for (int u = 0; u < count; ++u) rank += (__builtin_amdgcn_readlane(my, u) < my) ? 1 : 0;
     } else {
-      for (int u = 0; u < count; ++u) rank += (a.cell_part[s_row[wave][u]] < my) ? 1 : 0;
+      for (int u = 0; u < count; ++u) rank += (s_id[u] < my) ? 1 : 0;
     }
     if (!act) continue;
     const int64_t slot = base + rank;
@@ -692,15 +719,24 @@ static void lb_launch_nl(lb_engine* e, int small, const lb_nl_args& a) {
   // measured (MI355X, B = 8): 3^3-cell stencils favour the wave-per-receiver kernel (TGV3D 0.28 ->
   // 0.18 ms per step), 3^2-cell stencils the staged per-cell kernel (DAM2D 0.11 vs 0.15 ms)
   static const char* force = getenv("LB_NL_KERNEL");  // "cell" | "wave": ablation override
-  const bool per_wave = force ? force[0] == 'w' : e->g.nstencil == 27;
-  if (e->g.f32) {  // dtype=float32 geometry: the wave-per-receiver kernel with every result rounded to float
-    const int nb = (int)((e->BN + NLW_WAVES - 1) / NLW_WAVES);
-    hipLaunchKernelGGL((k_nlw<MODE, true>), dim3(nb), dim3(64 * NLW_WAVES), 0, e->stream, e->g, e->BN, e->ctrl, a);
-    return;
-  }
+  // dense fall-back (e->nl_dense, sticky): the staged per-cell kernel is bounded by LB_MAX_STENCIL_CAND candidates
+  // and LB_MAX_ROW neighbors; beyond that the wave-per-receiver kernel with a row buffer sized from the largest
+  // degree runs (the reference re-allocates for ANY occupancy, rollout.py:134-151)
+  const bool per_wave = e->nl_dense || e->g.f32 || (force ? force[0] == 'w' : e->g.nstencil == 27);
   if (per_wave) {
     const int nb = (int)((e->BN + NLW_WAVES - 1) / NLW_WAVES);
-    hipLaunchKernelGGL((k_nlw<MODE>), dim3(nb), dim3(64 * NLW_WAVES), 0, e->stream, e->g, e->BN, e->ctrl, a);
+    lb_nl_args aw = a;
+    aw.row_cap = e->row_cap > LB_MAX_ROW ? e->row_cap : LB_MAX_ROW;
+    const size_t lds = sizeof(int) * 2 * NLW_WAVES * (size_t)aw.row_cap;
+    if (e->g.f32) {  // dtype=float32 geometry: every result rounded to float
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_nlw<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_nlw<MODE, true>), dim3(nb), dim3(64 * NLW_WAVES), lds, e->stream, e->g, e->BN, e->ctrl, aw);
+    } else {
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_nlw<MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_nlw<MODE>), dim3(nb), dim3(64 * NLW_WAVES), lds, e->stream, e->g, e->BN, e->ctrl, aw);
+    }
     return;
   }
   const int ncell_tot = e->g.B * e->g.ncells;
@@ -810,6 +846,19 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
     std::vector<int32_t> occ(g.B);
     LB_HIP(hipMemcpyAsync(occ.data(), e->nedges_b, sizeof(int32_t) * g.B, hipMemcpyDeviceToHost, s));
     LB_HIP(hipStreamSynchronize(s));
+    // dense fall-back: a stencil with more candidates than the staged kernel holds, or a particle with more
+    // neighbors than its row buffer, switches to the wave-per-receiver kernel with a row buffer of the measured size
+    if (e->ctrl_host->density_error == 1 && !e->nl_dense) {
+      e->nl_dense = true;
+      e->ctrl_host->density_error = 0;
+      LB_HIP(hipMemcpyAsync(&e->ctrl->density_error, &e->ctrl_host->density_error, sizeof(int32_t), hipMemcpyHostToDevice, s));
+      return lbk_nl_build(e, want_efeat64);  // count again with the kernel that has no candidate limit
+    }
+    if (e->ctrl_host->max_deg > LB_MAX_ROW) e->nl_dense = true;
+    if (e->nl_dense) {
+      e->row_cap = std::max(LB_MAX_ROW, (e->ctrl_host->max_deg + 63) / 64 * 64);
+      if (e->row_cap > LB_MAX_ROW_DENSE) e->row_cap = LB_MAX_ROW_DENSE;  // (> that many neighbors: LB_ERR_DENSITY)
+    }
     // room for this list AND for the capacity lb_nl_allocate is about to freeze
     // (B * int(max_b occupancy * multiplier)): growing later would drop the list just built
     int32_t occ_max = 0;
