@@ -285,6 +285,17 @@ int lb_sinkhorn(lb_engine* eng, const double* pred_dev, int32_t pred_T, const do
                 int32_t target_T, int32_t stride, double threshold, double* out_dev, int32_t n_out,
                 int32_t* iters_out_host);
 
+/* MetricsComputer(ot_backend="pot") - evaluate/metrics.py:178-196: POT's sinkhorn2(a, b, M, reg, numItermax,
+ * stopThr) (the reference passes reg=0.1, numItermax=500, stopThr=1e-05) on the xy / xx / yy float32 cost
+ * matrices with uniform weights, out[b][k] = clip(xy - 0.5 * (xx + yy), 0) evaluated in float32 like the reference
+ * (each sinkhorn2 value is rounded to float32 first).  POT is an optional dependency of the reference; its
+ * Sinkhorn-Knopp iteration is restated in oracle/sinkhorn_pot_oracle.py.  Same frame selection / shapes as
+ * lb_sinkhorn.  info_out_host (optional, HOST, B*n_out*6 int32): iterations of the three solves, then how each
+ * loop ended (0 numItermax reached, 1 err < stopThr, 2 numerical stop: previous scalings kept). */
+int lb_sinkhorn_pot(lb_engine* eng, const double* pred_dev, int32_t pred_T, const double* target_dev,
+                    int32_t target_T, int32_t stride, double reg, int32_t num_iter_max, double stop_thr,
+                    double* out_dev, int32_t n_out, int32_t* info_out_host);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------ */
 
 /* Enable per-kernel-class HIP-event timing on the engine stream.  Classes: see lb_timer_name. */

@@ -79,6 +79,8 @@ _SIGS = {
     "lb_rollout": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_int32)]),
     "lb_ekin": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_double, C.c_double, _P, C.c_int32]),
     "lb_sinkhorn": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_double, _P, C.c_int32, _P]),
+    "lb_sinkhorn_pot": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_double, _P,
+                                  C.c_int32, _P]),
     "lb_metrics": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
     "lb_timers_enable": (C.c_int, [_P, C.c_int32]),
     "lb_timers_reset": (C.c_int, [_P]),

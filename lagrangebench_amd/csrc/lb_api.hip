@@ -219,6 +219,7 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   A(lb_alloc(&e->cell_start, nc + 1));
   A(lb_alloc(&e->cell_part, (size_t)BN));
   A(lb_alloc(&e->deg, (size_t)BN));
+  A(lb_alloc(&e->nl_wg_sum, (size_t)BN / 8 + 2));
   A(lb_alloc(&e->row_ptr, (size_t)BN + 1));
   A(lb_alloc(&e->scan_part, (size_t)((BN > (int64_t)nc ? BN : (int64_t)nc) / 2048 + 2)));
   A(lb_alloc(&e->cpos, (size_t)d->dim * BN));
@@ -246,10 +247,12 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   memset(&c0, 0, sizeof(c0));
   c0.overflow_step = -1;
   c0.math_step = LB_MATH_NO_STEP;
+  c0.nl_epoch = 1;
   c0.ln_inv_d = 1.0f / LB_D;
   if (hipMemcpy(e->ctrl, &c0, sizeof(c0), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemset(e->blocks_done, 0, sizeof(int32_t)) != hipSuccess ||
       hipMemset(e->ptype, 0, sizeof(int32_t) * BN) != hipSuccess ||
+      hipMemset(e->nl_wg_sum, 0, sizeof(uint32_t) * (BN / 8 + 2)) != hipSuccess ||
       hipMemset(e->row_ptr, 0, sizeof(int32_t) * (BN + 1)) != hipSuccess) {
     lb_engine_destroy(e);
     return lb_fail(LB_ERR_HIP, "engine init copies failed");
@@ -263,7 +266,7 @@ extern "C" void lb_engine_destroy(lb_engine* e) {
   lb_timers_collect(e);
   for (auto ev : e->epool) (void)hipEventDestroy(ev);
   void* bufs[] = {e->win, e->ptype, e->force, e->ctrl, e->cell_of, e->cell_count, e->cell_start,
-                  e->cell_part, e->deg, e->row_ptr, e->scan_part, e->cpos, e->tmp_send, e->tmp_feat, e->tmp_feat64,
+                  e->cell_part, e->deg, e->nl_wg_sum, e->row_ptr, e->scan_part, e->cpos, e->tmp_send, e->tmp_feat, e->tmp_feat64,
                   e->senders, e->receivers, e->efeat, e->efeat64,
                   e->overflow, e->nedges_b, e->xnode, e->nlat, e->agg, e->psr, e->elat, e->msg,
                   e->part, e->acc, e->blocks_done, e->persist_bar};
@@ -331,6 +334,12 @@ extern "C" int lb_read_window(lb_engine* e, double* out) {
 
 // --------------------------------------------------------------------------- neighbor list
 static int lb_check_density(lb_engine* e) {
+  if (e->ctrl_host->persist_error == 2) {
+    e->nl_one_off = true;  // k_nl_small gave up waiting for a predecessor workgroup: back to the multi-launch build
+    (void)hipMemsetAsync(&e->ctrl->persist_error, 0, sizeof(int32_t), e->stream);
+    return lb_fail(LB_ERR_STATE, "single-launch neighbor build: a predecessor workgroup's edge count never arrived; "
+                                 "results of this call are invalid, the engine now uses the multi-launch build");
+  }
   if (e->ctrl_host->persist_error) {
     e->persist_off = true;  // stay on the multi-launch path from now on
     (void)hipMemsetAsync(&e->ctrl->persist_error, 0, sizeof(int32_t), e->stream);
@@ -1125,6 +1134,19 @@ extern "C" int lb_sinkhorn(lb_engine* e, const double* pred_dev, int32_t pred_T,
   const int expect = (T + stride - 1) / stride;  // len(x[0::stride])
   if (n_out != expect) return lb_fail(LB_ERR_ARG, "n_out must be ceil(T/stride) = %d", expect);
   return lbk_sinkhorn(e, pred_dev, pred_T, target_dev, target_T, stride, n_out, threshold, out_dev, iters_out_host);
+}
+
+extern "C" int lb_sinkhorn_pot(lb_engine* e, const double* pred_dev, int32_t pred_T, const double* target_dev,
+                               int32_t target_T, int32_t stride, double reg, int32_t num_iter_max, double stop_thr,
+                               double* out_dev, int32_t n_out, int32_t* info_out_host) {
+  if (!e || !pred_dev || !target_dev || !out_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  if (stride < 1 || pred_T < 1 || target_T < 1) return lb_fail(LB_ERR_ARG, "need stride >= 1 and T >= 1");
+  if (!(reg > 0) || num_iter_max < 1 || !(stop_thr >= 0)) return lb_fail(LB_ERR_ARG, "need reg > 0, numItermax >= 1, stopThr >= 0");
+  const int T = pred_T < target_T ? pred_T : target_T;
+  const int expect = (T + stride - 1) / stride;  // len(x[0::stride])
+  if (n_out != expect) return lb_fail(LB_ERR_ARG, "n_out must be ceil(T/stride) = %d", expect);
+  return lbk_sinkhorn_pot(e, pred_dev, pred_T, target_dev, target_T, stride, n_out, reg, num_iter_max, stop_thr, out_dev,
+                          info_out_host);
 }
 
 extern "C" int lb_metrics(lb_engine* e, const double* pred_dev, int32_t pred_T,

@@ -36,6 +36,7 @@ struct lb_ctrl {
   float ln_inv_d;          // LayerNorm over a latent narrower than the 128-wide tiles (zero-padded weights):
   float ln_pad;            // mean = sum / d, var = (sum_128 (x-mean)^2 - pad * mean^2) / d, pad = 128 - d
   int32_t persist_error;   // lb_persist.hip: a grid-barrier spin timed out (the launch gave up; results are invalid)
+  int32_t nl_epoch;        // k_nl_small: build counter that tags the per-workgroup edge counts (never 0 mod 2^16)
   int32_t math_step;       // first rollout step at which a range-guard flag was raised (0x7fffffff = none): lb_rollout
                            // resumes THERE in exact fp32 instead of repeating the rollout
 };
@@ -110,6 +111,8 @@ struct lb_engine {
   int32_t* cell_fill;  // [B*ncells]
   int32_t* cell_part;  // [BN] particle ids grouped by cell
   int32_t* deg;        // [BN]
+  bool nl_one_off = false;        // k_nl_small timed out once: multi-launch build from now on
+  uint32_t* nl_wg_sum = nullptr;  // [BN / 8 + 1] k_nl_small: epoch-tagged edge counts of the workgroups
   int32_t* row_ptr;    // [BN+1]
   int32_t* scan_part;  // partial sums of the two-level scans
   double* cpos;        // [dim][BN] newest-frame positions in cell-sorted order
@@ -331,6 +334,8 @@ int lbk_metrics(lb_engine* e, const double* pred, int pred_T, const double* targ
 // lb_sinkhorn.hip
 int lbk_sinkhorn(lb_engine* e, const double* pred, int pred_T, const double* target, int target_T, int stride,
                  int n_out, double threshold, double* out_dev, int32_t* iters_host);
+int lbk_sinkhorn_pot(lb_engine* e, const double* pred, int pred_T, const double* target, int target_T, int stride,
+                     int n_out, double reg, int max_it, double thr, double* out_dev, int32_t* info_host);
 
 int lbk_node_features_raw(lb_engine* e, float* xnode, int kpad);
 

@@ -709,6 +709,219 @@ __global__ void __launch_bounds__(LB_SMALL_T)
                      &s_any);
 }
 
+// ---------------------------------------------------------------- one trajectory, <= 4096 particles: ONE launch
+// Round 3.  On a 2.5 k-particle trajectory the update path above is four dependent launches (cells -> search ->
+// degree scan -> compaction: 44 us of a 310 us step, every one a chain of 3 - 5 memory round trips).  Here the
+// whole build is one launch with one dependency level:
+//   * every workgroup stages ALL N newest-frame positions + cell coordinates in LDS (N * (8 dim + 4) bytes);
+//   * one wave per receiver sweeps the N candidates in id order, 64 per step: integer test "candidate's cell is in the
+//     receiver's 3^dim stencil (wrapping, like the rolled cell buffer)" - the fp64 predicate runs only in the steps
+//     where some lane passed it.  Same candidate set, same predicate, same operand order as k_nl; the hits come out
+//     sorted by sender id, so the rank pass is gone;
+//   * rows go straight into the CSR arrays: a workgroup publishes the edge count of its NLS_WAVES receivers in one
+//     word (build epoch << 16 | count, agent-scope release store) and adds up the words of the workgroups before it
+//     (workgroups are dispatched in index order, so a predecessor is running or done; bounded spin);
+//   * the last workgroup also histograms the cells (max_cell_occ for the did_buffer_overflow flag) and does
+//     k_row_finish's job.
+#define NLS_WAVES 8
+#define NLS_THREADS (64 * NLS_WAVES)
+struct lb_nls_args {
+  const double* win;
+  int32_t *senders, *receivers;
+  float* efeat;
+  double* efeat64;
+  int32_t *deg, *row_ptr, *overflow, *nedges_b;
+  uint32_t* wg_sum;  // [ceil(N / NLS_WAVES)]
+  int64_t e_alloc;
+  int32_t e_cap, cell_capacity, npad;
+  int32_t* host_flag;
+};
+
+template <bool F32>
+__global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __restrict__ ctrl, lb_nls_args a) {
+  extern __shared__ double s_dynd[];
+  if (ctrl->overflow_step >= 0) return;
+  const int N = g.N, npad = a.npad;
+  double* const s_p = s_dynd;                                      // [dim][npad]
+  int* const s_cell = reinterpret_cast<int*>(s_p + g.dim * npad);  // [npad] x | y << 11 | z << 22
+  int* const s_row = s_cell + npad;                                // [NLS_WAVES][LB_MAX_ROW]
+  int* const s_cnt = s_row + NLS_WAVES * LB_MAX_ROW;               // [NLS_WAVES], [8] base, [9] max occupancy
+  int* const s_hist = s_cnt + 16;                                  // last workgroup: [ncells]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int step = ctrl->step;
+  const uint32_t epoch = (uint32_t)ctrl->nl_epoch & 0xffffu;
+  const bool last = blockIdx.x == gridDim.x - 1;
+  if (tid < 16) s_cnt[tid] = 0;
+  if (last && g.use_cell_list)
+    for (int c = tid; c < g.ncells; c += NLS_THREADS) s_hist[c] = 0;
+  // ---- stage positions + cell coordinates (k_cells_small's arithmetic: int(position / cell_size), clamped)
+  double inv_cs[3];
+  for (int d = 0; d < 3; ++d) inv_cs[d] = d < g.dim ? 1.0 / g.cell_size[d] : 0.0;
+  for (int i = tid; i < N; i += NLS_THREADS) {
+    int packed = 0;
+    for (int d = 0; d < g.dim; ++d) {
+      const double p = lb_pos(a.win, g, N, step, g.isl - 1, d, i);
+      s_p[d * npad + i] = p;
+      // the quotient decides through its integer part only: the reciprocal product is exact enough unless it lands
+      // within 1e-6 (relative) of an integer (or, in f32 mode, of a float rounding up to one) - then divide
+      double q = p * inv_cs[d];
+      const double fr = q - floor(q), tol = 1e-6 * (fabs(q) + 1.0);
+      if (fr < tol || fr > 1.0 - tol) q = lb_r(p / g.cell_size[d], F32);
+      int c = __double2int_rz(q);
+      c = c < 0 ? 0 : (c >= g.ncell[d] ? g.ncell[d] - 1 : c);
+      packed |= c << (11 * d);
+    }
+    s_cell[i] = packed;
+  }
+  __syncthreads();
+  if (last && g.use_cell_list) {
+    for (int i = tid; i < N; i += NLS_THREADS) {
+      const int pc = s_cell[i];
+      const int h = (pc & 0x7ff) + g.ncell[0] * (((pc >> 11) & 0x7ff) + g.ncell[1] * (pc >> 22));
+      atomicAdd(&s_hist[h], 1);
+    }
+    __syncthreads();
+    int mx = 0;
+    for (int c = tid; c < g.ncells; c += NLS_THREADS) mx = max(mx, s_hist[c]);
+    if (mx > 0) atomicMax(&s_cnt[9], mx);
+  }
+  // ---- sweep
+  const int r = blockIdx.x * NLS_WAVES + wave;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int count = 0;
+  double pr[3] = {0, 0, 0};
+  int* const row = s_row + wave * LB_MAX_ROW;
+  if (r < N) {
+    for (int d = 0; d < g.dim; ++d) pr[d] = s_p[d * npad + r];
+    const int pc = s_cell[r];
+    int acc0[3], acc1[3], acc2[3];  // the three accepted cell coordinates per dimension (wrapping stencil)
+    for (int d = 0; d < 3; ++d) {
+      const int n = d < g.dim ? g.ncell[d] : 1;
+      const int c = (pc >> (11 * d)) & 0x7ff;
+      acc0[d] = c;
+      acc1[d] = c == 0 ? n - 1 : c - 1;
+      acc2[d] = c == n - 1 ? 0 : c + 1;
+    }
+    for (int c0 = 0; c0 < N; c0 += 64) {
+      const int j = c0 + lane;
+      bool adj = false;
+      if (j < N) {
+        const int qc = s_cell[j];
+        const int cx = qc & 0x7ff, cy = (qc >> 11) & 0x7ff, cz = qc >> 22;
+        adj = (cx == acc0[0] || cx == acc1[0] || cx == acc2[0]) && (cy == acc0[1] || cy == acc1[1] || cy == acc2[1]) &&
+              (cz == acc0[2] || cz == acc1[2] || cz == acc2[2]);
+      }
+      if (!__any(adj)) continue;
+      bool ok = false;
+      if (adj) {
+        // metric_sq(position[sender], position[receiver]) as in k_nl
+        double dd = lb_disp1(s_p[j], pr[0], g.box[0], g.half_box[0], g.periodic, F32);
+        double d2 = lb_r(dd * dd, F32);
+        for (int d = 1; d < g.dim; ++d) {
+          dd = lb_disp1(s_p[d * npad + j], pr[d], g.box[d], g.half_box[d], g.periodic, F32);
+          d2 = lb_r(d2 + lb_r(dd * dd, F32), F32);
+        }
+        ok = d2 < g.rc2;
+      }
+      const unsigned long long mask = __ballot(ok);
+      if (ok) {
+        const int pos = count + __popcll(mask & lt_mask);
+        if (pos < LB_MAX_ROW) row[pos] = j;
+      }
+      count += __popcll(mask);
+    }
+    if (lane == 0) {
+      a.deg[r] = count;
+      s_cnt[wave] = count;
+      if (count > LB_MAX_ROW) atomicExch(&ctrl->row_overflow, 1);  // re-allocate (-> the dense fall-back)
+    }
+  }
+  __syncthreads();
+  // ---- this workgroup's count out, the counts of the workgroups before it in
+  if (tid == 0) {
+    int tot = 0;
+    for (int w = 0; w < NLS_WAVES; ++w) tot += s_cnt[w];
+    __hip_atomic_store(&a.wg_sum[blockIdx.x], (epoch << 16) | (uint32_t)tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  {
+    int part = 0;
+    bool timed_out = false;
+    for (int p = tid; p < (int)blockIdx.x; p += NLS_THREADS) {
+      uint32_t v = 0;
+      int spins = 0;
+      do {
+        v = __hip_atomic_load(&a.wg_sum[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 16) == epoch) break;
+        __builtin_amdgcn_s_sleep(1);
+      } while (++spins < (1 << 22));
+      if ((v >> 16) != epoch) timed_out = true;
+      part += (int)(v & 0xffffu);
+    }
+    if (timed_out) atomicExch(&ctrl->persist_error, 2);
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0 && part) atomicAdd(&s_cnt[8], part);
+  }
+  __syncthreads();
+  int base = s_cnt[8];
+  for (int w = 0; w < wave; ++w) base += s_cnt[w];
+  // ---- rows straight into the CSR arrays (ascending sender id by construction)
+  if (r < N) {
+    if (lane == 0) a.row_ptr[r] = base;
+    const int cnt = min(count, LB_MAX_ROW);
+    for (int t0 = 0; t0 < cnt; t0 += 64) {
+      const int t = t0 + lane;
+      if (t >= cnt) break;
+      const int j = row[t];
+      const int64_t slot = (int64_t)base + t;
+      if (slot >= a.e_alloc) break;
+      a.senders[slot] = j;
+      a.receivers[slot] = r;
+      // features.py:115-124: disp(pos[receiver], pos[sender]) / r_c and its norm
+      double rd[3] = {0, 0, 0};
+      double s2 = 0.0;
+      for (int d = 0; d < g.dim; ++d) {
+        rd[d] = lb_r(lb_disp1(pr[d], s_p[d * npad + j], g.box[d], g.half_box[d], g.periodic, F32) / g.rc, F32);
+        s2 = (d == 0) ? lb_r(rd[d] * rd[d], F32) : lb_r(s2 + lb_r(rd[d] * rd[d], F32), F32);
+      }
+      const double dist = s2 > 0.0 ? lb_r(sqrt(s2), F32) : 0.0;
+      f32x4* ef = reinterpret_cast<f32x4*>(a.efeat + slot * 8);
+      ef[0] = (g.dim == 2) ? f32x4{(float)rd[0], (float)rd[1], (float)dist, 0.f}
+                           : f32x4{(float)rd[0], (float)rd[1], (float)rd[2], (float)dist};
+      ef[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.efeat64) {
+        double* e64 = a.efeat64 + slot * 4;
+        e64[0] = rd[0];
+        e64[1] = rd[1];
+        e64[2] = rd[2];
+        e64[3] = dist;
+      }
+    }
+  }
+  // ---- k_row_finish's job, by the workgroup that knows the total
+  if (last && tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    int total = s_cnt[8];
+    for (int w = 0; w < NLS_WAVES; ++w) total += s_cnt[w];
+    a.row_ptr[N] = total;
+    a.nedges_b[0] = total;
+    const int max_occ = s_cnt[9];
+    const int row_ov = __hip_atomic_load(&ctrl->row_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ov = (total > a.e_cap) || (g.use_cell_list && max_occ > a.cell_capacity) || row_ov;
+    a.overflow[0] = ov;
+    ctrl->max_cell_occ = max_occ;
+    ctrl->n_edges_unclamped = total;
+    ctrl->n_edges_total = (int)min((int64_t)total, a.e_alloc);
+    if ((ov || (int64_t)total > a.e_alloc) && ctrl->overflow_step < 0) {
+      ctrl->overflow_step = step;
+      if (a.host_flag) *a.host_flag = step;
+    }
+    __hip_atomic_store(&ctrl->row_overflow, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next build
+    int ne = ctrl->nl_epoch + 1;
+    if ((ne & 0xffff) == 0) ++ne;
+    ctrl->nl_epoch = ne;
+  }
+}
+
 // ----------------------------------------------------------------------------------- host
 // `small` = staged-candidate capacity of the one-wave variant to use (a multiple of 128 up to
 // NL_SMALL_MAXC), or 0 for the 256-thread / 2048-candidate variant.  The LDS footprint of the
@@ -772,6 +985,42 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   static const bool small_ok = !(getenv("LB_SMALL_FUSED") && getenv("LB_SMALL_FUSED")[0] == '0');
   const bool small_rows = small_ok && BN <= LB_SMALL_N;
   const bool small_cells = small_rows && ncell_tot <= LB_SMALL_N;
+  // one trajectory of <= 4096 particles on the update path: the whole build is ONE launch (k_nl_small)
+  static const bool one_ok = !(getenv("LB_NL_ONE") && getenv("LB_NL_ONE")[0] == '0');
+  if (one_ok && small_ok && frozen && g.B == 1 && BN <= LB_SMALL_N && g.ncells <= LB_SMALL_N && !e->nl_dense && !e->nl_one_off &&
+      e->nl_wg_sum && g.ncell[0] < 2048 && g.ncell[1] < 2048 && g.ncell[2] < 1024) {
+    lb_tic(e, LB_T_NEIGH);
+    lb_nls_args a{};
+    a.win = e->win;
+    a.senders = e->senders;
+    a.receivers = e->receivers;
+    a.efeat = e->efeat;
+    a.efeat64 = want_efeat64 ? e->efeat64 : nullptr;
+    a.deg = e->deg;
+    a.row_ptr = e->row_ptr;
+    a.overflow = e->overflow;
+    a.nedges_b = e->nedges_b;
+    a.wg_sum = e->nl_wg_sum;
+    a.e_alloc = e->e_alloc;
+    a.e_cap = e->e_cap;
+    a.cell_capacity = e->cell_capacity;
+    a.npad = (int)((BN + 63) / 64 * 64);
+    a.host_flag = e->host_flag_dev;
+    const size_t lds = (size_t)a.npad * (8 * g.dim + 4) + sizeof(int) * (NLS_WAVES * LB_MAX_ROW + 16 + (g.use_cell_list ? g.ncells : 0));
+    const int nb = (int)((BN + NLS_WAVES - 1) / NLS_WAVES);
+    if (g.f32) {
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_nl_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_nl_small<true>), dim3(nb), dim3(NLS_THREADS), lds, s, g, e->ctrl, a);
+    } else {
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_nl_small<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_nl_small<false>), dim3(nb), dim3(NLS_THREADS), lds, s, g, e->ctrl, a);
+    }
+    lb_toc(e);
+    LB_HIP(hipGetLastError());
+    return LB_OK;
+  }
   lb_tic(e, LB_T_CELLS);
   if (small_cells) {
     hipLaunchKernelGGL(k_cells_small, dim3(1), dim3(LB_SMALL_T), 0, s, g, BN, e->win, e->ctrl, e->cell_of,

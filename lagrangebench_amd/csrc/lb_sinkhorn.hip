@@ -264,3 +264,202 @@ int lbk_sinkhorn(lb_engine* e, const double* pred, int pred_T, const double* tar
   LB_HIP(hipStreamSynchronize(e->stream));
   return LB_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// ot_backend="pot" - metrics.py:178-196: POT's sinkhorn2(a, b, M, reg=0.1, numItermax=500, stopThr=1e-05)
+// for the xy / xx / yy problems, clip(xy - 0.5 (xx + yy), 0) in float32.  POT is an optional import of the
+// reference (not in poetry.lock); the published Sinkhorn-Knopp scaling iteration it runs for method="sinkhorn"
+// is restated in oracle/sinkhorn_pot_oracle.py ("parity unpinned") and followed here step for step:
+//   u = 1/n, v = 1/m, K = exp(-M/reg);  every iteration: v = b / (K^T u), u = 1 / ((K / a) v);
+//   K^T u == 0 or a non-finite u / v -> the previous (u, v) are kept and the loop ends;
+//   every 10th iteration (ii % 10 == 0): err = || v * (K^T u) - b ||_2, stop below stopThr;
+//   value = sum_ij u_i K_ij v_j M_ij.
+// Matrix-free like the OTT path (K_ij is one exp of a recomputed cost).  The stop decisions are taken on the
+// device (lb_pot_ctrl), the host looks at them once per 10 iterations; fp64 arithmetic on the float32 cost.
+struct lb_pot_ctrl {
+  int cur, stopped, bad, iters;
+  double err, loss;
+};
+
+// MODE 0: v_new[q] = num / sum_p u_cur[p] K(p,q)            raises bad on a zero sum / non-finite result
+// MODE 1: u_new[q] = 1 / (inv_a * sum_p v_new[p] K(q,p))    raises bad on a non-finite result
+// MODE 2: out[q]   = v_cur[q] * sum_p u_cur[p] K(p,q)       (column marginal of the plan)
+// MODE 3: out[q]   = v_cur[q] * sum_p u_cur[p] K(p,q) M(p,q) (loss terms; runs after the loop ended)
+template <int MODE>
+__global__ void __launch_bounds__(SK_THREADS) k_pot_sweep(lb_geom g, lb_sk_prob pr, lb_pot_ctrl* __restrict__ ctrl,
+                                                          const double* __restrict__ src2,
+                                                          double* __restrict__ dst2,
+                                                          const double* __restrict__ scale2, int ld, double num,
+                                                          double inv_reg, double* __restrict__ out) {
+  if (MODE != 3 && ctrl->stopped) return;
+  const int cur = ctrl->cur;
+  // sources: MODE 0/2/3 read u_cur, MODE 1 reads v_new;  scale (MODE 2/3): v_cur
+  const double* h = src2 + (int64_t)(MODE == 1 ? (cur ^ 1) : cur) * ld;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q0 = (blockIdx.x * SK_WAVES + wave) * SK_QB;
+  if (q0 >= pr.nq) return;
+  double qp[SK_QB][3], s[SK_QB];
+  for (int k = 0; k < SK_QB; ++k) {
+    const int q = min(q0 + k, pr.nq - 1);
+    for (int d = 0; d < 3; ++d) qp[k][d] = d < g.dim ? pr.Q[(int64_t)q * g.dim + d] : 0.0;
+    s[k] = 0.0;
+  }
+  for (int p = lane; p < pr.np; p += 64) {
+    double pp[3];
+    for (int d = 0; d < 3; ++d) pp[d] = d < g.dim ? pr.P[(int64_t)p * g.dim + d] : 0.0;
+    const double hp = h[p];
+    for (int k = 0; k < SK_QB; ++k) {
+      const double c = pr.swap ? lb_sk_cost(g, qp[k], pp) : lb_sk_cost(g, pp, qp[k]);
+      const double t = hp * exp(-c * inv_reg);
+      s[k] = s[k] + (MODE == 3 ? t * c : t);
+    }
+  }
+  for (int k = 0; k < SK_QB; ++k) {
+    for (int off = 32; off > 0; off >>= 1) s[k] = s[k] + __shfl_xor(s[k], off);
+    if (lane == 0 && q0 + k < pr.nq) {
+      const int q = q0 + k;
+      if (MODE == 0) {
+        const double v = num / s[k];
+        dst2[(int64_t)(cur ^ 1) * ld + q] = v;
+        if (s[k] == 0.0 || !isfinite(v)) ctrl->bad = 1;
+      } else if (MODE == 1) {
+        const double u = 1.0 / (num * s[k]);
+        dst2[(int64_t)(cur ^ 1) * ld + q] = u;
+        if (!isfinite(u)) ctrl->bad = 1;
+      } else {
+        out[q] = scale2[(int64_t)cur * ld + q] * s[k];
+      }
+    }
+  }
+}
+
+// OP 0: end of one iteration - a flagged iteration keeps the previous (u, v) and ends the loop
+// OP 1: err = || marg - target ||_2, stop below thr                     OP 2: loss = sum(marg)
+__global__ void __launch_bounds__(256) k_pot_ctrl(int op, lb_pot_ctrl* __restrict__ ctrl, const double* __restrict__ v,
+                                                  int n, double target, double thr) {
+  __shared__ double sh[256];
+  if (op == 0) {
+    if (threadIdx.x == 0 && !ctrl->stopped) {
+      if (ctrl->bad) ctrl->stopped = 2;
+      else ctrl->cur ^= 1;
+      ctrl->iters += 1;
+    }
+    return;
+  }
+  if (op == 1 && ctrl->stopped) return;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double d = v[i] - target;
+    s = s + (op == 1 ? d * d : v[i]);
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (op == 1) {
+      ctrl->err = sqrt(sh[0]);
+      if (ctrl->err < thr) ctrl->stopped = 1;
+    } else {
+      ctrl->loss = sh[0];
+    }
+  }
+}
+
+namespace {
+struct PotScratch {
+  double *u2 = nullptr, *v2 = nullptr, *marg = nullptr;
+  lb_pot_ctrl *ctrl = nullptr, *host = nullptr;
+  ~PotScratch() {
+    for (void* p : {(void*)u2, (void*)v2, (void*)marg, (void*)ctrl})
+      if (p) (void)hipFree(p);
+    if (host) (void)hipHostFree(host);
+  }
+};
+
+template <int MODE>
+void pot_launch(lb_engine* e, const lb_sk_prob& pr, PotScratch& s, const double* src2, double* dst2,
+                const double* scale2, int ld, double num, double inv_reg) {
+  const int nb = (pr.nq + SK_WAVES * SK_QB - 1) / (SK_WAVES * SK_QB);
+  hipLaunchKernelGGL((k_pot_sweep<MODE>), dim3(nb), dim3(SK_THREADS), 0, e->stream, e->g, pr, s.ctrl, src2, dst2,
+                     scale2, ld, num, inv_reg, s.marg);
+}
+}  // namespace
+
+// sinkhorn2(a, b, M, reg, numItermax, stopThr) for uniform a (n) and b (m); the float32 value the reference's
+// callback returns, plus the iterations run and how the loop ended (0 numItermax, 1 converged, 2 numerical stop).
+static int pot_solve(lb_engine* e, PotScratch& s, int ld, const double* X, int n, const double* Y, int m, double reg,
+                     int max_it, double thr, float* value, int* iters_out, int* how_out) {
+  hipStream_t st = e->stream;
+  std::vector<double> init((size_t)2 * ld, 0.0);
+  LB_HIP(hipMemsetAsync(s.ctrl, 0, sizeof(lb_pot_ctrl), st));
+  for (int i = 0; i < n; ++i) init[i] = 1.0 / n;
+  LB_HIP(hipMemcpyAsync(s.u2, init.data(), sizeof(double) * 2 * ld, hipMemcpyHostToDevice, st));
+  LB_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < ld; ++i) init[i] = i < m ? 1.0 / m : 0.0;
+  LB_HIP(hipMemcpyAsync(s.v2, init.data(), sizeof(double) * 2 * ld, hipMemcpyHostToDevice, st));
+  LB_HIP(hipStreamSynchronize(st));
+  const lb_sk_prob over_i{X, Y, n, m, 0};  // outputs = columns j (y), reduce over rows i (x)
+  const lb_sk_prob over_j{Y, X, m, n, 1};  // outputs = rows i (x), reduce over columns j (y)
+  const double a = 1.0 / n, b = 1.0 / m, inv_reg = 1.0 / reg;
+  for (int ii = 0; ii < max_it; ++ii) {
+    pot_launch<0>(e, over_i, s, s.u2, s.v2, nullptr, ld, b, inv_reg);
+    pot_launch<1>(e, over_j, s, s.v2, s.u2, nullptr, ld, 1.0 / a, inv_reg);
+    hipLaunchKernelGGL(k_pot_ctrl, dim3(1), dim3(256), 0, st, 0, s.ctrl, nullptr, 0, 0.0, 0.0);
+    if (ii % 10 == 0) {
+      pot_launch<2>(e, over_i, s, s.u2, nullptr, s.v2, ld, 0.0, inv_reg);
+      hipLaunchKernelGGL(k_pot_ctrl, dim3(1), dim3(256), 0, st, 1, s.ctrl, s.marg, m, b, thr);
+      LB_HIP(hipMemcpyAsync(s.host, s.ctrl, sizeof(lb_pot_ctrl), hipMemcpyDeviceToHost, st));
+      LB_HIP(hipStreamSynchronize(st));
+      if (s.host->stopped) break;
+    }
+  }
+  pot_launch<3>(e, over_i, s, s.u2, nullptr, s.v2, ld, 0.0, inv_reg);
+  hipLaunchKernelGGL(k_pot_ctrl, dim3(1), dim3(256), 0, st, 2, s.ctrl, s.marg, m, 0.0, 0.0);
+  LB_HIP(hipMemcpyAsync(s.host, s.ctrl, sizeof(lb_pot_ctrl), hipMemcpyDeviceToHost, st));
+  LB_HIP(hipStreamSynchronize(st));
+  LB_HIP(hipGetLastError());
+  *value = (float)s.host->loss;
+  if (iters_out) *iters_out = s.host->iters;
+  if (how_out) *how_out = s.host->stopped;
+  return LB_OK;
+}
+
+int lbk_sinkhorn_pot(lb_engine* e, const double* pred, int pred_T, const double* target, int target_T, int stride,
+                     int n_out, double reg, int max_it, double thr, double* out_dev, int32_t* info_host) {
+  const int N = e->g.N, dim = e->g.dim;
+  PotScratch s;
+  LB_HIP(hipMalloc((void**)&s.u2, sizeof(double) * 2 * N));
+  LB_HIP(hipMalloc((void**)&s.v2, sizeof(double) * 2 * N));
+  LB_HIP(hipMalloc((void**)&s.marg, sizeof(double) * N));
+  LB_HIP(hipMalloc((void**)&s.ctrl, sizeof(lb_pot_ctrl)));
+  LB_HIP(hipHostMalloc((void**)&s.host, sizeof(lb_pot_ctrl)));
+  std::vector<double> res((size_t)e->g.B * n_out);
+  for (int b = 0; b < e->g.B; ++b)
+    for (int k = 0; k < n_out; ++k) {
+      const int t = k * stride;
+      const double* X = pred + ((int64_t)b * pred_T + t) * N * dim;
+      const double* Y = target + ((int64_t)b * target_T + t) * N * dim;
+      float v[3];
+      int it[3], how[3];
+      int rc = pot_solve(e, s, N, X, N, Y, N, reg, max_it, thr, &v[0], &it[0], &how[0]);
+      if (!rc) rc = pot_solve(e, s, N, X, N, X, N, reg, max_it, thr, &v[1], &it[1], &how[1]);
+      if (!rc) rc = pot_solve(e, s, N, Y, N, Y, N, reg, max_it, thr, &v[2], &it[2], &how[2]);
+      if (rc) return rc;
+      // metrics.py:183-186 in float32: clip(ab - 0.5 * (a + b), 0)
+      const float d = v[0] - 0.5f * (v[1] + v[2]);
+      res[(size_t)b * n_out + k] = (double)(d > 0.0f ? d : (d == d ? 0.0f : d));
+      if (info_host) {
+        int32_t* o = info_host + ((size_t)b * n_out + k) * 6;
+        for (int j = 0; j < 3; ++j) {
+          o[j] = it[j];
+          o[3 + j] = how[j];
+        }
+      }
+    }
+  LB_HIP(hipMemcpyAsync(out_dev, res.data(), sizeof(double) * res.size(), hipMemcpyHostToDevice, e->stream));
+  LB_HIP(hipStreamSynchronize(e->stream));
+  return LB_OK;
+}

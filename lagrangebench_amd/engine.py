@@ -353,6 +353,22 @@ class RolloutEngine:
             return out, np.frombuffer(iters, dtype=np.int32).reshape(self.B, n_out, 3).copy()
         return out
 
+    def sinkhorn_pot(self, pred: torch.Tensor, target: torch.Tensor, stride: int, reg: float = 0.1,
+                     num_iter_max: int = 500, stop_thr: float = 1e-5, return_info: bool = False):
+        """ot_backend="pot" (metrics.py:178-196): clip(sinkhorn2_xy - 0.5 (sinkhorn2_xx + sinkhorn2_yy), 0) of every
+        stride-th frame pair of (B,T,N,dim) rollouts -> (B, n_out)."""
+        p = _dev(pred if pred.dim() == 4 else pred[None], torch.float64, self.device)
+        t = _dev(target if target.dim() == 4 else target[None], torch.float64, self.device)
+        T = min(p.shape[1], t.shape[1])
+        n_out = (T + stride - 1) // stride
+        out = torch.empty((self.B, n_out), dtype=torch.float64, device=self.device)
+        info = (C.c_int32 * (self.B * n_out * 6))()
+        check(self.lib.lb_sinkhorn_pot(self._h, ptr(p), p.shape[1], ptr(t), t.shape[1], int(stride), float(reg),
+                                       int(num_iter_max), float(stop_thr), ptr(out), n_out, info), "lb_sinkhorn_pot")
+        if return_info:
+            return out, np.frombuffer(info, dtype=np.int32).reshape(self.B, n_out, 6).copy()
+        return out
+
     def segment_sum(self, msg: torch.Tensor) -> torch.Tensor:
         msg = _dev(msg, torch.float32, self.device)
         out = torch.empty((self.B * self.N, msg.shape[1]), dtype=torch.float32, device=self.device)

@@ -140,3 +140,105 @@ def test_sinkhorn_full_size_properties():
     assert abs(d_1 - d_1r) <= 1e-3 * d_1                         # symmetric up to the convergence threshold
     perm = rng.permutation(N)
     assert abs(div(y1[perm], x) - d_1) <= 1e-6 * d_1
+
+
+# ---- ot_backend="pot" (metrics.py:178-196) -----------------------------------------------------------------------
+def test_pot_oracle_matches_closed_form_and_float32_run():
+    """Sinkhorn-Knopp restatement: (1) uniform 2 x 2 problem -> the closed-form plan's <P, C>; (2) the same iteration
+    run in float32 (what POT does on the reference's float32 inputs) lands within 2e-5 relative of the float64
+    restatement - the tolerance the GPU test quotes against the reference."""
+    from oracle import sinkhorn_pot_oracle as PK
+    C = np.array([[0.3, 1.1], [0.9, 0.2]], np.float32)
+    a = b = np.array([0.5, 0.5])
+    for reg in (0.5, 0.3):
+        val, it, how = PK.sinkhorn2(a, b, C, reg=reg, numItermax=5000, stopThr=1e-11)
+        Cd = C.astype(np.float64)
+        delta = Cd[0, 0] + Cd[1, 1] - Cd[0, 1] - Cd[1, 0]
+        s = np.exp(-delta / (2 * reg))
+        t = 0.5 * s / (1 + s)
+        P = np.array([[t, 0.5 - t], [0.5 - t, t]])
+        assert how == 1 and abs(val - (P * Cd).sum()) < 1e-8, (reg, val, (P * Cd).sum(), it)
+    rng = np.random.default_rng(3)
+    disp, _ = O.space_periodic(np.array([1.0, 1.0]))
+    x = rng.random((300, 2))
+    y = np.mod(x + 0.02 * rng.standard_normal(x.shape), 1.0)
+    M = SK.distance_matrix(disp, x, y)
+    a = b = np.ones(300) / 300
+    v64, it64, how64 = PK.sinkhorn2(a, b, M)
+    # float32 re-run of the same loop
+    a32, M32 = a.astype(np.float32), M
+    u, v = a32.copy(), a32.copy()
+    K = np.exp(M32 / np.float32(-0.1))
+    Kp = (np.float32(1) / a32)[:, None] * K
+    for ii in range(500):
+        v = a32 / (K.T @ u)
+        u = np.float32(1) / (Kp @ v)
+        if ii % 10 == 0 and np.linalg.norm(np.einsum("i,ij,j->j", u, K, v) - a32) < 1e-5:
+            break
+    v32 = float((u[:, None] * K * v[None, :] * M32).sum())
+    assert how64 == 1 and it64 == ii + 1
+    assert abs(v32 - v64) < 2e-5 * abs(v64), (v32, v64)
+    # the divergence: zero for identical clouds, positive and growing with the perturbation, float32 typed
+    d0 = PK.sinkhorn_divergence_pot(disp, x, x)
+    d1 = PK.sinkhorn_divergence_pot(disp, x, y)
+    d2 = PK.sinkhorn_divergence_pot(disp, x, np.mod(x + 0.05 * rng.standard_normal(x.shape), 1.0))
+    assert d0.dtype == np.float32 and d0 == 0 and 0 < d1 < d2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small2d", "small3d"])
+def test_sinkhorn_pot_engine_matches_oracle(name):
+    """lb_sinkhorn_pot vs the Sinkhorn-Knopp restatement: same iteration counts and loop exits, each value within
+    1e-9 relative (both fp64 on the float32 cost; the reference's float32 run sits within 2e-5, see the CPU test),
+    including the numerical-stop branch (K underflows -> previous scalings kept)."""
+    torch = pytest.importorskip("torch")
+    from oracle import sinkhorn_pot_oracle as PK
+    from lagrangebench_amd.data import make_case
+    from tests._common import hip_case, oracle_case
+    ds = make_case(name, n_trajs=2, extra_seq_length=6)
+    isl = ds.input_seq_length
+    hcase, ocase = hip_case(ds), oracle_case(ds)
+    pos = np.stack([ds[0][0], ds[1][0]]).astype(np.float64)
+    roll = np.transpose(pos, (0, 2, 1, 3))
+    rng = np.random.default_rng(1)
+    dx = float(ds.metadata["dx"])
+    target = roll[:, isl:]
+    pred = target + 0.05 * dx * rng.standard_normal(target.shape) * np.arange(1, target.shape[1] + 1)[None, :, None, None]
+    eng = hcase.engine(2)
+    stride = 2
+    out, info = eng.sinkhorn_pot(torch.from_numpy(pred), torch.from_numpy(target), stride, return_info=True)
+    out = out.cpu().numpy()
+    assert out.shape == (2, 3)
+    for b in range(2):
+        for k, t in enumerate(range(0, target.shape[1], stride)):
+            d, oi = PK.sinkhorn_divergence_pot(ocase.displacement, pred[b, t], target[b, t], return_info=True)
+            assert tuple(info[b, k, :3]) == oi["iters"] and tuple(info[b, k, 3:]) == oi["how"], (info[b, k], oi)
+            scale = float(oi["values"][0])
+            assert abs(out[b, k] - float(d)) <= 3e-7 * scale, (b, k, out[b, k], d)   # a float32 ulp of the values
+            assert out[b, k] >= 0 and np.float32(out[b, k]) == out[b, k]
+    z = eng.sinkhorn_pot(torch.from_numpy(target), torch.from_numpy(target), 3).cpu().numpy()
+    assert (z == 0).all()
+    # numerical stop: reg so small that every K(x_i, y_j) underflows for a shifted cloud -> K^T u == 0 at ii = 0
+    box = np.asarray(ds.metadata["bounds"], np.float64)
+    shifted = target[:, :1] + 0.37 * (box[:, 1] - box[:, 0])
+    o2, i2 = eng.sinkhorn_pot(torch.from_numpy(shifted), torch.from_numpy(target[:, :1]), 1, reg=1e-6, return_info=True)
+    val, it, how = PK.sinkhorn2(np.ones(target.shape[2]) / target.shape[2], np.ones(target.shape[2]) / target.shape[2],
+                                SK.distance_matrix(ocase.displacement, shifted[0, 0], target[0, 0]), reg=1e-6)
+    assert how == 2 and it == 1 and i2[0, 0, 0] == 1 and i2[0, 0, 3] == 2
+
+
+@pytest.mark.gpu
+def test_metrics_computer_pot_backend():
+    torch = pytest.importorskip("torch")
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.evaluate import MetricsComputer
+    from tests._common import hip_case
+    ds = make_case("small2d", n_trajs=1, extra_seq_length=4)
+    hcase = hip_case(ds)
+    pos = np.transpose(ds[0][0].astype(np.float64), (1, 0, 2))[ds.input_seq_length:]
+    rng = np.random.default_rng(0)
+    pred = pos + 0.02 * float(ds.metadata["dx"]) * rng.standard_normal(pos.shape)
+    mc = MetricsComputer(["sinkhorn"], hcase.displacement, ds.metadata, ds.input_seq_length, stride=2,
+                         ot_backend="pot", case=hcase)
+    sk = mc(pred, pos)["sinkhorn"]
+    assert sk.dtype == torch.float32 and sk.shape == (2,) and bool((sk >= 0).all())
