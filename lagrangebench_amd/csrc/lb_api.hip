@@ -252,7 +252,7 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   if (hipMemcpy(e->ctrl, &c0, sizeof(c0), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemset(e->blocks_done, 0, sizeof(int32_t)) != hipSuccess ||
       hipMemset(e->ptype, 0, sizeof(int32_t) * BN) != hipSuccess ||
-      hipMemset(e->nl_wg_sum, 0, sizeof(uint32_t) * (BN / 8 + 2)) != hipSuccess ||
+      hipMemset(e->nl_wg_sum, 0, sizeof(unsigned long long) * (BN / 8 + 2)) != hipSuccess ||
       hipMemset(e->row_ptr, 0, sizeof(int32_t) * (BN + 1)) != hipSuccess) {
     lb_engine_destroy(e);
     return lb_fail(LB_ERR_HIP, "engine init copies failed");
@@ -997,6 +997,13 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
                           int32_t n_steps, double* pred_out_dev, int32_t* n_realloc_out) {
   if (!e || !g || !traj_dev || !pred_out_dev) return lb_fail(LB_ERR_ARG, "null argument");
   if (g->eng != e) return lb_fail(LB_ERR_ARG, "model was created for another engine");
+  // the node-feature rows of every step ride along with its neighbor search
+  struct FeatJob {
+    lb_engine* e;
+    ~FeatJob() { e->feat_job = lb_feat_job{}; }
+  } feat_guard{e};
+  LB_TRY(lb_gns_bind(e, g));
+  e->feat_job = lb_feat_job{e->xnode, g->embed, g->desc.embedding_size, g->desc.num_particle_types, e->g.kpad, e->ptype, e->force};
   LB_TRY(lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, n_realloc_out));
   if (e->f16x2 && e->math_auto) {
     // The guard records the FIRST step at which a flag was raised (lb_ctrl::math_step): every step before it is
@@ -1026,8 +1033,24 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
 // One rollout step (neighbor list -> model -> integrator) enqueued on e->stream.
 static int lb_enqueue_step(lb_engine* e, int (*forward)(lb_engine*, void*), void* model,
                            const double* traj_dev, int32_t T, double* pred_out_dev, int32_t n_steps) {
-  LB_TRY(lbk_nl_build(e, false));
-  LB_TRY(forward(e, model));
+  // two launches ride along with others in a rollout step (LB_STEP_FUSE=0 switches that off): the node-feature rows
+  // are written by extra workgroups of the neighbor search (lb_engine::feat_job, set by the model's rollout entry),
+  // the integrator runs in the decoder's epilogue (lb_engine::integ_job)
+  static const bool fuse = !(getenv("LB_STEP_FUSE") && getenv("LB_STEP_FUSE")[0] == '0');
+  const lb_feat_job fj = e->feat_job;
+  if (!fuse) e->feat_job.xnode = nullptr;
+  e->feat_done = false;
+  int rc = lbk_nl_build(e, false);
+  e->feat_job = fj;
+  e->integ_done = false;
+  e->integ_job = lb_integ_job{e->win, e->blocks_done, e->ptype, traj_dev, T, pred_out_dev, n_steps, fuse ? 1 : 0};
+  if (!rc) rc = forward(e, model);
+  e->feat_done = false;
+  e->integ_job.on = 0;
+  const bool integrated = e->integ_done;
+  e->integ_done = false;
+  if (rc) return rc;
+  if (integrated) return LB_OK;
   return lbk_integrate(e, e->acc, 4, nullptr, traj_dev, T, pred_out_dev, n_steps);
 }
 

@@ -360,11 +360,13 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
   const int L = g->desc.num_mp_steps;
   int rc;
 
-  lb_tic(e, LB_T_NODEFEAT);
-  rc = lbk_node_features(e, e->xnode, g->embed, g->desc.embedding_size,
-                         g->desc.num_particle_types, nullptr, nullptr, nullptr, nullptr);
-  lb_toc(e);
-  if (rc) return rc;
+  if (!(e->feat_done && e->feat_job.xnode == e->xnode)) {  // (rollout step: written by the neighbor-search launch)
+    lb_tic(e, LB_T_NODEFEAT);
+    rc = lbk_node_features(e, e->xnode, g->embed, g->desc.embedding_size,
+                           g->desc.num_particle_types, nullptr, nullptr, nullptr, nullptr);
+    lb_toc(e);
+    if (rc) return rc;
+  }
 
   // Kernel families.  f16x2 (default): M-split kernels on small graphs, else k_edge16v / k_edge_enc16v (edges) and
   // k_node16s (nodes).  Exact fp32 (LB_MATH=f32, or the range guard's fall-back): k_edge16<*, f32> and the 32-row

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "lb_f16x2.h"
+#include "lb_features.h"
 
 #define MFMA16F(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define GD_THREADS 512
@@ -224,13 +225,15 @@ struct lb_dec16_args {
   float unscale;     // result of the w1 product is multiplied by this (power of two) before b1 is added
   float* acc_out;    // [rows][4]
   int out_dim;
+  lb_integ_job integ;  // rollout step: integrate_fn + window advance in the epilogue (on = 0: stand-alone forward)
 };
 
 template <bool F16>
-__global__ void __launch_bounds__(GD_THREADS, 2) k_decoder16(lb_dec16_args a) {
+__global__ void __launch_bounds__(GD_THREADS, 2) k_decoder16(lb_dec16_args a, lb_geom geom) {
   constexpr int NW1 = F16 ? 512 : 4096;
   __shared__ f32x4 sW[4096 + NW1 + 33];
   const int poisoned = a.ctrl->overflow_step;  // acted on after the staging loads are in flight
+  const int step = a.ctrl->step;
   const int tid = threadIdx.x;
   {
     const f32x4* g0 = reinterpret_cast<const f32x4*>(a.w0);
@@ -298,6 +301,20 @@ __global__ void __launch_bounds__(GD_THREADS, 2) k_decoder16(lb_dec16_args a) {
       bool bad = false;
       for (int d = 0; d < a.out_dim; ++d) bad |= !(fabsf(o[d]) <= 3.0e38f);
       if (bad) lb_raise_math(a.ctrl, LB_MATH_NONFINITE);
+      if (a.integ.on) {
+        const float av[4] = {o[0], o[1], o[2], o[3]};
+        lb_integrate_body(geom, a.n_rows, a.integ.win, step, a.integ.ptype, av, nullptr, a.integ.traj, a.integ.T,
+                          a.integ.pred, a.integ.pred_T, row);
+      }
+    }
+  }
+  // the step counter is advanced by the LAST workgroup to finish (k_integrate's job; every workgroup has made its last
+  // read of ctrl->step - the range guard's - by then)
+  if (a.integ.on) {
+    __syncthreads();
+    if (tid == 0 && atomicAdd(a.integ.blocks_done, 1) == (int)gridDim.x - 1) {
+      *a.integ.blocks_done = 0;
+      const_cast<lb_ctrl*>(a.ctrl)->step = step + 1;
     }
   }
 }
@@ -316,10 +333,14 @@ int lbk_decoder16(lb_engine* e, lb_gns* g) {
   a.out_dim = g->desc.out_dim;
   const int64_t tiles = std::max<int64_t>(1, (e->BN + 15) / 16);
   const int grid = (int)std::min<int64_t>(512, (tiles + GD_WAVES - 1) / GD_WAVES);
+  if (e->integ_job.on && g->desc.out_dim == e->g.dim) {  // rollout step: the integrator rides along
+    a.integ = e->integ_job;
+    e->integ_done = true;
+  }
   if (e->f16x2)
-    hipLaunchKernelGGL((k_decoder16<true>), dim3(grid), dim3(GD_THREADS), 0, e->stream, a);
+    hipLaunchKernelGGL((k_decoder16<true>), dim3(grid), dim3(GD_THREADS), 0, e->stream, a, e->g);
   else
-    hipLaunchKernelGGL((k_decoder16<false>), dim3(grid), dim3(GD_THREADS), 0, e->stream, a);
+    hipLaunchKernelGGL((k_decoder16<false>), dim3(grid), dim3(GD_THREADS), 0, e->stream, a, e->g);
   LB_HIP(hipGetLastError());
   return LB_OK;
 }

@@ -63,6 +63,27 @@ struct lb_geom {
   double force_split, force_lo[3], force_hi[3];
 };
 
+// node features of ONE rollout step riding along with the neighbor search (lb_engine::feat_job)
+struct lb_feat_job {
+  float* xnode;        // [BN][kpad] network input rows (null = no job)
+  const float* embed;  // particle-type embedding table or null
+  int32_t emb, ntypes, kpad;
+  const int32_t* ptype;
+  const double* force;
+};
+
+// integrator of ONE rollout step riding along with the decoder (lb_engine::integ_job)
+struct lb_integ_job {
+  double* win;          // null = no job
+  int32_t* blocks_done;
+  const int32_t* ptype;
+  const double* traj;
+  int32_t T;
+  double* pred;
+  int32_t pred_T;
+  int32_t on;
+};
+
 enum lb_timer_class {
   LB_T_CELLS = 0,    // cell binning: count + scan + fill
   LB_T_NEIGH,        // stencil search: count pass + row scan + fill pass (+edge features)
@@ -111,8 +132,12 @@ struct lb_engine {
   int32_t* cell_fill;  // [B*ncells]
   int32_t* cell_part;  // [BN] particle ids grouped by cell
   int32_t* deg;        // [BN]
+  lb_feat_job feat_job{};    // rollout step: node features ride along with the neighbor search (xnode == null: no job)
+  bool feat_done = false;    // ... and were written by it: the model's forward skips its own feature launch
+  lb_integ_job integ_job{};  // rollout step: the integrator rides along with the decoder (win == null: no job)
+  bool integ_done = false;
   bool nl_one_off = false;        // k_nl_small timed out once: multi-launch build from now on
-  uint32_t* nl_wg_sum = nullptr;  // [BN / 8 + 1] k_nl_small: epoch-tagged edge counts of the workgroups
+  unsigned long long* nl_wg_sum = nullptr;  // [BN / 8 + 2] k_nl_small: epoch-tagged words of the workgroups
   int32_t* row_ptr;    // [BN+1]
   int32_t* scan_part;  // partial sums of the two-level scans
   double* cpos;        // [dim][BN] newest-frame positions in cell-sorted order

@@ -29,7 +29,7 @@
 // atomic-free segmented aggregation.
 #include <cstdlib>
 
-#include "lb_device.h"
+#include "lb_features.h"
 
 #define SCAN_THREADS 256
 #define SCAN_CHUNK (SCAN_THREADS * 8)
@@ -258,6 +258,8 @@ struct lb_nl_args {
   int64_t e_alloc;
   int32_t maxd;
   int32_t row_cap;          // k_nlw: LDS row-buffer entries per wave (>= LB_MAX_ROW)
+  lb_feat_job feat;         // NL_ROWS in a rollout step: every search wave also writes the node-feature row of its
+  const double* win;        //   receiver (lb_features.h; xnode == null: no job)
 };
 
 template <int MODE, int NL_THREADS, int MAXC, bool F32 = false>
@@ -342,6 +344,7 @@ __global__ void __launch_bounds__(NL_THREADS)
   for (int k = wave; k < own_cnt; k += NL_WAVES) {
     if (own_off + k >= M) break;  // truncated stencil (density error already flagged)
     const int gr = s_id[own_off + k];
+    if (MODE == NL_ROWS && a.feat.xnode) lb_node_features_wave(g, BN, a.win, ctrl->step, a.feat, gr);
     double pr[3] = {0, 0, 0};
     for (int d = 0; d < g.dim; ++d) pr[d] = s_p[d][own_off + k];
     int count = 0;
@@ -458,6 +461,7 @@ __global__ void __launch_bounds__(64 * NLW_WAVES)
   const int64_t r = (int64_t)blockIdx.x * NLW_WAVES + wave;  // receiver slot in cell-sorted order
   if (r >= BN) return;
   const int gr = a.cell_part[r];
+  if (MODE == NL_ROWS && a.feat.xnode) lb_node_features_wave(g, BN, a.win, ctrl->step, a.feat, gr);
   const int gc = a.cell_of[gr];
   const int b = gc / g.ncells, h = gc % g.ncells;
   {
@@ -714,106 +718,166 @@ __global__ void __launch_bounds__(LB_SMALL_T)
 // degree scan -> compaction: 44 us of a 310 us step, every one a chain of 3 - 5 memory round trips).  Here the
 // whole build is one launch with one dependency level:
 //   * every workgroup stages ALL N newest-frame positions + cell coordinates in LDS (N * (8 dim + 4) bytes);
-//   * one wave per receiver sweeps the N candidates in id order, 64 per step: integer test "candidate's cell is in the
-//     receiver's 3^dim stencil (wrapping, like the rolled cell buffer)" - the fp64 predicate runs only in the steps
-//     where some lane passed it.  Same candidate set, same predicate, same operand order as k_nl; the hits come out
-//     sorted by sender id, so the rank pass is gone;
+//   * every workgroup also builds, per dimension, one N-bit mask per cell coordinate ("the particles whose x cell is
+//     v") with LDS atomics; a receiver's stencil candidates are then (X[x-1]|X[x]|X[x+1]) & (Y..) & (Z..) - lane w
+//     of its wave owns the 64 ids of word w - expanded in ascending id order into the wave's row buffer, and the
+//     fp64 predicate (same operand order as k_nl) runs on that short list only.  Same candidate set as the rolled
+//     3^dim stencil of k_nl (the masks wrap); the hits come out sorted by sender id, so the rank pass is gone;
 //   * rows go straight into the CSR arrays: a workgroup publishes the edge count of its NLS_WAVES receivers in one
 //     word (build epoch << 16 | count, agent-scope release store) and adds up the words of the workgroups before it
 //     (workgroups are dispatched in index order, so a predecessor is running or done; bounded spin);
 //   * the last workgroup also histograms the cells (max_cell_occ for the did_buffer_overflow flag) and does
 //     k_row_finish's job.
-#define NLS_WAVES 8
+#define NLS_WAVES 16  // at most; the launch uses ceil(N / 256) waves so that every CU gets at most one workgroup
 #define NLS_THREADS (64 * NLS_WAVES)
+#define NLS_CAND 512  // stencil candidates per receiver (row buffer entries; >= LB_MAX_ROW)
 struct lb_nls_args {
   const double* win;
   int32_t *senders, *receivers;
   float* efeat;
   double* efeat64;
   int32_t *deg, *row_ptr, *overflow, *nedges_b;
-  uint32_t* wg_sum;  // [ceil(N / NLS_WAVES)]
+  unsigned long long* wg_sum;  // [ceil(N / NLS_WAVES)]
   int64_t e_alloc;
   int32_t e_cap, cell_capacity, npad;
   int32_t* host_flag;
+  lb_feat_job feat;  // node features of this step: every wave writes the row of its receiver (xnode == null: no job)
+  long long* dbg;  // LB_NLS_DBG=1: [3 workgroups][8] wall-clock stamps (first, middle, last workgroup)
 };
+#define NLS_STAMP(k)                                                                                       \
+  do {                                                                                                     \
+    if (a.dbg && tid == 0) {                                                                               \
+      const int wsel = blockIdx.x == 0 ? 0 : ((int)blockIdx.x == (int)gridDim.x / 2 ? 1 : (last ? 2 : -1)); \
+      if (wsel >= 0) a.dbg[wsel * 8 + (k)] = wall_clock64();                                               \
+    }                                                                                                      \
+  } while (0)
 
 template <bool F32>
 __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __restrict__ ctrl, lb_nls_args a) {
   extern __shared__ double s_dynd[];
   if (ctrl->overflow_step >= 0) return;
   const int N = g.N, npad = a.npad;
-  double* const s_p = s_dynd;                                      // [dim][npad]
-  int* const s_cell = reinterpret_cast<int*>(s_p + g.dim * npad);  // [npad] x | y << 11 | z << 22
-  int* const s_row = s_cell + npad;                                // [NLS_WAVES][LB_MAX_ROW]
-  int* const s_cnt = s_row + NLS_WAVES * LB_MAX_ROW;               // [NLS_WAVES], [8] base, [9] max occupancy
-  int* const s_hist = s_cnt + 16;                                  // last workgroup: [ncells]
+  const int nwv = blockDim.x >> 6, nwords = npad >> 6;
+  double* const s_p = s_dynd;  // [dim][npad]
+  unsigned long long* const s_tab = reinterpret_cast<unsigned long long*>(s_p + g.dim * npad);  // per dim [ncell[d]][nwords]
+  const int tab_off[3] = {0, g.ncell[0] * nwords, (g.ncell[0] + g.ncell[1]) * nwords};
+  const int tab_len = (g.ncell[0] + g.ncell[1] + (g.dim == 3 ? g.ncell[2] : 0)) * nwords;
+  int* const s_cell = reinterpret_cast<int*>(s_tab + (g.use_cell_list ? tab_len : 0));  // [npad] x | y << 11 | z << 22
+  int* const s_row = s_cell + npad;                                                      // [waves][NLS_CAND]
+  int* const s_cnt = s_row + nwv * NLS_CAND;  // [0..15] row sizes, [16] base, [17] flags, [18] max occ
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int step = ctrl->step;
-  const uint32_t epoch = (uint32_t)ctrl->nl_epoch & 0xffffu;
+  const unsigned long long epoch = (unsigned long long)((uint32_t)ctrl->nl_epoch & 0xffffu);
   const bool last = blockIdx.x == gridDim.x - 1;
-  if (tid < 16) s_cnt[tid] = 0;
-  if (last && g.use_cell_list)
-    for (int c = tid; c < g.ncells; c += NLS_THREADS) s_hist[c] = 0;
-  // ---- stage positions + cell coordinates (k_cells_small's arithmetic: int(position / cell_size), clamped)
-  double inv_cs[3];
-  for (int d = 0; d < 3; ++d) inv_cs[d] = d < g.dim ? 1.0 / g.cell_size[d] : 0.0;
-  for (int i = tid; i < N; i += NLS_THREADS) {
-    int packed = 0;
-    for (int d = 0; d < g.dim; ++d) {
-      const double p = lb_pos(a.win, g, N, step, g.isl - 1, d, i);
-      s_p[d * npad + i] = p;
-      // the quotient decides through its integer part only: the reciprocal product is exact enough unless it lands
-      // within 1e-6 (relative) of an integer (or, in f32 mode, of a float rounding up to one) - then divide
-      double q = p * inv_cs[d];
-      const double fr = q - floor(q), tol = 1e-6 * (fabs(q) + 1.0);
-      if (fr < tol || fr > 1.0 - tol) q = lb_r(p / g.cell_size[d], F32);
-      int c = __double2int_rz(q);
-      c = c < 0 ? 0 : (c >= g.ncell[d] ? g.ncell[d] - 1 : c);
-      packed |= c << (11 * d);
+  NLS_STAMP(0);
+  if (tid < 32) s_cnt[tid] = 0;
+  if (g.use_cell_list)
+    for (int k = tid; k < tab_len; k += blockDim.x) s_tab[k] = 0ull;
+  // ---- stage positions + cell coordinates (k_cells_small's arithmetic: int(position / cell_size), clamped);
+  // all loads of a thread are issued before the first is used
+  {
+    constexpr int PER = 4;  // npad <= 256 * waves
+    const int slot = (step + g.isl - 1) % g.isl;
+    const double* const w0 = a.win + (int64_t)slot * g.dim * N;
+    double pv[PER][3];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + (int)blockDim.x * k;
+      const int ic = i < N ? i : N - 1;
+      pv[k][0] = w0[ic];
+      pv[k][1] = w0[N + ic];
+      pv[k][2] = g.dim == 3 ? w0[2 * N + ic] : 0.0;
     }
-    s_cell[i] = packed;
+    double inv_cs[3];
+    for (int d = 0; d < 3; ++d) inv_cs[d] = d < g.dim ? 1.0 / g.cell_size[d] : 0.0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + (int)blockDim.x * k;
+      if (i < npad) {
+        int packed = 0;
+        for (int d = 0; d < g.dim; ++d) {
+          const double p = pv[k][d];
+          s_p[d * npad + i] = p;
+          // the quotient decides through its integer part only: the reciprocal product is exact enough unless it
+          // lands within 1e-6 (relative) of an integer (or, in f32 mode, of a float rounding up to one) - then divide
+          double q = p * inv_cs[d];
+          const double fr = q - floor(q), tol = 1e-6 * (fabs(q) + 1.0);
+          if (fr < tol || fr > 1.0 - tol) q = lb_r(p / g.cell_size[d], F32);
+          int c = __double2int_rz(q);
+          c = c < 0 ? 0 : (c >= g.ncell[d] ? g.ncell[d] - 1 : c);
+          packed |= c << (11 * d);
+        }
+        s_cell[i] = i < N ? packed : -1;
+      }
+    }
+  }
+  __syncthreads();  // (positions + cells staged, tables zeroed)
+  // the per-dimension masks: lane l owns word l; in step k it takes particle 64 l + ((k + l) & 63) - 64 different LDS
+  // banks for the cell reads, 64 different words for the ORs (atomics only against the other waves' steps)
+  if (g.use_cell_list && lane < nwords) {
+    for (int k = wave; k < 64; k += nwv) {
+      const int b = (k + lane) & 63;
+      const int pc = s_cell[lane * 64 + b];
+      if (pc >= 0)
+        for (int d = 0; d < g.dim; ++d)
+          atomicOr(&s_tab[tab_off[d] + ((pc >> (11 * d)) & 0x7ff) * nwords + lane], 1ull << b);
+    }
   }
   __syncthreads();
-  if (last && g.use_cell_list) {
-    for (int i = tid; i < N; i += NLS_THREADS) {
-      const int pc = s_cell[i];
-      const int h = (pc & 0x7ff) + g.ncell[0] * (((pc >> 11) & 0x7ff) + g.ncell[1] * (pc >> 22));
-      atomicAdd(&s_hist[h], 1);
-    }
-    __syncthreads();
-    int mx = 0;
-    for (int c = tid; c < g.ncells; c += NLS_THREADS) mx = max(mx, s_hist[c]);
-    if (mx > 0) atomicMax(&s_cnt[9], mx);
-  }
-  // ---- sweep
-  const int r = blockIdx.x * NLS_WAVES + wave;
+  NLS_STAMP(1);
+  // ---- pass 1 (bit masks): the candidates of the receiver's 3^dim stencil cells, in id order, into the row buffer
+  const int r = blockIdx.x * nwv + wave;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  int count = 0;
+  int count = 0, same = 0, flags = 0;
   double pr[3] = {0, 0, 0};
-  int* const row = s_row + wave * LB_MAX_ROW;
+  int* const row = s_row + wave * NLS_CAND;
   if (r < N) {
+    if (a.feat.xnode) lb_node_features_wave(g, N, a.win, step, a.feat, r);
     for (int d = 0; d < g.dim; ++d) pr[d] = s_p[d * npad + r];
-    const int pc = s_cell[r];
-    int acc0[3], acc1[3], acc2[3];  // the three accepted cell coordinates per dimension (wrapping stencil)
-    for (int d = 0; d < 3; ++d) {
-      const int n = d < g.dim ? g.ncell[d] : 1;
-      const int c = (pc >> (11 * d)) & 0x7ff;
-      acc0[d] = c;
-      acc1[d] = c == 0 ? n - 1 : c - 1;
-      acc2[d] = c == n - 1 ? 0 : c + 1;
-    }
-    for (int c0 = 0; c0 < N; c0 += 64) {
-      const int j = c0 + lane;
-      bool adj = false;
-      if (j < N) {
-        const int qc = s_cell[j];
-        const int cx = qc & 0x7ff, cy = (qc >> 11) & 0x7ff, cz = qc >> 22;
-        adj = (cx == acc0[0] || cx == acc1[0] || cx == acc2[0]) && (cy == acc0[1] || cy == acc1[1] || cy == acc2[1]) &&
-              (cz == acc0[2] || cz == acc1[2] || cz == acc2[2]);
+    int ncand = N;  // (no cell list: every particle is a candidate, pass 2 walks the ids)
+    if (g.use_cell_list) {
+      const int pc = s_cell[r];
+      unsigned long long m = ~0ull, ms = ~0ull;
+      if (lane < nwords) {
+        for (int d = 0; d < g.dim; ++d) {
+          const int n = g.ncell[d], c = (pc >> (11 * d)) & 0x7ff;
+          const unsigned long long* T = s_tab + tab_off[d] + lane;
+          const unsigned long long t0 = T[c * nwords];  // the stencil wraps like jax-md's rolled cell buffer
+          m &= t0 | T[(c == 0 ? n - 1 : c - 1) * nwords] | T[(c == n - 1 ? 0 : c + 1) * nwords];
+          ms &= t0;
+        }
+      } else {
+        m = 0ull;
+        ms = 0ull;
       }
-      if (!__any(adj)) continue;
+      int mine = __popcll(m), off = mine;
+      same = __popcll(ms);
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(off, o);
+        if (lane >= o) off += v;
+      }
+      ncand = __shfl(off, 63);
+      off -= mine;
+      for (int o = 32; o > 0; o >>= 1) same += __shfl_xor(same, o);
+      while (m) {
+        const int b = __ffsll((long long)m) - 1;
+        if (off < NLS_CAND) row[off] = lane * 64 + b;
+        ++off;
+        m &= m - 1;
+      }
+    }
+    if (g.use_cell_list && ncand > NLS_CAND) {  // (the host checks cell_capacity * 3^dim <= NLS_CAND; flagged like an over-long row)
+      flags = 1;
+      ncand = NLS_CAND;
+    }
+    // ---- pass 2 (fp64): the predicate on the candidates; the hits overwrite the front of the row buffer in order
+    for (int c0 = 0; c0 < ncand; c0 += 64) {
+      const int t = c0 + lane;
       bool ok = false;
-      if (adj) {
+      int j = 0;
+      if (t < ncand) {
+        j = g.use_cell_list ? row[t] : t;
         // metric_sq(position[sender], position[receiver]) as in k_nl
         double dd = lb_disp1(s_p[j], pr[0], g.box[0], g.half_box[0], g.periodic, F32);
         double d2 = lb_r(dd * dd, F32);
@@ -824,45 +888,63 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
         ok = d2 < g.rc2;
       }
       const unsigned long long mask = __ballot(ok);
+      // (in place: hit k of this sweep lands at count + k <= c0 + lane's own index, and every lane has read its j)
       if (ok) {
         const int pos = count + __popcll(mask & lt_mask);
-        if (pos < LB_MAX_ROW) row[pos] = j;
+        if (pos < NLS_CAND) row[pos] = j;
       }
       count += __popcll(mask);
     }
+    if (count > LB_MAX_ROW) flags = 1;  // re-allocate (-> the dense fall-back), like k_nl
     if (lane == 0) {
       a.deg[r] = count;
       s_cnt[wave] = count;
-      if (count > LB_MAX_ROW) atomicExch(&ctrl->row_overflow, 1);  // re-allocate (-> the dense fall-back)
+      if (flags) atomicOr(&s_cnt[17], 1);
+      atomicMax(&s_cnt[18], same);
     }
   }
   __syncthreads();
-  // ---- this workgroup's count out, the counts of the workgroups before it in
+  NLS_STAMP(3);
+  // ---- this workgroup's word out (epoch | max occupancy seen | overflow | edge count), its predecessors' in
   if (tid == 0) {
     int tot = 0;
-    for (int w = 0; w < NLS_WAVES; ++w) tot += s_cnt[w];
-    __hip_atomic_store(&a.wg_sum[blockIdx.x], (epoch << 16) | (uint32_t)tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    for (int w = 0; w < nwv; ++w) tot += s_cnt[w];
+    const unsigned long long word = (epoch << 48) | ((unsigned long long)(s_cnt[18] & 0xffff) << 32) |
+                                    ((unsigned long long)(s_cnt[17] & 1) << 31) | (unsigned long long)(tot & 0x7fffffff);
+    __hip_atomic_store(&a.wg_sum[blockIdx.x], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  NLS_STAMP(4);
   {
-    int part = 0;
+    int part = 0, occ = 0, ovf = 0;
     bool timed_out = false;
-    for (int p = tid; p < (int)blockIdx.x; p += NLS_THREADS) {
-      uint32_t v = 0;
+    for (int p = tid; p < (int)blockIdx.x; p += (int)blockDim.x) {
+      unsigned long long v = 0;
       int spins = 0;
       do {
         v = __hip_atomic_load(&a.wg_sum[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((v >> 16) == epoch) break;
+        if ((v >> 48) == epoch) break;
         __builtin_amdgcn_s_sleep(1);
       } while (++spins < (1 << 22));
-      if ((v >> 16) != epoch) timed_out = true;
-      part += (int)(v & 0xffffu);
+      if ((v >> 48) != epoch) timed_out = true;
+      part += (int)(v & 0x7fffffffu);
+      ovf |= (int)((v >> 31) & 1);
+      occ = max(occ, (int)((v >> 32) & 0xffff));
     }
     if (timed_out) atomicExch(&ctrl->persist_error, 2);
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-    if (lane == 0 && part) atomicAdd(&s_cnt[8], part);
+    for (int off = 32; off > 0; off >>= 1) {
+      part += __shfl_xor(part, off);
+      ovf |= __shfl_xor(ovf, off);
+      occ = max(occ, __shfl_xor(occ, off));
+    }
+    if (lane == 0 && (int)blockIdx.x > wave * 64) {
+      if (part) atomicAdd(&s_cnt[16], part);
+      if (ovf) atomicOr(&s_cnt[17], 1);
+      atomicMax(&s_cnt[18], occ);
+    }
   }
   __syncthreads();
-  int base = s_cnt[8];
+  NLS_STAMP(5);
+  int base = s_cnt[16];
   for (int w = 0; w < wave; ++w) base += s_cnt[w];
   // ---- rows straight into the CSR arrays (ascending sender id by construction)
   if (r < N) {
@@ -897,16 +979,15 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
       }
     }
   }
+  NLS_STAMP(6);
   // ---- k_row_finish's job, by the workgroup that knows the total
   if (last && tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    int total = s_cnt[8];
-    for (int w = 0; w < NLS_WAVES; ++w) total += s_cnt[w];
+    int total = s_cnt[16];
+    for (int w = 0; w < nwv; ++w) total += s_cnt[w];
     a.row_ptr[N] = total;
     a.nedges_b[0] = total;
-    const int max_occ = s_cnt[9];
-    const int row_ov = __hip_atomic_load(&ctrl->row_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int ov = (total > a.e_cap) || (g.use_cell_list && max_occ > a.cell_capacity) || row_ov;
+    const int max_occ = s_cnt[18];
+    const int ov = (total > a.e_cap) || (g.use_cell_list && max_occ > a.cell_capacity) || (s_cnt[17] & 1);
     a.overflow[0] = ov;
     ctrl->max_cell_occ = max_occ;
     ctrl->n_edges_unclamped = total;
@@ -915,11 +996,11 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
       ctrl->overflow_step = step;
       if (a.host_flag) *a.host_flag = step;
     }
-    __hip_atomic_store(&ctrl->row_overflow, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next build
     int ne = ctrl->nl_epoch + 1;
     if ((ne & 0xffff) == 0) ++ne;
     ctrl->nl_epoch = ne;
   }
+  NLS_STAMP(7);
 }
 
 // ----------------------------------------------------------------------------------- host
@@ -936,9 +1017,16 @@ static void lb_launch_nl(lb_engine* e, int small, const lb_nl_args& a) {
   // and LB_MAX_ROW neighbors; beyond that the wave-per-receiver kernel with a row buffer sized from the largest
   // degree runs (the reference re-allocates for ANY occupancy, rollout.py:134-151)
   const bool per_wave = e->nl_dense || e->g.f32 || (force ? force[0] == 'w' : e->g.nstencil == 27);
+  // NL_ROWS in a rollout step: every search wave also writes the node-feature row of its receiver
+  const bool ride = MODE == NL_ROWS && e->feat_job.xnode && !a.efeat64;
+  if (ride) e->feat_done = true;
   if (per_wave) {
     const int nb = (int)((e->BN + NLW_WAVES - 1) / NLW_WAVES);
     lb_nl_args aw = a;
+    if (ride) {
+      aw.feat = e->feat_job;
+      aw.win = e->win;
+    }
     aw.row_cap = e->row_cap > LB_MAX_ROW ? e->row_cap : LB_MAX_ROW;
     const size_t lds = sizeof(int) * 2 * NLW_WAVES * (size_t)aw.row_cap;
     if (e->g.f32) {  // dtype=float32 geometry: every result rounded to float
@@ -953,10 +1041,16 @@ static void lb_launch_nl(lb_engine* e, int small, const lb_nl_args& a) {
     return;
   }
   const int ncell_tot = e->g.B * e->g.ncells;
-#define LB_NL_CASE(C)                                                                              \
-  case C:                                                                                          \
-    hipLaunchKernelGGL((k_nl<MODE, 64, C>), dim3(ncell_tot), dim3(64), 0, e->stream, e->g, e->BN,  \
-                       e->ctrl, a);                                                                \
+  lb_nl_args ac = a;
+  if (ride) {
+    ac.feat = e->feat_job;
+    ac.win = e->win;
+  }
+  const int ride64 = 0, ride256 = 0;
+#define LB_NL_CASE(C)                                                                                       \
+  case C:                                                                                                   \
+    hipLaunchKernelGGL((k_nl<MODE, 64, C>), dim3(ncell_tot + ride64), dim3(64), 0, e->stream, e->g, e->BN,  \
+                       e->ctrl, ac);                                                                        \
     break;
   switch (small) {
     LB_NL_CASE(128)
@@ -968,8 +1062,8 @@ static void lb_launch_nl(lb_engine* e, int small, const lb_nl_args& a) {
     LB_NL_CASE(896)
     LB_NL_CASE(1024)
     default:
-      hipLaunchKernelGGL((k_nl<MODE, 256, LB_MAX_STENCIL_CAND>), dim3(ncell_tot), dim3(256), 0,
-                         e->stream, e->g, e->BN, e->ctrl, a);
+      hipLaunchKernelGGL((k_nl<MODE, 256, LB_MAX_STENCIL_CAND>), dim3(ncell_tot + ride256), dim3(256), 0,
+                         e->stream, e->g, e->BN, e->ctrl, ac);
   }
 #undef LB_NL_CASE
 }
@@ -987,8 +1081,13 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   const bool small_cells = small_rows && ncell_tot <= LB_SMALL_N;
   // one trajectory of <= 4096 particles on the update path: the whole build is ONE launch (k_nl_small)
   static const bool one_ok = !(getenv("LB_NL_ONE") && getenv("LB_NL_ONE")[0] == '0');
-  if (one_ok && small_ok && frozen && g.B == 1 && BN <= LB_SMALL_N && g.ncells <= LB_SMALL_N && !e->nl_dense && !e->nl_one_off &&
-      e->nl_wg_sum && g.ncell[0] < 2048 && g.ncell[1] < 2048 && g.ncell[2] < 1024) {
+  const int nls_npad = (int)((BN + 63) / 64 * 64);
+  const int nls_waves = (int)std::min<int64_t>(NLS_WAVES, std::max<int64_t>(1, (BN + 255) / 256));
+  const int64_t nls_tab = g.use_cell_list ? (int64_t)(g.ncell[0] + g.ncell[1] + (g.dim == 3 ? g.ncell[2] : 0)) * (nls_npad / 64) : 0;
+  const size_t nls_lds = (size_t)nls_npad * (8 * g.dim + 4) + 8 * (size_t)nls_tab + sizeof(int) * ((size_t)nls_waves * NLS_CAND + 32);
+  if (one_ok && small_ok && frozen && g.B == 1 && BN <= LB_SMALL_N && !e->nl_dense && !e->nl_one_off && nls_lds <= 150 * 1024 &&
+      (!g.use_cell_list || (int64_t)e->cell_capacity * g.nstencil <= NLS_CAND) &&
+      e->nl_wg_sum && g.ncell[0] < 2048 && g.ncell[1] < 2048 && g.ncell[2] < 1024 && NLS_CAND >= LB_MAX_ROW) {
     lb_tic(e, LB_T_NEIGH);
     lb_nls_args a{};
     a.win = e->win;
@@ -1004,18 +1103,39 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
     a.e_alloc = e->e_alloc;
     a.e_cap = e->e_cap;
     a.cell_capacity = e->cell_capacity;
-    a.npad = (int)((BN + 63) / 64 * 64);
+    a.npad = nls_npad;
     a.host_flag = e->host_flag_dev;
-    const size_t lds = (size_t)a.npad * (8 * g.dim + 4) + sizeof(int) * (NLS_WAVES * LB_MAX_ROW + 16 + (g.use_cell_list ? g.ncells : 0));
-    const int nb = (int)((BN + NLS_WAVES - 1) / NLS_WAVES);
+    static const bool nls_dbg = getenv("LB_NLS_DBG") && getenv("LB_NLS_DBG")[0] == '1';
+    static long long* dbg_dev = nullptr;
+    if (nls_dbg && !dbg_dev) LB_HIP(hipMalloc((void**)&dbg_dev, sizeof(long long) * 24));
+    a.dbg = nls_dbg ? dbg_dev : nullptr;
+    const int nwv = nls_waves;
+    const size_t lds = nls_lds;
+    const int nb = (int)((BN + nwv - 1) / nwv);
+    if (e->feat_job.xnode && !want_efeat64) {
+      a.feat = e->feat_job;
+      e->feat_done = true;
+    }
     if (g.f32) {
       if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)k_nl_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_nl_small<true>), dim3(nb), dim3(NLS_THREADS), lds, s, g, e->ctrl, a);
+      hipLaunchKernelGGL((k_nl_small<true>), dim3(nb), dim3(64 * nwv), lds, s, g, e->ctrl, a);
     } else {
       if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)k_nl_small<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_nl_small<false>), dim3(nb), dim3(NLS_THREADS), lds, s, g, e->ctrl, a);
+      hipLaunchKernelGGL((k_nl_small<false>), dim3(nb), dim3(64 * nwv), lds, s, g, e->ctrl, a);
+    }
+    if (nls_dbg) {
+      long long h[24];
+      LB_HIP(hipStreamSynchronize(s));
+      LB_HIP(hipMemcpy(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost));
+      static int n_print = 0;
+      if (n_print++ % 16 == 8)
+        for (int w = 0; w < 3; ++w) {
+          fprintf(stderr, "k_nl_small wg%d (10 ns ticks from wg0 start):", w);
+          for (int k = 0; k < 8; ++k) fprintf(stderr, " %lld", h[w * 8 + k] - h[0]);
+          fprintf(stderr, "\n");
+        }
     }
     lb_toc(e);
     LB_HIP(hipGetLastError());

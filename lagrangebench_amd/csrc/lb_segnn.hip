@@ -529,7 +529,8 @@ int lbk_segnn_forward(lb_engine* e, lb_segnn* m) {
   };
 
   lb_tic(e, LB_T_NODEFEAT);
-  LB_TRY(lbk_node_features_raw(e, m->xnode, 32));
+  if (!(e->feat_done && e->feat_job.xnode == m->xnode))  // (rollout step: written by the neighbor-search launch)
+    LB_TRY(lbk_node_features_raw(e, m->xnode, 32));
   hipLaunchKernelGGL(k_sg_edge_prep, dim3(nb_e), dim3(256), 0, s, e->ctrl, e->g.dim, e->efeat,
                      m->eattr, m->msgsv, ecap);
   hipLaunchKernelGGL(k_sg_node_prep, dim3(nb_n), dim3(256), 0, s, e->g, BN, e->ctrl, m->xnode, 32,
@@ -649,5 +650,8 @@ extern "C" int lb_segnn_rollout(lb_engine* e, lb_segnn* m, const double* traj_de
                                 int32_t n_steps, double* pred_out_dev, int32_t* n_realloc_out) {
   if (!e || !m || !traj_dev || !pred_out_dev) return lb_fail(LB_ERR_ARG, "null argument");
   if (m->eng != e) return lb_fail(LB_ERR_ARG, "model was created for another engine");
-  return lb_rollout_generic(e, sg_forward_thunk, m, traj_dev, T, n_steps, pred_out_dev, n_realloc_out);
+  e->feat_job = lb_feat_job{m->xnode, nullptr, 0, 1, 32, e->ptype, e->force};  // node-feature rows ride along with the search
+  const int rc = lb_rollout_generic(e, sg_forward_thunk, m, traj_dev, T, n_steps, pred_out_dev, n_realloc_out);
+  e->feat_job = lb_feat_job{};
+  return rc;
 }

@@ -12,7 +12,7 @@
 // with unit stride across lanes; the window is a ring of isl slots (frame f of the window that
 // starts at step s lives in slot (s+f) % isl), so advancing the window writes ONE frame instead
 // of the reference's concatenate-and-copy of the whole (N, isl, dim) array.
-#include "lb_device.h"
+#include "lb_features.h"
 
 __global__ void k_load_window(lb_geom g, int64_t BN, const double* __restrict__ traj, int T, int t0,
                               int step, double* __restrict__ win, lb_ctrl* __restrict__ ctrl) {
@@ -78,9 +78,9 @@ int lbk_read_window(lb_engine* e, double* out) {
 }
 
 // -------------------------------------------------------------------------- node features
-// One thread per particle.  Writes the fp32 network input row [vel_hist | vel_mag | bound | force |
-// embedding | 0-pad] (gns.py:135-169 column order) and, when asked, the fp64 feature arrays the
-// Python FeatureDict exposes.
+// One thread per particle (body: lb_features.h).  Writes the fp32 network input row [vel_hist | vel_mag | bound |
+// force | embedding | 0-pad] (gns.py:135-169 column order) and, when asked, the fp64 feature arrays the Python
+// FeatureDict exposes.
 __global__ void k_node_features(lb_geom g, int64_t BN, const double* __restrict__ win,
                                 const lb_ctrl* __restrict__ ctrl, const int32_t* __restrict__ ptype,
                                 const double* __restrict__ force_buf, float* __restrict__ xnode,
@@ -90,71 +90,8 @@ __global__ void k_node_features(lb_geom g, int64_t BN, const double* __restrict_
   if (xnode && ctrl->overflow_step >= 0) return;
   int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gi >= BN) return;
-  const int step = ctrl->step;
-  const int K = g.isl - 1, dim = g.dim;
-  float* x = xnode ? xnode + gi * g.kpad : nullptr;
-  int col = 0;
-  double pprev[3], pcur[3] = {0, 0, 0};
-  for (int d = 0; d < dim; ++d) pprev[d] = lb_pos(win, g, BN, step, 0, d, gi);
-  for (int t = 0; t < K; ++t) {
-    double s2 = 0.0;
-    for (int d = 0; d < dim; ++d) {
-      pcur[d] = lb_pos(win, g, BN, step, t + 1, d, gi);
-      const double v = lb_disp1(pcur[d], pprev[d], g.box[d], g.half_box[d], g.periodic, g.f32);
-      const double nv = lb_r(lb_r(v - g.vel_mean[d], g.f32) / g.vel_std[d], g.f32);
-      if (x) x[t * dim + d] = (float)nv;
-      if (vel_hist) vel_hist[gi * (K * dim) + t * dim + d] = nv;
-      s2 = (d == 0) ? lb_r(nv * nv, g.f32) : lb_r(s2 + lb_r(nv * nv, g.f32), g.f32);
-      pprev[d] = pcur[d];
-    }
-    if (g.has_vel_mag) {
-      const double m = lb_r(sqrt(s2), g.f32);
-      if (x) x[K * dim + t] = (float)m;
-      if (vel_mag) vel_mag[gi * K + t] = m;
-    }
-  }
-  col = K * dim + (g.has_vel_mag ? K : 0);
-  if (K == 0)
-    for (int d = 0; d < dim; ++d) pcur[d] = lb_pos(win, g, BN, step, 0, d, gi);
-  if (g.has_bound) {
-    for (int d = 0; d < dim; ++d) {
-      double lo = lb_r(lb_r(pcur[d] - g.bound_lo[d], g.f32) / g.rc, g.f32);
-      double hi = lb_r(lb_r(g.bound_hi[d] - pcur[d], g.f32) / g.rc, g.f32);
-      lo = fmin(fmax(lo, -1.0), 1.0);
-      hi = fmin(fmax(hi, -1.0), 1.0);
-      if (x) {
-        x[col + d] = (float)lo;
-        x[col + dim + d] = (float)hi;
-      }
-      if (bound) {
-        bound[gi * 2 * dim + d] = lo;
-        bound[gi * 2 * dim + dim + d] = hi;
-      }
-    }
-    col += 2 * dim;
-  }
-  if (g.force_kind != LB_FORCE_NONE) {
-    for (int d = 0; d < dim; ++d) {
-      double f;
-      if (g.force_kind == LB_FORCE_PIECEWISE)
-        f = (pcur[g.force_axis] > g.force_split) ? g.force_hi[d] : g.force_lo[d];
-      else
-        f = force_buf[gi * dim + d];
-      if (x) x[col + d] = (float)f;
-      if (force_out) force_out[gi * dim + d] = f;
-    }
-    col += dim;
-  }
-  if (x) {
-    if (ntypes > 1) {
-      int t = ptype[gi];
-      if (t < 0) t += ntypes;  // jnp negative index wraps (PAD_VALUE = -1 -> last row)
-      t = t < 0 ? 0 : (t >= ntypes ? ntypes - 1 : t);
-      for (int j = 0; j < emb; ++j) x[col + j] = embed[t * emb + j];
-      col += emb;
-    }
-    for (int j = col; j < g.kpad; ++j) x[j] = 0.f;
-  }
+  lb_node_features_body(g, BN, win, ctrl->step, ptype, force_buf, xnode, embed, emb, ntypes, vel_hist, vel_mag, bound,
+                        force_out, gi);
 }
 
 int lbk_node_features(lb_engine* e, float* xnode, const float* embed, int emb, int ntypes,
@@ -199,26 +136,7 @@ __global__ void k_integrate(lb_geom g, int64_t BN, double* __restrict__ win,
     }
   }
   if (gi >= BN) return;
-  const int b = (int)(gi / g.N), i = (int)(gi % g.N);
-  const int pt = ptype[gi];
-  const bool kinematic = (pt == 1) || (pt == 2) || (pt == -1);  // utils.py:28-35
-  const int slot_new = (step + g.isl) % g.isl;
-  int tf = g.isl + step;
-  if (tf > T - 1) tf = T - 1;  // JAX clamps the out-of-range gather (rollout.py:159)
-  for (int d = 0; d < g.dim; ++d) {
-    double out;
-    if (kinematic) {
-      out = target ? target[gi * g.dim + d] : traj[(gi * T + tf) * g.dim + d];
-    } else {
-      const double p1 = lb_pos(win, g, BN, step, g.isl - 1, d, gi);
-      const double p0 = lb_pos(win, g, BN, step, g.isl - 2, d, gi);
-      const double a = lb_r(g.acc_mean[d] + lb_r((double)acc[gi * acc_stride + d] * g.acc_std[d], g.f32), g.f32);
-      const double v = lb_disp1(p1, p0, g.box[d], g.half_box[d], g.periodic, g.f32);
-      out = lb_shift1(p1, lb_r(v + a, g.f32), g.box[d], g.periodic, g.f32);
-    }
-    win[((int64_t)slot_new * g.dim + d) * BN + gi] = out;
-    if (pred && step < pred_T) pred[(((int64_t)b * pred_T + step) * g.N + i) * g.dim + d] = out;
-  }
+  lb_integrate_body(g, BN, win, step, ptype, acc + gi * acc_stride, target, traj, T, pred, pred_T, gi);
 }
 
 // case.integrate alone (stateless), case.py:230-259.

@@ -21,6 +21,8 @@ SWITCHES = [
     {"LB_EDGE_NT_MIN_TILES": "0"},                        # nontemporal edge-latent streams also on small graphs
     {"LB_GUARD": "full", "LB_MSPLIT": "0"},               # every tile of the wave-per-tile edge kernel range-tested
     {"LB_PERSIST": "1"},                                  # all message-passing layers in one persistent launch
+    {"LB_NL_ONE": "0"},                                   # four-launch neighbor build also for one small trajectory
+    {"LB_STEP_FUSE": "0"},                                # node features / integrator as launches of their own
     {"LB_TEST_RESUME_AT": "3"},                           # guard fires at step 3: the rollout resumes there in fp32
 ]
 
