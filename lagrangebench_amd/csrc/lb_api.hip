@@ -295,6 +295,9 @@ int lb_ensure_edges(lb_engine* e, int64_t need) {
   LB_TRY(lb_alloc(&e->part, (size_t)(n / 16 + 2) * 2 * LB_D));  // sized for the 16-row tiles
   LB_TRY(lb_alloc(&e->senders, (size_t)n));
   LB_TRY(lb_alloc(&e->receivers, (size_t)n));
+  // (kernels may gather through index rows past the current edge count before they know it: keep every row a valid id)
+  LB_HIP(hipMemsetAsync(e->senders, 0, sizeof(int32_t) * (size_t)n, e->stream));
+  LB_HIP(hipMemsetAsync(e->receivers, 0, sizeof(int32_t) * (size_t)n, e->stream));
   LB_TRY(lb_alloc(&e->efeat, (size_t)n * 8));
   LB_TRY(lb_alloc(&e->efeat64, (size_t)n * 4));
   LB_TRY(lb_alloc(&e->elat, (size_t)(n + 32) * LB_D));  // tile-blocked in the 16-row kernels: pad to a tile

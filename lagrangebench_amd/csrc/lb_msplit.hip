@@ -28,6 +28,7 @@
 // (LARGE / non-finite) and a per-tile maximum combined across the waves (TINY), one atomicOr per wave and launch.
 #include <stdio.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <string.h>
 
 #include <algorithm>
@@ -85,13 +86,17 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
   __shared__ f32x4 sB1[4 * 2 * 64];
   __shared__ f32x4 sB2[4 * 2 * 64];
   __shared__ __attribute__((aligned(16))) f32x2m sRed[16 * 4];
-  __shared__ __attribute__((aligned(16))) float sMx[2][4];
+  __shared__ __attribute__((aligned(16))) int sMx[2][4];
   const int poisoned = a.ctrl->overflow_step;
   const int E = a.ctrl->n_edges_total;
   const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
   MS_STAMP(0);
+  // XCD-contiguous tile walk: the receivers of an XCD's edge tiles are (mostly) the nodes of the same XCD's node
+  // tiles, so the aggregated messages / projections cross kernels through that XCD's L2.  (Tried in round 3: a
+  // round-robin walk whose first tile does not wait for the edge count - the edge launch gains 0.1 us, the node
+  // launch that reads agg / part from seven other L2s loses 1 us.)
   const int ntiles = (E + 15) >> 4;
   ms_walk wk;
   if (poisoned >= 0 || !wk.init(ntiles)) return;  // uniform over the workgroup
@@ -147,10 +152,11 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
     }
     const int rcur = nr, rb = nrb;
     if (it < 3) MS_STAMP(1 + 8 * it);
-    ms_stage<false>(sB1, w, lane, ve[0], ve[1]);
+    uint32_t orv;
+    ms_stage<false>(sB1, w, lane, ve[0], ve[1], orv, guard.big);
     {
-      const float m = ms_wave_max(guard.see(ve[0], ve[1]));
-      if (lane == 0) sMx[0][w] = m;
+      const int c = guard.code(orv);
+      if (lane == 0) sMx[0][w] = c;
     }
     // the next tile's loads (and the indices of the one after) go out before this tile's GEMMs
     issue(min(t + wk.stride, wk.q_last));
@@ -159,18 +165,19 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
     __syncthreads();
     if (it < 3) MS_STAMP(3 + 8 * it);
     ms_gemm<4, 2>(sB1, lane, w0h, w0l, acc);
-    guard.tile_max(sMx[0]);
-    ms_stage<true>(sB2, w, lane, acc[0], acc[1]);
+    guard.tile_codes(sMx[0]);
+    uint32_t orv2;
+    ms_stage<true>(sB2, w, lane, acc[0], acc[1], orv2, guard.big);
     {
-      const float m = ms_wave_max(guard.see(acc[0], acc[1]));
-      if (lane == 0) sMx[1][w] = m;
+      const int c = guard.code(orv2);
+      if (lane == 0) sMx[1][w] = c;
     }
     if (it < 3) MS_STAMP(4 + 8 * it);
     __syncthreads();
     if (it < 3) MS_STAMP(5 + 8 * it);
     f32x4 acc2[2] = {b1v[0], b1v[1]};
     ms_gemm<4, 2>(sB2, lane, w1h, w1l, acc2);
-    guard.tile_max(sMx[1]);
+    guard.tile_codes(sMx[1]);
     {
       const f32x2m p = ms_ln_local(acc2[0], acc2[1]);
       if (g == 0) sRed[n * 4 + w] = p;
@@ -230,7 +237,7 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
 __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_enc_ms(lb_ems_args a) {
   __shared__ f32x4 sB2[4 * 2 * 64];
   __shared__ __attribute__((aligned(16))) f32x2m sRed[16 * 4];
-  __shared__ __attribute__((aligned(16))) float sMx[4];
+  __shared__ __attribute__((aligned(16))) int sMx[4];
   const int poisoned = a.ctrl->overflow_step;
   const int E = a.ctrl->n_edges_total;
   const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
@@ -278,15 +285,16 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_enc_ms(lb_ems_args a) {
       for (int c = 0; c < 2; ++c) acc[c] = MFMA16H(w0h[c][0], bh, acc[c]);
     }
     issue(min(t + wk.stride, wk.q_last));
-    ms_stage<true>(sB2, w, lane, acc[0], acc[1]);
+    uint32_t orv;
+    ms_stage<true>(sB2, w, lane, acc[0], acc[1], orv, guard.big);
     {
-      const float m = ms_wave_max(guard.see(acc[0], acc[1]));
-      if (lane == 0) sMx[w] = m;
+      const int c = guard.code(orv);
+      if (lane == 0) sMx[w] = c;
     }
     __syncthreads();
     f32x4 acc2[2] = {b1v[0], b1v[1]};
     ms_gemm<4, 2>(sB2, lane, w1h, w1l, acc2);
-    guard.tile_max(sMx);
+    guard.tile_codes(sMx);
     {
       const f32x2m p = ms_ln_local(acc2[0], acc2[1]);
       if (g == 0) sRed[n * 4 + w] = p;
@@ -321,13 +329,15 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a) {
   __shared__ f32x4 sB2[T][4 * 2 * 64];
   __shared__ f32x4 sB3[PROJ ? T : 1][4 * 2 * 64];
   __shared__ __attribute__((aligned(16))) f32x2m sRed[T][16 * 4];
-  __shared__ __attribute__((aligned(16))) float sMx[3][T][4];
+  __shared__ __attribute__((aligned(16))) int sMx[3][T][4];
   const int poisoned = a.ctrl->overflow_step;
   const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
   const int ntiles = (int)((a.n_rows + 15) >> 4);
   ms_walk wk;
+  // (acting on the poison flag only after the first loads are out - the trick of the edge kernels - measured SLOWER
+  // here: 9.4 -> 10.3 us per launch on TGV2D-2.5k)
   if (poisoned >= 0 || !wk.init((ntiles + T - 1) / T)) return;
   const f32x4* xin4 = reinterpret_cast<const f32x4*>(a.xin);
   const bool has_x = w < NKA;  // this wave holds an input k-block (uniform)
@@ -423,17 +433,11 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a) {
     if (it < 2) MS_STAMP(3 + 12 * it);
 #pragma unroll
     for (int i = 0; i < T; ++i) {
-      float m = 0.f;
-      if (has_x) {
-        ms_stage<false>(sB1[i], w, lane, xa[i][0], xa[i][1]);
-        m = guard.see(xa[i][0], xa[i][1]);
-      }
-      if constexpr (AGG) {
-        ms_stage<false>(sB1[i], NKA + w, lane, ag[i][0], ag[i][1]);
-        m = fmaxf(m, guard.see(ag[i][0], ag[i][1]));
-      }
-      m = ms_wave_max(m);
-      if (lane == 0) sMx[0][i][w] = m;
+      uint32_t orv = 0u, orv2 = 0u;  // the tile's first operand is [rows | aggregated messages]: one code for both
+      if (has_x) ms_stage<false>(sB1[i], w, lane, xa[i][0], xa[i][1], orv, guard.big);
+      if constexpr (AGG) ms_stage<false>(sB1[i], NKA + w, lane, ag[i][0], ag[i][1], orv2, guard.big);
+      const int c = guard.code(orv | orv2);
+      if (lane == 0) sMx[0][i][w] = c;
     }
     if (it < 2) MS_STAMP(4 + 12 * it);
     __syncthreads();
@@ -447,10 +451,11 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a) {
     }
 #pragma unroll
     for (int i = 0; i < T; ++i) {
-      guard.tile_max(sMx[0][i]);
-      ms_stage<true>(sB2[i], w, lane, acc[i][0], acc[i][1]);
-      const float m = ms_wave_max(guard.see(acc[i][0], acc[i][1]));
-      if (lane == 0) sMx[1][i][w] = m;
+      guard.tile_codes(sMx[0][i]);
+      uint32_t orv;
+      ms_stage<true>(sB2[i], w, lane, acc[i][0], acc[i][1], orv, guard.big);
+      const int c = guard.code(orv);
+      if (lane == 0) sMx[1][i][w] = c;
     }
     if (it < 2) MS_STAMP(6 + 12 * it);
     __syncthreads();
@@ -464,7 +469,7 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a) {
     }
 #pragma unroll
     for (int i = 0; i < T; ++i) {
-      guard.tile_max(sMx[1][i]);
+      guard.tile_codes(sMx[1][i]);
       const f32x2m p = ms_ln_local(acc2[i][0], acc2[i][1]);
       if (g == 0) sRed[i][n * 4 + w] = p;
     }
@@ -484,9 +489,10 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a) {
         if (valid[i]) reinterpret_cast<f32x4*>(a.nlat)[rcv[i] * 32 + 8 * w + 4 * c + g] = y[i][c];
       }
       if constexpr (PROJ) {
-        ms_stage<false>(sB3[i], w, lane, y[i][0], y[i][1]);
-        const float m = ms_wave_max(guard.see(y[i][0], y[i][1]));
-        if (lane == 0) sMx[2][i][w] = m;
+        uint32_t orv;
+        ms_stage<false>(sB3[i], w, lane, y[i][0], y[i][1], orv, guard.big);
+        const int c = guard.code(orv);
+        if (lane == 0) sMx[2][i][w] = c;
       }
     }
     if (it < 2) MS_STAMP(10 + 12 * it);
@@ -495,7 +501,7 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a) {
       if (it < 2) MS_STAMP(11 + 12 * it);
 #pragma unroll
       for (int i = 0; i < T; ++i) {
-        guard.tile_max(sMx[2][i]);
+        guard.tile_codes(sMx[2][i]);
         f32x4 accp[4] = {bpv[0], bpv[1], bpv[2], bpv[3]};
         ms_gemm<4, 4>(sB3[i], lane, wph, wpl, accp);
         if (valid[i]) {
@@ -554,7 +560,8 @@ int lbk_edge_ms(lb_engine* e, const lb_ems_args& a_in) {
   return LB_OK;
 }
 
-int lbk_edge_enc_ms(lb_engine* e, const lb_ems_args& a) {
+int lbk_edge_enc_ms(lb_engine* e, const lb_ems_args& a_in) {
+  lb_ems_args a = a_in;
   const int64_t tiles_cap = ((int64_t)e->e_cap * e->g.B + 15) / 16;
   hipLaunchKernelGGL(k_edge_enc_ms, dim3(ms_grid(tiles_cap, 2)), dim3(MS_THREADS), 0, e->stream, a);
   LB_HIP(hipGetLastError());

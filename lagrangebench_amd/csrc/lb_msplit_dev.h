@@ -10,11 +10,19 @@ typedef float f32x2m __attribute__((ext_vector_type(2)));
 typedef _Float16 h2m __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2m __attribute__((ext_vector_type(2)));
 
-// LB_MS_DBG=1 (debug): wave 0 of workgroup 0 stamps the shader clock at phase boundaries
+// Built with -DLB_MS_STAMPS (debug builds only; LB_MS_DBG=1 then prints them): wave 0 of workgroup 0 stamps the shader
+// clock at phase boundaries.  Not in the product library: the run-time test alone cost ~60 scalar instructions and nine
+// exec-mask round trips per tile.
+#ifdef LB_MS_STAMPS
 #define MS_STAMP(k)                                                              \
   do {                                                                           \
     if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[k] = clock64();      \
   } while (0)
+#else
+#define MS_STAMP(k) \
+  do {              \
+  } while (0)
+#endif
 #define MS_WAVES 4
 #define MS_THREADS (MS_WAVES * 64)
 
@@ -59,29 +67,36 @@ __device__ __forceinline__ float ms_absmax4(const f32x4& x) {
   return fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
 }
 
-// 8 values (this wave's two output blocks of one row) -> fp16 hi (RNE) and lo = fp16(x - hi), as one B-fragment
-// k-block entry: elements 0-3 from block c = 0, 4-7 from c = 1
+// write this wave's 32 features x 16 rows (C layout) as k-block kb of a tile's B-fragment image [kb][part][lane].
+// Round-3b instruction diet (the M-split kernels are bound by VALU issue: every wave repeats the per-tile work):
+// ReLU as an integer max, the split on the mixed-precision fma (lb_split8v: 12 VALU per 8 values instead of 30),
+// and the range guard fed from what the split produces anyway - `orv` receives the OR of the fp16 `hi` bit patterns
+// (TINY test, lb_tile_tiny's encoding), `big` the running max |operand| through v_max3 with |abs| modifiers.
 template <bool RELU>
-__device__ __forceinline__ void ms_split8(const f32x4& x0, const f32x4& x1, h8& hi, h8& lo) {
-  f32x2m a[4] = {{x0[0], x0[1]}, {x0[2], x0[3]}, {x1[0], x1[1]}, {x1[2], x1[3]}};
-  h2m hh[4], ll[4];
+__device__ __forceinline__ void ms_stage(f32x4* img, int kb, int lane, const f32x4& x0, const f32x4& x1, uint32_t& orv,
+                                         float& big) {
+  f32x4 r0 = x0, r1 = x1;
+  if (RELU) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (RELU) a[i] = f32x2m{fmaxf(a[i][0], 0.f), fmaxf(a[i][1], 0.f)};
-    hh[i] = __builtin_convertvector(a[i], h2m);
-    ll[i] = __builtin_convertvector(a[i] - __builtin_convertvector(hh[i], f32x2m), h2m);
+    for (int j = 0; j < 4; ++j) {
+      const float f0 = x0[j], f1 = x1[j];
+      r0[j] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, f0), 0));
+      r1[j] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, f1), 0));
+    }
   }
-  hi = h8{hh[0][0], hh[0][1], hh[1][0], hh[1][1], hh[2][0], hh[2][1], hh[3][0], hh[3][1]};
-  lo = h8{ll[0][0], ll[0][1], ll[1][0], ll[1][1], ll[2][0], ll[2][1], ll[3][0], ll[3][1]};
-}
-
-// write this wave's 32 features x 16 rows (C layout) as k-block kb of a tile's B-fragment image [kb][part][lane]
-template <bool RELU>
-__device__ __forceinline__ void ms_stage(f32x4* img, int kb, int lane, const f32x4& x0, const f32x4& x1) {
   h8 hi, lo;
-  ms_split8<RELU>(x0, x1, hi, lo);
+  lb_split8v(r0, r1, hi, lo);
   img[(kb * 2 + 0) * 64 + lane] = __builtin_bit_cast(f32x4, hi);
   img[(kb * 2 + 1) * 64 + lane] = __builtin_bit_cast(f32x4, lo);
+  typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+  const u32x4s u = __builtin_bit_cast(u32x4s, hi);
+  orv = (u[0] | u[1]) | (u[2] | u[3]);
+  asm("v_max3_f32 %0, |%1|, |%2|, %0\n\t"
+      "v_max3_f32 %0, |%3|, |%4|, %0\n\t"
+      "v_max3_f32 %0, |%5|, |%6|, %0\n\t"
+      "v_max3_f32 %0, |%7|, |%8|, %0"
+      : "+v"(big)
+      : "v"(r0[0]), "v"(r0[1]), "v"(r0[2]), "v"(r0[3]), "v"(r1[0]), "v"(r1[1]), "v"(r1[2]), "v"(r1[3]));
 }
 
 // acc[c] += W_c^T B over NKB k-blocks for this wave's NB output blocks: weights from registers, B fragments from the
@@ -142,28 +157,30 @@ __device__ __forceinline__ void ms_ln_combine(const f32x2m* red, int n, float in
   rs = 1.0f / sqrtf(fmaxf(m2 - pad * (mean * mean), 0.f) * inv_d + 1e-5f);
 }
 
-// running range-guard state of a wave (see the header)
+// running range-guard state of a wave (see the header).  LARGE: `big` = max |x| over every GEMM operand element this
+// wave staged (ms_stage; a value that leaves the fp16 range is seen BEFORE its `hi` becomes inf).  TINY: per tile and
+// operand, the OR of the `hi` bit patterns says whether every element is below 2^-11 (exponent bits 14:12 clear) and
+// not all are zero; the 4 waves hold 32 features each of the tile's rows, so each posts a 2-bit code (1 = something
+// non-zero, 2 = something >= 2^-11) and the tile is TINY iff the OR of the four codes is exactly 1.
 struct ms_guard {
-  float big;  // max |x| over every operand seen
+  float big;
   int flags;
-  __device__ __forceinline__ float see(const f32x4& x0, const f32x4& x1) {
-    const float m = fmaxf(ms_absmax4(x0), ms_absmax4(x1));
-    big = fmaxf(big, m);
-    if (!(m == m)) flags |= LB_MATH_LARGE;  // NaN
-    return m;
+  // this wave's code for one staged operand (wave-uniform; lane 0 writes it to the tile's slot before the barrier)
+  __device__ __forceinline__ int code(uint32_t orv) const {
+    return (__any((orv & 0x70007000u) != 0u) ? 2 : 0) | (__any((orv & 0x7fff7fffu) != 0u) ? 1 : 0);
   }
-  // tile-wide maximum of an operand, combined over the 4 waves through `slot` (4 floats, written before a barrier)
-  __device__ __forceinline__ void tile_max(const float* slot) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(slot);
-    const float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
-    if (m > 0.f && m < 0.0009765625f) flags |= LB_MATH_TINY;
+  // after the barrier: the four waves' codes of one operand (`slot`: 4 ints)
+  __device__ __forceinline__ void tile_codes(const int* slot) {
+    typedef int i32x4s __attribute__((ext_vector_type(4)));
+    const i32x4s c = *reinterpret_cast<const i32x4s*>(slot);
+    if (((c[0] | c[1]) | (c[2] | c[3])) == 1) flags |= LB_MATH_TINY;
   }
   __device__ __forceinline__ void commit(const lb_ctrl* ctrl, int lane) {
     const float m = ms_wave_max(big);
     int f = flags;
     if (!(m < 32768.f)) f |= LB_MATH_LARGE;  // close to the fp16 range, inf
-    const bool any_nan = __any(f & LB_MATH_LARGE), any_tiny = __any(f & LB_MATH_TINY);
-    f = (any_nan ? LB_MATH_LARGE : 0) | (any_tiny ? LB_MATH_TINY : 0);
+    const bool any_large = __any(f & LB_MATH_LARGE), any_tiny = __any(f & LB_MATH_TINY);
+    f = (any_large ? LB_MATH_LARGE : 0) | (any_tiny ? LB_MATH_TINY : 0);
     if (lane == 0 && f) lb_raise_math(ctrl, f);
   }
 };

@@ -752,16 +752,20 @@ struct lb_nls_args {
     }                                                                                                      \
   } while (0)
 
-template <bool F32>
+// DIM is a template parameter: under a loop bounded by the run-time dimension the per-dimension register arrays are
+// indexed by a run-time value and land in scratch (144 B per lane, every access a memory round trip)
+template <bool F32, int DIM>
 __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __restrict__ ctrl, lb_nls_args a) {
   extern __shared__ double s_dynd[];
+  if (a.dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+    a.dbg[24 + (blockIdx.x == 0 ? 0 : 1)] = wall_clock64();
   if (ctrl->overflow_step >= 0) return;
   const int N = g.N, npad = a.npad;
   const int nwv = blockDim.x >> 6, nwords = npad >> 6;
   double* const s_p = s_dynd;  // [dim][npad]
-  unsigned long long* const s_tab = reinterpret_cast<unsigned long long*>(s_p + g.dim * npad);  // per dim [ncell[d]][nwords]
+  unsigned long long* const s_tab = reinterpret_cast<unsigned long long*>(s_p + DIM * npad);  // per dim [ncell[d]][nwords]
   const int tab_off[3] = {0, g.ncell[0] * nwords, (g.ncell[0] + g.ncell[1]) * nwords};
-  const int tab_len = (g.ncell[0] + g.ncell[1] + (g.dim == 3 ? g.ncell[2] : 0)) * nwords;
+  const int tab_len = (g.ncell[0] + g.ncell[1] + (DIM == 3 ? g.ncell[2] : 0)) * nwords;
   int* const s_cell = reinterpret_cast<int*>(s_tab + (g.use_cell_list ? tab_len : 0));  // [npad] x | y << 11 | z << 22
   int* const s_row = s_cell + npad;                                                      // [waves][NLS_CAND]
   int* const s_cnt = s_row + nwv * NLS_CAND;  // [0..15] row sizes, [16] base, [17] flags, [18] max occ
@@ -778,7 +782,7 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
   {
     constexpr int PER = 4;  // npad <= 256 * waves
     const int slot = (step + g.isl - 1) % g.isl;
-    const double* const w0 = a.win + (int64_t)slot * g.dim * N;
+    const double* const w0 = a.win + (int64_t)slot * DIM * N;
     double pv[PER][3];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -786,16 +790,16 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
       const int ic = i < N ? i : N - 1;
       pv[k][0] = w0[ic];
       pv[k][1] = w0[N + ic];
-      pv[k][2] = g.dim == 3 ? w0[2 * N + ic] : 0.0;
+      pv[k][2] = DIM == 3 ? w0[2 * N + ic] : 0.0;
     }
     double inv_cs[3];
-    for (int d = 0; d < 3; ++d) inv_cs[d] = d < g.dim ? 1.0 / g.cell_size[d] : 0.0;
+    _Pragma("unroll") for (int d = 0; d < 3; ++d) inv_cs[d] = d < DIM ? 1.0 / g.cell_size[d] : 0.0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int i = tid + (int)blockDim.x * k;
       if (i < npad) {
         int packed = 0;
-        for (int d = 0; d < g.dim; ++d) {
+        _Pragma("unroll") for (int d = 0; d < DIM; ++d) {
           const double p = pv[k][d];
           s_p[d * npad + i] = p;
           // the quotient decides through its integer part only: the reciprocal product is exact enough unless it
@@ -819,7 +823,7 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
       const int b = (k + lane) & 63;
       const int pc = s_cell[lane * 64 + b];
       if (pc >= 0)
-        for (int d = 0; d < g.dim; ++d)
+        _Pragma("unroll") for (int d = 0; d < DIM; ++d)
           atomicOr(&s_tab[tab_off[d] + ((pc >> (11 * d)) & 0x7ff) * nwords + lane], 1ull << b);
     }
   }
@@ -833,13 +837,13 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
   int* const row = s_row + wave * NLS_CAND;
   if (r < N) {
     if (a.feat.xnode) lb_node_features_wave(g, N, a.win, step, a.feat, r);
-    for (int d = 0; d < g.dim; ++d) pr[d] = s_p[d * npad + r];
+    _Pragma("unroll") for (int d = 0; d < DIM; ++d) pr[d] = s_p[d * npad + r];
     int ncand = N;  // (no cell list: every particle is a candidate, pass 2 walks the ids)
     if (g.use_cell_list) {
       const int pc = s_cell[r];
       unsigned long long m = ~0ull, ms = ~0ull;
       if (lane < nwords) {
-        for (int d = 0; d < g.dim; ++d) {
+        _Pragma("unroll") for (int d = 0; d < DIM; ++d) {
           const int n = g.ncell[d], c = (pc >> (11 * d)) & 0x7ff;
           const unsigned long long* T = s_tab + tab_off[d] + lane;
           const unsigned long long t0 = T[c * nwords];  // the stencil wraps like jax-md's rolled cell buffer
@@ -881,7 +885,7 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
         // metric_sq(position[sender], position[receiver]) as in k_nl
         double dd = lb_disp1(s_p[j], pr[0], g.box[0], g.half_box[0], g.periodic, F32);
         double d2 = lb_r(dd * dd, F32);
-        for (int d = 1; d < g.dim; ++d) {
+        _Pragma("unroll") for (int d = 1; d < DIM; ++d) {
           dd = lb_disp1(s_p[d * npad + j], pr[d], g.box[d], g.half_box[d], g.periodic, F32);
           d2 = lb_r(d2 + lb_r(dd * dd, F32), F32);
         }
@@ -961,13 +965,13 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
       // features.py:115-124: disp(pos[receiver], pos[sender]) / r_c and its norm
       double rd[3] = {0, 0, 0};
       double s2 = 0.0;
-      for (int d = 0; d < g.dim; ++d) {
+      _Pragma("unroll") for (int d = 0; d < DIM; ++d) {
         rd[d] = lb_r(lb_disp1(pr[d], s_p[d * npad + j], g.box[d], g.half_box[d], g.periodic, F32) / g.rc, F32);
         s2 = (d == 0) ? lb_r(rd[d] * rd[d], F32) : lb_r(s2 + lb_r(rd[d] * rd[d], F32), F32);
       }
       const double dist = s2 > 0.0 ? lb_r(sqrt(s2), F32) : 0.0;
       f32x4* ef = reinterpret_cast<f32x4*>(a.efeat + slot * 8);
-      ef[0] = (g.dim == 2) ? f32x4{(float)rd[0], (float)rd[1], (float)dist, 0.f}
+      ef[0] = (DIM == 2) ? f32x4{(float)rd[0], (float)rd[1], (float)dist, 0.f}
                            : f32x4{(float)rd[0], (float)rd[1], (float)rd[2], (float)dist};
       ef[1] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (a.efeat64) {
@@ -1085,7 +1089,7 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   const int nls_waves = (int)std::min<int64_t>(NLS_WAVES, std::max<int64_t>(1, (BN + 255) / 256));
   const int64_t nls_tab = g.use_cell_list ? (int64_t)(g.ncell[0] + g.ncell[1] + (g.dim == 3 ? g.ncell[2] : 0)) * (nls_npad / 64) : 0;
   const size_t nls_lds = (size_t)nls_npad * (8 * g.dim + 4) + 8 * (size_t)nls_tab + sizeof(int) * ((size_t)nls_waves * NLS_CAND + 32);
-  if (one_ok && small_ok && frozen && g.B == 1 && BN <= LB_SMALL_N && !e->nl_dense && !e->nl_one_off && nls_lds <= 150 * 1024 &&
+  if (one_ok && small_ok && frozen && g.B == 1 && (g.dim == 2 || g.dim == 3) && BN <= LB_SMALL_N && !e->nl_dense && !e->nl_one_off && nls_lds <= 150 * 1024 &&
       (!g.use_cell_list || (int64_t)e->cell_capacity * g.nstencil <= NLS_CAND) &&
       e->nl_wg_sum && g.ncell[0] < 2048 && g.ncell[1] < 2048 && g.ncell[2] < 1024 && NLS_CAND >= LB_MAX_ROW) {
     lb_tic(e, LB_T_NEIGH);
@@ -1107,7 +1111,7 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
     a.host_flag = e->host_flag_dev;
     static const bool nls_dbg = getenv("LB_NLS_DBG") && getenv("LB_NLS_DBG")[0] == '1';
     static long long* dbg_dev = nullptr;
-    if (nls_dbg && !dbg_dev) LB_HIP(hipMalloc((void**)&dbg_dev, sizeof(long long) * 24));
+    if (nls_dbg && !dbg_dev) LB_HIP(hipMalloc((void**)&dbg_dev, sizeof(long long) * 32));
     a.dbg = nls_dbg ? dbg_dev : nullptr;
     const int nwv = nls_waves;
     const size_t lds = nls_lds;
@@ -1116,17 +1120,20 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
       a.feat = e->feat_job;
       e->feat_done = true;
     }
+#define LB_NLS_LAUNCH(F, D)                                                                                      \
+  do {                                                                                                          \
+    if (lds > 48 * 1024)                                                                                        \
+      (void)hipFuncSetAttribute((const void*)k_nl_small<F, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_nl_small<F, D>), dim3(nb), dim3(64 * nwv), lds, s, g, e->ctrl, a);                    \
+  } while (0)
     if (g.f32) {
-      if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void*)k_nl_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_nl_small<true>), dim3(nb), dim3(64 * nwv), lds, s, g, e->ctrl, a);
+      if (g.dim == 3) LB_NLS_LAUNCH(true, 3); else LB_NLS_LAUNCH(true, 2);
     } else {
-      if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void*)k_nl_small<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_nl_small<false>), dim3(nb), dim3(64 * nwv), lds, s, g, e->ctrl, a);
+      if (g.dim == 3) LB_NLS_LAUNCH(false, 3); else LB_NLS_LAUNCH(false, 2);
     }
+#undef LB_NLS_LAUNCH
     if (nls_dbg) {
-      long long h[24];
+      long long h[32];
       LB_HIP(hipStreamSynchronize(s));
       LB_HIP(hipMemcpy(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost));
       static int n_print = 0;
@@ -1134,7 +1141,7 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
         for (int w = 0; w < 3; ++w) {
           fprintf(stderr, "k_nl_small wg%d (10 ns ticks from wg0 start):", w);
           for (int k = 0; k < 8; ++k) fprintf(stderr, " %lld", h[w * 8 + k] - h[0]);
-          fprintf(stderr, "\n");
+          fprintf(stderr, "  | entry wg0 %lld, last wg %lld\n", h[24] - h[0], h[25] - h[0]);
         }
     }
     lb_toc(e);
