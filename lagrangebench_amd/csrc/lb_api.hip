@@ -584,6 +584,11 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     lb_pack_weight16h(src, K, M, Kp, tmp.data(), Mp);
     return put(tmp.data(), tmp.size());
   };
+  auto put_packed32h = [&](const float* src) -> size_t {  // D x D, 32-edge-tile fragment order (lb_edge32.hip)
+    std::vector<float> tmp((size_t)D * D);
+    lb_pack_weight32h(src, D, D, tmp.data());
+    return put(tmp.data(), tmp.size());
+  };
   auto put_packed = [&](const float* src, int K, int M, int Kp, int Mp) -> size_t {
     std::vector<float> tmp((size_t)Kp * Mp);
     lb_pack_weight(src, K, M, Kp, Mp, tmp.data());
@@ -639,7 +644,7 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
   const size_t o_ee_w1_16 = put_packed16(p_enc_edge + (size_t)d->edge_in * D + D, D, D, D);
   const size_t o_ee_w0_16h = put_packed16h(p_enc_edge, d->edge_in, D, 32);
   const size_t o_ee_w1_16h = put_packed16h(p_enc_edge + (size_t)d->edge_in * D + D, D, D, D);
-  std::vector<size_t> o_pe_w0_16(L), o_pe_w1_16(L), o_pe_w0_16h(L), o_pe_w1_16h(L);
+  std::vector<size_t> o_pe_w0_16(L), o_pe_w1_16(L), o_pe_w0_16h(L), o_pe_w1_16h(L), o_pe_w0_32h(L), o_pe_w1_32h(L);
   std::vector<Off> o_pe(L), o_pn(L);
   std::vector<size_t> o_pw(L), o_pb(L);
   for (int k = 0; k < L; ++k) {
@@ -670,10 +675,12 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     o.w0 = put_packed(w0 + (size_t)2 * D * D, D, D, D, D);  // edge rows only
     o_pe_w0_16[k] = put_packed16(w0 + (size_t)2 * D * D, D, D, D);
     o_pe_w0_16h[k] = put_packed16h(w0 + (size_t)2 * D * D, D, D, D);
+    o_pe_w0_32h[k] = put_packed32h(w0 + (size_t)2 * D * D);
     o.b0 = put(b0, D);
     p += (size_t)3 * D * D + D;
     o_pe_w1_16[k] = put_packed16(p, D, D, D);
     o_pe_w1_16h[k] = put_packed16h(p, D, D, D);
+    o_pe_w1_32h[k] = put_packed32h(p);
     o.w1 = put_packed(p, D, D, D, D); p += (size_t)D * D;
     o.b1 = put(p, D); p += D;
     o.ln = true;
@@ -806,6 +813,8 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     g->proj_w_h2.push_back(g->blob + o_pw_h2[k]);
     g->proc_edge_w0_16h.push_back(g->blob + o_pe_w0_16h[k]);
     g->proc_edge_w1_16h.push_back(g->blob + o_pe_w1_16h[k]);
+    g->proc_edge_w0_32h.push_back(g->blob + o_pe_w0_32h[k]);
+    g->proc_edge_w1_32h.push_back(g->blob + o_pe_w1_32h[k]);
   }
   g->ms_enc_node = g->blob + o_ms_enc_node;
   g->ms_enc_edge = g->blob + o_ms_enc_edge;

@@ -537,7 +537,15 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       b.agg = e->agg;
       b.part = e->part;
       b.skip_elat_store = skip;
-      rc = (e->f16x2 && e->fused_agg) ? lbk_edge16v(e, b) : lbk_edge16(e, b, true, e->f16x2 != 0);
+      // LB_EDGE32=1: 32-edge tiles on the 32x32x16 MFMA (lb_edge32.hip)
+      static const bool edge32 = getenv("LB_EDGE32") && getenv("LB_EDGE32")[0] == '1';
+      if (e->f16x2 && e->fused_agg && edge32) {
+        b.w0p = g->proc_edge_w0_32h[k];
+        b.w1p = g->proc_edge_w1_32h[k];
+        rc = lbk_edge32(e, b);
+      } else {
+        rc = (e->f16x2 && e->fused_agg) ? lbk_edge16v(e, b) : lbk_edge16(e, b, true, e->f16x2 != 0);
+      }
     }
     lb_toc(e);
     if (rc) return rc;

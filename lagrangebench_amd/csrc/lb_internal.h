@@ -262,6 +262,7 @@ struct lb_gns {
   const float* enc_edge_w0_16h;                // f16x2 (hi|lo) packings
   const float* enc_edge_w1_16h;
   std::vector<const float*> proc_edge_w0_16h, proc_edge_w1_16h;
+  std::vector<const float*> proc_edge_w0_32h, proc_edge_w1_32h;  // 32-edge-tile fragment order (lb_edge32.hip)
   // f16x2 node-MLP packings: w0 (Kpad x 128), w1 (128 x 128), projection (128 x 256)
   const float* enc_node_w0_h;
   const float* enc_node_w1_h;
@@ -406,6 +407,9 @@ void lb_pack_weight16h(const float* w, int K, int M, int Kpad, float* out, int M
 int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const float* w1h,
                 const float* wph2, int npa, int npb, bool resid);
 int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc, bool f16x2);
+// lb_edge32.hip: the processor edge kernel on 32-edge tiles (w0p / w1p: lb_pack_weight32h images)
+void lb_pack_weight32h(const float* w, int K, int M, float* out);
+int lbk_edge32(lb_engine* e, const lb_edge16_args& a);
 // lb_edge16v.hip: processor edge kernel (f16x2, fused aggregation, two waves per SIMD)
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a);
 int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a);
