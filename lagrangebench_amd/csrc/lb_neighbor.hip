@@ -624,6 +624,88 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// NL_ROWS -> CSR for batches of at most LB_CSCAN_N nodes: degree scan, k_row_finish and the compaction in ONE launch
+// (they were four: two scan passes, finish, compact - ~19 us of a 0.6 ms step on one 8 k-particle trajectory).  Every
+// workgroup adds up the degrees of the nodes before its own 16 itself (<= 64 KiB of L2-resident integers, 16-byte
+// loads); the last workgroup, which thereby knows every total, does k_row_finish's job.
+#define LB_CSCAN_N 16384
+__global__ void __launch_bounds__(256)
+    k_nl_compact_scan(lb_geom g, int64_t BN, lb_ctrl* __restrict__ ctrl, const int32_t* __restrict__ deg,
+                      int32_t* __restrict__ row_ptr, int32_t maxd, const int32_t* __restrict__ tsend,
+                      const float* __restrict__ tfeat, const double* __restrict__ tfeat64,
+                      int32_t* __restrict__ senders, int32_t* __restrict__ receivers, float* __restrict__ efeat,
+                      double* __restrict__ efeat64, int64_t e_alloc, int32_t* __restrict__ overflow,
+                      int32_t* __restrict__ nedges_b, int32_t cell_capacity, int32_t e_cap, int32_t* host_flag) {
+  __shared__ int s_red[4], s_deg[16], s_b[64];
+  if (ctrl->overflow_step >= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int node0 = blockIdx.x * 16;
+  const bool last = blockIdx.x == gridDim.x - 1;
+  // sum of deg[0 .. node0): node0 is a multiple of 16, so whole int4s
+  typedef int i32x4c __attribute__((ext_vector_type(4)));
+  const i32x4c* d4 = reinterpret_cast<const i32x4c*>(deg);
+  int part = 0;
+  for (int i = tid; i < (node0 >> 2); i += 256) {
+    const i32x4c v = d4[i];
+    part += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  if (lane == 0) s_red[wave] = part;
+  if (tid < 16) s_deg[tid] = (node0 + tid < BN) ? deg[node0 + tid] : 0;
+  __syncthreads();
+  const int base0 = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  const int q = tid >> 4;  // this 16-lane group's node
+  int base = base0;
+  for (int j = 0; j < q; ++j) base += s_deg[j];
+  const int64_t gnode = (int64_t)node0 + q;
+  if (gnode < BN) {
+    if ((tid & 15) == 0) row_ptr[gnode] = base;
+    const int d = min(s_deg[q], maxd);
+    for (int k = tid & 15; k < d; k += 16) {
+      const int64_t src = gnode * maxd + k, dst = (int64_t)base + k;
+      if (dst >= e_alloc) break;
+      senders[dst] = tsend[src];
+      receivers[dst] = (int32_t)gnode;
+      f32x4* ef = reinterpret_cast<f32x4*>(efeat + dst * 8);
+      ef[0] = reinterpret_cast<const f32x4*>(tfeat)[src];
+      ef[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (efeat64 && tfeat64)
+        for (int c = 0; c < 4; ++c) efeat64[dst * 4 + c] = tfeat64[src * 4 + c];
+    }
+  }
+  if (!last) return;
+  // ---- k_row_finish's job: per-trajectory edge counts (B <= 64 here), overflow flags, the control block
+  int total = base0;
+  for (int j = 0; j < 16; ++j) total += s_deg[j];
+  for (int b = 0; b < g.B; ++b) {
+    int eb = 0;
+    for (int i = tid; i < g.N; i += 256) eb += deg[(int64_t)b * g.N + i];
+    for (int off = 32; off > 0; off >>= 1) eb += __shfl_xor(eb, off);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = eb;
+    __syncthreads();
+    if (tid == 0) s_b[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int any = 0;
+    for (int b = 0; b < g.B; ++b) {
+      const int eb = s_b[b];
+      nedges_b[b] = eb;
+      const int ov = (eb > e_cap) || (g.use_cell_list && ctrl->max_cell_occ > cell_capacity) || ctrl->row_overflow;
+      overflow[b] = ov;
+      any |= ov;
+    }
+    row_ptr[BN] = total;
+    ctrl->n_edges_unclamped = total;
+    ctrl->n_edges_total = (int)min((int64_t)total, e_alloc);
+    if ((any || (int64_t)total > e_alloc) && ctrl->overflow_step < 0) {
+      ctrl->overflow_step = ctrl->step;
+      if (host_flag) *host_flag = ctrl->step;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------- row scan
 // After the two-level scan of the degrees: per-trajectory edge counts, did_buffer_overflow flags
 // and the control block, all on the device (no host sync).
@@ -1007,6 +1089,278 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
   NLS_STAMP(7);
 }
 
+// ----------------------------------------------- one trajectory, 4096 < N <= 8192 particles (3D: 8 k): k_nl_mid
+// k_nl_small's scheme where the positions no longer fit LDS next to the masks: only the per-dimension masks, the cell
+// coordinates and the row buffers are staged (TGV3D-8k: 39 + 32 + 32 KiB); candidates' positions come from the window in
+// global memory (L2) for the short candidate list only.  A lane owns up to two mask words (ids 64 l .. and 64 (l + 64)
+// ..), a wave searches NLM_RPW consecutive receivers one after the other, a workgroup of 16 waves owns 16 NLM_RPW
+// consecutive receivers (contiguous, so the CSR offsets work as in k_nl_small).  Replaces, on one 8 k-particle
+// trajectory, memset + cell count + 2 scan passes + cell fill + k_nlw + scan / finish / compact: 9 launches.
+#define NLM_N 8192
+#define NLM_WAVES 16
+#define NLM_RPW 2
+template <bool F32, int DIM>
+__global__ void __launch_bounds__(64 * NLM_WAVES) k_nl_mid(lb_geom g, lb_ctrl* __restrict__ ctrl, lb_nls_args a) {
+  extern __shared__ double s_dynd[];
+  if (ctrl->overflow_step >= 0) return;
+  const int N = g.N, npad = a.npad, nwords = npad >> 6;
+  unsigned long long* const s_tab = reinterpret_cast<unsigned long long*>(s_dynd);  // per dim [ncell[d]][nwords]
+  const int tab_off[3] = {0, g.ncell[0] * nwords, (g.ncell[0] + g.ncell[1]) * nwords};
+  const int tab_len = (g.ncell[0] + g.ncell[1] + (DIM == 3 ? g.ncell[2] : 0)) * nwords;
+  int* const s_cell = reinterpret_cast<int*>(s_tab + tab_len);  // [npad] x | y << 11 | z << 22 (pad: -1)
+  int* const s_row = s_cell + npad;                              // [NLM_WAVES][NLS_CAND]
+  int* const s_cnt = s_row + NLM_WAVES * NLS_CAND;               // [0..31] row sizes, [32] base, [33] flags, [34] max occ
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int step = ctrl->step;
+  const unsigned long long epoch = (unsigned long long)((uint32_t)ctrl->nl_epoch & 0xffffu);
+  const bool last = blockIdx.x == gridDim.x - 1;
+  if (tid < 48) s_cnt[tid] = 0;
+  for (int k = tid; k < tab_len; k += blockDim.x) s_tab[k] = 0ull;
+  const int slot = (step + g.isl - 1) % g.isl;
+  const double* const w0 = a.win + (int64_t)slot * DIM * N;
+  {
+    constexpr int PER = NLM_N / (64 * NLM_WAVES);
+    double pv[PER][3];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + 64 * NLM_WAVES * k;
+      const int ic = i < N ? i : N - 1;
+      pv[k][0] = w0[ic];
+      pv[k][1] = w0[N + ic];
+      pv[k][2] = DIM == 3 ? w0[2 * N + ic] : 0.0;
+    }
+    double inv_cs[3];
+    _Pragma("unroll") for (int d = 0; d < 3; ++d) inv_cs[d] = d < DIM ? 1.0 / g.cell_size[d] : 0.0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + 64 * NLM_WAVES * k;
+      if (i < npad) {
+        int packed = 0;
+        _Pragma("unroll") for (int d = 0; d < DIM; ++d) {
+          const double p = pv[k][d];
+          double q = p * inv_cs[d];  // (see k_nl_small: exact division only near an integer)
+          const double fr = q - floor(q), tol = 1e-6 * (fabs(q) + 1.0);
+          if (fr < tol || fr > 1.0 - tol) q = lb_r(p / g.cell_size[d], F32);
+          int c = __double2int_rz(q);
+          c = c < 0 ? 0 : (c >= g.ncell[d] ? g.ncell[d] - 1 : c);
+          packed |= c << (11 * d);
+        }
+        s_cell[i] = i < N ? packed : -1;
+      }
+    }
+  }
+  __syncthreads();
+  // masks: lane l owns words l and l + 64; in step k it takes particle 64 word + ((k + l) & 63)
+  for (int wi = 0; wi < 2; ++wi) {
+    const int word = lane + 64 * wi;
+    if (word < nwords)
+      for (int k = wave; k < 64; k += NLM_WAVES) {
+        const int b = (k + lane) & 63;
+        const int pc = s_cell[word * 64 + b];
+        if (pc >= 0)
+          _Pragma("unroll") for (int d = 0; d < DIM; ++d)
+            atomicOr(&s_tab[tab_off[d] + ((pc >> (11 * d)) & 0x7ff) * nwords + word], 1ull << b);
+      }
+  }
+  __syncthreads();
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int r0 = (blockIdx.x * NLM_WAVES + wave) * NLM_RPW;
+  int* const row = s_row + wave * NLS_CAND;
+  int cnt_i[NLM_RPW], flags = 0, same_max = 0;
+  // pass 1 + 2 per receiver; the hits of receiver i stay in row[hit_base[i] ..)
+  int hit_base[NLM_RPW + 1];
+  hit_base[0] = 0;
+#pragma unroll
+  for (int i = 0; i < NLM_RPW; ++i) {
+    const int r = r0 + i;
+    cnt_i[i] = 0;
+    hit_base[i + 1] = hit_base[i];
+    if (r >= N) continue;
+    if (a.feat.xnode) lb_node_features_wave(g, N, a.win, step, a.feat, r);
+    double pr[3] = {0, 0, 0};
+    _Pragma("unroll") for (int d = 0; d < DIM; ++d) pr[d] = w0[d * N + r];
+    const int pc = s_cell[r];
+    unsigned long long m[2], ms[2];
+#pragma unroll
+    for (int wi = 0; wi < 2; ++wi) {
+      const int word = lane + 64 * wi;
+      m[wi] = ~0ull;
+      ms[wi] = ~0ull;
+      if (word < nwords) {
+        _Pragma("unroll") for (int d = 0; d < DIM; ++d) {
+          const int n = g.ncell[d], c = (pc >> (11 * d)) & 0x7ff;
+          const unsigned long long* T = s_tab + tab_off[d] + word;
+          const unsigned long long t0 = T[c * nwords];
+          m[wi] &= t0 | T[(c == 0 ? n - 1 : c - 1) * nwords] | T[(c == n - 1 ? 0 : c + 1) * nwords];
+          ms[wi] &= t0;
+        }
+      } else {
+        m[wi] = 0ull;
+        ms[wi] = 0ull;
+      }
+    }
+    // offsets: all ids of the first 64 words come before those of the second 64: two scans in one (16 + 16 bits)
+    const int mine = __popcll(m[0]) | (__popcll(m[1]) << 16);
+    int sc = mine, same = __popcll(ms[0]) + __popcll(ms[1]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(sc, o);
+      if (lane >= o) sc += v;
+    }
+    const int tot = __shfl(sc, 63);
+    const int tot0 = tot & 0xffff, ncand_all = tot0 + (tot >> 16);
+    for (int o = 32; o > 0; o >>= 1) same += __shfl_xor(same, o);
+    same_max = max(same_max, same);
+    const int cbase = hit_base[i];  // candidates are expanded behind the previous receiver's hits
+    int off0 = cbase + (sc & 0xffff) - (mine & 0xffff), off1 = cbase + tot0 + (sc >> 16) - (mine >> 16);
+    const int room = NLS_CAND;
+    unsigned long long mm = m[0];
+    while (mm) {
+      const int b = __ffsll((long long)mm) - 1;
+      if (off0 < room) row[off0] = lane * 64 + b;
+      ++off0;
+      mm &= mm - 1;
+    }
+    mm = m[1];
+    while (mm) {
+      const int b = __ffsll((long long)mm) - 1;
+      if (off1 < room) row[off1] = (lane + 64) * 64 + b;
+      ++off1;
+      mm &= mm - 1;
+    }
+    int ncand = ncand_all;
+    if (cbase + ncand > room) {
+      flags = 1;
+      ncand = max(room - cbase, 0);
+    }
+    int count = 0;
+    for (int c0 = 0; c0 < ncand; c0 += 64) {
+      const int t = c0 + lane;
+      bool ok = false;
+      int j = 0;
+      if (t < ncand) {
+        j = row[cbase + t];
+        double dd = lb_disp1(w0[j], pr[0], g.box[0], g.half_box[0], g.periodic, F32);
+        double d2 = lb_r(dd * dd, F32);
+        _Pragma("unroll") for (int d = 1; d < DIM; ++d) {
+          dd = lb_disp1(w0[d * N + j], pr[d], g.box[d], g.half_box[d], g.periodic, F32);
+          d2 = lb_r(d2 + lb_r(dd * dd, F32), F32);
+        }
+        ok = d2 < g.rc2;
+      }
+      const unsigned long long mask = __ballot(ok);
+      if (ok) row[cbase + count + __popcll(mask & lt_mask)] = j;  // in place: lands at or before the lane's own slot
+      count += __popcll(mask);
+    }
+    if (count > LB_MAX_ROW) flags = 1;
+    cnt_i[i] = count;
+    hit_base[i + 1] = cbase + min(count, LB_MAX_ROW);
+    if (lane == 0) {
+      a.deg[r] = count;
+      s_cnt[wave * NLM_RPW + i] = count;
+    }
+  }
+  if (lane == 0) {
+    if (flags) atomicOr(&s_cnt[33], 1);
+    atomicMax(&s_cnt[34], same_max);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+    for (int w = 0; w < NLM_WAVES * NLM_RPW; ++w) tot += s_cnt[w];
+    const unsigned long long word = (epoch << 48) | ((unsigned long long)(s_cnt[34] & 0xffff) << 32) |
+                                    ((unsigned long long)(s_cnt[33] & 1) << 31) | (unsigned long long)(tot & 0x7fffffff);
+    __hip_atomic_store(&a.wg_sum[blockIdx.x], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  {
+    int part = 0, occ = 0, ovf = 0;
+    bool timed_out = false;
+    for (int p = tid; p < (int)blockIdx.x; p += (int)blockDim.x) {
+      unsigned long long v = 0;
+      int spins = 0;
+      do {
+        v = __hip_atomic_load(&a.wg_sum[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 48) == epoch) break;
+        __builtin_amdgcn_s_sleep(1);
+      } while (++spins < (1 << 22));
+      if ((v >> 48) != epoch) timed_out = true;
+      part += (int)(v & 0x7fffffffu);
+      ovf |= (int)((v >> 31) & 1);
+      occ = max(occ, (int)((v >> 32) & 0xffff));
+    }
+    if (timed_out) atomicExch(&ctrl->persist_error, 2);
+    for (int off = 32; off > 0; off >>= 1) {
+      part += __shfl_xor(part, off);
+      ovf |= __shfl_xor(ovf, off);
+      occ = max(occ, __shfl_xor(occ, off));
+    }
+    if (lane == 0 && (int)blockIdx.x > wave * 64) {
+      if (part) atomicAdd(&s_cnt[32], part);
+      if (ovf) atomicOr(&s_cnt[33], 1);
+      atomicMax(&s_cnt[34], occ);
+    }
+  }
+  __syncthreads();
+  int base = s_cnt[32];
+  for (int w = 0; w < wave * NLM_RPW; ++w) base += s_cnt[w];
+#pragma unroll
+  for (int i = 0; i < NLM_RPW; ++i) {
+    const int r = r0 + i;
+    if (r >= N) continue;
+    if (lane == 0) a.row_ptr[r] = base;
+    double pr[3] = {0, 0, 0};
+    _Pragma("unroll") for (int d = 0; d < DIM; ++d) pr[d] = w0[d * N + r];
+    const int cnt = min(cnt_i[i], LB_MAX_ROW);
+    for (int t0 = 0; t0 < cnt; t0 += 64) {
+      const int t = t0 + lane;
+      if (t >= cnt) break;
+      const int j = row[hit_base[i] + t];
+      const int64_t slot_e = (int64_t)base + t;
+      if (slot_e >= a.e_alloc) break;
+      a.senders[slot_e] = j;
+      a.receivers[slot_e] = r;
+      double rd[3] = {0, 0, 0};
+      double s2 = 0.0;
+      _Pragma("unroll") for (int d = 0; d < DIM; ++d) {
+        rd[d] = lb_r(lb_disp1(pr[d], w0[d * N + j], g.box[d], g.half_box[d], g.periodic, F32) / g.rc, F32);
+        s2 = (d == 0) ? lb_r(rd[d] * rd[d], F32) : lb_r(s2 + lb_r(rd[d] * rd[d], F32), F32);
+      }
+      const double dist = s2 > 0.0 ? lb_r(sqrt(s2), F32) : 0.0;
+      f32x4* ef = reinterpret_cast<f32x4*>(a.efeat + slot_e * 8);
+      ef[0] = (DIM == 2) ? f32x4{(float)rd[0], (float)rd[1], (float)dist, 0.f}
+                         : f32x4{(float)rd[0], (float)rd[1], (float)rd[2], (float)dist};
+      ef[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.efeat64) {
+        double* e64 = a.efeat64 + slot_e * 4;
+        e64[0] = rd[0];
+        e64[1] = rd[1];
+        e64[2] = rd[2];
+        e64[3] = dist;
+      }
+    }
+    base += cnt_i[i];
+  }
+  if (last && tid == 0) {
+    int total = s_cnt[32];
+    for (int w = 0; w < NLM_WAVES * NLM_RPW; ++w) total += s_cnt[w];
+    a.row_ptr[N] = total;
+    a.nedges_b[0] = total;
+    const int max_occ = s_cnt[34];
+    const int ov = (total > a.e_cap) || (max_occ > a.cell_capacity) || (s_cnt[33] & 1);
+    a.overflow[0] = ov;
+    ctrl->max_cell_occ = max_occ;
+    ctrl->n_edges_unclamped = total;
+    ctrl->n_edges_total = (int)min((int64_t)total, a.e_alloc);
+    if ((ov || (int64_t)total > a.e_alloc) && ctrl->overflow_step < 0) {
+      ctrl->overflow_step = step;
+      if (a.host_flag) *a.host_flag = step;
+    }
+    int ne = ctrl->nl_epoch + 1;
+    if ((ne & 0xffff) == 0) ++ne;
+    ctrl->nl_epoch = ne;
+  }
+}
+
 // ----------------------------------------------------------------------------------- host
 // `small` = staged-candidate capacity of the one-wave variant to use (a multiple of 128 up to
 // NL_SMALL_MAXC), or 0 for the 256-thread / 2048-candidate variant.  The LDS footprint of the
@@ -1120,10 +1474,15 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
       a.feat = e->feat_job;
       e->feat_done = true;
     }
+  // (the dynamic-LDS limit is raised ONCE per kernel instance - the first launch after an allocation runs outside a
+  // hipGraph capture - to the 150 KiB the routing above admits)
 #define LB_NLS_LAUNCH(F, D)                                                                                      \
   do {                                                                                                          \
-    if (lds > 48 * 1024)                                                                                        \
-      (void)hipFuncSetAttribute((const void*)k_nl_small<F, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    static bool raised = false;                                                                                 \
+    if (!raised) {                                                                                              \
+      (void)hipFuncSetAttribute((const void*)k_nl_small<F, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+      raised = true;                                                                                            \
+    }                                                                                                           \
     hipLaunchKernelGGL((k_nl_small<F, D>), dim3(nb), dim3(64 * nwv), lds, s, g, e->ctrl, a);                    \
   } while (0)
     if (g.f32) {
@@ -1147,6 +1506,58 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
     lb_toc(e);
     LB_HIP(hipGetLastError());
     return LB_OK;
+  }
+  // one trajectory of up to 8192 particles with a cell list whose masks fit LDS: k_nl_mid (one launch)
+  {
+    const int npad_m = (int)((BN + 63) / 64 * 64);
+    const int64_t tab_m = (int64_t)(g.ncell[0] + g.ncell[1] + (g.dim == 3 ? g.ncell[2] : 0)) * (npad_m / 64);
+    const size_t lds_m = 8 * (size_t)tab_m + sizeof(int) * ((size_t)npad_m + NLM_WAVES * NLS_CAND + 48);
+    static const bool mid_ok = !(getenv("LB_NL_MID") && getenv("LB_NL_MID")[0] == '0');
+    if (mid_ok && one_ok && small_ok && frozen && g.B == 1 && BN > LB_SMALL_N && BN <= NLM_N && g.use_cell_list &&
+        (g.dim == 2 || g.dim == 3) && !e->nl_dense && !e->nl_one_off && lds_m <= 150 * 1024 &&
+        (int64_t)e->cell_capacity * g.nstencil <= NLS_CAND / NLM_RPW && e->nl_wg_sum && g.ncell[0] < 2048 &&
+        g.ncell[1] < 2048 && g.ncell[2] < 1024) {
+      lb_tic(e, LB_T_NEIGH);
+      lb_nls_args a{};
+      a.win = e->win;
+      a.senders = e->senders;
+      a.receivers = e->receivers;
+      a.efeat = e->efeat;
+      a.efeat64 = want_efeat64 ? e->efeat64 : nullptr;
+      a.deg = e->deg;
+      a.row_ptr = e->row_ptr;
+      a.overflow = e->overflow;
+      a.nedges_b = e->nedges_b;
+      a.wg_sum = e->nl_wg_sum;
+      a.e_alloc = e->e_alloc;
+      a.e_cap = e->e_cap;
+      a.cell_capacity = e->cell_capacity;
+      a.npad = npad_m;
+      a.host_flag = e->host_flag_dev;
+      if (e->feat_job.xnode && !want_efeat64) {
+        a.feat = e->feat_job;
+        e->feat_done = true;
+      }
+      const int nb = (int)((BN + NLM_WAVES * NLM_RPW - 1) / (NLM_WAVES * NLM_RPW));
+#define LB_NLM_LAUNCH(F, D)                                                                                     \
+  do {                                                                                                          \
+    static bool raised = false;                                                                                 \
+    if (!raised) {                                                                                              \
+      (void)hipFuncSetAttribute((const void*)k_nl_mid<F, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+      raised = true;                                                                                            \
+    }                                                                                                           \
+    hipLaunchKernelGGL((k_nl_mid<F, D>), dim3(nb), dim3(64 * NLM_WAVES), lds_m, s, g, e->ctrl, a);             \
+  } while (0)
+      if (g.f32) {
+        if (g.dim == 3) LB_NLM_LAUNCH(true, 3); else LB_NLM_LAUNCH(true, 2);
+      } else {
+        if (g.dim == 3) LB_NLM_LAUNCH(false, 3); else LB_NLM_LAUNCH(false, 2);
+      }
+#undef LB_NLM_LAUNCH
+      lb_toc(e);
+      LB_HIP(hipGetLastError());
+      return LB_OK;
+    }
   }
   lb_tic(e, LB_T_CELLS);
   if (small_cells) {
@@ -1192,6 +1603,17 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
     lb_launch_nl<NL_ROWS>(e, small, a);
   } else {
     lb_launch_nl<NL_COUNT>(e, small, a);
+  }
+  // update path of a small batch: scan + finish + compaction in one launch (LB_NL_CSCAN=0: the separate launches)
+  static const bool cscan_ok = !(getenv("LB_NL_CSCAN") && getenv("LB_NL_CSCAN")[0] == '0');
+  if (rows && cscan_ok && small_ok && BN <= LB_CSCAN_N && g.B <= 64) {
+    hipLaunchKernelGGL(k_nl_compact_scan, dim3((int)((BN + 15) / 16)), dim3(256), 0, s, g, BN, e->ctrl, e->deg, e->row_ptr,
+                       e->maxd, e->tmp_send, e->tmp_feat, want_efeat64 ? e->tmp_feat64 : (const double*)nullptr,
+                       e->senders, e->receivers, e->efeat, want_efeat64 ? e->efeat64 : (double*)nullptr, e->e_alloc,
+                       e->overflow, e->nedges_b, e->cell_capacity, e->e_cap, e->host_flag_dev);
+    lb_toc(e);
+    LB_HIP(hipGetLastError());
+    return LB_OK;
   }
   if (small_rows) {
     hipLaunchKernelGGL(k_rows_small, dim3(1), dim3(LB_SMALL_T), 0, s, g, e->deg, e->row_ptr, (int)BN, e->ctrl,

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_gns_persist(lb_persist_args a
   __shared__ f32x4 sB2[4 * 2 * 64];
   __shared__ f32x4 sB3[4 * 2 * 64];
   __shared__ __attribute__((aligned(16))) f32x2m sRed[16 * 4];
-  __shared__ __attribute__((aligned(16))) int sMx[3][4];
+  __shared__ __attribute__((aligned(16))) float sMx[3][4];
   __shared__ int sOk;
   const int poisoned = a.ctrl->overflow_step;
   const int E = a.ctrl->n_edges_total;
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_gns_persist(lb_persist_args a
   const f32x4* elat4 = reinterpret_cast<const f32x4*>(a.elat);
   const f32x4* nlat4 = reinterpret_cast<const f32x4*>(a.nlat);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  ms_guard guard{0.f, 0};
+  ps_guard guard{0.f, 0};
   unsigned epoch = 0;
 
   // edge-phase prefetch state
@@ -209,28 +209,26 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_gns_persist(lb_persist_args a
             acc[c] = nps[c] + npr[c];
           }
           const int rcur = nr, rb = nrb;
-          uint32_t orv1;
-          ms_stage<false>(sB1, w, lane, ve[0], ve[1], orv1, guard.big);
+          ps_stage<false>(sB1, w, lane, ve[0], ve[1]);
           {
-            const int c = guard.code(orv1);
-            if (lane == 0) sMx[0][w] = c;
+            const float m = ms_wave_max(guard.see(ve[0], ve[1]));
+            if (lane == 0) sMx[0][w] = m;
           }
           issue_own(min(t + we.stride, we.q_last));
           issue_psr();
           load_idx(min(t + 2 * we.stride, we.q_last));
           __syncthreads();
           ms_gemm<4, 2>(sB1, lane, w0h, w0l, acc);
-          guard.tile_codes(sMx[0]);
-          uint32_t orv2;
-          ms_stage<true>(sB2, w, lane, acc[0], acc[1], orv2, guard.big);
+          guard.tile_max(sMx[0]);
+          ps_stage<true>(sB2, w, lane, acc[0], acc[1]);
           {
-            const int c = guard.code(orv2);
-            if (lane == 0) sMx[1][w] = c;
+            const float m = ms_wave_max(guard.see(acc[0], acc[1]));
+            if (lane == 0) sMx[1][w] = m;
           }
           __syncthreads();
           f32x4 acc2[2] = {b1v[0], b1v[1]};
           ms_gemm<4, 2>(sB2, lane, w1h, w1l, acc2);
-          guard.tile_codes(sMx[1]);
+          guard.tile_max(sMx[1]);
           {
             const f32x2m p = ms_ln_local(acc2[0], acc2[1]);
             if (g == 0) sRed[n * 4 + w] = p;
@@ -310,27 +308,25 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_gns_persist(lb_persist_args a
         for (int it = 0; it < wn.n_iter; ++it, t += wn.stride) {
           if (it > 0) node_rows_own(t, rc, valid);
           node_agg(rc);
-          uint32_t orv_x, orv_a;
-          ms_stage<false>(sB1, w, lane, xa[0], xa[1], orv_x, guard.big);
-          ms_stage<false>(sB1, 4 + w, lane, ag[0], ag[1], orv_a, guard.big);
+          ps_stage<false>(sB1, w, lane, xa[0], xa[1]);
+          ps_stage<false>(sB1, 4 + w, lane, ag[0], ag[1]);
           {
-            const int c = guard.code(orv_x | orv_a);
-            if (lane == 0) sMx[0][w] = c;
+            const float m = ms_wave_max(fmaxf(guard.see(xa[0], xa[1]), guard.see(ag[0], ag[1])));
+            if (lane == 0) sMx[0][w] = m;
           }
           __syncthreads();
           f32x4 acc[2] = {b0v[0], b0v[1]};
           ms_gemm<8, 2>(sB1, lane, w0h, w0l, acc);
-          guard.tile_codes(sMx[0]);
-          uint32_t orv3;
-          ms_stage<true>(sB2, w, lane, acc[0], acc[1], orv3, guard.big);
+          guard.tile_max(sMx[0]);
+          ps_stage<true>(sB2, w, lane, acc[0], acc[1]);
           {
-            const int c = guard.code(orv3);
-            if (lane == 0) sMx[1][w] = c;
+            const float m = ms_wave_max(guard.see(acc[0], acc[1]));
+            if (lane == 0) sMx[1][w] = m;
           }
           __syncthreads();
           f32x4 acc2[2] = {b1v[0], b1v[1]};
           ms_gemm<4, 2>(sB2, lane, w1h, w1l, acc2);
-          guard.tile_codes(sMx[1]);
+          guard.tile_max(sMx[1]);
           {
             const f32x2m p = ms_ln_local(acc2[0], acc2[1]);
             if (g == 0) sRed[n * 4 + w] = p;
@@ -347,14 +343,13 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_gns_persist(lb_persist_args a
             if (valid) reinterpret_cast<f32x4*>(a.nlat)[rc * 32 + 8 * w + 4 * c + g] = y[c];
           }
           if (proj) {
-            uint32_t orv4;
-            ms_stage<false>(sB3, w, lane, y[0], y[1], orv4, guard.big);
+            ps_stage<false>(sB3, w, lane, y[0], y[1]);
             {
-              const int c = guard.code(orv4);
-              if (lane == 0) sMx[2][w] = c;
+              const float m = ms_wave_max(guard.see(y[0], y[1]));
+              if (lane == 0) sMx[2][w] = m;
             }
             __syncthreads();
-            guard.tile_codes(sMx[2]);
+            guard.tile_max(sMx[2]);
             f32x4 accp[4] = {bpv[0], bpv[1], bpv[2], bpv[3]};
             ms_gemm<4, 4>(sB3, lane, wph, wpl, accp);
             if (valid) {
