@@ -1099,6 +1099,7 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
 #define NLM_N 8192
 #define NLM_WAVES 16
 #define NLM_RPW 2
+#define NLM_ROWBUF 1024  // row buffer per wave: the hits of the receivers done (<= 256 each) + 768 candidates
 template <bool F32, int DIM>
 __global__ void __launch_bounds__(64 * NLM_WAVES) k_nl_mid(lb_geom g, lb_ctrl* __restrict__ ctrl, lb_nls_args a) {
   extern __shared__ double s_dynd[];
@@ -1108,8 +1109,8 @@ __global__ void __launch_bounds__(64 * NLM_WAVES) k_nl_mid(lb_geom g, lb_ctrl* _
   const int tab_off[3] = {0, g.ncell[0] * nwords, (g.ncell[0] + g.ncell[1]) * nwords};
   const int tab_len = (g.ncell[0] + g.ncell[1] + (DIM == 3 ? g.ncell[2] : 0)) * nwords;
   int* const s_cell = reinterpret_cast<int*>(s_tab + tab_len);  // [npad] x | y << 11 | z << 22 (pad: -1)
-  int* const s_row = s_cell + npad;                              // [NLM_WAVES][NLS_CAND]
-  int* const s_cnt = s_row + NLM_WAVES * NLS_CAND;               // [0..31] row sizes, [32] base, [33] flags, [34] max occ
+  int* const s_row = s_cell + npad;                              // [NLM_WAVES][NLM_ROWBUF]
+  int* const s_cnt = s_row + NLM_WAVES * NLM_ROWBUF;               // [0..31] row sizes, [32] base, [33] flags, [34] max occ
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int step = ctrl->step;
   const unsigned long long epoch = (unsigned long long)((uint32_t)ctrl->nl_epoch & 0xffffu);
@@ -1165,7 +1166,7 @@ __global__ void __launch_bounds__(64 * NLM_WAVES) k_nl_mid(lb_geom g, lb_ctrl* _
   __syncthreads();
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int r0 = (blockIdx.x * NLM_WAVES + wave) * NLM_RPW;
-  int* const row = s_row + wave * NLS_CAND;
+  int* const row = s_row + wave * NLM_ROWBUF;
   int cnt_i[NLM_RPW], flags = 0, same_max = 0;
   // pass 1 + 2 per receiver; the hits of receiver i stay in row[hit_base[i] ..)
   int hit_base[NLM_RPW + 1];
@@ -1213,7 +1214,7 @@ __global__ void __launch_bounds__(64 * NLM_WAVES) k_nl_mid(lb_geom g, lb_ctrl* _
     same_max = max(same_max, same);
     const int cbase = hit_base[i];  // candidates are expanded behind the previous receiver's hits
     int off0 = cbase + (sc & 0xffff) - (mine & 0xffff), off1 = cbase + tot0 + (sc >> 16) - (mine >> 16);
-    const int room = NLS_CAND;
+    const int room = NLM_ROWBUF;
     unsigned long long mm = m[0];
     while (mm) {
       const int b = __ffsll((long long)mm) - 1;
@@ -1511,11 +1512,11 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   {
     const int npad_m = (int)((BN + 63) / 64 * 64);
     const int64_t tab_m = (int64_t)(g.ncell[0] + g.ncell[1] + (g.dim == 3 ? g.ncell[2] : 0)) * (npad_m / 64);
-    const size_t lds_m = 8 * (size_t)tab_m + sizeof(int) * ((size_t)npad_m + NLM_WAVES * NLS_CAND + 48);
+    const size_t lds_m = 8 * (size_t)tab_m + sizeof(int) * ((size_t)npad_m + NLM_WAVES * NLM_ROWBUF + 48);
     static const bool mid_ok = !(getenv("LB_NL_MID") && getenv("LB_NL_MID")[0] == '0');
     if (mid_ok && one_ok && small_ok && frozen && g.B == 1 && BN > LB_SMALL_N && BN <= NLM_N && g.use_cell_list &&
         (g.dim == 2 || g.dim == 3) && !e->nl_dense && !e->nl_one_off && lds_m <= 150 * 1024 &&
-        (int64_t)e->cell_capacity * g.nstencil <= NLS_CAND / NLM_RPW && e->nl_wg_sum && g.ncell[0] < 2048 &&
+        (int64_t)e->cell_capacity * g.nstencil <= NLM_ROWBUF - LB_MAX_ROW * (NLM_RPW - 1) && e->nl_wg_sum && g.ncell[0] < 2048 &&
         g.ncell[1] < 2048 && g.ncell[2] < 1024) {
       lb_tic(e, LB_T_NEIGH);
       lb_nls_args a{};
