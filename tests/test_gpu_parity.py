@@ -184,6 +184,45 @@ CASES = [("small2d", 1.0), ("small3d", 1.0), ("tgv2d", 0.6), ("rpf2d", 0.5), ("t
          ("ldc3d", 0.5), ("dam2d", 0.3)]
 
 
+@pytest.mark.parametrize("name,scale", [("small2d", 1.0), ("small3d", 1.0), ("tgv2d", 1.0), ("rpf2d", 1.0), ("dam2d", 0.5),
+                                        ("tgv3d", 1.0), ("ldc3d", 1.0)])
+def test_single_trajectory_update_path_bitexact(name, scale):
+    """One trajectory per engine (the BASELINE configs as stated): the UPDATE path builds the list in one launch
+    (k_nl_small up to 4096 particles, k_nl_mid up to 8192 where its masks fit LDS; k_nl_compact_scan otherwise).  Edge
+    list, edge features, edge count and did_buffer_overflow of an update on a LATER frame equal the oracle's
+    preprocess_eval bit for bit; the same update with the capacity shrunk below the edge count flags overflow."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    ds = make_case(name, n_trajs=1, extra_seq_length=4, scale=scale)
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    isl = ds.input_seq_length
+    pos, pt = ds[0]
+    N = pos.shape[0]
+    _, nbrs = hcase.allocate_eval((pos[None][:, :, :isl], pt[None]))
+    _, on = ocase.allocate_eval((pos[:, :isl].astype(np.float64), pt))
+    for shift in (1, 3):
+        win = pos[:, shift:shift + isl]
+        feats, nbrs = hcase.preprocess_eval((win[None], pt[None]), nbrs)
+        of, on = ocase.preprocess_eval((win.astype(np.float64), pt), on)
+        assert not bool(nbrs.did_buffer_overflow.any()) and not bool(on.did_buffer_overflow)
+        idx = _np(nbrs.idx)[0]
+        want = O.canonical_edges(on.idx, N)
+        ne = want.shape[1]
+        assert int(_np(nbrs.n_edges)[0]) == ne
+        assert (idx[:, :ne] == want).all() and (idx[:, ne:] == N).all(), f"{name}: edge list differs (shift {shift})"
+        real = on.idx[0] < N
+        order = np.lexsort((on.idx[1][real], on.idx[0][real]))
+        assert np.array_equal(_np(feats["rel_disp"])[0][:ne], of["rel_disp"][real][order])
+        assert np.array_equal(_np(feats["rel_dist"])[0][:ne], of["rel_dist"][real][order])
+        assert np.array_equal(_np(feats["vel_hist"])[0], of["vel_hist"])
+    # overflow flag of the single-launch build
+    eng = hcase.engine(1)
+    st = eng.stats()
+    eng.nl_set_capacity(eng.cell_capacity, st["n_edges_total"] - 5)
+    eng.nl_update()
+    assert int(eng.nl_flags()[0]) == 1
+
+
 @pytest.mark.parametrize("name,scale", CASES)
 def test_neighbors_and_features_bitexact(name, scale):
     _need_gpu()
