@@ -136,12 +136,31 @@ __device__ __forceinline__ void lb_node_features_wave(const lb_geom& g, int64_t 
 
 // integrate_fn + kinematic select + window advance + prediction store for particle gi (case.py:230-259,
 // rollout.py:61-73,165-167); `accv` = the network's normalised acceleration of this particle
+// what the integrator reads of particle gi, fetched ahead of the arithmetic that produces its acceleration
+struct lb_integ_in {  // (named components, selected with compares: an array indexed by the run-time d lands in scratch)
+  double p1x, p1y, p1z, p0x, p0y, p0z;
+  int pt;
+};
+__device__ __forceinline__ double lb_sel3(int d, double x, double y, double z) { return d == 0 ? x : (d == 1 ? y : z); }
+__device__ __forceinline__ lb_integ_in lb_integrate_fetch(const lb_geom& g, int64_t BN, const double* __restrict__ win,
+                                                          int step, const int32_t* __restrict__ ptype, int64_t gi) {
+  lb_integ_in in;
+  in.pt = ptype[gi];
+  in.p1x = lb_pos(win, g, BN, step, g.isl - 1, 0, gi);
+  in.p0x = lb_pos(win, g, BN, step, g.isl - 2, 0, gi);
+  in.p1y = lb_pos(win, g, BN, step, g.isl - 1, 1, gi);  // (dim >= 2)
+  in.p0y = lb_pos(win, g, BN, step, g.isl - 2, 1, gi);
+  in.p1z = g.dim == 3 ? lb_pos(win, g, BN, step, g.isl - 1, 2, gi) : 0.0;
+  in.p0z = g.dim == 3 ? lb_pos(win, g, BN, step, g.isl - 2, 2, gi) : 0.0;
+  return in;
+}
 __device__ __forceinline__ void lb_integrate_body(const lb_geom& g, int64_t BN, double* __restrict__ win, int step,
                                                   const int32_t* __restrict__ ptype, const float* accv,
                                                   const double* __restrict__ target, const double* __restrict__ traj,
-                                                  int T, double* __restrict__ pred, int pred_T, int64_t gi) {
+                                                  int T, double* __restrict__ pred, int pred_T, int64_t gi,
+                                                  const lb_integ_in* pre = nullptr) {
   const int b = (int)(gi / g.N), i = (int)(gi % g.N);
-  const int pt = ptype[gi];
+  const int pt = pre ? pre->pt : ptype[gi];
   const bool kinematic = (pt == 1) || (pt == 2) || (pt == -1);  // utils.py:28-35
   const int slot_new = (step + g.isl) % g.isl;
   int tf = g.isl + step;
@@ -151,8 +170,8 @@ __device__ __forceinline__ void lb_integrate_body(const lb_geom& g, int64_t BN, 
     if (kinematic) {
       out = target ? target[gi * g.dim + d] : traj[(gi * T + tf) * g.dim + d];
     } else {
-      const double p1 = lb_pos(win, g, BN, step, g.isl - 1, d, gi);
-      const double p0 = lb_pos(win, g, BN, step, g.isl - 2, d, gi);
+      const double p1 = pre ? lb_sel3(d, pre->p1x, pre->p1y, pre->p1z) : lb_pos(win, g, BN, step, g.isl - 1, d, gi);
+      const double p0 = pre ? lb_sel3(d, pre->p0x, pre->p0y, pre->p0z) : lb_pos(win, g, BN, step, g.isl - 2, d, gi);
       const double a = lb_r(g.acc_mean[d] + lb_r((double)accv[d] * g.acc_std[d], g.f32), g.f32);
       const double v = lb_disp1(p1, p0, g.box[d], g.half_box[d], g.periodic, g.f32);
       out = lb_shift1(p1, lb_r(v + a, g.f32), g.box[d], g.periodic, g.f32);

@@ -258,6 +258,9 @@ __global__ void __launch_bounds__(GD_THREADS, 2) k_decoder16(lb_dec16_args a, lb
     const bool valid = row < a.n_rows;
     const int64_t rowc = valid ? row : a.n_rows - 1;
     f32x4 v[8], acc[8];
+    // rollout step: what the integrator reads of this row goes out with the tile's other loads
+    lb_integ_in pre{};
+    if (a.integ.on && valid && g == 0) pre = lb_integrate_fetch(geom, a.n_rows, a.integ.win, step, a.integ.ptype, row);
     const f32x4* xr = reinterpret_cast<const f32x4*>(a.nlat) + rowc * 32 + g;
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) v[mb] = xr[4 * mb];
@@ -304,7 +307,7 @@ __global__ void __launch_bounds__(GD_THREADS, 2) k_decoder16(lb_dec16_args a, lb
       if (a.integ.on) {
         const float av[4] = {o[0], o[1], o[2], o[3]};
         lb_integrate_body(geom, a.n_rows, a.integ.win, step, a.integ.ptype, av, nullptr, a.integ.traj, a.integ.T,
-                          a.integ.pred, a.integ.pred_T, row);
+                          a.integ.pred, a.integ.pred_T, row, &pre);
       }
     }
   }
