@@ -303,22 +303,27 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (NS_SLOTS == 4 ? 1 : 2) : 4
 // wave and weight chunk.  One 8-wave workgroup per CU owns 16 tiles: the 320 KiB of weights cross L2 -> LDS once per CU
 // instead of twice (82 instead of 164 MB per launch), every chunk barrier serves two tiles, and the two tiles' MFMA
 // chains interleave inside a step.  232 VGPRs, two waves per SIMD, no scratch.
-// MEASURED (TGV3D-8k x 8, bench.py timer class node_mlp): 56.8 us per launch against 51.3 us for k_node16s<.., 8, 2> -
-// SLOWER, like the 16-wave workgroup of round 2: the launch is ONE round of workgroups, i.e. one workgroup's chain of
-// ten chunk steps, and a step lasts as long as a direct-to-LDS refill takes to land (~2 - 3 us under load) whatever the
-// amount of MFMA work or weight traffic in it.  Parity green (tests/test_switches_gpu.py).  Opt-in: LB_NODE_T2=1.
+// MEASURED (TGV3D-8k x 8, bench.py timer class node_mlp): 55.2 us per launch (five steps of 64 KiB; ten steps of
+// 32 KiB: 56.8) against 50.5 us for k_node16s<.., 8, 2> - SLOWER, like the 16-wave workgroup of round 2.  Neither the
+// weight traffic (halved) nor the number of chunk steps (halved again) is what bounds the launch.  What does: it moves
+// ~2.6 - 3 KB per node through HBM (latents + aggregates in, latents + projections out: 165 - 200 MB = 33 - 40 us at the
+// 5 TB/s this access pattern gets), and since the launch is ONE round of workgroups every workgroup loads, multiplies and
+// stores at the same time as all the others - memory and matrix phases do not overlap across the chip; two
+// 8-tile workgroups per CU drifting out of phase (the default) recover some of that, one 16-tile workgroup does not.
+// Parity green (tests/test_switches_gpu.py).  Opt-in: LB_NODE_T2=1.
 template <bool PROJ>
 __global__ void __launch_bounds__(512, 2)
     k_node16s2(lb_node_args a, const f32x4* __restrict__ w0h, const f32x4* __restrict__ w1h,
                const f32x4* __restrict__ wph) {
-  constexpr int NW = 8, NS_SLOTS = 2, T = 2;
-  __shared__ f32x4 sB[NS_SLOTS][NS_CHUNK];
-  __shared__ f32x4 sP[192];
+  // 64 KiB chunks (two of the 32 KiB chunks of k_node16s, which are consecutive in the packed images) through a
+  // two-slot 128 KiB ring: FIVE steps - W0 rows of the latents, W0 rows of the aggregates, W1, projection halves
+  constexpr int NW = 8, T = 2, CH = 2 * NS_CHUNK;
+  extern __shared__ f32x4 sB2[];  // [2][CH] ring, then 192 vectors
+  f32x4* const sP = sB2 + 2 * CH;
   if (a.ctrl->overflow_step >= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
-  constexpr int NCH0 = 4;
-  constexpr int n_chunks = NCH0 + 2 + (PROJ ? 4 : 0);
+  constexpr int n_chunks = 3 + (PROJ ? 2 : 0);
   if (tid < 128) {
     const float* src = tid < 32 ? a.b0 : (tid < 64 ? a.b1 : (tid < 96 ? a.ln_s : a.ln_o));
     sP[tid] = reinterpret_cast<const f32x4*>(src)[tid & 31];
@@ -326,40 +331,27 @@ __global__ void __launch_bounds__(512, 2)
     sP[tid] = (PROJ && a.bp) ? reinterpret_cast<const f32x4*>(a.bp)[tid - 128] : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   auto issue_chunk = [&](int c) {
-    const f32x4* src;
-    if (c < NCH0)
-      src = w0h + (size_t)c * NS_CHUNK;
-    else if (c < NCH0 + 2)
-      src = w1h + (size_t)(c - NCH0) * NS_CHUNK;
-    else
-      src = wph + (size_t)(c - NCH0 - 2) * NS_CHUNK;
-    f32x4* slot = sB[c % NS_SLOTS];
+    const f32x4* src = c < 2 ? w0h + (size_t)c * CH : (c == 2 ? w1h : wph + (size_t)(c - 3) * CH);
+    f32x4* slot = sB2 + (c & 1) * CH;
 #pragma unroll
-    for (int i = 0; i < 32 / NW; ++i) {
+    for (int i = 0; i < CH / 64 / NW; ++i) {
       const int piece = wave + NW * i;
       const uint32_t voff = (uint32_t)(piece * 64 + lane) * 16u;
       const uint32_t lo = (uint32_t)(uintptr_t)(lds_ptr)(slot + piece * 64);
       asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lo) : "memory");
     }
   };
-  constexpr int DPC = 32 / NW;
-#define NS2_STEP(c)                                                                    \
-  do {                                                                                 \
-    constexpr int later = ((c) + NS_SLOTS - 2 < n_chunks ? NS_SLOTS - 2 : n_chunks - 1 - (c)); \
-    static_assert(later * DPC == 0, "two-slot ring");                                  \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
-    if constexpr ((c) == 0) {                                                          \
-      __syncthreads();                                                                 \
-    } else {                                                                           \
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                  \
-    }                                                                                  \
+  // step c: chunk c has landed (it is the oldest outstanding group; everything issued later - the other slot's refill
+  // and this step's own data loads - may stay in flight: vmcnt counts in order)
+#define NS2_STEP(c, later_ops)                                                     \
+  do {                                                                             \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(later_ops) : "memory");               \
+    if constexpr ((c) == 0) {                                                      \
+      __syncthreads();                                                             \
+    } else {                                                                       \
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");              \
+    }                                                                              \
   } while (0)
-#define NS2_REFILL(c)                                                          \
-  do {                                                                         \
-    if constexpr ((c) >= 1 && (c)-1 + NS_SLOTS < n_chunks) issue_chunk((c)-1 + NS_SLOTS); \
-  } while (0)
-  issue_chunk(0);
-  issue_chunk(1);
   int64_t row[T], rowc[T];
   bool valid[T];
 #pragma unroll
@@ -368,10 +360,7 @@ __global__ void __launch_bounds__(512, 2)
     valid[i] = row[i] < a.n_rows;
     rowc[i] = valid[i] ? row[i] : a.n_rows - 1;
   }
-  lds_cptr lane_b[NS_SLOTS];
-#pragma unroll
-  for (int i = 0; i < NS_SLOTS; ++i) lane_b[i] = (lds_cptr)(sB[i] + lane);
-  const lds_cptr vecp = (lds_cptr)(sP + g);
+  // data first (rows + CSR bounds), then the two ring slots: a wait for the rows must not cover the weights
   f32x4 va[T][8];
   int k0[T], k1[T];
 #pragma unroll
@@ -385,66 +374,60 @@ __global__ void __launch_bounds__(512, 2)
       k1[i] = a.row_ptr[rowc[i] + 1];
     }
   }
+  issue_chunk(0);
+  issue_chunk(1);
+  const lds_cptr buf0 = (lds_cptr)(sB2 + lane), buf1 = (lds_cptr)(sB2 + CH + lane);
+  const lds_cptr vecp = (lds_cptr)(sP + g);
   const bool probe = wave == 0;
-#define NS2_BUF(c) lane_b[(c) % NS_SLOTS]
-  constexpr int C1 = NCH0, CP = NCH0 + 2;
   f32x4 acc[T][8], h0[T][4], h1[T][4];
-  NS2_STEP(0);
+  // ---- step 0: W0, latent rows
+  NS2_STEP(0, 8);  // (chunk 1's eight pieces may still be in flight)
   if (probe) lb_range_probe(a.ctrl, va[0], 8);
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    lb_load_agg_half<0>(a, rowc[i], g, k0[i], k1[i], h0[i]);
+    lb_load_agg_half<4>(a, rowc[i], g, k0[i], k1[i], h1[i]);
+  }
 #pragma unroll
   for (int i = 0; i < T; ++i) {
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) acc[i][mb] = vecp[4 * mb];
     const f32x4 v01[4] = {va[i][0], va[i][1], va[i][2], va[i][3]};
-    lb_gemm16v<false, 2>(NS2_BUF(0), v01, acc[i]);
-  }
-  NS2_STEP(1);
-#pragma unroll
-  for (int i = 0; i < T; ++i) lb_load_agg_half<0>(a, rowc[i], g, k0[i], k1[i], h0[i]);
-  NS2_REFILL(1);
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
+    lb_gemm16v<false, 2>(buf0, v01, acc[i]);
     const f32x4 v23[4] = {va[i][4], va[i][5], va[i][6], va[i][7]};
-    lb_gemm16v<false, 2>(NS2_BUF(1), v23, acc[i]);
+    lb_gemm16v<false, 2>(buf0 + NS_CHUNK, v23, acc[i]);
   }
-  NS2_STEP(2);
-#pragma unroll
-  for (int i = 0; i < T; ++i) lb_load_agg_half<4>(a, rowc[i], g, k0[i], k1[i], h1[i]);
-  NS2_REFILL(2);
-#pragma unroll
-  for (int i = 0; i < T; ++i) lb_gemm16v<false, 2>(NS2_BUF(2), h0[i], acc[i]);
-  NS2_STEP(3);
-  NS2_REFILL(3);
+  // ---- step 1: W0, aggregated messages
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // chunk 1 + the aggregates
+  issue_chunk(2);  // slot 0 is free: W1
   if (probe) {
     lb_range_probe(a.ctrl, h0[0], 4);
     lb_range_probe(a.ctrl, h1[0], 4);
   }
 #pragma unroll
-  for (int i = 0; i < T; ++i) lb_gemm16v<false, 2>(NS2_BUF(3), h1[i], acc[i]);
-  if (probe) lb_range_probe(a.ctrl, acc[0], 8);
-  f32x4 acc2[T][8];
-  NS2_STEP(C1);
-  NS2_REFILL(C1);
-#pragma unroll
   for (int i = 0; i < T; ++i) {
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) acc2[i][mb] = vecp[32 + 4 * mb];
-    const f32x4 v01[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-    lb_gemm16v<true, 2>(NS2_BUF(C1), v01, acc2[i]);
+    lb_gemm16v<false, 2>(buf1, h0[i], acc[i]);
+    lb_gemm16v<false, 2>(buf1 + NS_CHUNK, h1[i], acc[i]);
   }
-  NS2_STEP(C1 + 1);
-  f32x4 res[T][8];
+  if (probe) lb_range_probe(a.ctrl, acc[0], 8);
+  // ---- step 2: W1 (ReLU folded into the operand split); the residual rows are requested behind the refill
+  f32x4 acc2[T][8], res[T][8];
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (PROJ) issue_chunk(3);  // slot 1 is free
 #pragma unroll
   for (int i = 0; i < T; ++i) {
     const f32x4* xr = reinterpret_cast<const f32x4*>(a.xin) + rowc[i] * 32 + g;
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) res[i][mb] = xr[4 * mb];
   }
-  NS2_REFILL(C1 + 1);
 #pragma unroll
   for (int i = 0; i < T; ++i) {
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc2[i][mb] = vecp[32 + 4 * mb];
+    const f32x4 v01[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+    lb_gemm16v<true, 2>(buf0, v01, acc2[i]);
     const f32x4 v23[4] = {acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
-    lb_gemm16v<true, 2>(NS2_BUF(C1 + 1), v23, acc2[i]);
+    lb_gemm16v<true, 2>(buf0 + NS_CHUNK, v23, acc2[i]);
   }
   f32x4 y[T][8];
 #pragma unroll
@@ -452,54 +435,53 @@ __global__ void __launch_bounds__(512, 2)
     lb_layernorm16(acc2[i], vecp + 64, vecp + 96, y[i], a.ctrl->ln_inv_d, a.ctrl->ln_pad);
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) y[i][mb] = lb_pk_add(res[i][mb], y[i][mb]);
-    if (valid[i]) {
-      f32x4* nr = reinterpret_cast<f32x4*>(a.nlat) + row[i] * 32 + g;
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) nr[4 * mb] = y[i][mb];
-    }
   }
   if (probe) lb_range_probe(a.ctrl, y[0], 8);
   if constexpr (PROJ) {
+    // ---- steps 3, 4: projection halves [Ws | Wr]
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      f32x4 accp[T][8];
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (half == 0) {
-        NS2_STEP(CP);
-        NS2_REFILL(CP);
-      } else {
-        NS2_STEP(CP + 2);
-        NS2_REFILL(CP + 2);
+        issue_chunk(4);  // slot 0 is free
+        // the node latents go out behind the refill (their drain is waited for with the next chunk, not before it)
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+          if (valid[i]) {
+            f32x4* nr = reinterpret_cast<f32x4*>(a.nlat) + row[i] * 32 + g;
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) nr[4 * mb] = y[i][mb];
+          }
       }
+      const lds_cptr bp = half == 0 ? buf1 : buf0;
 #pragma unroll
       for (int i = 0; i < T; ++i) {
+        f32x4 accp[8];
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb) accp[i][mb] = vecp[128 + 32 * half + 4 * mb];
+        for (int mb = 0; mb < 8; ++mb) accp[mb] = vecp[128 + 32 * half + 4 * mb];
         const f32x4 v01[4] = {y[i][0], y[i][1], y[i][2], y[i][3]};
-        lb_gemm16v<false, 2>(half == 0 ? NS2_BUF(CP) : NS2_BUF(CP + 2), v01, accp[i]);
-      }
-      if (half == 0) {
-        NS2_STEP(CP + 1);
-        NS2_REFILL(CP + 1);
-      } else {
-        NS2_STEP(CP + 3);
-        NS2_REFILL(CP + 3);
-      }
-#pragma unroll
-      for (int i = 0; i < T; ++i) {
+        lb_gemm16v<false, 2>(bp, v01, accp);
         const f32x4 v23[4] = {y[i][4], y[i][5], y[i][6], y[i][7]};
-        lb_gemm16v<false, 2>(half == 0 ? NS2_BUF(CP + 1) : NS2_BUF(CP + 3), v23, accp[i]);
+        lb_gemm16v<false, 2>(bp + NS_CHUNK, v23, accp);
         if (valid[i]) {
           f32x4* pr = reinterpret_cast<f32x4*>(a.psr) + row[i] * 64 + 32 * half + g;
 #pragma unroll
-          for (int mb = 0; mb < 8; ++mb) pr[4 * mb] = accp[i][mb];
+          for (int mb = 0; mb < 8; ++mb) pr[4 * mb] = accp[mb];
         }
       }
     }
+  } else {
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+      if (valid[i]) {
+        f32x4* nr = reinterpret_cast<f32x4*>(a.nlat) + row[i] * 32 + g;
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) nr[4 * mb] = y[i][mb];
+      }
   }
-#undef NS2_BUF
+  (void)n_chunks;
 }
 #undef NS2_STEP
-#undef NS2_REFILL
 
 int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const float* w1h, const float* wph2,
                 int npa, int npb, bool resid) {
@@ -533,10 +515,24 @@ int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const flo
   static const int t2 = getenv("LB_NODE_T2") ? atoi(getenv("LB_NODE_T2")) : 0;  // 2: also on small launches (tests)
   if (t2 && npa == 4 && npb == 4 && resid && (nw == 8 || t2 == 2)) {
     dim3 grid2((unsigned)((tiles + 15) / 16)), block2(512);
-    if (proj)
-      LB_LAUNCH_TIMED(e, (k_node16s2<true>), grid2, block2, a, w0, w1, wp);
-    else
-      LB_LAUNCH_TIMED(e, (k_node16s2<false>), grid2, block2, a, w0, w1, wp);
+    const size_t lds2 = sizeof(f32x4) * (4 * NS_CHUNK + 192);  // 128 KiB ring + the bias / LayerNorm vectors
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute((const void*)k_node16s2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      (void)hipFuncSetAttribute((const void*)k_node16s2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      raised = true;
+    }
+    if (e->ext_armed && !e->ext_used) {
+      if (proj)
+        hipExtLaunchKernelGGL((k_node16s2<true>), grid2, block2, lds2, e->stream, e->trecs.back().a, e->trecs.back().b, 0, a, w0, w1, wp);
+      else
+        hipExtLaunchKernelGGL((k_node16s2<false>), grid2, block2, lds2, e->stream, e->trecs.back().a, e->trecs.back().b, 0, a, w0, w1, wp);
+      e->ext_used = true;
+    } else if (proj) {
+      hipLaunchKernelGGL((k_node16s2<true>), grid2, block2, lds2, e->stream, a, w0, w1, wp);
+    } else {
+      hipLaunchKernelGGL((k_node16s2<false>), grid2, block2, lds2, e->stream, a, w0, w1, wp);
+    }
   } else if (npa == 4 && npb == 4 && resid)
     LB_NS_P(4, 4, true);
   else if (npa == 1 && npb == 0 && !resid)
