@@ -125,6 +125,30 @@ __device__ __forceinline__ float lb_node_feature_column(const lb_geom& g, int64_
   }
   return 0.f;
 }
+// the rows of `count` particles (ids[0 .. count), e.g. the own particles of a cell) by one wave: (particle, column)
+// pairs are dealt out to the lanes four rounds at a time, so that the position loads of up to 256 columns are in flight
+// together (one row at a time cost the per-cell search kernel a memory round trip per particle)
+template <typename IDS>
+__device__ __forceinline__ void lb_node_features_wave_multi(const lb_geom& g, int64_t BN, const double* __restrict__ win,
+                                                            int step, const lb_feat_job& f, IDS ids, int count) {
+  const int lane = threadIdx.x & 63, kp = f.kpad, total = count * kp;
+  for (int base = 0; base < total; base += 256) {
+    float v[4];
+    int64_t dst[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + 64 * u + lane;
+      const bool ok = idx < total;
+      const int p = ok ? idx / kp : 0, col = ok ? idx - p * kp : 0;
+      const int64_t gi = ids(p);
+      dst[u] = ok ? gi * kp + col : -1;
+      v[u] = lb_node_feature_column(g, BN, win, step, f, gi, col);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (dst[u] >= 0) f.xnode[dst[u]] = v[u];
+  }
+}
 __device__ __forceinline__ void lb_node_features_wave(const lb_geom& g, int64_t BN, const double* __restrict__ win,
                                                       int step, const lb_feat_job& f, int64_t gi) {
   float* const x = f.xnode + gi * f.kpad;

@@ -260,7 +260,9 @@ struct lb_nl_args {
   int32_t row_cap;          // k_nlw: LDS row-buffer entries per wave (>= LB_MAX_ROW)
   lb_feat_job feat;         // NL_ROWS in a rollout step: every search wave also writes the node-feature row of its
   const double* win;        //   receiver (lb_features.h; xnode == null: no job)
+  int32_t nb_search;        // k_nl: workgroups of the search proper; the ones behind them write feature rows (0: none)
 };
+#define NL_FEAT_ROWS 8      // feature rows per wave of a k_nl feature workgroup
 
 template <int MODE, int NL_THREADS, int MAXC, bool F32 = false>
 __global__ void __launch_bounds__(NL_THREADS)
@@ -272,6 +274,15 @@ __global__ void __launch_bounds__(NL_THREADS)
   __shared__ int s_cstart[28], s_coff[29];
 
   if (ctrl->overflow_step >= 0) return;
+  if (MODE == NL_ROWS && a.nb_search > 0 && (int)blockIdx.x >= a.nb_search) {
+    // rollout step: the workgroups behind the search's write the node-feature rows (NL_FEAT_ROWS consecutive particles
+    // per wave, all their loads in flight together; they run beside the per-cell search, which is a latency chain)
+    const int64_t first = ((int64_t)(blockIdx.x - a.nb_search) * NL_WAVES + (threadIdx.x >> 6)) * NL_FEAT_ROWS;
+    const int cnt = (int)min((int64_t)NL_FEAT_ROWS, BN - first);
+    if (cnt > 0)
+      lb_node_features_wave_multi(g, BN, a.win, ctrl->step, a.feat, [&](int p) -> int64_t { return first + p; }, cnt);
+    return;
+  }
   const int tid = threadIdx.x;
   const int gc = blockIdx.x;
   const int b = gc / g.ncells, h = gc % g.ncells;
@@ -344,7 +355,6 @@ __global__ void __launch_bounds__(NL_THREADS)
   for (int k = wave; k < own_cnt; k += NL_WAVES) {
     if (own_off + k >= M) break;  // truncated stencil (density error already flagged)
     const int gr = s_id[own_off + k];
-    if (MODE == NL_ROWS && a.feat.xnode) lb_node_features_wave(g, BN, a.win, ctrl->step, a.feat, gr);
     double pr[3] = {0, 0, 0};
     for (int d = 0; d < g.dim; ++d) pr[d] = s_p[d][own_off + k];
     int count = 0;
@@ -1404,8 +1414,10 @@ static void lb_launch_nl(lb_engine* e, int small, const lb_nl_args& a) {
   if (ride) {
     ac.feat = e->feat_job;
     ac.win = e->win;
+    ac.nb_search = ncell_tot;
   }
-  const int ride64 = 0, ride256 = 0;
+  const int ride64 = ride ? (int)((e->BN + NL_FEAT_ROWS - 1) / NL_FEAT_ROWS) : 0;
+  const int ride256 = ride ? (int)((e->BN + 4 * NL_FEAT_ROWS - 1) / (4 * NL_FEAT_ROWS)) : 0;
 #define LB_NL_CASE(C)                                                                                       \
   case C:                                                                                                   \
     hipLaunchKernelGGL((k_nl<MODE, 64, C>), dim3(ncell_tot + ride64), dim3(64), 0, e->stream, e->g, e->BN,  \
