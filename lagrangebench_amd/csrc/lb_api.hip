@@ -767,7 +767,19 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
         wsr_of(pe_w0[k + 1], wsr);
         o_ms_pn[k] = put_ms({{pn_w0[k], 2 * D, D, 8, 1, true}, {pn_w1[k], D, D, 4, 1, true}, {wsr.data(), D, 2 * D, 4, 2, true}});
       } else {
-        o_ms_pn[k] = put_ms({{pn_w0[k], 2 * D, D, 8, 1, true}, {pn_w1[k], D, D, 4, 1, true}});
+        // last layer: [W0 | W1 | decoder W0 | decoder W1 (out_dim block, scaled like dec_w1_h)] - k_node_ms<DEC>
+        std::vector<float> img((size_t)8 * 4096 + 4 * 4096 + 4 * 4096 + 2048, 0.f), tmp((size_t)4 * 4096);
+        lb_pack_ms(pn_w0[k], 2 * D, D, 8, 1, true, img.data());
+        lb_pack_ms(pn_w1[k], D, D, 4, 1, true, img.data() + (size_t)8 * 4096);
+        lb_pack_ms(p_dec, D, D, 4, 1, true, img.data() + (size_t)12 * 4096);
+        {
+          const float* w1d = p_dec + (size_t)D * D + D;
+          std::vector<float> scaled(w1d, w1d + (size_t)D * d->out_dim);
+          for (float& x : scaled) x = x / dec_unscale;  // dec_unscale is a power of two: exact
+          lb_pack_ms(scaled.data(), D, d->out_dim, 4, 1, true, tmp.data());
+          memcpy(img.data() + (size_t)16 * 4096, tmp.data(), sizeof(float) * 2048);  // block 0 = outputs 0 .. 15
+        }
+        o_ms_pn[k] = put(img.data(), img.size());
       }
     }
   }

@@ -373,7 +373,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
   // k_node_mlp.  Stand-alone aggregation (lb_set_fused_aggregation(0)): k_edge16 writes the messages, k_segment_sum
   // adds them up.
   auto node_mlp = [&](const lb_mlp_w& w, const float* xin, int kq, bool with_agg, bool resid, int next,
-                      const float* ms_img, const float* w0h, const float* w1h, bool ms) -> int {
+                      const float* ms_img, const float* w0h, const float* w1h, bool ms, bool dec = false) -> int {
     const bool proj = next < L;
     lb_node_args a{};
     a.ctrl = e->ctrl;
@@ -411,7 +411,18 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       m.ln_o = a.ln_o;
       m.bp = a.bp;
       m.psr = e->psr;
-      return lbk_node_ms(e, m, kq / 4, with_agg, resid, proj);
+      if (dec) {  // last layer: decoder (+ integrator in a rollout step) in the same launch
+        m.bd0 = g->dec.b0;
+        m.bd1 = g->dec.b1;
+        m.dec_unscale = g->dec_unscale;
+        m.acc_out = e->acc;
+        m.out_dim = g->desc.out_dim;
+        if (e->integ_job.on && g->desc.out_dim == e->g.dim) {
+          m.integ = e->integ_job;
+          e->integ_done = true;
+        }
+      }
+      return lbk_node_ms(e, m, kq / 4, with_agg, resid, proj, dec);
     }
     if (e->f16x2)
       return lbk_node16s(e, a, w0h, w1h, proj ? g->proj_w_h2[next] : nullptr, kq / 4, with_agg ? 4 : 0, resid);
@@ -434,6 +445,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
   lb_toc(e);
   if (rc) return rc;
 
+  bool decoded = false;  // the decoder ran inside the last layer's node launch
   lb_tic(e, LB_T_ENC_EDGE);
   if (ms_ee) {
     lb_ems_args m{};
@@ -555,15 +567,20 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       lb_toc(e);
       if (rc) return rc;
     }
+    // M-split node kernel on the last layer: the decoder rides along (LB_MS_DEC=0: separate k_decoder16 launch)
+    static const bool ms_dec_ok = !(getenv("LB_MS_DEC") && getenv("LB_MS_DEC")[0] == '0');
+    const bool with_dec = ms_pn && ms_dec_ok && k == L - 1 && e->f16x2 && g->desc.out_dim <= 4;
     lb_tic_single(e, LB_T_NODE_MLP);
     rc = node_mlp(g->proc_node[k], e->nlat, 16, true, true, k + 1, g->ms_proc_node[k], g->proc_node_w0_h[k],
-                  g->proc_node_w1_h[k], ms_pn);
+                  g->proc_node_w1_h[k], ms_pn, with_dec);
     lb_toc(e);
+    decoded = with_dec;
     if (rc) return rc;
     if (g->tap)
       LB_HIP(hipMemcpyAsync(g->tap + (size_t)(k + 1) * BN * LB_D, e->nlat, sizeof(float) * BN * LB_D,
                             hipMemcpyDeviceToDevice, s));
   }
+  if (decoded) return LB_OK;
   lb_tic(e, LB_T_DECODER);
   rc = lbk_decoder16(e, g);
   lb_toc(e);

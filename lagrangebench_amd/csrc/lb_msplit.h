@@ -36,6 +36,14 @@ struct lb_nms_args {      // node kernel
   const float* ln_o;
   const float* bp;        // [256] projection bias
   float* psr;             // out [rows][256]
+  // DEC (last processor layer): the decoder MLP (gns.py:125-133) and, in a rollout step, the integrator run in this
+  // launch's epilogue; `w` then continues with [decoder W0 | out_dim block of decoder W1 (scaled, see dec_unscale)]
+  const float* bd0;       // [128] decoder hidden bias
+  const float* bd1;       // [>= 4] decoder output bias
+  float dec_unscale;
+  float* acc_out;         // [rows][4]
+  int32_t out_dim;
+  lb_integ_job integ;     // on = 0: stand-alone forward
   long long* dbg;         // LB_MS_DBG=1: shader-clock stamps of workgroup 0 (null in the product path)
 };
 
@@ -72,5 +80,5 @@ struct lb_persist_args {
 void lb_pack_ms(const float* w, int K, int M, int nkb, int npw, bool perm, float* out);
 int lbk_edge_ms(lb_engine* e, const lb_ems_args& a);
 int lbk_edge_enc_ms(lb_engine* e, const lb_ems_args& a);
-int lbk_node_ms(lb_engine* e, const lb_nms_args& a, int nka, bool agg, bool resid, bool proj);
+int lbk_node_ms(lb_engine* e, const lb_nms_args& a, int nka, bool agg, bool resid, bool proj, bool dec = false);
 int lbk_gns_persist(lb_engine* e, const lb_persist_args& a);

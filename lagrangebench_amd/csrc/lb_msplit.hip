@@ -34,6 +34,7 @@
 #include <algorithm>
 
 #include "lb_msplit_dev.h"
+#include "lb_features.h"
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
@@ -322,15 +323,18 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_enc_ms(lb_ems_args a) {
 // aggregated messages.  Wave w owns output blocks 2w, 2w+1 of both Linears and 4w .. 4w+3 of the 256-wide
 // projection: 320 registers of weights (one wave per SIMD, 512 registers each).  T tiles of 16 nodes per iteration
 // (their loads are in flight together; the weights are reused from registers).
-template <int NKA, bool AGG, bool RESID, bool PROJ, int T>
-__global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a) {
+// DEC (last layer, no projection): decoder MLP + (rollout step) integrator in the epilogue - one launch less per step.
+template <int NKA, bool AGG, bool RESID, bool PROJ, int T, bool DEC = false>
+__global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geom geom) {
+  static_assert(!(DEC && PROJ), "the decoder follows the LAST layer");
   constexpr int NK0 = NKA + (AGG ? 4 : 0);
   __shared__ f32x4 sB1[T][NK0 * 2 * 64];
   __shared__ f32x4 sB2[T][4 * 2 * 64];
-  __shared__ f32x4 sB3[PROJ ? T : 1][4 * 2 * 64];
+  __shared__ f32x4 sB3[(PROJ || DEC) ? T : 1][4 * 2 * 64];
   __shared__ __attribute__((aligned(16))) f32x2m sRed[T][16 * 4];
   __shared__ __attribute__((aligned(16))) int sMx[3][T][4];
   const int poisoned = a.ctrl->overflow_step;
+  const int step = a.ctrl->step;
   const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -338,7 +342,17 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a) {
   ms_walk wk;
   // (acting on the poison flag only after the first loads are out - the trick of the edge kernels - measured SLOWER
   // here: 9.4 -> 10.3 us per launch on TGV2D-2.5k)
-  if (poisoned >= 0 || !wk.init((ntiles + T - 1) / T)) return;
+  const bool has_work = wk.init((ntiles + T - 1) / T);
+  if (poisoned >= 0) return;
+  if (!has_work) {
+    if constexpr (DEC) {  // (an idle workgroup still counts towards "everybody has finished")
+      if (a.integ.on && tid == 0 && atomicAdd(a.integ.blocks_done, 1) == (int)gridDim.x - 1) {
+        *a.integ.blocks_done = 0;
+        const_cast<lb_ctrl*>(a.ctrl)->step = step + 1;
+      }
+    }
+    return;
+  }
   const f32x4* xin4 = reinterpret_cast<const f32x4*>(a.xin);
   const bool has_x = w < NKA;  // this wave holds an input k-block (uniform)
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -413,6 +427,15 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a) {
     const f32x4* wb1 = wb + 8 * NK0 * 2 * 64;
     ms_wload<4, 2>(wb1, 2 * w, w1h, w1l);
     if constexpr (PROJ) ms_wload<4, 4>(wb1 + 8 * 4 * 2 * 64, 4 * w, wph, wpl);
+  }
+  h8 wd0h[DEC ? 2 : 1][4], wd0l[DEC ? 2 : 1][4], wd1h[1][4], wd1l[1][4];
+  f32x4 bd0v[2] = {};
+  if constexpr (DEC) {
+    const f32x4* wbd = reinterpret_cast<const f32x4*>(a.w) + lane + 8 * NK0 * 2 * 64 + 8 * 4 * 2 * 64;
+    ms_wload<4, 2>(wbd, 2 * w, wd0h, wd0l);
+    ms_wload<4, 1>(wbd + 8 * 4 * 2 * 64, 0, wd1h, wd1l);
+    bd0v[0] = reinterpret_cast<const f32x4*>(a.bd0)[8 * w + g];
+    bd0v[1] = reinterpret_cast<const f32x4*>(a.bd0)[8 * w + 4 + g];
   }
   f32x4 b0v[2], b1v[2], lns[2], lno[2], bpv[4];
 #pragma unroll
@@ -510,10 +533,72 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a) {
         }
       }
     }
+    if constexpr (DEC) {
+      // ---- decoder: hidden = relu(Wd0^T y + bd0) (this wave's two blocks), out = Wd1^T hidden (one 16-wide block,
+      // computed by every wave, used by wave 0), then the integrator for the tile's 16 nodes (lanes g == 0 of wave 0)
+      lb_integ_in pre[T == 1 ? 1 : 1];  // (prefetched only in the one-tile variant: the two-tile one has no registers to spare)
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        if constexpr (T == 1) {
+          if (a.integ.on && w == 0 && g == 0 && valid[i])
+            pre[0] = lb_integrate_fetch(geom, a.n_rows, a.integ.win, step, a.integ.ptype, rcv[i]);
+        }
+        uint32_t orv;
+        ms_stage<false>(sB3[i], w, lane, y[i][0], y[i][1], orv, guard.big);
+        const int c = guard.code(orv);
+        if (lane == 0) sMx[2][i][w] = c;
+      }
+      __syncthreads();
+      f32x4 hd[T][2];
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        guard.tile_codes(sMx[2][i]);
+        hd[i][0] = bd0v[0];
+        hd[i][1] = bd0v[1];
+        ms_gemm<4, 2>(sB3[i], lane, wd0h, wd0l, hd[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < T; ++i) {  // (sB2 / sMx[1] were last read before the LayerNorm barrier)
+        uint32_t orv;
+        ms_stage<true>(sB2[i], w, lane, hd[i][0], hd[i][1], orv, guard.big);
+        const int c = guard.code(orv);
+        if (lane == 0) sMx[1][i][w] = c;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        guard.tile_codes(sMx[1][i]);
+        f32x4 o[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+        ms_gemm<4, 1>(sB2[i], lane, wd1h, wd1l, o);
+        if (w == 0 && g == 0 && valid[i]) {
+          const f32x4 b1v = *reinterpret_cast<const f32x4*>(a.bd1);
+          const f32x4 acc_o = o[0] * a.dec_unscale + b1v;
+          reinterpret_cast<f32x4*>(a.acc_out)[rcv[i]] = acc_o;
+          bool bad = false;
+          for (int d = 0; d < a.out_dim; ++d) bad |= !(fabsf(acc_o[d]) <= 3.0e38f);
+          if (bad) lb_raise_math(a.ctrl, LB_MATH_NONFINITE);
+          if (a.integ.on) {
+            const float av[4] = {acc_o[0], acc_o[1], acc_o[2], acc_o[3]};
+            lb_integrate_body(geom, a.n_rows, a.integ.win, step, a.integ.ptype, av, nullptr, a.integ.traj, a.integ.T,
+                              a.integ.pred, a.integ.pred_T, rcv[i], T == 1 ? &pre[0] : nullptr);
+          }
+        }
+      }
+    }
     if (it < 2) MS_STAMP(12 + 12 * it);
   }
   MS_STAMP(30);
   guard.commit(a.ctrl, lane);
+  if constexpr (DEC) {
+    // the step counter is advanced by the LAST workgroup to finish (k_integrate's job)
+    if (a.integ.on) {
+      __syncthreads();
+      if (tid == 0 && atomicAdd(a.integ.blocks_done, 1) == (int)gridDim.x - 1) {
+        *a.integ.blocks_done = 0;
+        const_cast<lb_ctrl*>(a.ctrl)->step = step + 1;
+      }
+    }
+  }
   MS_STAMP(31);
 }
 
@@ -568,7 +653,7 @@ int lbk_edge_enc_ms(lb_engine* e, const lb_ems_args& a_in) {
   return LB_OK;
 }
 
-int lbk_node_ms(lb_engine* e, const lb_nms_args& a_in, int nka, bool agg, bool resid, bool proj) {
+int lbk_node_ms(lb_engine* e, const lb_nms_args& a_in, int nka, bool agg, bool resid, bool proj, bool dec) {
   lb_nms_args a = a_in;
   a.dbg = ms_dbg_buf();
   const int64_t tiles = (a.n_rows + 15) / 16;
@@ -576,16 +661,26 @@ int lbk_node_ms(lb_engine* e, const lb_nms_args& a_in, int nka, bool agg, bool r
   static const int t_env = getenv("LB_MS_NODE_T") ? atoi(getenv("LB_MS_NODE_T")) : 0;
   const bool t2 = t_env ? t_env == 2 : tiles > 256;
   const dim3 grid(ms_grid(t2 ? (tiles + 1) / 2 : tiles, 1)), block(MS_THREADS);
+  if (dec) {  // last processor layer + decoder (+ integrator)
+    if (!(nka == 4 && agg && resid && !proj)) return lb_fail(LB_ERR_UNSUPPORTED, "k_node_ms<DEC>: processor shape only");
+    if (t2)
+      LB_LAUNCH_TIMED(e, (k_node_ms<4, true, true, false, 2, true>), grid, block, a, e->g);
+    else
+      LB_LAUNCH_TIMED(e, (k_node_ms<4, true, true, false, 1, true>), grid, block, a, e->g);
+    ms_dbg_dump("node+dec", a.dbg);
+    LB_HIP(hipGetLastError());
+    return LB_OK;
+  }
 #define LB_NMS(A, G, R)                                                          \
   do {                                                                           \
     if (proj && t2)                                                              \
-      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, true, 2>), grid, block, a);         \
+      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, true, 2>), grid, block, a, e->g);   \
     else if (proj)                                                               \
-      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, true, 1>), grid, block, a);         \
+      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, true, 1>), grid, block, a, e->g);   \
     else if (t2)                                                                 \
-      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, false, 2>), grid, block, a);        \
+      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, false, 2>), grid, block, a, e->g);  \
     else                                                                         \
-      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, false, 1>), grid, block, a);        \
+      LB_LAUNCH_TIMED(e, (k_node_ms<A, G, R, false, 1>), grid, block, a, e->g);  \
   } while (0)
   if (nka == 4 && agg && resid)
     LB_NMS(4, true, true);

@@ -25,6 +25,7 @@ SWITCHES = [
     {"LB_NODE_T2": "2", "LB_MSPLIT": "0"},                # node kernel with two tiles per wave and weight chunk
     {"LB_NL_ONE": "0"},                                   # four-launch neighbor build also for one small trajectory
     {"LB_NL_ONE": "0", "LB_NL_CSCAN": "0"},               # ... and degree scan / finish / compaction as separate launches
+    {"LB_MS_DEC": "0"},                                   # decoder as a launch of its own also behind the M-split node kernel
     {"LB_STEP_FUSE": "0"},                                # node features / integrator as launches of their own
     {"LB_TEST_RESUME_AT": "3"},                           # guard fires at step 3: the rollout resumes there in fp32
 ]
