@@ -465,13 +465,21 @@ __global__ void __launch_bounds__(64 * NLW_WAVES)
   const int row_cap = a.row_cap;
   __shared__ int s_cstart[NLW_WAVES][28], s_coff[NLW_WAVES][29];
   if (ctrl->overflow_step >= 0) return;
+  if (MODE == NL_ROWS && a.nb_search > 0 && (int)blockIdx.x >= a.nb_search) {
+    // rollout step: the workgroups behind the search's write the node-feature rows (as in k_nl; inside the receiver's
+    // own wave the row cost the batch search +19 us - one more round trip in a chain of five)
+    const int64_t first = ((int64_t)(blockIdx.x - a.nb_search) * NLW_WAVES + (threadIdx.x >> 6)) * NL_FEAT_ROWS;
+    const int cnt = (int)min((int64_t)NL_FEAT_ROWS, BN - first);
+    if (cnt > 0)
+      lb_node_features_wave_multi(g, BN, a.win, ctrl->step, a.feat, [&](int p) -> int64_t { return first + p; }, cnt);
+    return;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int* const s_row = s_dyn + (size_t)wave * 2 * row_cap;
   int* const s_id = s_row + row_cap;
   const int64_t r = (int64_t)blockIdx.x * NLW_WAVES + wave;  // receiver slot in cell-sorted order
   if (r >= BN) return;
   const int gr = a.cell_part[r];
-  if (MODE == NL_ROWS && a.feat.xnode) lb_node_features_wave(g, BN, a.win, ctrl->step, a.feat, gr);
   const int gc = a.cell_of[gr];
   const int b = gc / g.ncells, h = gc % g.ncells;
   {
@@ -1390,11 +1398,14 @@ static void lb_launch_nl(lb_engine* e, int small, const lb_nl_args& a) {
   const bool ride = MODE == NL_ROWS && e->feat_job.xnode && !a.efeat64;
   if (ride) e->feat_done = true;
   if (per_wave) {
-    const int nb = (int)((e->BN + NLW_WAVES - 1) / NLW_WAVES);
+    const int nb_s = (int)((e->BN + NLW_WAVES - 1) / NLW_WAVES);
+    int nb = nb_s;
     lb_nl_args aw = a;
     if (ride) {
       aw.feat = e->feat_job;
       aw.win = e->win;
+      aw.nb_search = nb_s;
+      nb = nb_s + (int)((e->BN + NLW_WAVES * NL_FEAT_ROWS - 1) / (NLW_WAVES * NL_FEAT_ROWS));
     }
     aw.row_cap = e->row_cap > LB_MAX_ROW ? e->row_cap : LB_MAX_ROW;
     const size_t lds = sizeof(int) * 2 * NLW_WAVES * (size_t)aw.row_cap;
