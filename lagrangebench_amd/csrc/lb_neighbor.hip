@@ -828,6 +828,19 @@ __global__ void __launch_bounds__(LB_SMALL_T)
 //     (workgroups are dispatched in index order, so a predecessor is running or done; bounded spin);
 //   * the last workgroup also histograms the cells (max_cell_occ for the did_buffer_overflow flag) and does
 //     k_row_finish's job.
+// cell coordinate of a position: int(position / cell_size) clamped to the grid (k_cells_small's arithmetic).  The fp64
+// quotient decides only near an integer: a float product locates the value first (|error| < 4e-4 for |q| < 2000), and
+// only inside a 1e-3 band around an integer - or far outside the grid - is the exact (in f32 mode: float-rounded)
+// quotient evaluated.  Every workgroup of the single-launch builds recomputes ALL N coordinates, and in fp64 that
+// was VALU time (k_nl_mid: 8.5 of 35 us).
+template <bool F32>
+__device__ __forceinline__ int lb_cell_coord(double p, float inv_cs32, double cs, int n) {
+  const float q = (float)p * inv_cs32;
+  const float fl = floorf(q), fr = q - fl;
+  int c = (int)fl;
+  if (fr < 1e-3f || fr > 0.999f || !(fabsf(q) < 2000.f)) c = __double2int_rz(lb_r(p / cs, F32));
+  return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
 #define NLS_WAVES 16  // at most; the launch uses ceil(N / 256) waves so that every CU gets at most one workgroup
 #define NLS_THREADS (64 * NLS_WAVES)
 #define NLS_CAND 512  // stencil candidates per receiver (row buffer entries; >= LB_MAX_ROW)
@@ -892,8 +905,8 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
       pv[k][1] = w0[N + ic];
       pv[k][2] = DIM == 3 ? w0[2 * N + ic] : 0.0;
     }
-    double inv_cs[3];
-    _Pragma("unroll") for (int d = 0; d < 3; ++d) inv_cs[d] = d < DIM ? 1.0 / g.cell_size[d] : 0.0;
+    float inv_cs[3];
+    _Pragma("unroll") for (int d = 0; d < 3; ++d) inv_cs[d] = d < DIM ? (float)(1.0 / g.cell_size[d]) : 0.f;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int i = tid + (int)blockDim.x * k;
@@ -902,14 +915,7 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
         _Pragma("unroll") for (int d = 0; d < DIM; ++d) {
           const double p = pv[k][d];
           s_p[d * npad + i] = p;
-          // the quotient decides through its integer part only: the reciprocal product is exact enough unless it
-          // lands within 1e-6 (relative) of an integer (or, in f32 mode, of a float rounding up to one) - then divide
-          double q = p * inv_cs[d];
-          const double fr = q - floor(q), tol = 1e-6 * (fabs(q) + 1.0);
-          if (fr < tol || fr > 1.0 - tol) q = lb_r(p / g.cell_size[d], F32);
-          int c = __double2int_rz(q);
-          c = c < 0 ? 0 : (c >= g.ncell[d] ? g.ncell[d] - 1 : c);
-          packed |= c << (11 * d);
+          packed |= lb_cell_coord<F32>(p, inv_cs[d], g.cell_size[d], g.ncell[d]) << (11 * d);
         }
         s_cell[i] = i < N ? packed : -1;
       }
@@ -1148,22 +1154,15 @@ __global__ void __launch_bounds__(64 * NLM_WAVES) k_nl_mid(lb_geom g, lb_ctrl* _
       pv[k][1] = w0[N + ic];
       pv[k][2] = DIM == 3 ? w0[2 * N + ic] : 0.0;
     }
-    double inv_cs[3];
-    _Pragma("unroll") for (int d = 0; d < 3; ++d) inv_cs[d] = d < DIM ? 1.0 / g.cell_size[d] : 0.0;
+    float inv_cs[3];
+    _Pragma("unroll") for (int d = 0; d < 3; ++d) inv_cs[d] = d < DIM ? (float)(1.0 / g.cell_size[d]) : 0.f;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int i = tid + 64 * NLM_WAVES * k;
       if (i < npad) {
         int packed = 0;
-        _Pragma("unroll") for (int d = 0; d < DIM; ++d) {
-          const double p = pv[k][d];
-          double q = p * inv_cs[d];  // (see k_nl_small: exact division only near an integer)
-          const double fr = q - floor(q), tol = 1e-6 * (fabs(q) + 1.0);
-          if (fr < tol || fr > 1.0 - tol) q = lb_r(p / g.cell_size[d], F32);
-          int c = __double2int_rz(q);
-          c = c < 0 ? 0 : (c >= g.ncell[d] ? g.ncell[d] - 1 : c);
-          packed |= c << (11 * d);
-        }
+        _Pragma("unroll") for (int d = 0; d < DIM; ++d)
+          packed |= lb_cell_coord<F32>(pv[k][d], inv_cs[d], g.cell_size[d], g.ncell[d]) << (11 * d);
         s_cell[i] = i < N ? packed : -1;
       }
     }
@@ -1253,23 +1252,35 @@ __global__ void __launch_bounds__(64 * NLM_WAVES) k_nl_mid(lb_geom g, lb_ctrl* _
       ncand = max(room - cbase, 0);
     }
     int count = 0;
-    for (int c0 = 0; c0 < ncand; c0 += 64) {
-      const int t = c0 + lane;
-      bool ok = false;
-      int j = 0;
-      if (t < ncand) {
-        j = row[cbase + t];
-        double dd = lb_disp1(w0[j], pr[0], g.box[0], g.half_box[0], g.periodic, F32);
-        double d2 = lb_r(dd * dd, F32);
-        _Pragma("unroll") for (int d = 1; d < DIM; ++d) {
-          dd = lb_disp1(w0[d * N + j], pr[d], g.box[d], g.half_box[d], g.periodic, F32);
-          d2 = lb_r(d2 + lb_r(dd * dd, F32), F32);
-        }
-        ok = d2 < g.rc2;
+    // four sweeps of 64 candidates at a time: their position loads (L2) are in flight together - one sweep at a time
+    // every sweep was a memory round trip of its own (9 us per receiver)
+    for (int c0 = 0; c0 < ncand; c0 += 256) {
+      int jj[4];
+      double pj[4][DIM];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = c0 + 64 * u + lane;
+        jj[u] = t < ncand ? row[cbase + t] : r;
+        _Pragma("unroll") for (int d = 0; d < DIM; ++d) pj[u][d] = w0[d * N + jj[u]];
       }
-      const unsigned long long mask = __ballot(ok);
-      if (ok) row[cbase + count + __popcll(mask & lt_mask)] = j;  // in place: lands at or before the lane's own slot
-      count += __popcll(mask);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = c0 + 64 * u + lane;
+        bool ok = false;
+        if (t < ncand) {
+          double dd = lb_disp1(pj[u][0], pr[0], g.box[0], g.half_box[0], g.periodic, F32);
+          double d2 = lb_r(dd * dd, F32);
+          _Pragma("unroll") for (int d = 1; d < DIM; ++d) {
+            dd = lb_disp1(pj[u][d], pr[d], g.box[d], g.half_box[d], g.periodic, F32);
+            d2 = lb_r(d2 + lb_r(dd * dd, F32), F32);
+          }
+          ok = d2 < g.rc2;
+        }
+        const unsigned long long mask = __ballot(ok);
+        // in place: a hit lands at or before the slot its candidate was read from, and this batch has been read
+        if (ok) row[cbase + count + __popcll(mask & lt_mask)] = jj[u];
+        count += __popcll(mask);
+      }
     }
     if (count > LB_MAX_ROW) flags = 1;
     cnt_i[i] = count;
