@@ -24,7 +24,7 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=o
 # per-file extras.  lb_edge16v.hip: the SLP vectoriser packs the LayerNorm / scan arithmetic into
 # v_pk_*_f32 pairs, which need register-pair shuffles (v_mov) and cannot carry a DPP operand.
 EXTRA_FLAGS = {"lb_edge16v.hip": ["-fno-slp-vectorize"], "lb_edge32.hip": ["-fno-slp-vectorize"], "lb_node16s.hip": ["-fno-slp-vectorize"],
-               "lb_gns_generic.hip": ["-fno-slp-vectorize"], "lb_msplit.hip": ["-fno-slp-vectorize"], "lb_persist.hip": ["-fno-slp-vectorize"]}
+               "lb_gns_generic.hip": ["-fno-slp-vectorize"], "lb_segnn_msg.hip": ["-fno-slp-vectorize"], "lb_msplit.hip": ["-fno-slp-vectorize"], "lb_persist.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -1,6 +1,7 @@
-// lb_segnn_msg.hip - the SEGNN message function of one layer as ONE kernel:
-//   gather f_sender, f_receiver -> O3TensorProductGate -> O3TensorProductGate -> segment_sum
-// (SEGNNLayer._message + jraph aggregation, lagrangebench/models/segnn.py:280-304,306-311; e3nn
+// lb_segnn_msg.hip - the SEGNN message and update functions of one layer, ONE kernel each:
+//   k_sg_msg:  gather f_sender, f_receiver -> O3TensorProductGate -> O3TensorProductGate -> segment_sum
+//   k_sg_upd:  [f | agg] -> O3TensorProductGate -> O3TensorProduct -> f +=
+// (SEGNNLayer._message / _update + jraph aggregation, lagrangebench/models/segnn.py:280-334; e3nn
 // conventions as in oracle/segnn_oracle.py).  blocks_per_step == 2 only; other depths use the
 // per-block kernel of lb_segnn.hip.
 //
@@ -9,7 +10,7 @@
 // kernel reads two 512-B node rows (L2/MALL resident) + 40 B of list data, and per receiver it
 // writes one 512-B row.
 //
-// Arithmetic: 16-edge tiles on v_mfma_f32_16x16x32_f16 in the f16x2 split scheme of lb_edge16.hip
+// Arithmetic: 16-edge tiles on v_mfma_f32_16x16x32_f16 in the f16x2 split scheme of lb_f16x2.h
 // (x = hi + lo, products lo*hi + hi*lo + hi*hi, fp32 accumulate).  Layout: lane (n = l&15, g = l>>4)
 // holds, for edge n, the features 16 mb + 4 g + j of a 128-float SV row [s | vx | vy | vz]
 // (mb 0,1 = scalars, 2,3 = x, 4,5 = y, 6,7 = z); a K-step of 32 is exactly one of those groups.
@@ -20,301 +21,381 @@
 // (constants folded into the weights on the host); the two message features (|r|, r) enter through
 // fp32 FMAs on the accumulator start values.  Gate activations and the gating product are in-lane:
 // the gate of vector channel m sits in the same (lane, register) as the channel itself.
+//
+// Round 4 (the kernel is bound by VALU issue, not by the matrix pipe or by memory: 916 VALU + 66
+// transcendental + 144 MFMA instructions per tile in round 3):
+//   * 2D cases never touch the z component: a_z = 0 and v_z = 0 on every node, so out_v[z] is exactly 0
+//     in the reference too - the DIM = 2 instantiation skips its gathers, splits, MFMAs, gates, scan;
+//   * the gate constants live in the weights: every S column is pre-scaled by -log2(e) (sigmoid(x) =
+//     rcp(1 + exp2(z)), silu(x) ~ z * sigmoid: v_exp_f32 + v_add + v_rcp_f32 [+ v_mul]), the
+//     second-moment constant of the sigmoid sits in the T / V matrices, the one of the silu in the rows
+//     of the NEXT block that consume it;
+//   * the message feature r enters through T (r_c = a_c |r| / Y1: one FMA per T entry instead of one
+//     multiply per V entry);
+//   * fp16 hi/lo split on the mixed-precision fma (lb_split8v: 12 instead of 20 VALU per 8 values), the
+//     segmented scan as v_fmac_f32_dpp asm blocks (lb_scan8: no v_mov_dpp + packed-fma pairs), no
+//     row_ptr gathers (lb_edge_probe), no zeroing of invalid rows (they are their own segments and
+//     are never stored);
+//   * per k-group ONE explicit pair of s_waitcnt (lo fragments, then hi fragments) and s_setprio around
+//     the MFMA phases, as in lb_gemm16v;
+//   * prologue: the weight image travels through registers and the first tile's indices are requested
+//     while it is in flight (one dependent round trip less - the B = 1 launches are latency chains).
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
-#include "lb_device.h"
+#include "lb_f16x2.h"
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-#define MFMA16H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
-
-#define SGM_THREADS 512
-#define SGM_WAVES 8
+// the library is built with -ffp-contract=off for the fp64 geometry (bit-exact against the oracle); the network
+// arithmetic of this file is compared at 1e-5 and wants its multiply-adds fused
+#pragma clang fp contract(fast)
 
 static constexpr float SG_Y0 = 0.28209479177387814f;
 static constexpr float SG_Y1 = 0.4886025119029199f;
 static constexpr float SG_C_SILU = 1.6765620f;
 static constexpr float SG_C_SIGMOID = 1.8462292f;
+static constexpr float SG_NL2E = -1.4426950408889634f;      // -log2(e): z = SG_NL2E * x
+static constexpr float SG_K_SILU = SG_C_SILU / SG_NL2E;     // C_silu * silu(x) = SG_K_SILU * z * sigma(z)
 
-// LDS image of one layer, in f32x4 units (see lb_sg_msg_image below)
+// LDS image of one message layer, in f32x4 units (lb_sg_msg_image below)
+// (tools/sg_msg_bench ablation: NOMFMA drops the matrix instructions of sg_operand)
+template <bool NOMFMA>
+__device__ __forceinline__ f32x4 sg_mfma(const h8& a, const h8& b, const f32x4& c) {
+  if constexpr (NOMFMA) {
+    asm volatile("" ::"v"(a), "v"(b));  // operands stay alive: LDS reads and splits are kept
+    return c;
+  } else {
+    return MFMA16H(a, b, c);
+  }
+}
+#define SG_MFMA(a, b, c) sg_mfma<NOMFMA>((a), (b), (c))
 #define SGM_WS0 0      // K=128 x M=64  hi|lo: 4 p x 4 mbo x 2 x 64
 #define SGM_WT0 2048   // K=64  x M=32: 2 x 2 x 2 x 64
 #define SGM_WV0 2560
+#define SGM_B1 3072    // second lane base (the ds offset field is 16 bits)
 #define SGM_WS1 3072   // K=64 x M=64: 2 x 4 x 2 x 64
 #define SGM_WT1 4096   // K=32 x M=32: 1 x 2 x 2 x 64
 #define SGM_WV1 4352
-#define SGM_VEC 4608   // fp32 vectors: b0(16) wdS(16) wrS(16) wdT(8) wrV(8) b1(16) = 80 f32x4
+#define SGM_VEC 4608   // fp32 vectors: b0(16) wdS(16) wrS(16) wdT(8) wrT(8) b1(16) = 80 f32x4
 #define SGM_IMAGE 4688
 
-__device__ __forceinline__ void sg_split8(const f32x4& x0, const f32x4& x1, h8& hi, h8& lo) {
-  const f32x2_t a[4] = {{x0[0], x0[1]}, {x0[2], x0[3]}, {x1[0], x1[1]}, {x1[2], x1[3]}};
-  h2_t hh[4], ll[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    hh[i] = __builtin_convertvector(a[i], h2_t);
-    const f32x2_t back = __builtin_convertvector(hh[i], f32x2_t);
-    ll[i] = __builtin_convertvector(a[i] - back, h2_t);
-  }
-  hi = h8{hh[0][0], hh[0][1], hh[1][0], hh[1][1], hh[2][0], hh[2][1], hh[3][0], hh[3][1]};
-  lo = h8{ll[0][0], ll[0][1], ll[1][0], ll[1][1], ll[2][0], ll[2][1], ll[3][0], ll[3][1]};
-}
+__device__ __forceinline__ h8 sg_frag(lds_cptr base, int idx) { return __builtin_bit_cast(h8, base[idx]); }
 
-// MFMA issue discipline (measured on gfx950 / ROCm 7.2, see DESIGN.md "MFMA accumulate-chain hazard"):
-// an accumulate chain acc = mfma(a, b, acc) whose links are issued with fewer than ~4 independent
-// MFMAs in between intermittently loses a link's contribution (hipcc rotates the accumulator
-// registers, vDst != SrcC, and then under-spaces the dependent v_mfma_f32_16x16x32_f16).  Every
-// pass below therefore walks >= 6 independent accumulators before it touches one again.
-
-// One tensor-product block on an operand row X (8 f32x4: s0 s1 x0 x1 y0 y1 z0 z1) with edge
-// attribute a[3]; ws/wt/wv: LDS matrices packed by lb_pack_weight16h (4 / 2 / 2 output blocks),
-// ps: K-step of this operand's scalar group in WS (its vector group is ps + 1), pt: its K-step in
-// WT and WV.
-//   group 1 (B = s):              S[0..3] += Ws(ps),  T[0..1] += Wt(pt)          6 accumulators
-//   group 2 (B = v.a, vx, vy, vz): S[0..3] += Ws(ps+1), V[c][0..1] += Wv(pt)     10 accumulators
-__device__ __forceinline__ void sg_operand(const f32x4* __restrict__ ws, const f32x4* __restrict__ wt,
-                                           const f32x4* __restrict__ wv, int ps, int pt, int lane,
-                                           const f32x4 (&X)[8], const float (&a)[3], f32x4 (&S)[4],
-                                           f32x4 (&T)[2], f32x4 (&V)[3][2]) {
+// One tensor-product block on an operand row X (8 f32x4: s0 s1 x0 x1 y0 y1 z0 z1) with edge / node
+// attribute a[3].  ws: this lane's LDS pointer to the operand's scalar k-group of WS (NSB output
+// blocks of 16, [mbo][hi|lo][64 lanes]; the vector k-group follows); wt / wv: to its k-group of WT / WV.
+//   group 1 (B = s):              S[0..NS) += Ws,   T[0..1] += Wt          NS + 2 accumulators
+//   group 2 (B = v.a, v_c):       S[0..NS) += Ws',  V[c][0..1] += Wv       NS + 2 NC accumulators
+// NC = vector components carried (2 in 2D: the z component is identically zero).
+template <int NC, int NS, int NSB, bool PRIO, bool NOMFMA = false>
+__device__ __forceinline__ void sg_operand(lds_cptr ws, lds_cptr wt, lds_cptr wv, const f32x4 (&X)[8],
+                                           const float (&a)[3], f32x4 (&S)[4], f32x4 (&T)[2],
+                                           f32x4 (&V)[3][2]) {
   {
-    h8 bh, bl, sh[4], sl[4], th[2], tl[2];
-    sg_split8(X[0], X[1], bh, bl);
+    h8 sl[NS], tl[2], sh[NS], th[2], bh, bl;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      sh[m] = __builtin_bit_cast(h8, ws[((ps * 4 + m) * 2 + 0) * 64 + lane]);
-      sl[m] = __builtin_bit_cast(h8, ws[((ps * 4 + m) * 2 + 1) * 64 + lane]);
-    }
+    for (int m = 0; m < NS; ++m) sl[m] = sg_frag(ws, (m * 2 + 1) * 64);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      th[m] = __builtin_bit_cast(h8, wt[((pt * 2 + m) * 2 + 0) * 64 + lane]);
-      tl[m] = __builtin_bit_cast(h8, wt[((pt * 2 + m) * 2 + 1) * 64 + lane]);
-    }
+    for (int m = 0; m < 2; ++m) tl[m] = sg_frag(wt, (m * 2 + 1) * 64);
+    SB();
 #pragma unroll
-    for (int m = 0; m < 4; ++m) S[m] = MFMA16H(sl[m], bh, S[m]);
+    for (int m = 0; m < NS; ++m) sh[m] = sg_frag(ws, (m * 2) * 64);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) T[m] = MFMA16H(tl[m], bh, T[m]);
+    for (int m = 0; m < 2; ++m) th[m] = sg_frag(wt, (m * 2) * 64);
+    SB();
+    lb_split8v(X[0], X[1], bh, bl);
+    SB();
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(NS + 2));
 #pragma unroll
-    for (int m = 0; m < 4; ++m) S[m] = MFMA16H(sh[m], bl, S[m]);
+    for (int m = 0; m < NS; ++m) S[m] = SG_MFMA(sl[m], bh, S[m]);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) T[m] = MFMA16H(th[m], bl, T[m]);
+    for (int m = 0; m < 2; ++m) T[m] = SG_MFMA(tl[m], bh, T[m]);
+    SB();
+    __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(0));
 #pragma unroll
-    for (int m = 0; m < 4; ++m) S[m] = MFMA16H(sh[m], bh, S[m]);
+    for (int m = 0; m < NS; ++m) S[m] = SG_MFMA(sh[m], bl, S[m]);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) T[m] = MFMA16H(th[m], bh, T[m]);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int m = 0; m < 2; ++m) T[m] = SG_MFMA(th[m], bl, T[m]);
+#pragma unroll
+    for (int m = 0; m < NS; ++m) S[m] = SG_MFMA(sh[m], bh, S[m]);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) T[m] = SG_MFMA(th[m], bh, T[m]);
+    SB();
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
   }
   {
-    h8 dh, dl, vh[3], vl[3], sh[4], sl[4], wh[2], wl[2];
-    const f32x4 d0 = X[2] * a[0] + X[4] * a[1] + X[6] * a[2];
-    const f32x4 d1 = X[3] * a[0] + X[5] * a[1] + X[7] * a[2];
-    sg_split8(d0, d1, dh, dl);
+    h8 sl[NS], wl[2], sh[NS], wh[2], dh, dl, vh[NC], vl[NC];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) sg_split8(X[2 + 2 * c], X[3 + 2 * c], vh[c], vl[c]);
+    for (int m = 0; m < NS; ++m) sl[m] = sg_frag(ws, ((NSB + m) * 2 + 1) * 64);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      sh[m] = __builtin_bit_cast(h8, ws[(((ps + 1) * 4 + m) * 2 + 0) * 64 + lane]);
-      sl[m] = __builtin_bit_cast(h8, ws[(((ps + 1) * 4 + m) * 2 + 1) * 64 + lane]);
+    for (int m = 0; m < 2; ++m) wl[m] = sg_frag(wv, (m * 2 + 1) * 64);
+    SB();
+#pragma unroll
+    for (int m = 0; m < NS; ++m) sh[m] = sg_frag(ws, ((NSB + m) * 2) * 64);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) wh[m] = sg_frag(wv, (m * 2) * 64);
+    SB();
+    f32x4 d0 = X[2] * a[0] + X[4] * a[1], d1 = X[3] * a[0] + X[5] * a[1];
+    if constexpr (NC == 3) {
+      d0 = d0 + X[6] * a[2];
+      d1 = d1 + X[7] * a[2];
     }
+    lb_split8v(d0, d1, dh, dl);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      wh[m] = __builtin_bit_cast(h8, wv[((pt * 2 + m) * 2 + 0) * 64 + lane]);
-      wl[m] = __builtin_bit_cast(h8, wv[((pt * 2 + m) * 2 + 1) * 64 + lane]);
-    }
-#define SGM_PASS(SA, DB, WA, VB)                                            \
-  _Pragma("unroll") for (int m = 0; m < 4; ++m) S[m] = MFMA16H(SA[m], DB, S[m]); \
-  _Pragma("unroll") for (int c = 0; c < 3; ++c) _Pragma("unroll") for (int m = 0; m < 2; ++m) \
-      V[c][m] = MFMA16H(WA[m], VB[c], V[c][m]);
-    SGM_PASS(sl, dh, wl, vh)
-    SGM_PASS(sh, dl, wh, vl)
-    SGM_PASS(sh, dh, wh, vh)
-#undef SGM_PASS
-    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < NC; ++c) lb_split8v(X[2 + 2 * c], X[3 + 2 * c], vh[c], vl[c]);
+    SB();
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(NS + 2));
+#pragma unroll
+    for (int m = 0; m < NS; ++m) S[m] = SG_MFMA(sl[m], dh, S[m]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) V[c][m] = SG_MFMA(wl[m], vh[c], V[c][m]);
+    SB();
+    __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(0));
+#pragma unroll
+    for (int m = 0; m < NS; ++m) S[m] = SG_MFMA(sh[m], dl, S[m]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) V[c][m] = SG_MFMA(wh[m], vl[c], V[c][m]);
+#pragma unroll
+    for (int m = 0; m < NS; ++m) S[m] = SG_MFMA(sh[m], dh, S[m]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) V[c][m] = SG_MFMA(wh[m], vh[c], V[c][m]);
+    SB();
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
   }
 }
 
-__device__ __forceinline__ f32x4 sg_silu4(const f32x4& x) {
-  f32x4 y;
+// sigma(x) on z = -log2(e) x (the scale is in the weights): v_exp_f32, v_rcp_f32 per value, the "1 +" packed
+__device__ __forceinline__ f32x4 sg_sig4(const f32x4& z) {
+  f32x4 e;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) y[j] = (SG_C_SILU * x[j]) * __builtin_amdgcn_rcpf(1.f + __expf(-x[j]));
-  return y;
+  for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(z[j]);
+  const f32x2v one = {1.f, 1.f};
+  const f32x2v d0 = lb_lo2(e) + one, d1 = lb_hi2(e) + one;
+  return f32x4{__builtin_amdgcn_rcpf(d0[0]), __builtin_amdgcn_rcpf(d0[1]), __builtin_amdgcn_rcpf(d1[0]),
+               __builtin_amdgcn_rcpf(d1[1])};
 }
-__device__ __forceinline__ f32x4 sg_sigmoid4(const f32x4& x) {
-  f32x4 y;
+
+// e3nn gate on the accumulators of one block: H_s = z sigma(z) (the silu's constants are folded into the
+// consumer's weights, or applied by the caller), H_v[c] = (V[c] + T a_c) sigma(gate); packed fp32 (v_pk_*: one
+// issue slot for two values - a single wave issues one VALU instruction per ~5 cycles whatever its width)
+template <int NC>
+__device__ __forceinline__ void sg_gate(const f32x4 (&S)[4], const f32x4 (&T)[2], const f32x4 (&V)[3][2],
+                                        const float (&at)[3], f32x4 (&H)[8]) {
+  const f32x4 g0 = sg_sig4(S[2]), g1 = sg_sig4(S[3]);
+  const f32x4 s0 = sg_sig4(S[0]), s1 = sg_sig4(S[1]);
+  H[0] = lb_cat2(lb_lo2(S[0]) * lb_lo2(s0), lb_hi2(S[0]) * lb_hi2(s0));
+  H[1] = lb_cat2(lb_lo2(S[1]) * lb_lo2(s1), lb_hi2(S[1]) * lb_hi2(s1));
 #pragma unroll
-  for (int j = 0; j < 4; ++j) y[j] = SG_C_SIGMOID * __builtin_amdgcn_rcpf(1.f + __expf(-x[j]));
-  return y;
+  for (int c = 0; c < NC; ++c) {
+    const f32x2v a2 = {at[c], at[c]};
+    H[2 + 2 * c] = lb_cat2(__builtin_elementwise_fma(lb_lo2(T[0]), a2, lb_lo2(V[c][0])) * lb_lo2(g0),
+                           __builtin_elementwise_fma(lb_hi2(T[0]), a2, lb_hi2(V[c][0])) * lb_hi2(g0));
+    H[3 + 2 * c] = lb_cat2(__builtin_elementwise_fma(lb_lo2(T[1]), a2, lb_lo2(V[c][1])) * lb_lo2(g1),
+                           __builtin_elementwise_fma(lb_hi2(T[1]), a2, lb_hi2(V[c][1])) * lb_hi2(g1));
+  }
 }
 
 struct lb_sg_msg_args {
   const lb_ctrl* ctrl;
   const int32_t* senders;
   const int32_t* receivers;
-  const int32_t* row_ptr;
   const float* efeat;   // [E][8]
   const float* f;       // [BN][128] hidden state
   const float* image;   // SGM_IMAGE f32x4 of this layer
   float* agg;           // [BN][128]
   float* part;          // [ceil(E/16)][2][128]
-  float* msg;           // ablation (MODE & 2): [E][128]
-  int32_t dim;
+  long long* dbg;       // tools/sg_msg_bench (ABL & 32): per wave of workgroup 0, cycles per tile segment
 };
 
-// Schedules (MODE bit 0 = no register prefetch, bit 1 = ablation: write per-edge messages instead
-// of the fused aggregation):  <1, 768> (default) three waves per SIMD, each wave loads its own tile and
-// the other two hide the latency (see k_edge16n);  <0, 512> two waves per SIMD with a software
-// pipeline inside the wave (LB_EDGE_WAVES=2).
-template <int DBG, int NT>
-__global__ void __launch_bounds__(NT, NT / 256) k_sg_msg(lb_sg_msg_args a) {
+// WPS waves per SIMD (one workgroup of WPS * 256 threads per CU); each wave loads its own tile (only the
+// next tile's two indices travel ahead) and the other waves of the SIMD hide the latency.
+// ABL (tools/sg_msg_bench.hip only, 0 in the product): 1 no row gathers, 2 no MFMAs, 4 no gates, 8 no scan, 16 no stores.
+template <int DIM, int WPS, bool PRIO, int ABL = 0, int SM = 0x1ff>
+__global__ void __launch_bounds__(WPS * 256, 1) k_sg_msg(lb_sg_msg_args a) {
+  constexpr int NT = WPS * 256, WAVES = WPS * 4, NC = DIM;
   __shared__ f32x4 sW[SGM_IMAGE];
-  // the control block is read first and the poison flag acted on after the weight image is staged (LDS only):
-  // neither the flag nor the edge count is a round trip of its own in front of the loads
+  __shared__ int s_ticket;
+  // prologue order as in k_edge16v: control block, weight loads into registers, the first tile's indices
+  // while those are in flight, poison check, LDS writes, barrier
   const int poisoned = a.ctrl->overflow_step;
   const int E = a.ctrl->n_edges_total;
   const int tid = threadIdx.x;
+  constexpr int NST = (SGM_IMAGE + NT - 1) / NT;
+  f32x4 st[NST];
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.image);
-    for (int i = tid; i < SGM_IMAGE; i += NT) sW[i] = src[i];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int i = tid + k * NT;
+      st[k] = src[i < SGM_IMAGE ? i : SGM_IMAGE - 1];
+    }
   }
-  if (poisoned >= 0) return;
-  __syncthreads();
   const int ntiles = (E + 15) >> 4;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
-  const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * (NT / 64) + wave;
-  const int stride = (gridDim.x >> 3) * (NT / 64);
+  // Tile walk: XCD x (= blockIdx % 8) owns a contiguous eighth of the receiver-sorted list, each of its workgroups a
+  // contiguous chunk of that, and the waves of a workgroup draw tiles from an LDS ticket counter.  (A static strided
+  // walk lets the SIMD's oldest wave - the issue arbiter prefers it - finish its tiles at ~55 % of the launch and
+  // leaves the youngest to run alone at the end: stamps in profiles/r04_sg_msg_bench.txt.)  Which wave computes a
+  // tile does not change a bit of the result: aggregates and partial slots are per tile.
+  const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
   const int t_lo = (int)(((int64_t)ntiles * xcd) >> 3), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) >> 3);
-  int t = t_lo + slot;
-  if (t >= t_hi) return;
-  const f32x4* f4 = reinterpret_cast<const f32x4*>(a.f);
-  const f32x4* ef4 = reinterpret_cast<const f32x4*>(a.efeat);
-  const f32x4* vec = &sW[SGM_VEC];
+  const int per = (t_hi - t_lo + nwg - 1) / nwg;
+  const int c_lo = t_lo + wg * per, c_hi = min(t_hi, c_lo + per);
+  int t = c_lo + wave;  // first tile: static, so that its indices can be requested before the barrier
   auto rowc_of = [&](int tt) -> int64_t {
     const int row = tt * 16 + n;
-    return row < E ? row : E - 1;
+    return row < E ? row : (E > 0 ? E - 1 : 0);
   };
-
-  // software pipeline: rows of the next tile + indices of the tile after it are in flight while
-  // the current tile computes; every load is unconditional (clamped), see lb_edge16.hip
-  const int n_iter = (t_hi - 1 - t) / stride + 1;
-  const int t_last = t + (n_iter - 1) * stride;
-  f32x4 fs_n[8], fr_n[8], ef_n;
-  int s_n, r_n, r_pref;
-  auto issue = [&](int tt, int s, int r) {
-    const int64_t rc = rowc_of(tt);
-    const f32x4* ps = f4 + (int64_t)s * 32 + g;
-    const f32x4* pr = f4 + (int64_t)r * 32 + g;
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-      fs_n[mb] = ps[4 * mb];
-      fr_n[mb] = pr[4 * mb];
-    }
-    ef_n = ef4[rc * 2];
-  };
-  {
+  int s_c = 0, r_c = 0;
+  if (t < c_hi) {
     const int64_t rc = rowc_of(t);
-    const int s0 = a.senders[rc], r0 = a.receivers[rc];
-    issue(t, s0, r0);
-    r_pref = r0;
-    const int64_t rn = rowc_of(min(t + stride, t_last));
-    s_n = a.senders[rn];
-    r_n = a.receivers[rn];
+    s_c = a.senders[rc];
+    r_c = a.receivers[rc];
   }
+  if (poisoned >= 0) return;
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int i = tid + k * NT;
+    if (i < SGM_IMAGE) sW[i] = st[k];
+  }
+  if (tid == 0) s_ticket = WAVES;
+  __syncthreads();
+  if (t >= c_hi) return;
+  uint32_t off0 = (uint32_t)(uintptr_t)(lds_cptr)(sW + lane);
+  uint32_t off1 = (uint32_t)(uintptr_t)(lds_cptr)(sW + SGM_B1 + lane);
+  uint32_t off2 = (uint32_t)(uintptr_t)(lds_cptr)(sW + SGM_VEC + g);
+  asm volatile("" : "+v"(off0), "+v"(off1), "+v"(off2));
+  const lds_cptr w0 = (lds_cptr)(uintptr_t)off0, w1 = (lds_cptr)(uintptr_t)off1, vec = (lds_cptr)(uintptr_t)off2;
+  const f32x4* ef4 = reinterpret_cast<const f32x4*>(a.efeat);
+  int n_iter = 0;
+  asm volatile("" : "+v"(s_c), "+v"(r_c));
+  long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define SG_STAMP(i)                                         \
+  if constexpr ((ABL & 32) && ((SM >> i) & 1)) {            \
+    const long long now = __builtin_readcyclecounter();     \
+    stamp[i] += now - tprev;                                \
+    tprev = now;                                            \
+  }                                                         \
+  if constexpr (ABL & 64) __builtin_amdgcn_s_sleep(1);      \
+  if constexpr (ABL & 128) {                                \
+    SB();                                                   \
+    __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(0));            \
+    SB();                                                   \
+  }                                                         \
+  if constexpr (ABL & 256) {                                \
+    (void)__builtin_amdgcn_s_memtime();                     \
+  }
+  if constexpr (ABL & 32) tprev = __builtin_readcyclecounter();
 
-  for (int it = 0; it < n_iter; ++it, t += stride) {
-    f32x4 fs[8], fr[8];
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-      fs[mb] = fs_n[mb];
-      fr[mb] = fr_n[mb];
-    }
-    f32x4 ef = ef_n;
-    int r_cur = r_pref;
-    if (DBG & 1) {  // no register prefetch: load this tile now
-      const int64_t rc = rowc_of(t);
-      const int s0 = a.senders[rc], r0 = a.receivers[rc];
-      issue(t, s0, r0);
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) {
-        fs[mb] = fs_n[mb];
-        fr[mb] = fr_n[mb];
-      }
-      r_cur = r0;
-    } else {
-    issue(min(t + stride, t_last), s_n, r_n);
-    r_pref = r_n;
+  while (t < c_hi) {
+    ++n_iter;
+    // the next tile's ticket (one lane draws, the wave reads it back as a scalar)
+    int t_next;
     {
-      const int64_t rn = rowc_of(min(t + 2 * stride, t_last));
-      s_n = a.senders[rn];
-      r_n = a.receivers[rn];
+      int k = 0;
+      if (lane == 0) k = atomicAdd(&s_ticket, 1);
+      t_next = c_lo + __builtin_amdgcn_readfirstlane(k);
     }
+    const int r_cur = r_c;
+    f32x4 fs[8], fr[8];
+    {
+      // 32-bit byte offsets from the scalar base (global_load saddr form: no 64-bit address arithmetic per lane;
+      // the host refuses node tables beyond 4 GiB)
+      const f32x4* ps = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.f) + ((uint32_t)s_c * 512u + (uint32_t)g * 16u));
+      const f32x4* pr = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.f) + ((uint32_t)r_c * 512u + (uint32_t)g * 16u));
+#pragma unroll
+      for (int mb = 0; mb < 2 + 2 * NC; ++mb) fs[mb] = (ABL & 1) ? f32x4{.1f, .2f, (float)s_c * 1e-6f, (float)mb} : ps[4 * mb];
+#pragma unroll
+      for (int mb = 0; mb < 2 + 2 * NC; ++mb) fr[mb] = (ABL & 1) ? f32x4{.3f, .1f, (float)r_c * 1e-6f, (float)mb} : pr[4 * mb];
     }
-    if (DBG & 1) ef = ef_n;
+    // The row gathers go FIRST: they depend only on indices that were delivered a tile ago.  (With the edge-feature
+    // load in front of them hipcc once reused a dead lane of ITS destination as the gathers' address register - a
+    // WAW hazard it resolved with s_waitcnt vmcnt(0): two serialised memory round trips per tile, and a full drain of
+    // the previous tile's stores.)
+    SB();
+    f32x4 ef = ef4[rowc_of(t) * 2];
+    SB();
+    {
+      const int64_t rn = rowc_of(min(t_next, c_hi - 1));
+      s_c = a.senders[rn];
+      r_c = a.receivers[rn];
+    }
+    int rb = lb_edge_probe(a.receivers, t, lane, E);
+    asm volatile("" : "+v"(ef));  // all four lanes of ef stay allocated until the loads above are issued (same hazard)
     // edge attribute a = Y1 r/|r| (0 for the self edge), message features |r| (rel_dist) and r
-    const float rx = ef[0], ry = ef[1], rz = a.dim == 3 ? ef[2] : 0.f, dist = a.dim == 3 ? ef[3] : ef[2];
-    const float nrm = sqrtf(rx * rx + ry * ry + rz * rz);
-    const float inv = nrm == 0.f ? 0.f : SG_Y1 * __builtin_amdgcn_rcpf(nrm);
-    const float at[3] = {rx * inv, ry * inv, rz * inv};
-    const float rr3[3] = {rx, ry, rz};
-    const float dotr = rx * at[0] + ry * at[1] + rz * at[2];
-
+    float at[3], dist, dotr, rmag;
+    {
+      const float rx = ef[0], ry = ef[1], rz = DIM == 3 ? ef[2] : 0.f;
+      dist = DIM == 3 ? ef[3] : ef[2];
+      const float n2 = DIM == 3 ? rx * rx + ry * ry + rz * rz : rx * rx + ry * ry;
+      const float rs = n2 == 0.f ? 0.f : __builtin_amdgcn_rsqf(n2);  // v_rsq_f32 (1 ulp); 0 for the self edge
+      const float inv = SG_Y1 * rs;
+      at[0] = rx * inv;
+      at[1] = ry * inv;
+      at[2] = DIM == 3 ? rz * inv : 0.f;
+      dotr = (n2 * rs) * SG_Y1;            // r . a = |r| Y1
+      rmag = (n2 * rs) * (1.0f / SG_Y1);   // r_c = a_c * rmag
+    }
+    SG_STAMP(0)  // loads issued, attribute arithmetic
     // ---- block 0: [f_s | f_r | (r, |r|)] (x) a -> gate
     f32x4 S[4], T[2], V[3][2];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) S[m] = vec[4 * m + g] + vec[16 + 4 * m + g] * dist + vec[32 + 4 * m + g] * dotr;
+    for (int m = 0; m < 4; ++m) S[m] = vec[4 * m] + vec[16 + 4 * m] * dist + vec[32 + 4 * m] * dotr;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      T[m] = vec[48 + 4 * m + g] * dist;
+      T[m] = vec[48 + 4 * m] * dist + vec[56 + 4 * m] * rmag;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) V[c][m] = vec[56 + 4 * m + g] * rr3[c];
+      for (int c = 0; c < 3; ++c) V[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    sg_operand(&sW[SGM_WS0], &sW[SGM_WT0], &sW[SGM_WV0], 0, 0, lane, fs, at, S, T, V);
-    sg_operand(&sW[SGM_WS0], &sW[SGM_WT0], &sW[SGM_WV0], 2, 1, lane, fr, at, S, T, V);
+    SG_STAMP(1)  // accumulator start values (LDS vectors)
+    sg_operand<NC, 4, 4, PRIO, (ABL & 2) != 0>(w0 + SGM_WS0 * 1, w0 + SGM_WT0, w0 + SGM_WV0, fs, at, S, T, V);
+    SG_STAMP(2)  // sender operand (incl. the wait for its rows)
+    sg_operand<NC, 4, 4, PRIO, (ABL & 2) != 0>(w0 + SGM_WS0 + 2 * 512, w0 + SGM_WT0 + 256, w0 + SGM_WV0 + 256, fr, at, S, T, V);
+    SG_STAMP(3)  // receiver operand
     f32x4 H[8];
-    {
-      const f32x4 g0 = sg_sigmoid4(S[2]), g1 = sg_sigmoid4(S[3]);
-      H[0] = sg_silu4(S[0]);
-      H[1] = sg_silu4(S[1]);
+    if constexpr (ABL & 4) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        H[2 + 2 * c] = (V[c][0] + T[0] * at[c]) * g0;
-        H[3 + 2 * c] = (V[c][1] + T[1] * at[c]) * g1;
-      }
+      for (int mb = 0; mb < 2 + 2 * NC; ++mb) H[mb] = mb < 4 ? S[mb] : (mb < 6 ? T[mb - 4] + V[0][mb - 4] : V[1][mb - 6]);
+    } else {
+      sg_gate<NC>(S, T, V, at, H);
     }
+    SG_STAMP(4)  // gate 0
     // ---- block 1: h (x) a -> gate
 #pragma unroll
-    for (int m = 0; m < 4; ++m) S[m] = vec[64 + 4 * m + g];
+    for (int m = 0; m < 4; ++m) S[m] = vec[64 + 4 * m];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       T[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 3; ++c) V[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    sg_operand(&sW[SGM_WS1], &sW[SGM_WT1], &sW[SGM_WV1], 0, 0, lane, H, at, S, T, V);
+    sg_operand<NC, 4, 4, PRIO, (ABL & 2) != 0>(w1 + (SGM_WS1 - SGM_B1), w1 + (SGM_WT1 - SGM_B1), w1 + (SGM_WV1 - SGM_B1), H, at, S, T, V);
+    SG_STAMP(5)  // block 1 operand
+    // take delivery of the next tile's indices while only loads are in flight (in-order vmcnt, see k_edge16v)
+    asm volatile("" : "+v"(s_c), "+v"(r_c), "+v"(rb));
     f32x4 y[8];
-    {
-      const f32x4 g0 = sg_sigmoid4(S[2]), g1 = sg_sigmoid4(S[3]);
-      y[0] = sg_silu4(S[0]);
-      y[1] = sg_silu4(S[1]);
+    if constexpr (ABL & 4) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        y[2 + 2 * c] = (V[c][0] + T[0] * at[c]) * g0;
-        y[3 + 2 * c] = (V[c][1] + T[1] * at[c]) * g1;
-      }
+      for (int mb = 0; mb < 2 + 2 * NC; ++mb) y[mb] = mb < 4 ? S[mb] : (mb < 6 ? T[mb - 4] + V[0][mb - 4] : V[1][mb - 6]);
+    } else {
+      sg_gate<NC>(S, T, V, at, y);
     }
-    // ---- fused segment_sum over the receiver-sorted list (same scheme as k_edge16's epilogue)
+    y[0] = y[0] * SG_K_SILU;
+    y[1] = y[1] * SG_K_SILU;
+    SG_STAMP(6)  // gate 1
+    // ---- fused segment_sum over the receiver-sorted list (k_edge16v's epilogue)
     const int row = t * 16 + n;
     const bool valid = row < E;
-    if (DBG & 2) {  // ablation: plain per-edge message rows, reduced by k_segment_sum
-      if (valid) {
-        f32x4* mr = reinterpret_cast<f32x4*>(a.msg) + (int64_t)row * 32 + g;
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) mr[4 * mb] = y[mb];
-      }
-      continue;
-    }
     const int rr = valid ? r_cur : (-1 - n);
     const int r_prev = __builtin_amdgcn_update_dpp(-2, rr, 0x111, 0xF, 0xF, false);
     const bool head = (n == 0) || (rr != r_prev);
@@ -324,27 +405,34 @@ __global__ void __launch_bounds__(NT, NT / 256) k_sg_msg(lb_sg_msg_args a) {
     const bool tail = (n == 15) || ((Hm >> (n + 1)) & 1u);
     const float m1 = (n >= 1 && segstart <= n - 1) ? 1.f : 0.f, m2 = (n >= 2 && segstart <= n - 2) ? 1.f : 0.f;
     const float m4 = (n >= 4 && segstart <= n - 4) ? 1.f : 0.f, m8 = (n >= 8 && segstart <= n - 8) ? 1.f : 0.f;
+    // (rows past the end of the list are copies of the last edge: finite, each its own segment, never stored)
+    if constexpr (!(ABL & 8))
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float x = valid ? y[mb][j] : 0.f;
-        x = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xF, 0xF, true)), m1, x);
-        x = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xF, 0xF, true)), m2, x);
-        x = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xF, 0xF, true)), m4, x);
-        x = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xF, 0xF, true)), m8, x);
-        y[mb][j] = x;
-      }
-    if (tail && valid) {
-      const int k0 = a.row_ptr[rr], k1 = a.row_ptr[rr + 1];
-      const bool complete = (k0 >> 4) == ((k1 - 1) >> 4);
-      float* dst = complete ? a.agg + (int64_t)rr * 128
-                            : a.part + ((int64_t)t * 2 + (k0 <= t * 16 ? 0 : 1)) * 128;
+    for (int mb = 0; mb < 2 + 2 * NC; mb += 2) lb_scan8(y[mb], y[mb + 1], m1, m2, m4, m8);
+    SG_STAMP(7)  // scan
+    if (tail && valid && !(ABL & 16)) {
+      int slot01;
+      const bool complete = lb_seg_complete(rb, rr, segstart, n, t, E, slot01);
+      float* dst = complete ? a.agg + (int64_t)rr * 128 : a.part + ((int64_t)t * 2 + slot01) * 128;
       f32x4* d4 = reinterpret_cast<f32x4*>(dst) + g;
 #pragma unroll
-      for (int mb = 0; mb < 8; ++mb) d4[4 * mb] = y[mb];
+      for (int mb = 0; mb < 2 + 2 * NC; ++mb) d4[4 * mb] = y[mb];
+      if constexpr (NC == 2) {  // consumers outside this file read whole rows
+        d4[24] = f32x4{0.f, 0.f, 0.f, 0.f};
+        d4[28] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    SG_STAMP(8)  // stores issued
+    t = t_next;
+  }
+  if constexpr (ABL & 32) {
+    if (blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) a.dbg[wave * 10 + i] = stamp[i];
+      a.dbg[wave * 10 + 9] = n_iter;
     }
   }
+#undef SG_STAMP
 }
 
 // Rows cut by a tile boundary: sum their per-tile partial slots in tile order (deterministic);
@@ -381,11 +469,11 @@ __global__ void __launch_bounds__(256) k_sg_agg_finish(const lb_ctrl* __restrict
 #define SGU_WS0 0      // K=128 x M=64
 #define SGU_WT0 2048   // K=64 x M=32
 #define SGU_WV0 2560
-#define SGU_WS1 3072   // K=64 x M=64 (columns 32..63 zero: the last block has no gates)
-#define SGU_WT1 4096
-#define SGU_WV1 4352
-#define SGU_VEC 4608   // b0 (16 f32x4), b1 (16, upper half zero)
-#define SGU_IMAGE 4640
+#define SGU_WS1 3072   // K=64 x M=32 (the last block has no gates): 2 x 2 x 2 x 64
+#define SGU_WT1 3584
+#define SGU_WV1 3840
+#define SGU_VEC 4096   // b0 (16 f32x4), b1 (8)
+#define SGU_IMAGE 4120
 
 struct lb_sg_upd_args {
   const lb_ctrl* ctrl;
@@ -398,21 +486,44 @@ struct lb_sg_upd_args {
   const float* part;
 };
 
-__global__ void __launch_bounds__(SGM_THREADS, 2) k_sg_upd(lb_sg_upd_args a) {
+template <int DIM, int NT>
+__global__ void __launch_bounds__(NT, 2) k_sg_upd(lb_sg_upd_args a) {
+  constexpr int NC = DIM, WAVES = NT / 64, NMB = 2 + 2 * NC;
   __shared__ f32x4 sW[SGU_IMAGE];
   const int poisoned = a.ctrl->overflow_step;  // acted on after the staging loads are in flight, see k_sg_msg
   const int tid = threadIdx.x;
+  constexpr int NST = (SGU_IMAGE + NT - 1) / NT;
+  f32x4 st[NST];
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.image);
-    for (int i = tid; i < SGU_IMAGE; i += SGM_THREADS) sW[i] = src[i];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int i = tid + k * NT;
+      st[k] = src[i < SGU_IMAGE ? i : SGU_IMAGE - 1];
+    }
   }
-  if (poisoned >= 0) return;
-  __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
   const int ntiles = (int)((a.n_rows + 15) >> 4);
-  const f32x4* vec = &sW[SGU_VEC];
-  for (int t = blockIdx.x * SGM_WAVES + wave; t < ntiles; t += gridDim.x * SGM_WAVES) {
+  const int E = a.ctrl->n_edges_total;
+  int t = blockIdx.x * WAVES + wave;
+  // the first tile's row_ptr pair travels with the weights
+  int k0n = 0, k1n = 0;
+  if (a.part != nullptr && t < ntiles) {
+    const int64_t row = (int64_t)t * 16 + n;
+    const int64_t rl = row < a.n_rows ? row : a.n_rows - 1;
+    k0n = a.row_ptr[rl];
+    k1n = a.row_ptr[rl + 1];
+  }
+  if (poisoned >= 0) return;
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int i = tid + k * NT;
+    if (i < SGU_IMAGE) sW[i] = st[k];
+  }
+  __syncthreads();
+  const lds_cptr w0 = (lds_cptr)(sW + lane), vec = (lds_cptr)(sW + SGU_VEC + g);
+  for (; t < ntiles; t += gridDim.x * WAVES) {
     const int64_t row = (int64_t)t * 16 + n;
     const bool valid = row < a.n_rows;
     const int64_t rl = valid ? row : a.n_rows - 1;
@@ -420,22 +531,28 @@ __global__ void __launch_bounds__(SGM_THREADS, 2) k_sg_upd(lb_sg_upd_args a) {
     const f32x4* arow = reinterpret_cast<const f32x4*>(a.agg) + rl * 32 + g;
     f32x4 X0[8], X1[8];
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) X0[mb] = frow[4 * mb];
+    for (int mb = 0; mb < NMB; ++mb) X0[mb] = frow[4 * mb];
     if (a.part == nullptr) {
 #pragma unroll
-      for (int mb = 0; mb < 8; ++mb) X1[mb] = arow[4 * mb];
+      for (int mb = 0; mb < NMB; ++mb) X1[mb] = arow[4 * mb];
     } else {
       // aggregated messages straight from k_sg_msg: whole rows sit in agg, rows cut by a 16-edge
       // tile boundary are the sum of their per-tile partial slots in tile order (deterministic)
-      const int E = a.ctrl->n_edges_total;
-      int k0 = a.row_ptr[rl], k1 = a.row_ptr[rl + 1];
+      int k0 = k0n, k1 = k1n;
       k0 = k0 < E ? k0 : E;
       k1 = k1 < E ? k1 : E;
+      {  // next tile's pair
+        const int tn = t + gridDim.x * WAVES;
+        const int64_t rown = (int64_t)(tn < ntiles ? tn : t) * 16 + n;
+        const int64_t rln = rown < a.n_rows ? rown : a.n_rows - 1;
+        k0n = a.row_ptr[rln];
+        k1n = a.row_ptr[rln + 1];
+      }
       const int t0 = k0 >> 4, t1 = (k1 - 1) >> 4;
       const bool single = t0 == t1;
       const int nsrc = (k1 <= k0) ? 0 : (single ? 1 : t1 - t0 + 1);
 #pragma unroll
-      for (int mb = 0; mb < 8; ++mb) X1[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int mb = 0; mb < NMB; ++mb) X1[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int s = 0; __any(s < nsrc); ++s) {
         if (s < nsrc) {
           const int tt = t0 + s;
@@ -443,7 +560,7 @@ __global__ void __launch_bounds__(SGM_THREADS, 2) k_sg_upd(lb_sg_upd_args a) {
                                     : a.part + ((int64_t)tt * 2 + (k0 <= (tt << 4) ? 0 : 1)) * 128;
           const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + g;
 #pragma unroll
-          for (int mb = 0; mb < 8; ++mb) X1[mb] = X1[mb] + s4[4 * mb];
+          for (int mb = 0; mb < NMB; ++mb) X1[mb] = X1[mb] + s4[4 * mb];
         }
       }
     }
@@ -451,40 +568,31 @@ __global__ void __launch_bounds__(SGM_THREADS, 2) k_sg_upd(lb_sg_upd_args a) {
     const float at[3] = {na[1], na[2], na[3]};
     f32x4 S[4], T[2], V[3][2];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) S[m] = vec[4 * m + g];
+    for (int m = 0; m < 4; ++m) S[m] = vec[4 * m];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       T[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 3; ++c) V[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    sg_operand(&sW[SGU_WS0], &sW[SGU_WT0], &sW[SGU_WV0], 0, 0, lane, X0, at, S, T, V);
-    sg_operand(&sW[SGU_WS0], &sW[SGU_WT0], &sW[SGU_WV0], 2, 1, lane, X1, at, S, T, V);
+    sg_operand<NC, 4, 4, true>(w0 + SGU_WS0, w0 + SGU_WT0, w0 + SGU_WV0, X0, at, S, T, V);
+    sg_operand<NC, 4, 4, true>(w0 + SGU_WS0 + 2 * 512, w0 + SGU_WT0 + 256, w0 + SGU_WV0 + 256, X1, at, S, T, V);
     f32x4 H[8];
-    {
-      const f32x4 g0 = sg_sigmoid4(S[2]), g1 = sg_sigmoid4(S[3]);
-      H[0] = sg_silu4(S[0]);
-      H[1] = sg_silu4(S[1]);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        H[2 + 2 * c] = (V[c][0] + T[0] * at[c]) * g0;
-        H[3 + 2 * c] = (V[c][1] + T[1] * at[c]) * g1;
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) S[m] = vec[16 + 4 * m + g];
+    sg_gate<NC>(S, T, V, at, H);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
+      S[m] = vec[16 + 4 * m];
       T[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 3; ++c) V[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    sg_operand(&sW[SGU_WS1], &sW[SGU_WT1], &sW[SGU_WV1], 0, 0, lane, H, at, S, T, V);
-    if (valid) {  // residual, segnn.py:331
+    sg_operand<NC, 2, 2, true>(w0 + SGU_WS1, w0 + SGU_WT1, w0 + SGU_WV1, H, at, S, T, V);
+    asm volatile("" : "+v"(k0n), "+v"(k1n));
+    if (valid) {  // residual, segnn.py:331 (2D: the z component stays the embedding's exact zero)
       frow[0] = X0[0] + S[0];
       frow[4] = X0[1] + S[1];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
+      for (int c = 0; c < NC; ++c) {
         frow[4 * (2 + 2 * c)] = X0[2 + 2 * c] + (V[c][0] + T[0] * at[c]);
         frow[4 * (3 + 2 * c)] = X0[3 + 2 * c] + (V[c][1] + T[1] * at[c]);
       }
@@ -495,16 +603,19 @@ __global__ void __launch_bounds__(SGM_THREADS, 2) k_sg_upd(lb_sg_upd_args a) {
 // ------------------------------------------------------------------------------ host side
 // LDS image of one layer from the raw block weights (oracle channel order):
 //   ws0 (130 x 64), wv0 (130 x 32), b0 (64); ws1 (64 x 64), wv1 (64 x 32), b1 (64).
+// Folded constants: S columns * -log2(e) (the gate evaluates exp2), T / V matrices * C_sigmoid, the block-1 rows
+// that consume block 0's scalars * C_silu / -log2(e) (k_sg_msg leaves them as z sigma(z)).
 void lb_sg_msg_image(const float* ws0, const float* wv0, const float* b0, const float* ws1,
                      const float* wv1, const float* b1, float* out /* SGM_IMAGE*4 floats */) {
   const float sc0 = 1.0f / sqrtf(130.f), sc1 = 1.0f / sqrtf(64.f), is3 = 0.5773502691896258f;
+  const float zs = SG_NL2E, cg = SG_C_SIGMOID, ks = SG_K_SILU;
   memset(out, 0, sizeof(float) * SGM_IMAGE * 4);
   std::vector<float> m;
   auto pack = [&](int K, int M, int off) { lb_pack_weight16h(m.data(), K, M, K, out + (size_t)off * 4, M); };
   // WS0: [sender s * Y0 | sender v / sqrt3 | receiver s * Y0 | receiver v / sqrt3]
   m.assign(128 * 64, 0.f);
   for (int k = 0; k < 128; ++k) {
-    const float f = ((k >> 5) & 1) ? is3 * sc0 : SG_Y0 * sc0;
+    const float f = (((k >> 5) & 1) ? is3 * sc0 : SG_Y0 * sc0) * zs;
     for (int j = 0; j < 64; ++j) m[k * 64 + j] = ws0[k * 64 + j] * f;
   }
   pack(128, 64, SGM_WS0);
@@ -512,35 +623,35 @@ void lb_sg_msg_image(const float* ws0, const float* wv0, const float* b0, const 
   m.assign(64 * 32, 0.f);
   for (int o = 0; o < 2; ++o)
     for (int k = 0; k < 32; ++k)
-      for (int j = 0; j < 32; ++j) m[(o * 32 + k) * 32 + j] = wv0[(o * 64 + k) * 32 + j] * sc0;
+      for (int j = 0; j < 32; ++j) m[(o * 32 + k) * 32 + j] = wv0[(o * 64 + k) * 32 + j] * (sc0 * cg);
   pack(64, 32, SGM_WT0);
   for (int o = 0; o < 2; ++o)
     for (int k = 0; k < 32; ++k)
-      for (int j = 0; j < 32; ++j) m[(o * 32 + k) * 32 + j] = wv0[(o * 64 + 32 + k) * 32 + j] * (SG_Y0 * sc0);
+      for (int j = 0; j < 32; ++j) m[(o * 32 + k) * 32 + j] = wv0[(o * 64 + 32 + k) * 32 + j] * (SG_Y0 * sc0 * cg);
   pack(64, 32, SGM_WV0);
   m.assign(64 * 64, 0.f);
   for (int k = 0; k < 64; ++k) {
-    const float f = (k >= 32) ? is3 * sc1 : SG_Y0 * sc1;
+    const float f = ((k >= 32) ? is3 * sc1 : SG_Y0 * sc1 * ks) * zs;
     for (int j = 0; j < 64; ++j) m[k * 64 + j] = ws1[k * 64 + j] * f;
   }
   pack(64, 64, SGM_WS1);
   m.assign(32 * 32, 0.f);
   for (int k = 0; k < 32; ++k)
-    for (int j = 0; j < 32; ++j) m[k * 32 + j] = wv1[k * 32 + j] * sc1;
+    for (int j = 0; j < 32; ++j) m[k * 32 + j] = wv1[k * 32 + j] * (sc1 * ks * cg);
   pack(32, 32, SGM_WT1);
   for (int k = 0; k < 32; ++k)
-    for (int j = 0; j < 32; ++j) m[k * 32 + j] = wv1[(32 + k) * 32 + j] * (SG_Y0 * sc1);
+    for (int j = 0; j < 32; ++j) m[k * 32 + j] = wv1[(32 + k) * 32 + j] * (SG_Y0 * sc1 * cg);
   pack(32, 32, SGM_WV1);
   float* v = out + (size_t)SGM_VEC * 4;
   for (int j = 0; j < 64; ++j) {
-    v[j] = b0[j];
-    v[64 + j] = ws0[128 * 64 + j] * (SG_Y0 * sc0);   // |r| row
-    v[128 + j] = ws0[129 * 64 + j] * (is3 * sc0);    // (r . a) row
-    v[256 + j] = b1[j];
+    v[j] = b0[j] * zs;
+    v[64 + j] = ws0[128 * 64 + j] * (SG_Y0 * sc0 * zs);   // |r| row
+    v[128 + j] = ws0[129 * 64 + j] * (is3 * sc0 * zs);    // (r . a) row
+    v[256 + j] = b1[j] * zs;
   }
   for (int j = 0; j < 32; ++j) {
-    v[192 + j] = wv0[128 * 32 + j] * sc0;            // |r| -> T
-    v[224 + j] = wv0[129 * 32 + j] * (SG_Y0 * sc0);  // r_c -> V_c
+    v[192 + j] = wv0[128 * 32 + j] * (sc0 * cg);            // |r| -> T
+    v[224 + j] = wv0[129 * 32 + j] * (SG_Y0 * sc0 * cg);    // r_c = a_c |r| / Y1 -> T (times |r| / Y1 in the kernel)
   }
 }
 
@@ -551,17 +662,22 @@ int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg,
   a.ctrl = e->ctrl;
   a.senders = e->senders;
   a.receivers = e->receivers;
-  a.row_ptr = e->row_ptr;
   a.efeat = e->efeat;
   a.f = f;
   a.image = image;
   a.agg = agg;
   a.part = e->part;
-  a.dim = e->g.dim;
-  a.msg = e->msg;
-  // three waves per SIMD, no register prefetch (round 1's measured best; the two-wave software-pipelined schedule and
-  // the per-edge-message ablation are template modes 0 / 2 of the kernel, no longer instantiated in the product)
-  hipLaunchKernelGGL((k_sg_msg<1, 768>), dim3(256), dim3(768), 0, e->stream, a);
+  if (e->BN * 512 >= ((int64_t)1 << 32)) return lb_fail(LB_ERR_UNSUPPORTED, "segnn: more than 8 M nodes per engine");
+  // no more workgroups than the frozen capacity has tiles for (B = 1: a launch is a latency chain)
+  constexpr int WPS = 3;
+  const int64_t tiles_cap = ((int64_t)e->e_cap * e->g.B + 15) / 16;
+  int64_t gr = (tiles_cap + WPS * 4 - 1) / (WPS * 4);
+  gr = (gr + 7) / 8 * 8;
+  const int grid = (int)(gr < 8 ? 8 : (gr > 256 ? 256 : gr));
+  if (e->g.dim == 2)
+    LB_LAUNCH_TIMED(e, (k_sg_msg<2, WPS, true>), dim3(grid), dim3(WPS * 256), a);
+  else
+    LB_LAUNCH_TIMED(e, (k_sg_msg<3, WPS, true>), dim3(grid), dim3(WPS * 256), a);
   if (finish) {  // consumers other than k_sg_upd want complete rows in agg
     const int nb = (int)((e->BN + 7) / 8);
     hipLaunchKernelGGL(k_sg_agg_finish, dim3(nb), dim3(256), 0, e->stream, e->ctrl, e->BN, e->row_ptr,
@@ -576,39 +692,40 @@ int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg,
 void lb_sg_upd_image(const float* ws0, const float* wv0, const float* b0, const float* ws1,
                      const float* wv1, const float* b1, float* out /* SGU_IMAGE*4 floats */) {
   const float sc0 = 1.0f / sqrtf(128.f), sc1 = 1.0f / sqrtf(64.f), is3 = 0.5773502691896258f;
+  const float zs = SG_NL2E, cg = SG_C_SIGMOID, ks = SG_K_SILU;
   memset(out, 0, sizeof(float) * SGU_IMAGE * 4);
   std::vector<float> m;
   auto pack = [&](int K, int M, int off) { lb_pack_weight16h(m.data(), K, M, K, out + (size_t)off * 4, M); };
   m.assign(128 * 64, 0.f);
   for (int k = 0; k < 128; ++k) {
-    const float f = ((k >> 5) & 1) ? is3 * sc0 : sc0;  // node attribute a0 == 1
+    const float f = (((k >> 5) & 1) ? is3 * sc0 : sc0) * zs;  // node attribute a0 == 1
     for (int j = 0; j < 64; ++j) m[k * 64 + j] = ws0[k * 64 + j] * f;
   }
   pack(128, 64, SGU_WS0);
   m.assign(64 * 32, 0.f);
   for (int o = 0; o < 2; ++o)
     for (int k = 0; k < 32; ++k)
-      for (int j = 0; j < 32; ++j) m[(o * 32 + k) * 32 + j] = wv0[(o * 64 + k) * 32 + j] * sc0;
+      for (int j = 0; j < 32; ++j) m[(o * 32 + k) * 32 + j] = wv0[(o * 64 + k) * 32 + j] * (sc0 * cg);
   pack(64, 32, SGU_WT0);
   for (int o = 0; o < 2; ++o)
     for (int k = 0; k < 32; ++k)
-      for (int j = 0; j < 32; ++j) m[(o * 32 + k) * 32 + j] = wv0[(o * 64 + 32 + k) * 32 + j] * sc0;
+      for (int j = 0; j < 32; ++j) m[(o * 32 + k) * 32 + j] = wv0[(o * 64 + 32 + k) * 32 + j] * (sc0 * cg);
   pack(64, 32, SGU_WV0);
-  m.assign(64 * 64, 0.f);
+  m.assign(64 * 32, 0.f);
   for (int k = 0; k < 64; ++k) {
-    const float f = (k >= 32) ? is3 * sc1 : sc1;
-    for (int j = 0; j < 32; ++j) m[k * 64 + j] = ws1[k * 32 + j] * f;
+    const float f = (k >= 32) ? is3 * sc1 : sc1 * ks;
+    for (int j = 0; j < 32; ++j) m[k * 32 + j] = ws1[k * 32 + j] * f;
   }
-  pack(64, 64, SGU_WS1);
+  pack(64, 32, SGU_WS1);
   m.assign(32 * 32, 0.f);
   for (int k = 0; k < 32; ++k)
-    for (int j = 0; j < 32; ++j) m[k * 32 + j] = wv1[k * 32 + j] * sc1;
+    for (int j = 0; j < 32; ++j) m[k * 32 + j] = wv1[k * 32 + j] * (sc1 * ks);
   pack(32, 32, SGU_WT1);
   for (int k = 0; k < 32; ++k)
     for (int j = 0; j < 32; ++j) m[k * 32 + j] = wv1[(32 + k) * 32 + j] * sc1;
   pack(32, 32, SGU_WV1);
   float* v = out + (size_t)SGU_VEC * 4;
-  for (int j = 0; j < 64; ++j) v[j] = b0[j];
+  for (int j = 0; j < 64; ++j) v[j] = b0[j] * zs;
   for (int j = 0; j < 32; ++j) v[64 + j] = b1[j];
 }
 
@@ -626,8 +743,11 @@ int lbk_sg_update(lb_engine* e, float* f, const float* agg, const float* nattr, 
   a.row_ptr = e->row_ptr;
   a.part = combine_partials ? e->part : nullptr;
   const int ntiles = (int)((e->BN + 15) / 16);
-  const int nb = std::min(256, (ntiles + SGM_WAVES - 1) / SGM_WAVES);
-  hipLaunchKernelGGL(k_sg_upd, dim3(nb), dim3(SGM_THREADS), 0, e->stream, a);
+  const int nb = std::min(256, (ntiles + 7) / 8);
+  if (e->g.dim == 2)
+    LB_LAUNCH_TIMED(e, (k_sg_upd<2, 512>), dim3(nb), dim3(512), a);
+  else
+    LB_LAUNCH_TIMED(e, (k_sg_upd<3, 512>), dim3(nb), dim3(512), a);
   LB_HIP(hipGetLastError());
   return LB_OK;
 }

@@ -1,0 +1,314 @@
+// tools/sg_msg_bench.hip - micro-benchmark + cross-check of the fused SEGNN message / update kernels:
+// round 3's k_sg_msg / k_sg_upd (tools/museum/lb_segnn_msg_r03.hip) against round 4's, on a synthetic
+// receiver-sorted edge list of the DAM2D x B size (5740 particles, ~6.2 neighbors).  Prints us per launch, the
+// fp16-MFMA fraction of the 2.5 PF peak (issued products), ablations, and the max difference of the new kernels'
+// outputs from round 3's on identical raw weights.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -Ilagrangebench_amd/csrc tools/sg_msg_bench.hip -o tools/bin/sg_msg_bench
+//   tools/bin/sg_msg_bench [B=8] [dim=2] [iters=200]
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../lagrangebench_amd/csrc/lb_edge16.hip"
+#include "../lagrangebench_amd/csrc/lb_segnn_msg.hip"
+#undef SGM_WS0
+#undef SGM_WT0
+#undef SGM_WV0
+#undef SGM_WS1
+#undef SGM_WT1
+#undef SGM_WV1
+#undef SGM_VEC
+#undef SGM_IMAGE
+#undef SGU_WS0
+#undef SGU_WT0
+#undef SGU_WV0
+#undef SGU_WS1
+#undef SGU_WT1
+#undef SGU_WV1
+#undef SGU_VEC
+#undef SGU_IMAGE
+#undef MFMA16H
+namespace r03 {
+#include "museum/lb_segnn_msg_r03.hip"
+}
+
+thread_local std::string g_lb_err;
+int lb_fail(int code, const char*, ...) { return code; }
+
+template <typename F>
+static float time_it(F launch, int iters) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  // clocks: after an idle gap (the host-side checks) the first ~50 ms run 15 - 20 % slow - warm up for as long as we time
+  for (int i = 0; i < iters * 2; ++i) launch();
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0, 0);
+  for (int i = 0; i < iters; ++i) launch();
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return 1e3f * ms / iters;
+}
+
+static double maxdiff(const std::vector<float>& a, const std::vector<float>& b, double* ref_max) {
+  double d = 0, m = 0;
+  for (size_t i = 0; i < a.size(); ++i) {
+    if (std::isnan(a[i]) || std::isnan(b[i])) return 1e30;
+    d = std::max(d, (double)std::fabs(a[i] - b[i]));
+    m = std::max(m, (double)std::fabs(b[i]));
+  }
+  *ref_max = m;
+  return d;
+}
+
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 8, dim = argc > 2 ? atoi(argv[2]) : 2;
+  const int iters = argc > 3 ? atoi(argv[3]) : 200;
+  const int64_t N = (int64_t)B * 5740;
+  srand(1);
+  std::vector<int> s, r, rp(N + 1);
+  std::vector<float> ef;
+  for (int64_t i = 0; i < N; ++i) {
+    rp[i] = (int)s.size();
+    const int deg = 4 + rand() % 6;  // ~6.5 incl. the self edge
+    std::vector<int> nb;
+    nb.push_back((int)i);
+    for (int k = 1; k < deg; ++k) nb.push_back((int)((i + (rand() % 160) - 80 + N) % N));
+    std::sort(nb.begin(), nb.end());
+    for (int j : nb) {
+      s.push_back(j);
+      r.push_back((int)i);
+      float d[3] = {0, 0, 0};
+      if (j != i)
+        for (int c = 0; c < dim; ++c) d[c] = (rand() % 2001 - 1000) * 0.5e-3f;
+      const float dist = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      if (dim == 3) { float e8[8] = {d[0], d[1], d[2], dist, 0, 0, 0, 0}; ef.insert(ef.end(), e8, e8 + 8); }
+      else { float e8[8] = {d[0], d[1], dist, 0, 0, 0, 0, 0}; ef.insert(ef.end(), e8, e8 + 8); }
+    }
+  }
+  const int64_t E = (int64_t)s.size();
+  rp[N] = (int)E;
+  const int64_t ntiles = (E + 15) / 16;
+  lb_ctrl c{};
+  c.overflow_step = -1;
+  c.n_edges_total = (int)E;
+  lb_ctrl* dc;
+  int *ds, *dr, *drp;
+  float *def, *f, *f0, *agg, *part, *nattr, *img_new, *img_old, *uimg_new, *uimg_old;
+  (void)hipMalloc(&dc, sizeof(c));
+  (void)hipMemcpy(dc, &c, sizeof(c), hipMemcpyHostToDevice);
+  (void)hipMalloc(&ds, E * 4);
+  (void)hipMalloc(&dr, E * 4);
+  (void)hipMalloc(&drp, (N + 1) * 4);
+  (void)hipMalloc(&def, E * 32);
+  (void)hipMemcpy(ds, s.data(), E * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dr, r.data(), E * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(drp, rp.data(), (N + 1) * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(def, ef.data(), E * 32, hipMemcpyHostToDevice);
+  (void)hipMalloc(&f, N * 512);
+  (void)hipMalloc(&f0, N * 512);
+  (void)hipMalloc(&agg, N * 512);
+  (void)hipMalloc(&part, (ntiles + 2) * 1024);
+  (void)hipMalloc(&nattr, N * 16);
+  std::vector<float> hf((size_t)N * 128), hna((size_t)N * 4);
+  for (int64_t i = 0; i < N; ++i) {
+    for (int j = 0; j < 128; ++j) hf[i * 128 + j] = (dim == 2 && j >= 96) ? 0.f : (rand() % 2001 - 1000) * 1e-3f;
+    hna[i * 4] = 1.f;
+    for (int c2 = 0; c2 < 3; ++c2) hna[i * 4 + 1 + c2] = c2 < dim ? (rand() % 2001 - 1000) * 0.4e-3f : 0.f;
+  }
+  (void)hipMemcpy(f0, hf.data(), N * 512, hipMemcpyHostToDevice);
+  (void)hipMemcpy(f, hf.data(), N * 512, hipMemcpyHostToDevice);
+  (void)hipMemcpy(nattr, hna.data(), N * 16, hipMemcpyHostToDevice);
+  // raw block weights (oracle order) -> both images
+  auto rnd = [&](size_t n, float sc) { std::vector<float> v(n); for (auto& x : v) x = (rand() % 2001 - 1000) * 1e-3f * sc; return v; };
+  auto ws0 = rnd(130 * 64, 1.7f), wv0 = rnd(130 * 32, 1.7f), b0 = rnd(64, 0.1f), ws1 = rnd(64 * 64, 1.7f), wv1 = rnd(64 * 32, 1.7f), b1 = rnd(64, 0.1f);
+  auto uws0 = rnd(128 * 64, 1.7f), uwv0 = rnd(128 * 32, 1.7f), ub0 = rnd(64, 0.1f), uws1 = rnd(64 * 32, 1.7f), uwv1 = rnd(64 * 32, 1.7f), ub1 = rnd(32, 0.1f);
+  {
+    std::vector<float> im((size_t)lb_sg_msg_image_floats()), io((size_t)r03::lb_sg_msg_image_floats());
+    lb_sg_msg_image(ws0.data(), wv0.data(), b0.data(), ws1.data(), wv1.data(), b1.data(), im.data());
+    r03::lb_sg_msg_image(ws0.data(), wv0.data(), b0.data(), ws1.data(), wv1.data(), b1.data(), io.data());
+    (void)hipMalloc(&img_new, im.size() * 4);
+    (void)hipMalloc(&img_old, io.size() * 4);
+    (void)hipMemcpy(img_new, im.data(), im.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(img_old, io.data(), io.size() * 4, hipMemcpyHostToDevice);
+    std::vector<float> um((size_t)lb_sg_upd_image_floats()), uo((size_t)r03::lb_sg_upd_image_floats());
+    lb_sg_upd_image(uws0.data(), uwv0.data(), ub0.data(), uws1.data(), uwv1.data(), ub1.data(), um.data());
+    r03::lb_sg_upd_image(uws0.data(), uwv0.data(), ub0.data(), uws1.data(), uwv1.data(), ub1.data(), uo.data());
+    (void)hipMalloc(&uimg_new, um.size() * 4);
+    (void)hipMalloc(&uimg_old, uo.size() * 4);
+    (void)hipMemcpy(uimg_new, um.data(), um.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(uimg_old, uo.data(), uo.size() * 4, hipMemcpyHostToDevice);
+  }
+  r03::lb_sg_msg_args ao{};
+  ao.ctrl = dc; ao.senders = ds; ao.receivers = dr; ao.row_ptr = drp; ao.efeat = def; ao.f = f0; ao.image = img_old;
+  ao.agg = agg; ao.part = part; ao.dim = dim;
+  lb_sg_msg_args an{};
+  an.ctrl = dc; an.senders = ds; an.receivers = dr; an.efeat = def; an.f = f0; an.image = img_new; an.agg = agg; an.part = part;
+  long long* dbg;
+  (void)hipMalloc(&dbg, 16 * 10 * 8);
+  (void)hipMemset(dbg, 0, 16 * 10 * 8);
+  an.dbg = dbg;
+  const int nmf = dim == 2 ? 126 : 144;
+  printf("B=%d dim=%d N=%lld E=%lld tiles=%lld (%.2f tiles per SIMD); MFMA floor at 2.5 PF: %.1f us (%d MFMAs/tile)\n", B, dim,
+         (long long)N, (long long)E, (long long)ntiles, ntiles / 1024.0, ntiles * nmf * 16.0 * 16 * 32 * 2 / 2.5e15 * 1e6, nmf);
+  auto old_msg = [&] { hipLaunchKernelGGL((r03::k_sg_msg<1, 768>), dim3(256), dim3(768), 0, 0, ao); };
+  for (int i = 0; i < 3000; ++i) old_msg();  // clocks up
+  (void)hipDeviceSynchronize();
+  auto grab = [&](auto launch, std::vector<float>& a, std::vector<float>& p) {
+    (void)hipMemset(agg, 0, N * 512);
+    (void)hipMemset(part, 0, (ntiles + 2) * 1024);
+    launch();
+    (void)hipDeviceSynchronize();
+    a.resize(N * 128);
+    p.resize((ntiles + 2) * 256);
+    (void)hipMemcpy(a.data(), agg, N * 512, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(p.data(), part, (ntiles + 2) * 1024, hipMemcpyDeviceToHost);
+  };
+  std::vector<float> ra, rpart;
+  grab(old_msg, ra, rpart);
+  {  // run-to-run determinism of both kernels (bitwise): 20 runs each against their own first run
+    auto stable = [&](const char* name, auto launch) {
+      std::vector<float> a0, p0, a1, p1;
+      grab(launch, a0, p0);
+      int bad = 0;
+      for (int i = 0; i < 20; ++i) {
+        grab(launch, a1, p1);
+        bad += (memcmp(a0.data(), a1.data(), a0.size() * 4) != 0 || memcmp(p0.data(), p1.data(), p0.size() * 4) != 0);
+      }
+      printf("determinism %-40s %d of 20 runs differ bitwise from the first\n", name, bad);
+    };
+    stable("r03 k_sg_msg", old_msg);
+    if (dim == 2) stable("r04 k_sg_msg<2D,3,prio>", [&] { hipLaunchKernelGGL((k_sg_msg<2, 3, true, 0>), dim3(256), dim3(768), 0, 0, an); });
+    else stable("r04 k_sg_msg<3D,3,prio>", [&] { hipLaunchKernelGGL((k_sg_msg<3, 3, true, 0>), dim3(256), dim3(768), 0, 0, an); });
+    grab(old_msg, ra, rpart);
+  }
+  auto report = [&](const char* name, auto launch, bool check) {
+    double d0 = 0, d1 = 0, m0 = 1, m1 = 1;
+    if (check) {
+      std::vector<float> a2, p2;
+      grab(launch, a2, p2);
+      d0 = maxdiff(a2, ra, &m0);
+      d1 = maxdiff(p2, rpart, &m1);
+    }
+    const float us = time_it(launch, iters);
+    printf("%-52s %8.2f us  fp16-MFMA frac %.3f", name, us, ntiles * nmf * 16.0 * 16 * 32 * 2 / (us * 1e-6) / 2.5e15);
+    if (check) printf("   rel diff vs r03: agg %.2e part %.2e", d0 / m0, d1 / m1);
+    printf("\n");
+    fflush(stdout);
+  };
+  auto grid_for = [&](int wps) {
+    int64_t gr = (ntiles + wps * 4 - 1) / (wps * 4);
+    gr = (gr + 7) / 8 * 8;
+    return (int)(gr < 8 ? 8 : (gr > 256 ? 256 : gr));
+  };
+#define NEW(D, W, P, A) [&] { hipLaunchKernelGGL((k_sg_msg<D, W, P, A>), dim3(grid_for(W)), dim3(W * 256), 0, 0, an); }
+  report("r03 k_sg_msg<1,768> (3 waves/SIMD)", old_msg, true);
+  if (dim == 2) {
+    report("r04 k_sg_msg<2D, 3 waves, prio>", NEW(2, 3, true, 0), true);
+    report("r04 k_sg_msg<2D, 3 waves>", NEW(2, 3, false, 0), true);
+    report("r04 k_sg_msg<2D, 2 waves, prio>", NEW(2, 2, true, 0), true);
+    report("r04 k_sg_msg<3D code on 2D data, 3 waves, prio>", NEW(3, 3, true, 0), true);
+    printf("--- which stamp makes the stamped kernel faster?  one s_memtime stamp at a time\n");
+#define ST1(M) [&] { hipLaunchKernelGGL((k_sg_msg<2, 3, true, 32, M>), dim3(grid_for(3)), dim3(768), 0, 0, an); }
+    report("  stamp 0 only (after loads + attr)", ST1(1), false);
+    report("  stamp 1 only (after init)", ST1(2), false);
+    report("  stamp 2 only (after sender op)", ST1(4), false);
+    report("  stamp 3 only (after receiver op)", ST1(8), false);
+    report("  stamp 4 only (after gate 0)", ST1(16), false);
+    report("  stamp 5 only (after block 1 op)", ST1(32), false);
+    report("  stamp 6 only (after gate 1)", ST1(64), false);
+    report("  stamp 7 only (after scan)", ST1(128), false);
+    report("  stamp 8 only (after stores)", ST1(256), false);
+    report("  no stamp, only the final dbg store", ST1(0), false);
+    report("  all stamps", ST1(511), false);
+    report("r04 k_sg_msg<2D, 3 waves, prio> AGAIN (drift check)", NEW(2, 3, true, 0), false);
+    report("r03 k_sg_msg AGAIN (drift check)", old_msg, false);
+    report("r04 k_sg_msg<2D, 3 waves, prio> AGAIN (drift check)", NEW(2, 3, true, 0), false);
+    printf("--- what do the stamps change?  segment-boundary variants of <2D, 3 waves, prio>\n");
+    report("  s_sleep 1 at the 9 segment boundaries", NEW(2, 3, true, 64), true);
+    report("  sched_barrier + s_waitcnt lgkmcnt(0) at the boundaries", NEW(2, 3, true, 128), true);
+    report("  s_memtime (result unused) at the boundaries", NEW(2, 3, true, 256), true);
+    report("  the same, 2 waves", NEW(2, 2, true, 256), true);
+    printf("--- ablation of <2D, 3 waves, prio>\n");
+    report("  no row gathers", NEW(2, 3, true, 1), false);
+    report("  no MFMAs", NEW(2, 3, true, 2), false);
+    report("  no gates", NEW(2, 3, true, 4), false);
+    report("  no scan", NEW(2, 3, true, 8), false);
+    report("  no stores", NEW(2, 3, true, 16), false);
+    report("  no gathers, no stores", NEW(2, 3, true, 17), false);
+    report("  no gathers, MFMAs, stores (VALU + LDS)", NEW(2, 3, true, 19), false);
+    report("  no gathers, gates, scan, stores (MFMA + splits)", NEW(2, 3, true, 29), false);
+  } else {
+    report("r04 k_sg_msg<3D, 3 waves, prio>", NEW(3, 3, true, 0), true);
+    report("r04 k_sg_msg<3D, 3 waves>", NEW(3, 3, false, 0), true);
+    report("r04 k_sg_msg<3D, 2 waves, prio>", NEW(3, 2, true, 0), true);
+    printf("--- ablation of <3D, 3 waves, prio>\n");
+    report("  no row gathers", NEW(3, 3, true, 1), false);
+    report("  no MFMAs", NEW(3, 3, true, 2), false);
+    report("  no gates", NEW(3, 3, true, 4), false);
+    report("  no scan", NEW(3, 3, true, 8), false);
+    report("  no gathers, no stores", NEW(3, 3, true, 17), false);
+  }
+  if (dim == 2) {  // where does a wave's time go?  cycle stamps of workgroup 0 (s_memtime; +~10 % run time)
+        auto st = NEW(2, 3, true, 32);
+    st();
+    (void)hipDeviceSynchronize();
+    const float us = time_it(st, iters);
+    long long h[160];
+    (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    static const char* seg[9] = {"loads+attr", "init(LDS vec)", "sender op", "receiver op", "gate0", "block1 op", "gate1", "scan", "stores"};
+    printf("--- stamps <2D, 3 waves, prio> (%.2f us with stamps): cycles per tile and segment, waves 0, 4, 8 of workgroup 0 share SIMD 0\n", us);
+    for (int w = 0; w < 12; ++w) {
+      const double nt2 = (double)h[w * 10 + 9];
+      double tot = 0;
+      printf("  wave %2d (%2.0f tiles):", w, nt2);
+      for (int i = 0; i < 9; ++i) { printf(" %s %.0f", seg[i], h[w * 10 + i] / nt2); tot += h[w * 10 + i] / nt2; }
+      printf("  | total %.0f\n", tot);
+    }
+  }
+  // ---- update kernel: f += update([f | agg]) with the partial slots of the LAST message launch
+  {
+    grab(old_msg, ra, rpart);  // agg / part = round 3's message output
+    r03::lb_sg_upd_args uo{};
+    uo.ctrl = dc; uo.n_rows = N; uo.f = f; uo.agg = agg; uo.nattr = nattr; uo.image = uimg_old; uo.row_ptr = drp; uo.part = part;
+    lb_sg_upd_args un{};
+    un.ctrl = dc; un.n_rows = N; un.f = f; un.agg = agg; un.nattr = nattr; un.image = uimg_new; un.row_ptr = drp; un.part = part;
+    const int nt = (int)((N + 15) / 16);
+    const int nb = std::min(256, (nt + 7) / 8);
+    auto old_upd = [&] { hipLaunchKernelGGL(r03::k_sg_upd, dim3(nb), dim3(512), 0, 0, uo); };
+    auto grabf = [&](auto launch, std::vector<float>& o) {
+      (void)hipMemcpy(f, f0, N * 512, hipMemcpyDeviceToDevice);
+      launch();
+      (void)hipDeviceSynchronize();
+      o.resize(N * 128);
+      (void)hipMemcpy(o.data(), f, N * 512, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(f, f0, N * 512, hipMemcpyDeviceToDevice);
+    };
+    std::vector<float> rf;
+    grabf(old_upd, rf);
+    auto report_u = [&](const char* name, auto launch) {
+      std::vector<float> o;
+      grabf(launch, o);
+      double m = 1;
+      const double d = maxdiff(o, rf, &m);
+      // (timed on a fixed point: f is re-read and re-written, values drift but the work is the same; reset after)
+      const float us = time_it(launch, iters);
+      (void)hipMemcpy(f, f0, N * 512, hipMemcpyDeviceToDevice);
+      printf("%-52s %8.2f us   rel diff vs r03: f %.2e\n", name, us, d / m);
+      fflush(stdout);
+    };
+    report_u("r03 k_sg_upd", old_upd);
+    if (dim == 2) {
+      report_u("r04 k_sg_upd<2D, 512>", [&] { hipLaunchKernelGGL((k_sg_upd<2, 512>), dim3(nb), dim3(512), 0, 0, un); });
+      report_u("r04 k_sg_upd<3D code, 512>", [&] { hipLaunchKernelGGL((k_sg_upd<3, 512>), dim3(nb), dim3(512), 0, 0, un); });
+    } else {
+      report_u("r04 k_sg_upd<3D, 512>", [&] { hipLaunchKernelGGL((k_sg_upd<3, 512>), dim3(nb), dim3(512), 0, 0, un); });
+    }
+  }
+  return 0;
+}
