@@ -385,6 +385,16 @@ int lb_sg_upd_image_floats(void);
 int lbk_sg_update(lb_engine* e, float* f, const float* agg, const float* nattr, const float* image,
                   bool combine_partials);
 
+// lb_segnn_node.hip
+void lb_sg_embed_image(const float* ws, const float* wv, const float* b, int ns, int nv, float* out);
+int lb_sg_embed_image_floats(void);
+int lbk_sg_embed(lb_engine* e, const float* xnode, const float* image, float* f, float* nattr, int homogeneous,
+                 int vel_avg);
+void lb_sg_readout_image(const float* ws0, const float* wv0, const float* b0, const float* ws1, const float* wv1,
+                         const float* b1, const float* wo, float* out);
+int lb_sg_readout_image_floats(void);
+int lbk_sg_readout(lb_engine* e, const float* f, const float* nattr, const float* image, float* acc_out);
+
 // lb_api.hip: node-sized network scratch (allocated once per engine, xnode at the full 128-column width) and the
 // per-model constants that live in engine-wide state; several models may share one engine
 int lb_ensure_node_scratch(lb_engine* e);

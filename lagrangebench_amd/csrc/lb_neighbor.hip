@@ -159,11 +159,18 @@ __global__ void k_cell_fill(lb_geom g, int64_t BN, const double* __restrict__ wi
 // (the order of the particles INSIDE a cell is arbitrary in both: the rows are sorted by sender id later).
 #define LB_SMALL_N 4096
 #define LB_SMALL_T 1024
+// Round 4: the same kernel serves one mid-size trajectory that the single-launch builds refuse (DAM2D: 5740 particles,
+// 12.6 k cells, 262 mask rows): counts in dynamic LDS (up to LB_CELLS1_NCELL cells), up to LB_CELLS1_PER particles per
+// thread - memset + count + two scan passes + fill (25 us of launches on DAM2D) become one ~8 us launch.
+#define LB_CELLS1_PER 8
+#define LB_CELLS1_N (LB_SMALL_T * LB_CELLS1_PER)
+#define LB_CELLS1_NCELL 32768
+template <int PER>
 __global__ void __launch_bounds__(LB_SMALL_T)
     k_cells_small(lb_geom g, int64_t BN, const double* __restrict__ win, lb_ctrl* __restrict__ ctrl,
                   int32_t* __restrict__ cell_of, int32_t* __restrict__ cell_start, int32_t* __restrict__ cell_part,
                   double* __restrict__ cpos, int ncell_tot) {
-  __shared__ int s_cnt[LB_SMALL_N];
+  extern __shared__ int s_cnt[];  // [ncell_tot]
   __shared__ int s_scan[LB_SMALL_T];
   __shared__ int s_max;
   if (ctrl->overflow_step >= 0) return;
@@ -176,8 +183,15 @@ __global__ void __launch_bounds__(LB_SMALL_T)
   for (int c = tid; c < ncell_tot; c += LB_SMALL_T) s_cnt[c] = 0;
   __syncthreads();
   const int step = ctrl->step;
-  constexpr int PER = LB_SMALL_N / LB_SMALL_T;
   int gcs[PER], rk[PER];
+  double pos[PER][3];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {  // all position loads of a thread in flight together
+    const int64_t gi = tid + (int64_t)LB_SMALL_T * k;
+    const int64_t gc = gi < BN ? gi : BN - 1;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pos[k][d] = d < g.dim ? lb_pos(win, g, BN, step, g.isl - 1, d, gc) : 0.0;
+  }
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int64_t gi = tid + (int64_t)LB_SMALL_T * k;
@@ -186,12 +200,14 @@ __global__ void __launch_bounds__(LB_SMALL_T)
     if (gi < BN) {
       const int b = (int)(gi / g.N);
       int h = 0, mult = 1;
-      for (int d = 0; d < g.dim; ++d) {
-        double p = lb_pos(win, g, BN, step, g.isl - 1, d, gi);
-        int c = __double2int_rz(lb_r(p / g.cell_size[d], g.f32));  // jnp.array(position / cell_size, dtype=i32)
-        c = c < 0 ? 0 : (c >= g.ncell[d] ? g.ncell[d] - 1 : c);
-        h += c * mult;
-        mult *= g.ncell[d];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (d < g.dim) {
+          int c = __double2int_rz(lb_r(pos[k][d] / g.cell_size[d], g.f32));  // jnp.array(position / cell_size, dtype=i32)
+          c = c < 0 ? 0 : (c >= g.ncell[d] ? g.ncell[d] - 1 : c);
+          h += c * mult;
+          mult *= g.ncell[d];
+        }
       }
       const int gc = b * g.ncells + h;
       cell_of[gi] = gc;
@@ -238,7 +254,9 @@ __global__ void __launch_bounds__(LB_SMALL_T)
     if (gi < BN) {
       const int slot = s_cnt[gcs[k]] + rk[k];
       cell_part[slot] = (int32_t)gi;
-      for (int d = 0; d < g.dim; ++d) cpos[(int64_t)d * BN + slot] = lb_pos(win, g, BN, step, g.isl - 1, d, gi);
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        if (d < g.dim) cpos[(int64_t)d * BN + slot] = pos[k][d];
     }
   }
 }
@@ -1595,9 +1613,21 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
     }
   }
   lb_tic(e, LB_T_CELLS);
+  // (one mid-size trajectory that the single-launch builds above refused, e.g. DAM2D: binning still in one launch)
+  static const bool cells1_ok = !(getenv("LB_CELLS_ONE") && getenv("LB_CELLS_ONE")[0] == '0');
+  const bool mid_cells = cells1_ok && small_ok && frozen && g.B == 1 && BN <= LB_CELLS1_N && ncell_tot <= LB_CELLS1_NCELL;
   if (small_cells) {
-    hipLaunchKernelGGL(k_cells_small, dim3(1), dim3(LB_SMALL_T), 0, s, g, BN, e->win, e->ctrl, e->cell_of,
-                       e->cell_start, e->cell_part, e->cpos, ncell_tot);
+    hipLaunchKernelGGL((k_cells_small<LB_SMALL_N / LB_SMALL_T>), dim3(1), dim3(LB_SMALL_T), sizeof(int) * (size_t)ncell_tot, s, g,
+                       BN, e->win, e->ctrl, e->cell_of, e->cell_start, e->cell_part, e->cpos, ncell_tot);
+  } else if (mid_cells) {
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute((const void*)k_cells_small<LB_CELLS1_PER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                sizeof(int) * LB_CELLS1_NCELL);
+      raised = true;
+    }
+    hipLaunchKernelGGL((k_cells_small<LB_CELLS1_PER>), dim3(1), dim3(LB_SMALL_T), sizeof(int) * (size_t)ncell_tot, s, g, BN,
+                       e->win, e->ctrl, e->cell_of, e->cell_start, e->cell_part, e->cpos, ncell_tot);
   } else {
     LB_HIP(hipMemsetAsync(e->cell_count, 0, sizeof(int32_t) * 2 * (size_t)ncell_tot, s));
     // (max_cell_occ, max_deg, row_overflow are reset by k_cell_count)

@@ -91,6 +91,9 @@ struct lb_segnn {
   float* tap;
   std::vector<const float*> msg_image;  // per layer: LDS image of the fused message kernel
   std::vector<const float*> upd_image;  // per layer: LDS image of the fused update kernel
+  const float* embed_image = nullptr;    // k_sg_embed (node prep + O3Embedding), k_sg_readout (O3Decoder + integrator)
+  const float* readout_image = nullptr;
+  bool fused_node = false;
   bool fused_msg;  // gather + both message blocks + segment_sum in one kernel (blocks_per_step == 2)
 };
 
@@ -467,6 +470,19 @@ extern "C" int lb_segnn_create(lb_engine* e, const lb_segnn_desc* d, const float
       upd_image_off.push_back(put(uimg.data(), uimg.size()));
     }
   }
+  size_t embed_off = 0, readout_off = 0;
+  const bool node_ok = (B == 2) && m->node_ns <= 32 && m->node_nv <= 32;
+  if (node_ok) {
+    std::vector<float> ei((size_t)lb_sg_embed_image_floats());
+    lb_sg_embed_image(pend[0].raw_ws, pend[0].raw_wv, pend[0].raw_b, m->node_ns, m->node_nv, ei.data());
+    embed_off = put(ei.data(), ei.size());
+    const Pending& r0 = pend[1 + (size_t)L * 2 * B];
+    const Pending& r1 = pend[2 + (size_t)L * 2 * B];
+    const Pending& ro = pend[3 + (size_t)L * 2 * B];
+    std::vector<float> ri((size_t)lb_sg_readout_image_floats());
+    lb_sg_readout_image(r0.raw_ws, r0.raw_wv, r0.raw_b, r1.raw_ws, r1.raw_wv, r1.raw_b, ro.raw_wv, ri.data());
+    readout_off = put(ri.data(), ri.size());
+  }
   int rc = sg_alloc(&m->blob, host.size());
   if (!rc && hipMemcpy(m->blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
     rc = lb_fail(LB_ERR_HIP, "weight upload failed");
@@ -490,6 +506,13 @@ extern "C" int lb_segnn_create(lb_engine* e, const lb_segnn_desc* d, const float
   {
     const char* f = getenv("LB_SEGNN_FUSED");
     m->fused_msg = (B == 2) && !(f && f[0] == '0');
+    // LB_SEGNN_NODE=0: node prep / embedding / readout / integrator as round 3's separate launches
+    const char* fn = getenv("LB_SEGNN_NODE");
+    m->fused_node = m->fused_msg && node_ok && !(fn && fn[0] == '0');
+    if (node_ok) {
+      m->embed_image = m->blob + embed_off;
+      m->readout_image = m->blob + readout_off;
+    }
   }
   const int64_t BN = e->BN;
   if (!rc) rc = sg_alloc(&m->xnode, (size_t)BN * 32);
@@ -531,6 +554,13 @@ int lbk_segnn_forward(lb_engine* e, lb_segnn* m) {
   lb_tic(e, LB_T_NODEFEAT);
   if (!(e->feat_done && e->feat_job.xnode == m->xnode))  // (rollout step: written by the neighbor-search launch)
     LB_TRY(lbk_node_features_raw(e, m->xnode, 32));
+  if (m->fused_node) {
+    lb_toc(e);
+    lb_tic(e, LB_T_ENC_NODE);
+    int rc = lbk_sg_embed(e, m->xnode, m->embed_image, m->f, m->nattr, m->desc.homogeneous, m->desc.velocity_avg);
+    lb_toc(e);
+    if (rc) return rc;
+  } else {
   hipLaunchKernelGGL(k_sg_edge_prep, dim3(nb_e), dim3(256), 0, s, e->ctrl, e->g.dim, e->efeat,
                      m->eattr, m->msgsv, ecap);
   hipLaunchKernelGGL(k_sg_node_prep, dim3(nb_n), dim3(256), 0, s, e->g, BN, e->ctrl, m->xnode, 32,
@@ -538,9 +568,10 @@ int lbk_segnn_forward(lb_engine* e, lb_segnn* m) {
                      m->node_ns4, m->node_nv4, m->nodesv, m->nattr);
   lb_toc(e);
   LB_HIP(hipGetLastError());
+  }
 
   const int32_t s128[3] = {128, 128, 16};
-  {
+  if (!m->fused_node) {
     const float* xs[1] = {m->nodesv};
     const int32_t st[1] = {m->node_stride};
     lb_tic(e, LB_T_ENC_NODE);
@@ -607,6 +638,11 @@ int lbk_segnn_forward(lb_engine* e, lb_segnn* m) {
     LB_TRY(tap(k + 1));
   }
   lb_tic(e, LB_T_DECODER);
+  if (m->fused_node) {
+    int rc = lbk_sg_readout(e, m->f, m->nattr, m->readout_image, e->acc);
+    lb_toc(e);
+    return rc;
+  }
   const float* ncur = m->f;
   for (int i = 0; i < B; ++i) {
     const float* xs[1] = {ncur};

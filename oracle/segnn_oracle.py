@@ -110,7 +110,9 @@ def o3_tensor_product(p: Dict[str, np.ndarray], ops: List[SV], attr: np.ndarray)
     K = np.float32(xs.shape[1])
     scale = np.float32(1.0) / np.sqrt(K)
     s = (xs @ p["ws"]) * scale + p["b"] if p["ws"].shape[1] > 0 else np.zeros((len(xs), 0), np.float32)
-    v = np.einsum("rkc,km->rmc", xv, p["wv"]) * scale
+    # (R, K, 3) x (K, Mv) -> (R, Mv, 3) as one BLAS product per row block (the c_einsum form of the same contraction
+    # took 27 of the 33 s of a DAM2D-size forward)
+    v = np.matmul(np.ascontiguousarray(xv.transpose(0, 2, 1)), p["wv"]).transpose(0, 2, 1) * scale
     return SV(s, v)
 
 

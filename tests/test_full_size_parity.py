@@ -158,6 +158,52 @@ def test_full_size_segnn_dam2d_forward_vs_oracle():
     assert np.abs(acc - ref["acc"]).max() < 1e-5 * max(hid, float(np.abs(ref["acc"]).max()))
 
 
+def test_full_size_segnn_dam2d_rollout_vs_oracle():
+    """BASELINE configs[4] at full size, the ROLLOUT: 20 steps of lb_segnn_rollout (device step
+    loop: single-launch cell binning, search, k_sg_embed, 10 x (k_sg_msg + k_sg_upd), k_sg_readout with the integrator
+    in its epilogue) against the oracle's eval loop (NumPy neighbor list + oracle/segnn_oracle.py) on the same
+    trajectory and weights: every step's positions within 1e-6 dx, the 20-step MSE within 1e-5."""
+    import time
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import SEGNN, node_irreps
+    from oracle import segnn_oracle as S
+    L, n_steps = 10, 20
+    ds = make_case("dam2d", n_trajs=1, extra_seq_length=n_steps)
+    ds.magnitude_features = True
+    isl = ds.input_seq_length
+    irr = node_irreps(ds.metadata, isl, ds.external_force_fn is not None, True, False)
+    model = SEGNN(irr, "1x1o+1x0e", 64, 1, 1, "1x1o", num_mp_steps=L, n_vels=isl - 1, homogeneous_particles=False)
+    params = model.init_params(5)
+    params["output"]["wv"] = (params["output"]["wv"] * 0.01).astype(np.float32)  # accelerations of a physical size
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    pos, pt = ds[0]
+    N = len(pt)
+    assert N >= 5000
+    eng = hcase.engine(1)
+    eng.set_particle_type(pt[None])
+    traj = eng.prepare_traj(pos[None])
+    pred = _np(eng.rollout(model.handle(eng, params), traj, n_steps)[0])[0]  # (T, N, dim)
+
+    def oracle_apply(p, state, sample):
+        f, ptype = sample
+        return S.segnn_apply(p, f, ptype, isl - 1, False), state
+
+    t0 = time.time()
+    _, onb = ocase.allocate_eval((pos[:, :isl].astype(np.float64), pt))
+    ref, _, _ = O.eval_batched_rollout(oracle_apply, ocase, params, {}, (pos[None].astype(np.float64), pt[None]), onb,
+                                       n_rollout_steps=n_steps, t_window=isl)
+    ref = np.asarray(ref)[0]
+    print(f"[segnn dam2d rollout] oracle: {time.time() - t0:.1f} s for {n_steps} steps of {N} particles")
+    dx = float(ds.metadata["dx"])
+    err = np.abs(pred - ref).max(axis=(1, 2))
+    print("[segnn dam2d rollout] max |dpos| / dx per step:", np.array2string(err / dx, precision=2))
+    assert err.max() < 1e-6 * dx
+    truth = np.transpose(pos[:, isl:isl + n_steps], (1, 0, 2))
+    mse_h = ((pred - truth) ** 2).mean(axis=(1, 2))
+    mse_o = ((ref - truth) ** 2).mean(axis=(1, 2))
+    assert np.abs(mse_h - mse_o).max() <= 1e-5 and np.allclose(mse_h, mse_o, rtol=1e-3, atol=1e-12)
+
+
 def test_batched_40k_nodes_forward_vs_oracle():
     """B = 5 TGV3D-8k trajectories = 40 000 nodes in one graph: the size class of the benchmark line
     (lb_node16s single-pass node kernel from 16 k nodes, full 256-workgroup edge walk).  Per-layer
