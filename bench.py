@@ -73,6 +73,12 @@ def hip_case(ds):
         noise_std=ds.noise_std, external_force_fn=ds.force)
 
 
+def sg_msg_flops(n_edges, dim):
+    """fp16 MFMA products k_sg_msg issues per launch: block 0: S 128x64, T 64x32, V dim x 64x32; block 1: S 64x64,
+    T 32x32, V dim x 32x32; x 3 split passes (lo*hi + hi*lo + hi*hi), 2 flop per product."""
+    return n_edges * 2 * 3 * (128 * 64 + 64 * 32 + dim * 64 * 32 + 64 * 64 + 32 * 32 + dim * 32 * 32)
+
+
 def gns_widths(ds):
     dim, K = len(ds.box), ds.input_seq_length - 1
     node_in = K * dim + (K if getattr(ds, "magnitude_features", False) else 0)
@@ -433,7 +439,7 @@ def other_configs(device):
                                          "frac": byts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                          "note": "B = 1 graphs are launch-latency bound, not bandwidth bound"}
                 else:
-                    fl = E_tot * 2 * 3 * (128 * 64 + 64 * 32 + 3 * 64 * 32 + 64 * 64 + 32 * 32 + 3 * 32 * 32)
+                    fl = sg_msg_flops(E_tot, len(ds.box))
                     entry["roofline"] = {"kernel": "k_sg_msg (gather + 2 gated TP blocks + segment_sum, f16x2)",
                                          "bound": "mfma", "us_per_launch": round(us, 2),
                                          "achieved": fl / (us * 1e-6) / 1e12, "peak": MFMA_F16_PEAK_TF,
@@ -497,7 +503,9 @@ def run_segnn(args, rank, world, device):
     if fused:
         # k_sg_msg (f16x2): products actually executed per edge (s W_v^s computed once instead of 3x):
         # block 0: 128x64 + 64x32 + 3*64x32, block 1: 64x64 + 32x32 + 3*32x32; x3 split passes
-        flop_exec = E_tot * 2 * 3 * (128 * 64 + 64 * 32 + 3 * 64 * 32 + 64 * 64 + 32 * 32 + 3 * 32 * 32)
+        # (round 4: the vector products run on `dim` components - in 2D the z component is identically zero in the
+        # reference too and is skipped: 126 instead of 144 MFMAs per 16-edge tile)
+        flop_exec = sg_msg_flops(E_tot, len(ds.box))
         peak, kname = MFMA_F16_PEAK_TF, "k_sg_msg (gather + 2 gated TP blocks + segment_sum, f16x2)"
         msg_bytes = E_tot * (2 * 512 + 40) + B * N * 512   # two node rows per edge (L2/MALL), one row per receiver
     else:

@@ -35,11 +35,15 @@
 // small graphs use plain accesses.
 // GUARD: exhaustive TINY test of the f16x2 range guard on every tile (lb_tile_tiny; +8 % kernel time: lb_math_mode 3 /
 // LB_GUARD=full), else the sampled probe (first tile of every wave).
-template <int WPS, bool RELOAD, bool SKIP, int ABL = 0, bool PRIO = false, bool NT = true, bool GUARD = false>
+// TICKET (round 4): the waves of a workgroup draw their tiles from an LDS ticket counter inside the workgroup's contiguous
+// chunk instead of walking a static stride - the SIMD's issue arbiter prefers its oldest wave, which otherwise finishes its
+// share early and leaves the younger wave to run alone at the end of the launch (k_sg_msg: lb_segnn_msg.hip).
+template <int WPS, bool RELOAD, bool SKIP, int ABL = 0, bool PRIO = false, bool NT = true, bool GUARD = false, bool TICKET = false>
 __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
   constexpr int THREADS = WPS * 256, WAVES = WPS * 4;
   constexpr int NW0 = 4096;
   __shared__ f32x4 sW[NW0 + 4096 + 96];
+  __shared__ int s_ticket;
   // Prologue order (matters for small graphs, where a launch is a latency chain): the control block is read,
   // the weight loads are issued into registers, the first tile's indices are requested while those are in
   // flight, and only then the weights are written to LDS - "flag -> weights -> barrier -> indices -> gathers" was
@@ -64,10 +68,17 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
   // the wave index is uniform: keep the whole tile walk (t, stride, bounds) in scalar registers
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
-  const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * WAVES + wave;
-  const int stride = (gridDim.x >> 3) * WAVES;
-  const int t_lo = (int)(((int64_t)ntiles * xcd) >> 3), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) >> 3);
-  int t = t_lo + slot;
+  const int xcd = blockIdx.x & 7;
+  int stride = (gridDim.x >> 3) * WAVES;
+  int t_lo = (int)(((int64_t)ntiles * xcd) >> 3), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) >> 3);
+  int t = t_lo + (blockIdx.x >> 3) * WAVES + wave;
+  if constexpr (TICKET) {  // ticket k of workgroup b of the XCD -> tile t_lo + b + k * (workgroups per XCD): the workgroups
+    // still stream through the XCD's range side by side (contiguous chunks per workgroup measured 3 % slower than the
+    // static walk: 32 separate streams per XCD); first tile static
+    stride = gridDim.x >> 3;
+    t_lo += (blockIdx.x >> 3);
+    t = t_lo + wave * stride;
+  }
   auto rowc_of = [&](int tt) -> int64_t {
     const int row = tt * 16 + n;
     return row < E ? row : (E > 0 ? E - 1 : 0);
@@ -89,6 +100,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
       const float* src = tid < 32 ? a.b1 : (tid < 64 ? a.ln_s : a.ln_o);
       sW[NW0 + 4096 + tid] = reinterpret_cast<const f32x4*>(src)[tid & 31];
     }
+    if (TICKET && tid == 0) s_ticket = WAVES;
   }
   __syncthreads();
   if (t >= t_hi) return;
@@ -100,13 +112,19 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
   asm volatile("" : "+v"(off0), "+v"(off1), "+v"(off2));
   const lds_cptr w0b = (lds_cptr)(uintptr_t)off0, w1b = (lds_cptr)(uintptr_t)off1, vecb = (lds_cptr)(uintptr_t)off2;
   const f32x4* psr4 = reinterpret_cast<const f32x4*>(a.psr);
-  const int n_iter = (t_hi - 1 - t) / stride + 1;
-  const int t_last = t + (n_iter - 1) * stride;
+  const int n_iter = TICKET ? 0x7fffffff : (t_hi - 1 - t) / stride + 1;
+  const int t_last = TICKET ? t_hi - 1 : t + (n_iter - 1) * stride;
   // (the first tile's indices were waited for above, by the barrier: a wait at the loop header would also be
   // executed on the back edge, where it drains the previous tile's stores)
   asm volatile("" : "+v"(s_c), "+v"(r_c));
   int guard_tiny = 0;  // exhaustive TINY guard: every tile's two GEMM operands (lb_tile_tiny)
-  for (int it = 0; it < n_iter; ++it, t += stride) {
+  for (int it = 0; it < n_iter && t < t_hi; ++it) {
+    int t_next = t + stride;
+    if constexpr (TICKET) {  // the next tile's ticket: one lane draws, the wave reads it back as a scalar
+      int k = 0;
+      if (lane == 0) k = atomicAdd(&s_ticket, 1);
+      t_next = t_lo + __builtin_amdgcn_readfirstlane(k) * stride;
+    }
     f32x4 acc[8], ve[8];
     const int r_cur = r_c;
     const f32x4* er = reinterpret_cast<const f32x4*>(a.elat) + (int64_t)t * 512 + lane;
@@ -122,7 +140,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
         p0[mb] = (ABL & 1) ? f32x4{.1f, .2f, (float)s_c, (float)mb} : ps[4 * mb];
         acc[mb] = (ABL & 1) ? f32x4{.3f, .1f, (float)r_c, (float)mb} : pr[4 * mb];
       }
-      const int64_t rn = rowc_of(min(t + stride, t_last));
+      const int64_t rn = rowc_of(min(t_next, t_last));
       s_c = a.senders[rn];
       r_c = a.receivers[rn];
 #pragma unroll
@@ -201,6 +219,7 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb) d4[4 * mb] = y[mb];
     }
+    t = t_next;
   }
   if (guard_tiny && lane == 0) lb_raise_math(a.ctrl, LB_MATH_TINY);
 }
@@ -292,12 +311,20 @@ int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a) {
 // Two waves per SIMD, GEMM-phase priority (round 2's measured best; the software-prefetching, second-read and
 // three- / four-wave variants live on in tools/museum/lb_edge16v_r02.hip for tools/edge16v_bench).
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a) {
-#define LB_E16V_(NT, G, GU)                                                                             \
+  static const bool ticket = getenv("LB_EDGE_TICKET") && getenv("LB_EDGE_TICKET")[0] == '1';
+#define LB_E16V__(NT, G, GU, TK)                                                                        \
   do {                                                                                                  \
     if (a.skip_elat_store)                                                                              \
-      LB_LAUNCH_TIMED(e, (k_edge16v<2, false, true, 0, true, NT, GU>), dim3(G), dim3(512), a);          \
+      LB_LAUNCH_TIMED(e, (k_edge16v<2, false, true, 0, true, NT, GU, TK>), dim3(G), dim3(512), a);      \
     else                                                                                                \
-      LB_LAUNCH_TIMED(e, (k_edge16v<2, false, false, 0, true, NT, GU>), dim3(G), dim3(512), a);         \
+      LB_LAUNCH_TIMED(e, (k_edge16v<2, false, false, 0, true, NT, GU, TK>), dim3(G), dim3(512), a);     \
+  } while (0)
+#define LB_E16V_(NT, G, GU)       \
+  do {                            \
+    if (ticket)                   \
+      LB_E16V__(NT, G, GU, true); \
+    else                          \
+      LB_E16V__(NT, G, GU, false);\
   } while (0)
 #define LB_E16V(NT, G)        \
   do {                        \
@@ -323,6 +350,7 @@ int lbk_edge16v(lb_engine* e, const lb_edge16_args& a) {
     LB_E16V(true, grid);
 #undef LB_E16V
 #undef LB_E16V_
+#undef LB_E16V__
   LB_HIP(hipGetLastError());
   return LB_OK;
 }

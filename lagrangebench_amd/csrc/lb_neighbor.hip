@@ -157,6 +157,17 @@ __global__ void k_cell_fill(lb_geom g, int64_t BN, const double* __restrict__ wi
 // launch instead of memset + count + two scan passes + fill (each ~4-5 us of launch floor on a 2.5 k-particle
 // trajectory, where the whole step is 0.4 ms).  Same arithmetic and same outputs as the multi-launch path
 // (the order of the particles INSIDE a cell is arbitrary in both: the rows are sorted by sender id later).
+// cell coordinate of a position, int(position / cell_size) clamped to the grid: a float product locates the quotient and
+// the exact fp64 (f32 mode: float-rounded) quotient is evaluated only within 1e-3 of an integer or far outside the grid
+// (the comment block in front of k_nl_small has the error budget)
+template <bool F32>
+__device__ __forceinline__ int lb_cell_coord(double p, float inv_cs32, double cs, int n) {
+  const float q = (float)p * inv_cs32;
+  const float fl = floorf(q), fr = q - fl;
+  int c = (int)fl;
+  if (fr < 1e-3f || fr > 0.999f || !(fabsf(q) < 2000.f)) c = __double2int_rz(lb_r(p / cs, F32));
+  return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
 #define LB_SMALL_N 4096
 #define LB_SMALL_T 1024
 // Round 4: the same kernel serves one mid-size trajectory that the single-launch builds refuse (DAM2D: 5740 particles,
@@ -192,6 +203,9 @@ __global__ void __launch_bounds__(LB_SMALL_T)
 #pragma unroll
     for (int d = 0; d < 3; ++d) pos[k][d] = d < g.dim ? lb_pos(win, g, BN, step, g.isl - 1, d, gc) : 0.0;
   }
+  float inv_cs[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) inv_cs[d] = d < g.dim ? (float)(1.0 / g.cell_size[d]) : 0.f;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int64_t gi = tid + (int64_t)LB_SMALL_T * k;
@@ -203,8 +217,9 @@ __global__ void __launch_bounds__(LB_SMALL_T)
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         if (d < g.dim) {
-          int c = __double2int_rz(lb_r(pos[k][d] / g.cell_size[d], g.f32));  // jnp.array(position / cell_size, dtype=i32)
-          c = c < 0 ? 0 : (c >= g.ncell[d] ? g.ncell[d] - 1 : c);
+          // jnp.array(position / cell_size, dtype=i32), clamped (one workgroup does all N: the fp64 division was its time)
+          const int c = g.f32 ? lb_cell_coord<true>(pos[k][d], inv_cs[d], g.cell_size[d], g.ncell[d])
+                              : lb_cell_coord<false>(pos[k][d], inv_cs[d], g.cell_size[d], g.ncell[d]);
           h += c * mult;
           mult *= g.ncell[d];
         }
@@ -226,16 +241,24 @@ __global__ void __launch_bounds__(LB_SMALL_T)
     sum += v;
     mx = max(mx, v);
   }
-  s_scan[tid] = sum;
+  // inclusive scan over the 1024 thread sums: inside the wave with lane shifts, across the 16 waves through LDS
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if ((tid & 63) >= o) incl += v;
+  }
+  if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
   if (mx > 0) atomicMax(&s_max, mx);
   __syncthreads();
-  for (int off = 1; off < LB_SMALL_T; off <<= 1) {  // Hillis-Steele inclusive
-    const int add = (tid >= off) ? s_scan[tid - off] : 0;
-    __syncthreads();
-    s_scan[tid] += add;
-    __syncthreads();
+  int wbase = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < LB_SMALL_T / 64; ++w) {
+    const int v = s_scan[w];
+    if (w < (tid >> 6)) wbase += v;
+    total += v;
   }
-  int run = s_scan[tid] - sum;
+  int run = wbase + incl - sum;
   for (int j = 0; j < per; ++j) {
     const int c = c_lo + j;
     if (c < ncell_tot) {
@@ -245,7 +268,7 @@ __global__ void __launch_bounds__(LB_SMALL_T)
       run += v;
     }
   }
-  if (tid == LB_SMALL_T - 1) cell_start[ncell_tot] = s_scan[tid];
+  if (tid == LB_SMALL_T - 1) cell_start[ncell_tot] = total;
   if (tid == 0) ctrl->max_cell_occ = s_max;
   __syncthreads();
 #pragma unroll
@@ -851,14 +874,6 @@ __global__ void __launch_bounds__(LB_SMALL_T)
 // only inside a 1e-3 band around an integer - or far outside the grid - is the exact (in f32 mode: float-rounded)
 // quotient evaluated.  Every workgroup of the single-launch builds recomputes ALL N coordinates, and in fp64 that
 // was VALU time (k_nl_mid: 8.5 of 35 us).
-template <bool F32>
-__device__ __forceinline__ int lb_cell_coord(double p, float inv_cs32, double cs, int n) {
-  const float q = (float)p * inv_cs32;
-  const float fl = floorf(q), fr = q - fl;
-  int c = (int)fl;
-  if (fr < 1e-3f || fr > 0.999f || !(fabsf(q) < 2000.f)) c = __double2int_rz(lb_r(p / cs, F32));
-  return c < 0 ? 0 : (c >= n ? n - 1 : c);
-}
 #define NLS_WAVES 16  // at most; the launch uses ceil(N / 256) waves so that every CU gets at most one workgroup
 #define NLS_THREADS (64 * NLS_WAVES)
 #define NLS_CAND 512  // stencil candidates per receiver (row buffer entries; >= LB_MAX_ROW)
