@@ -202,6 +202,9 @@ def main():
         return
     value = world * B * N * K / dt
     ms_edge, n_edge = tm["edge_mlp"]
+    ms_last, n_last = tm.get("edge_mlp_last", (0.0, 0))   # last layer: no edge-latent store (its own timer class)
+    if n_edge == 0 and n_last > 0:                         # (one MP layer: the no-store variant is the only launch)
+        ms_edge, n_edge, ms_last, n_last = ms_last, n_last, 0.0, 0
     if n_edge == 0 and tm.get("processor", (0, 0))[1] > 0:   # all layers in one persistent launch: per-layer share
         ms_edge, n_edge = tm["processor"][0], tm["processor"][1] * L
     ms_agg, n_agg = tm["aggregate"]
@@ -231,9 +234,21 @@ def main():
     mfma["fp32_equivalent_algorithmic_tflops"] = flop_algo / (us_edge * 1e-6) / 1e12
     kern = eng.kernel_names()["edge"]  # the library names the kernel family it picked for this size / arithmetic
     pmc_key = kern.split("<")[0].split(" ")[0]
+    # the LAST layer's launch writes no edge latents (nobody reads them): E*520 + N*1024 algorithmic bytes, timed as
+    # its own class so that the dominant kernel above is not credited bytes that variant does not move
+    last_variant = None
+    if n_last > 0:
+        us_last = 1e3 * ms_last / n_last
+        last_bytes = E_tot * (D * 4 + 8) + BN * (2 * D * 4)
+        last_variant = {"kernel": kern + " [last layer: SKIP = no edge-latent store]", "us_per_launch": us_last,
+                        "launches": int(n_last), "bytes_per_launch": last_bytes,
+                        "achieved": last_bytes / (us_last * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": last_bytes / (us_last * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "note": "half the bytes, nearly the same time: this launch is bound by instruction issue / LDS "
+                                "weight reads, not by HBM (DESIGN.md section 5)"}
     if math_mode == "f16x2":
         roof = {"kernel": kern, "bound": "hbm", "achieved": gbs_edge, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs_edge / HBM_PEAK_GBS,
+                "frac": gbs_edge / HBM_PEAK_GBS, "last_layer_variant": last_variant,
                 "traffic": pmc_traffic(pmc_key, args.workload, B),
                 "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured by this run)",
                 "us_per_launch": us_edge, "launches": int(n_edge), "bytes_per_launch": edge_bytes,
@@ -309,10 +324,12 @@ def main():
     if world == 1 and not args.no_other_configs:
         del pred, traj, handle, eng
         out["other_configs"] = other_configs(device)
-    # Everything TIMED on the GPU is done.  The CPU-baseline legs now run as background processes on the host cores
-    # while the nested rocprofv3 passes (byte counters, nothing timed) re-run the GPU workload.
+    # Everything TIMED on the GPU is done.  The CPU-baseline legs run NOW, one after the other, with nothing else on the
+    # host (run beside the nested rocprofv3 passes their step times spread 3x); the PMC passes follow.
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_jobs = cpu_baseline_start(args)
+        out["cpu_baseline"] = cpu_baseline_collect(cpu_jobs)
+        cpu_jobs = None
     # roofline.traffic measured by THIS run: two nested rocprofv3 passes of the same command (FETCH_SIZE, WRITE_SIZE:
     # the counters do not fit one pass; --kernel-trace + --pmc only), after the timed region; any failure or a
     # missing rocprofv3 falls back to the committed table above
@@ -382,8 +399,8 @@ def other_configs(device):
     from lagrangebench_amd.data import make_case
     from lagrangebench_amd.models import GNS, SEGNN, node_irreps
     res = []
-    plan = [("tgv2d", "gns", 1, 20), ("tgv2d", "gns", 8, 20), ("rpf2d", "gns", 1, 400), ("ldc3d", "gns", 1, 20),
-            ("ldc3d", "gns", 8, 20), ("dam2d", "segnn", 1, 20), ("dam2d", "segnn", 8, 20)]
+    plan = [("tgv2d", "gns", 1, 20), ("tgv2d", "gns", 8, 20), ("rpf2d", "gns", 1, 400), ("tgv3d", "gns", 1, 20),
+            ("ldc3d", "gns", 1, 20), ("ldc3d", "gns", 8, 20), ("dam2d", "segnn", 1, 20), ("dam2d", "segnn", 8, 20)]
     for workload, kind, B, K in plan:
         try:
             ds = make_case(workload, n_trajs=B, extra_seq_length=K)
@@ -540,7 +557,7 @@ CPU_PLAN = {
     # costs ~1.8 s per step on this host: a bounded sample.  One rollout of warm + steps steps, every step timed
     # (the reference's step loop is host driven, rollout.py:125-169); the reported figure is the MEDIAN step.
     "tgv2d": {"steps": 20, "warm": 2},
-    "tgv3d": {"steps": 3, "warm": 1},
+    "tgv3d": {"steps": 5, "warm": 2},
 }
 
 
@@ -600,6 +617,7 @@ def cpu_baseline_leg(workload, L):
         "workload": workload, "value": len(pt) / dt, "unit": "particle-steps/s", "cores": cores,
         "cpu_model": cpu_model_string(), "host_threads": os.cpu_count(), "kind": "port",
         "ms_per_step": 1e3 * dt, "ms_per_step_all": [round(1e3 * float(t), 1) for t in steps],
+        "ms_per_step_min": round(1e3 * float(steps.min()), 1), "ms_per_step_max": round(1e3 * float(steps.max()), 1),
         "total_s": round(t_end - t_begin, 2),
         "sample": f"median step of a {n_steps}-step rollout of 1 {ds.name} trajectory (N={len(pt)}) after {n_warm} warm-up "
                   f"steps; torch-CPU network + NumPy neighbor list in the reference's padded/unfused shape",
@@ -634,8 +652,8 @@ def cpu_baseline_collect(job, timeout_s=240):
     res = dict(head) if head else {"value": None, "unit": "particle-steps/s", "cores": None, "kind": "port", "sample": "failed"}
     res["configs"] = legs
     res["note"] = ("JAX is not installable here: this is the reference-shaped CPU restatement, not JAX-CPU; the legs "
-                   "run one after the other in a background process on the host cores while the nested rocprofv3 "
-                   "passes (byte counters only) re-run the GPU workload")
+                   "run one after the other in their own process with nothing else on the host (the GPU work of this "
+                   "command is finished, the PMC passes have not started); spread in ms_per_step_min / _max")
     return res
 
 

@@ -43,7 +43,7 @@ extern "C" int lb_version(void) { return 100; }
 // ---------------------------------------------------------------------------------- timers
 static const char* k_timer_names[LB_T_COUNT] = {
     "cells", "neighbors", "node_features", "enc_node", "enc_edge", "edge_mlp",
-    "aggregate", "node_mlp", "decoder", "integrate", "misc", "processor"};
+    "aggregate", "node_mlp", "decoder", "integrate", "misc", "processor", "edge_mlp_last"};
 
 static hipEvent_t lb_get_event(lb_engine* e) {
   if (!e->epool.empty()) {

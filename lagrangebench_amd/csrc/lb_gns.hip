@@ -515,7 +515,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
   for (int k = 0; k < L && !(persist && e->persist_grid > 0); ++k) {
     const lb_mlp_w& pe = g->proc_edge[k];
     const bool skip = (k == L - 1) && e->fused_agg && !g->tap;  // the last layer's edge latents have no reader
-    lb_tic_single(e, LB_T_EDGE_MLP);
+    lb_tic_single(e, skip ? LB_T_EDGE_LAST : LB_T_EDGE_MLP);
     if (ms_pe) {
       lb_ems_args m{};
       m.ctrl = e->ctrl;

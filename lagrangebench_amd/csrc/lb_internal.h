@@ -97,6 +97,9 @@ enum lb_timer_class {
   LB_T_INTEGRATE,    // integrator + kinematic select + window shift + prediction store
   LB_T_MISC,
   LB_T_PROCESSOR,    // all message-passing layers as one persistent launch (lb_persist.hip)
+  LB_T_EDGE_LAST,    // the LAST processor layer's edge MLP when its updated edge latents have no reader (no store:
+                     // half the HBM bytes of the other layers' launches - timed apart so that the roofline of
+                     // LB_T_EDGE_MLP is not credited bytes this variant does not move)
   LB_T_COUNT
 };
 

@@ -171,9 +171,10 @@ def make_case(name: str, n_trajs: int = 1, extra_seq_length: int = 20, input_seq
         return SyntheticDataset(name, md, isl, extra_seq_length, n_trajs, make)
 
     if name == "ldc3d":
-        # lid-driven cavity: fluid block 24x24x12 inside a one-particle wall shell in x,y; z periodic;
-        # the top (y-max) wall row is the MOVING lid (type 2), the rest SOLID_WALL (type 1).
-        c = counts([26, 26, 12])
+        # lid-driven cavity: fluid block 32x18x12 inside a one-particle wall shell in x,y; z periodic;
+        # the top (y-max) wall row is the MOVING lid (type 2), the rest SOLID_WALL (type 1).  34 x 20 x 12 = 8160
+        # particles: the dataset's count (3D_LDC_8160_10kevery100, notebooks/datasets.ipynb cell 5).
+        c = counts([34, 20, 12])
         dx = 1.0 / 24.0 / max(scale, 1e-9) if scale != 1.0 else 1.0 / 24.0
         box = np.array([c[0] * dx, c[1] * dx, c[2] * dx])
         rc = 1.44 * dx  # 0.06 at dx = 1/24
@@ -214,6 +215,11 @@ def make_case(name: str, n_trajs: int = 1, extra_seq_length: int = 20, input_seq
         left = _lattice([1, nwy - 1], dx, origin=[0.5 * dx, 1.5 * dx])
         right = _lattice([1, nwy - 1], dx, origin=[(nwx - 0.5) * dx, 1.5 * dx])
         walls = np.concatenate([bottom, left, right])
+        if scale == 1.0 and len(fluid) + len(walls) < 5740:
+            # the dataset has 5740 particles (2D_DAM_5740_20kevery100: three wall layers); a second floor row below the
+            # first brings the synthetic case to the same count
+            extra = 5740 - len(fluid) - len(walls)
+            walls = np.concatenate([walls, _lattice([extra, 1], dx, origin=[0.5 * dx, -0.5 * dx])])
         lat = np.concatenate([fluid, walls])
         ptype0 = np.concatenate([np.zeros(len(fluid), np.int32), np.ones(len(walls), np.int32)])
         n = len(lat)

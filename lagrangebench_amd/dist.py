@@ -33,8 +33,32 @@ def _coll_device(device: Optional[torch.device]) -> torch.device:
     return device if device is not None else torch.device("cpu")
 
 
+def pin_rank_to_cores(local_rank: int, local_world: int) -> Optional[List[int]]:
+    """One rank = one GPU = one launch thread: at B = 1 a rank issues ~90 k kernel launches per second from a single
+    host thread, and 8 ranks that migrate across the host's cores (or oversubscribe it with 8 x OMP threads) lose that
+    rate.  Give rank r the r-th contiguous slice of the cores this process may run on and one OpenMP thread
+    (LB_DIST_PIN=0 switches it off).  Returns the cores chosen, or None."""
+    if os.environ.get("LB_DIST_PIN", "1") == "0" or local_world <= 1:
+        return None
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    os.environ.setdefault("MKL_NUM_THREADS", "1")
+    try:
+        torch.set_num_threads(1)
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // local_world
+        if per < 1:
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return mine
+    except (AttributeError, OSError, RuntimeError):
+        return None
+
+
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, local_rank, world = env_world()
+    if world > 1:
+        pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     # LB_DIST_FORCE_INIT=1: initialise the process group even for one rank (smoke test of the RCCL path on a one-GPU box)
     force = os.environ.get("LB_DIST_FORCE_INIT") == "1"
     if (world > 1 or force) and not dist.is_initialized():

@@ -20,6 +20,14 @@ What is dumped per case (all through the reference's public API, cited by file:l
   * model.apply(params, state, (features, particle_type)) -> "acc"
   * case.integrate(pred, positions) -> next position (case.py:230-259)
   * a 5-step _eval_batched_rollout prediction (evaluate/rollout.py:78-178)
+Round 4 - one extra fixture, jax_extras.npz, pins what is still [mem] besides the networks:
+  * MetricsComputer(["sinkhorn"], ot_backend="ott" | "pot") on a strided pair of rollouts (evaluate/metrics.py:127-213)
+  * a neighbor list with SEVERAL particles per cell (cell capacity >= 3) in jax-md's raw slot order
+    (case_setup/case.py:120-130): the reference's only golden list (tests/case_test.py:77-82) has capacity 1 and cannot
+    see the slot rotation / stencil order
+  * the GNS parameters written by the reference's own save_haiku (utils.py:61-91): the files' bytes, so that the
+    checkpoint reader (lagrangebench_amd/utils.py: load_haiku) is pinned to real module names and file layout
+  * get_dataset_stats (data/utils.py:9-45), anisotropic and isotropic
 """
 from __future__ import annotations
 
@@ -146,7 +154,79 @@ def main():
                                                 blocks_per_step=2, norm="none")(x), f"jax_segnn_{tag}.npz")
         except ImportError as exc:
             print("e3nn_jax missing, SEGNN fixture skipped:", exc)
+    extras(a, jax, jnp, hk, jmp, lagrangebench, models, NodeType)
     return 0
+
+
+def extras(a, jax, jnp, hk, jmp, lagrangebench, models, NodeType):
+    """jax_extras.npz: sinkhorn (ott / pot), a dense-cell neighbor list in raw slot order, a save_haiku checkpoint's
+    bytes, get_dataset_stats."""
+    import tempfile
+    from lagrangebench.data.utils import get_dataset_stats
+    from lagrangebench.evaluate.metrics import MetricsComputer
+    from lagrangebench.utils import save_haiku
+    out = {}
+    # ---- dense cells: dx = 0.02, r_c = 3 dx -> ~9 particles per 2D cell
+    dim, n_side, isl, n_extra, dx = 2, 18, 6, 21, 0.02
+    rc = 3.0 * dx
+    pos, box = _cloud(n_side, dim, dx, isl, n_extra, seed=11)
+    n = pos.shape[0]
+    ptype = np.zeros(n, np.int32)
+    md = _metadata(dim, n, box, dx, rc, isl + n_extra)
+    case = lagrangebench.case_builder(box=box, metadata=md, input_seq_length=isl,
+                                      cfg_neighbors={"backend": "jaxmd_vmap", "multiplier": 1.25},
+                                      cfg_model={"isotropic_norm": False, "magnitude_features": False},
+                                      noise_std=3e-4, external_force_fn=None, dtype=jnp.float64)
+    features, nbrs = case.allocate_eval((jnp.asarray(pos[:, :isl]), jnp.asarray(ptype)))
+    out["dense//position"] = pos
+    out["dense//metadata_json"] = np.array(json.dumps(md))
+    out["dense//idx"] = np.asarray(nbrs.idx)                      # raw jax-md order, padding = n
+    out["dense//cell_capacity"] = np.array(int(getattr(nbrs, "cell_list_capacity", 0) or 0))
+    out["dense//rel_disp"] = np.asarray(features["rel_disp"])
+    # the update path on a later frame (same capacities): preprocess_eval
+    f2, n2 = case.preprocess_eval((jnp.asarray(pos[:, 3:3 + isl]), jnp.asarray(ptype)), nbrs)
+    out["dense//idx_update"] = np.asarray(n2.idx)
+    # ---- sinkhorn: a 21-frame "prediction" (the cloud) against a perturbed "target", stride 10 -> frames 0, 10, 20
+    rng = np.random.default_rng(5)
+    pred = np.transpose(pos[:, isl:], (1, 0, 2)).astype(np.float64)          # (T, N, dim)
+    targ = np.mod(pred + rng.normal(0, 0.4 * dx, pred.shape), box)
+    out["sinkhorn//pred"], out["sinkhorn//target"] = pred, targ
+    for backend in ("ott", "pot"):
+        try:
+            mc = MetricsComputer(["sinkhorn"], case.displacement, md, isl, stride=10, ot_backend=backend)
+            out[f"sinkhorn//{backend}"] = np.asarray(mc(jnp.asarray(pred), jnp.asarray(targ))["sinkhorn"])
+        except Exception as exc:  # POT is an optional import of the reference
+            print(f"sinkhorn backend {backend} skipped: {exc!r}")
+    # ---- get_dataset_stats
+    md_aniso = dict(md, vel_mean=[0.01, -0.02], vel_std=[0.3 * dx, 0.5 * dx], acc_mean=[1e-4, 2e-4], acc_std=[0.04 * dx, 0.02 * dx])
+    for iso in (False, True):
+        st = get_dataset_stats(md_aniso, iso, 3e-4)
+        for q in ("acceleration", "velocity"):
+            for m in ("mean", "std"):
+                out[f"stats//iso{int(iso)}//{q}//{m}"] = np.asarray(st[q][m])
+    out["stats//metadata_json"] = np.array(json.dumps(md_aniso))
+    # ---- a checkpoint written by the reference's save_haiku
+    L = 2
+    model = hk.without_apply_rng(hk.transform_with_state(
+        lambda x: models.GNS(particle_dimension=dim, latent_size=128, blocks_per_step=2, num_mp_steps=L,
+                             num_particle_types=NodeType.SIZE, particle_type_embedding_size=16)(x)))
+    hk.mixed_precision.set_policy(models.GNS, jmp.get_policy("params=float32,compute=float32,output=float32"))
+    params, state = model.init(jax.random.PRNGKey(3), (features, jnp.asarray(ptype)))
+    pred_acc, _ = model.apply(params, state, (features, jnp.asarray(ptype)))
+    with tempfile.TemporaryDirectory() as d:
+        ck = os.path.join(d, "ckp")
+        os.makedirs(ck)
+        save_haiku(ck, params, state, None, {"step": 7, "loss": 0.5})
+        for fn in sorted(os.listdir(ck)):
+            fp = os.path.join(ck, fn)
+            if os.path.isfile(fp):
+                out[f"ckpt//{fn}"] = np.frombuffer(open(fp, "rb").read(), dtype=np.uint8)
+    out["ckpt//acc"] = np.asarray(pred_acc["acc"])
+    out["ckpt//num_mp_steps"] = np.array(L)
+    for k, v in features.items():
+        out[f"ckpt//feat//{k}"] = np.asarray(v)
+    np.savez_compressed(os.path.join(a.out, "jax_extras.npz"), **out)
+    print("wrote jax_extras.npz", sorted(out))
 
 
 if __name__ == "__main__":

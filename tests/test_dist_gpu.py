@@ -131,3 +131,33 @@ def test_bench_one_rank_over_rccl():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0 and np.isfinite(d["mse20_mean"])
+
+
+def test_bench_eight_ranks_on_this_box():
+    """The driver's 8-GPU command on the one-GPU box: `python -m torch.distributed.run --nproc-per-node 8 bench.py
+    --gpus 8` with the 8 ranks sharing the device (metric gather and max-over-ranks over gloo; on an 8-GPU node the
+    same command runs over RCCL with one rank per GPU).  Contract fields, all 8 ranks seen by the live process group,
+    whole-job aggregate over 8 x B trajectories (config 4: LDC3D trajectories, one per rank)."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < 8:
+        env["LB_DIST_BACKEND"] = "gloo"
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3",
+           "--warmup", "3", "--batch", "1", "--workload", "ldc3d", "--repeats", "2", "--no-cpu-baseline",
+           "--no-other-configs"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 3 and d["warmup"] == 3 and d["scaling"] == "weak"
+    assert d["dist"]["ranks_seen"] == list(range(8)) and d["dist"]["world_size"] == 8, d["dist"]
+    n = d["config"]["n_particles"]
+    assert n == 8160
+    assert abs(d["value"] - 8 * 1 * n * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]   # whole-job aggregate
+    assert np.isfinite(d["mse20_mean"])

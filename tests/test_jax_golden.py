@@ -139,3 +139,107 @@ def test_oracle_matches_jax_reference_segnn(path):
     params = segnn_params_from_haiku(hk, L)
     acc = S.segnn_apply(params, feats, pt, isl - 1, False)["acc"]
     assert rel_err(acc[:, :md["dim"]], z["acc"]) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------- jax_extras.npz
+EXTRAS = os.path.join(GOLD, "jax_extras.npz")
+NO_EXTRAS = ("no jax_extras.npz committed: run tests/golden/make_jax_golden.py where lagrangebench imports (Sinkhorn, "
+             "dense-cell neighbor order, save_haiku file layout and get_dataset_stats are pinned by it)")
+
+
+def _extras():
+    if not os.path.exists(EXTRAS):
+        pytest.skip(NO_EXTRAS)
+    return np.load(EXTRAS, allow_pickle=False)
+
+
+def _dense_case(z, builder):
+    md = json.loads(str(z["dense//metadata_json"]))
+    box = np.array([b[1] - b[0] for b in md["bounds"]])
+    case = builder(box, md, 6, cfg_neighbors={"multiplier": 1.25},
+                   cfg_model={"isotropic_norm": False, "magnitude_features": False}, noise_std=3e-4)
+    return md, case
+
+
+def test_oracle_matches_jax_reference_extras(tmp_path):
+    """CPU side of jax_extras.npz: jax-md's RAW slot order with several particles per cell (allocate and update path),
+    Sinkhorn through both OT backends, get_dataset_stats, and a checkpoint written by the reference's save_haiku read
+    back by this package's load_haiku and evaluated by the oracle."""
+    z = _extras()
+    pos = z["dense//position"]
+    pt = np.zeros(len(pos), np.int32)
+    md, case = _dense_case(z, O.case_builder)
+    feats, nbrs = case.allocate_eval((pos[:, :6].astype(np.float64), pt))
+    assert int(z["dense//cell_capacity"]) == 0 or int(z["dense//cell_capacity"]) >= 3
+    assert nbrs.idx.shape == z["dense//idx"].shape and (nbrs.idx == z["dense//idx"]).all(), "raw slot order (allocate)"
+    assert np.allclose(feats["rel_disp"], z["dense//rel_disp"], rtol=0, atol=1e-12)
+    _, n2 = case.preprocess_eval((pos[:, 3:9].astype(np.float64), pt), nbrs)
+    assert (n2.idx == z["dense//idx_update"]).all(), "raw slot order (update)"
+    # Sinkhorn (evaluate/metrics.py:127-213), frames 0, 10, 20
+    from oracle import sinkhorn_oracle as SK
+    from oracle import sinkhorn_pot_oracle as SP
+    pred, targ = z["sinkhorn//pred"], z["sinkhorn//target"]
+    if "sinkhorn//ott" in z.files:
+        got = SK.sinkhorn_rollout(case.displacement, pred, targ, 10)
+        assert np.allclose(got, z["sinkhorn//ott"], rtol=1e-4, atol=1e-9 * float(np.abs(z["sinkhorn//ott"]).max() + 1e-30))
+    if "sinkhorn//pot" in z.files:
+        got = np.array([SP.sinkhorn_divergence_pot(case.displacement, p, t) for p, t in zip(pred[::10], targ[::10])])
+        assert np.allclose(got, z["sinkhorn//pot"], rtol=2e-5, atol=1e-7)
+    # get_dataset_stats (data/utils.py:9-45)
+    from lagrangebench_amd.data.utils import get_dataset_stats
+    mds = json.loads(str(z["stats//metadata_json"]))
+    for iso in (0, 1):
+        st = get_dataset_stats(mds, bool(iso), 3e-4)
+        for q in ("acceleration", "velocity"):
+            for m in ("mean", "std"):
+                assert np.allclose(st[q][m], z[f"stats//iso{iso}//{q}//{m}"], rtol=1e-6, atol=0), (iso, q, m)
+    # the reference's checkpoint files -> load_haiku -> oracle forward
+    from lagrangebench_amd.utils import gns_params_from_haiku, load_haiku
+    ck = tmp_path / "ckp"
+    ck.mkdir()
+    for k in z.files:
+        if k.startswith("ckpt//") and k.count("//") == 1 and k.split("//")[1] not in ("acc", "num_mp_steps"):
+            (ck / k.split("//")[1]).write_bytes(z[k].tobytes())
+    params_hk, _, _, step = load_haiku(str(ck))
+    assert step == 7
+    L = int(z["ckpt//num_mp_steps"])
+    params = gns_params_from_haiku(params_hk, L, 2)
+    f = {k.split("//")[2]: z[k] for k in z.files if k.startswith("ckpt//feat//")}
+    acc = O.gns_apply(params, f, pt, num_mp_steps=L)["acc"]
+    assert rel_err(acc, z["ckpt//acc"]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_engine_matches_jax_reference_extras(tmp_path):
+    """GPU side of jax_extras.npz: the engine's edge list (canonical order) and Sinkhorn kernels against the reference,
+    and the reference's checkpoint evaluated by the HIP engine."""
+    import torch
+    from lagrangebench_amd.case_setup import case_builder
+    from lagrangebench_amd.evaluate.metrics import MetricsComputer
+    from lagrangebench_amd.models import GNS
+    from lagrangebench_amd.utils import gns_params_from_haiku, load_haiku
+    z = _extras()
+    pos = z["dense//position"]
+    n = len(pos)
+    pt = np.zeros(n, np.int32)
+    md, case = _dense_case(z, case_builder)
+    feats, nbrs = case.allocate_eval((pos[:, :6], pt))
+    assert (O.canonical_edges(nbrs.idx.cpu().numpy(), n) == O.canonical_edges(z["dense//idx"], n)).all()
+    pred = torch.as_tensor(z["sinkhorn//pred"], device="cuda")
+    targ = torch.as_tensor(z["sinkhorn//target"], device="cuda")
+    for backend, tol in (("ott", 1e-4), ("pot", 2e-5)):
+        if f"sinkhorn//{backend}" not in z.files:
+            continue
+        mc = MetricsComputer(["sinkhorn"], case.displacement, md, 6, stride=10, ot_backend=backend, case=case)
+        got = mc(pred, targ)["sinkhorn"].cpu().numpy()
+        assert np.allclose(got, z[f"sinkhorn//{backend}"], rtol=tol, atol=1e-7), backend
+    ck = tmp_path / "ckp"
+    ck.mkdir()
+    for k in z.files:
+        if k.startswith("ckpt//") and k.count("//") == 1 and k.split("//")[1] not in ("acc", "num_mp_steps"):
+            (ck / k.split("//")[1]).write_bytes(z[k].tobytes())
+    params_hk, _, _, _ = load_haiku(str(ck))
+    L = int(z["ckpt//num_mp_steps"])
+    params = gns_params_from_haiku(params_hk, L, 2)
+    acc = GNS(md["dim"], 128, 2, L, 16).apply(params, {}, (feats, pt))[0]["acc"].cpu().numpy()
+    assert rel_err(acc, z["ckpt//acc"]) < 1e-5
