@@ -215,6 +215,9 @@ int lb_adamw_step(lb_gns_train* t, float lr, float b1, float b2, float eps, floa
  * write: step >= 0 also restores the optimiser's step counter (bias correction). */
 int lb_gns_train_read(lb_gns_train* t, int32_t which, float* out_host, int64_t n_floats);
 int lb_gns_train_write(lb_gns_train* t, int32_t which, const float* in_host, int64_t n_floats, int64_t step);
+/* optax's `count`: AdamW steps taken so far (the bias-correction exponent of the NEXT step is count + 1); what a
+ * checkpoint has to store to resume bit-identically (utils.py:61-91 pickles it inside opt_state). */
+int64_t lb_gns_train_step_count(lb_gns_train* t);
 
 typedef struct lb_segnn lb_segnn;
 
@@ -244,12 +247,17 @@ int lb_segnn_forward(lb_engine* eng, lb_segnn* segnn, float* acc_out_dev);
 
 /* Arithmetic of the GNS GEMMs.  Default (LB_MATH unset) = mode 1: every fp32 operand is carried as an fp16
  * hi/lo pair on the fp16 MFMA (fp32-class accuracy, ~5x fewer matrix-pipe cycles than the fp32 MFMA) WITH a
- * sampled range guard: operands >= 2^15, operand tiles < 2^-10 or non-finite accelerations make
- * lb_gns_forward / lb_rollout repeat their work in mode 0 and the engine stays there.  set_mode: -1 query,
- * 0 exact fp32 MFMA, 1 guarded f16x2, 2 f16x2 without the switch (tests).  flags_out: guard bits raised
- * and not yet consumed (1 large, 2 tiny, 4 non-finite).  The reference computes the model in fp32
- * (runner.py:71-72). */
+ * range guard: operands >= 2^15 (sampled), operand ROWS whose values all sit below 2^-7 (tested on every tile of
+ * the batch edge / node kernels) or tiles below 2^-11 (small-graph kernels), and non-finite accelerations raise
+ * flags; lb_gns_forward / lb_rollout then redo the flagged forward / rollout step in mode 0 and return to mode 1
+ * (round 4: not sticky; after LB_GUARD_MAX_FALLBACKS = 3 flagged steps the rest of that rollout runs in mode 0).
+ * set_mode: -1 query, 0 exact fp32 MFMA, 1 guarded f16x2, 2 f16x2 without the switch (tests), 3 guarded with
+ * every k-group of every tile tested (LB_GUARD=full).  flags_out: guard bits raised and not yet consumed
+ * (1 large, 2 tiny, 4 non-finite).  The reference computes the model in fp32 (runner.py:71-72). */
 int lb_math_mode(lb_engine* eng, int32_t set_mode, int32_t* mode_out, int32_t* flags_out);
+
+/* Steps (or stand-alone forwards) the range guard has redone in exact fp32 since the engine was created. */
+int32_t lb_math_fallbacks(lb_engine* eng);
 
 /* Debug/parity tap: hidden node state after the embedding and after each layer,
  * ((num_mp_steps+1), B*N, 128) fp32 rows [s(32) | vx(32) | vy(32) | vz(32)], or NULL. */

@@ -74,6 +74,7 @@ _SIGS = {
     "lb_set_fused_aggregation": (C.c_int, [_P, C.c_int32]),
     "lb_gns_set_tap": (C.c_int, [_P, _P]),
     "lb_math_mode": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "lb_math_fallbacks": (C.c_int32, [_P]),
     "lb_integrate": (C.c_int, [_P, _P, _P, _P, C.c_int32]),
     "lb_case_integrate": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P]),
     "lb_rollout": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_int32)]),
@@ -96,6 +97,7 @@ _SIGS = {
     "lb_adamw_step": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     "lb_gns_train_read": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.c_int64]),
     "lb_gns_train_write": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.c_int64, C.c_int64]),
+    "lb_gns_train_step_count": (C.c_int64, [_P]),
     "lb_segment_sum": (C.c_int, [_P, _P, _P, C.c_int32]),
     "lb_segnn_create": (C.c_int, [_P, C.POINTER(SegnnDesc), _P, C.c_int64, C.POINTER(_P)]),
     "lb_segnn_destroy": (None, [_P]),

@@ -27,8 +27,22 @@ EXTRA_FLAGS = {"lb_edge16v.hip": ["-fno-slp-vectorize"], "lb_edge32.hip": ["-fno
                "lb_gns_generic.hip": ["-fno-slp-vectorize"], "lb_segnn_msg.hip": ["-fno-slp-vectorize"], "lb_segnn_node.hip": ["-fno-slp-vectorize"], "lb_msplit.hip": ["-fno-slp-vectorize"], "lb_persist.hip": ["-fno-slp-vectorize"]}
 
 
+def _rocm_root() -> str:
+    """ROCm install prefix: $ROCM_PATH, else `hipconfig --rocmpath`, else /opt/rocm."""
+    root = os.environ.get("ROCM_PATH")
+    if root and os.path.isdir(root):
+        return root
+    try:
+        out = subprocess.run(["hipconfig", "--rocmpath"], capture_output=True, text=True, timeout=30).stdout.strip()
+        if out and os.path.isdir(out):
+            return out
+    except (OSError, subprocess.SubprocessError):
+        pass
+    return "/opt/rocm"
+
+
 def _hipcc() -> str:
-    for c in ("/opt/rocm/bin/hipcc", "hipcc"):
+    for c in (os.path.join(_rocm_root(), "bin", "hipcc"), "/opt/rocm/bin/hipcc", "hipcc"):
         if os.path.exists(c) or c == "hipcc":
             return c
     raise RuntimeError("hipcc not found")
@@ -66,8 +80,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         # rocBLAS: the plain dense contractions of the TRAINING step (csrc/lb_train.hip); nothing on the rollout path
+        libdir = os.path.join(_rocm_root(), "lib")
         run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs +
-            ["-L/opt/rocm/lib", "-lrocblas", "-Wl,-rpath,/opt/rocm/lib"])
+            ["-L" + libdir, "-lrocblas", "-Wl,-rpath," + libdir])
     return LIB
 
 

@@ -144,6 +144,7 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
     e->math_auto = m ? 0 : 1;  // LB_MATH given: that arithmetic, no guard-driven switch
     const char* gf = getenv("LB_GUARD");
     e->guard_full = (gf && !strcmp(gf, "full")) ? 1 : 0;
+    e->guard_sampled = (gf && !strcmp(gf, "sampled")) ? 1 : 0;
   }
   lb_geom& g = e->g;
   memset(&g, 0, sizeof(g));
@@ -247,6 +248,7 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   memset(&c0, 0, sizeof(c0));
   c0.overflow_step = -1;
   c0.math_step = LB_MATH_NO_STEP;
+  c0.persist_step = LB_MATH_NO_STEP;
   c0.nl_epoch = 1;
   c0.ln_inv_d = 1.0f / LB_D;
   if (hipMemcpy(e->ctrl, &c0, sizeof(c0), hipMemcpyHostToDevice) != hipSuccess ||
@@ -951,8 +953,8 @@ static int lb_math_check(lb_engine* e, int* switched, int* flagged_step = nullpt
   }
   if (e->f16x2 && e->math_auto) {
     fprintf(stderr,
-            "[lbhip] f16x2 range guard raised (%s%s%s): continuing in exact-fp32 MFMA arithmetic from the flagged step\n",
-            flags & LB_MATH_LARGE ? "operand >= 2^15 " : "", flags & LB_MATH_TINY ? "operand tile < 2^-10 " : "",
+            "[lbhip] f16x2 range guard raised (%s%s%s): the flagged step is redone in exact-fp32 MFMA arithmetic\n",
+            flags & LB_MATH_LARGE ? "operand >= 2^15 " : "", flags & LB_MATH_TINY ? "operand row / tile below the fp16 split's range " : "",
             flags & LB_MATH_NONFINITE ? "non-finite acceleration" : "");
     e->f16x2 = 0;
     *switched = 1;
@@ -977,6 +979,8 @@ extern "C" int lb_math_mode(lb_engine* e, int32_t set_mode, int32_t* mode_out, i
   return LB_OK;
 }
 
+extern "C" int32_t lb_math_fallbacks(lb_engine* e) { return e ? e->math_fallbacks : 0; }
+
 extern "C" int lb_gns_forward(lb_engine* e, lb_gns* g, float* acc_out_dev) {
   if (!e || !g) return lb_fail(LB_ERR_ARG, "null argument");
   if (g->eng != e) return lb_fail(LB_ERR_ARG, "model was created for another engine");
@@ -987,7 +991,12 @@ extern "C" int lb_gns_forward(lb_engine* e, lb_gns* g, float* acc_out_dev) {
   if (e->f16x2 && e->math_auto) {  // guarded mode: one host sync per stand-alone forward (not the rollout path)
     int switched = 0;
     LB_TRY(lb_math_check(e, &switched));
-    if (switched) LB_TRY(lbk_gns_forward(e, g));
+    if (switched) {  // this forward again in exact fp32; the engine returns to guarded f16x2 (round 4: not sticky)
+      ++e->math_fallbacks;
+      const int rc = lbk_gns_forward(e, g);
+      e->f16x2 = 1;
+      if (rc) return rc;
+    }
   }
   if (acc_out_dev) {
     const int nb = (int)((e->BN + 255) / 256);
@@ -1030,12 +1039,15 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
   e->feat_job = lb_feat_job{e->xnode, g->embed, g->desc.embedding_size, g->desc.num_particle_types, e->g.kpad, e->ptype, e->force};
   LB_TRY(lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, n_realloc_out));
   if (e->f16x2 && e->math_auto) {
-    // The guard records the FIRST step at which a flag was raised (lb_ctrl::math_step): every step before it is
-    // valid f16x2 work, so the rollout RESUMES there in exact fp32 - window rebuilt from the input frames and the
-    // predictions already made - instead of being repeated from step 0 (round 2).  The engine then stays in fp32: a
-    // checkpoint that left fp16's range once is expected to do so again.
-    int switched = 0, s0 = 0;
-    // LB_TEST_RESUME_AT=k (tests only): behave as if the guard had fired at step k of this rollout
+    // The guard records the FIRST step at which a flag was raised (lb_ctrl::math_step).  Round 4: that ONE step is redone
+    // in exact fp32 - window rebuilt from the input frames and the predictions already made - and the rollout continues
+    // in f16x2 behind it (round 3 finished the rollout, and the engine's life, in fp32 at 2.3x the step time).  After
+    // LB_GUARD_MAX_FALLBACKS (3) flagged steps the rest of THIS rollout runs in fp32; the next rollout starts in f16x2
+    // again.  Steps before the flagged one are valid f16x2 work only if every tile was tested: with LB_GUARD=sampled
+    // (first tile of every wave, rounds 2-3) the rollout is repeated from step 0 instead.
+    static const int max_fb = getenv("LB_GUARD_MAX_FALLBACKS") ? atoi(getenv("LB_GUARD_MAX_FALLBACKS")) : 3;
+#ifdef LB_TEST_HOOKS
+    // LB_TEST_RESUME_AT=k (tests only, library built with -DLB_TEST_HOOKS): behave as if the guard had fired at step k
     static const int force_at = getenv("LB_TEST_RESUME_AT") ? atoi(getenv("LB_TEST_RESUME_AT")) : -1;
     if (force_at >= 0 && force_at < n_steps) {
       const int32_t inj[2] = {LB_MATH_TINY, force_at};
@@ -1043,13 +1055,26 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
       LB_HIP(hipMemcpyAsync(&e->ctrl->math_step, &inj[1], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
       LB_HIP(hipStreamSynchronize(e->stream));
     }
-    LB_TRY(lb_math_check(e, &switched, &s0));
-    if (switched) {
-      s0 = std::max(0, std::min(s0, n_steps - 1));
+#endif
+    int rc = LB_OK;
+    for (int fallbacks = 0;;) {
+      int switched = 0, s0 = 0;
+      rc = lb_math_check(e, &switched, &s0);
+      if (rc || !switched) break;   // (lb_math_check has put the engine on fp32)
+      s0 = e->guard_sampled ? 0 : std::max(0, std::min(s0, n_steps - 1));
       int32_t n2 = 0;
-      LB_TRY(lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, &n2, s0));
+      const bool rest = e->guard_sampled || ++fallbacks >= max_fb || s0 + 1 >= n_steps;
+      e->math_fallbacks += rest ? n_steps - s0 : 1;
+      rc = lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, &n2, s0, rest ? -1 : s0 + 1);
       if (n_realloc_out) *n_realloc_out += n2;
+      if (rc || rest) break;
+      e->f16x2 = 1;                 // back to guarded f16x2 behind the flagged step
+      rc = lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, &n2, s0 + 1);
+      if (n_realloc_out) *n_realloc_out += n2;
+      if (rc) break;
     }
+    e->f16x2 = 1;                   // not sticky: the next rollout / forward starts in guarded f16x2
+    if (rc) return rc;
   }
   return LB_OK;
 }
@@ -1080,7 +1105,7 @@ static int lb_enqueue_step(lb_engine* e, int (*forward)(lb_engine*, void*), void
 
 int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* model,
                        const double* traj_dev, int32_t T, int32_t n_steps, double* pred_out_dev,
-                       int32_t* n_realloc_out, int32_t start_step) {
+                       int32_t* n_realloc_out, int32_t start_step, int32_t stop_step) {
   if (T < e->g.isl) return lb_fail(LB_ERR_ARG, "trajectory shorter than input_seq_length");
   if (e->g.force_kind == LB_FORCE_BUFFER)
     return lb_fail(LB_ERR_UNSUPPORTED, "lb_rollout with LB_FORCE_BUFFER: drive the steps from the host");
@@ -1108,7 +1133,7 @@ int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* mo
     LB_HIP(hipStreamWaitEvent(e->gstream, e->step_ev[0], 0));
     e->stream = e->gstream;
   }
-  int n_realloc = 0;
+  int n_realloc = 0, n_retry = 0;
   if (start_step > 0)   // resume: window of step start_step from the input frames + the predictions made so far
     LB_TRY(lbk_load_window_resume(e, traj_dev, T, pred_out_dev, n_steps, start_step));
   else
@@ -1116,9 +1141,10 @@ int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* mo
   if (e->e_cap <= 0) LB_TRY(lb_nl_allocate(e, nullptr, nullptr, nullptr));
   int step = start_step;
   const int RA = 3;  // steps the host may run ahead of the device
-  while (step < n_steps) {
+  const int last = (stop_step >= 0 && stop_step < n_steps) ? stop_step : n_steps;  // steps [start_step, last) are run
+  while (step < last) {
     bool warm = false;  // the first step after a (re-)allocation runs uncaptured: lazy buffer growth
-    for (int s = step; s < n_steps; ++s) {
+    for (int s = step; s < last; ++s) {
       if (s - step >= RA) {
         // throttle: wait for step s-RA to retire, then look at the device-written host flag, so an
         // overflow costs at most RA steps of no-op launches instead of the rest of the rollout
@@ -1145,6 +1171,34 @@ int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* mo
     }
     LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, e->stream));
     LB_HIP(hipStreamSynchronize(e->stream));
+    if (e->ctrl_host->persist_error) {
+      // A bounded spin of a single-launch neighbor build (2) or of the persistent processor (1) timed out - a busy or
+      // shared GPU can starve a predecessor workgroup.  Everything from that step on is invalid, nothing before it:
+      // the engine leaves that path and the rollout RESUMES at the recorded step on the multi-launch path (ADVICE r03;
+      // round 3 surfaced LB_ERR_STATE here although the fall-back was one flag away).
+      if (e->ctrl_host->persist_error == 2) e->nl_one_off = true; else e->persist_off = true;
+      const int s_bad = std::max(start_step, std::min(e->ctrl_host->persist_step, last - 1));
+      const int32_t reset[2] = {0, LB_MATH_NO_STEP};
+      LB_HIP(hipMemcpyAsync(&e->ctrl->persist_error, &reset[0], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+      LB_HIP(hipMemcpyAsync(&e->ctrl->persist_step, &reset[1], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+      // (the steps computed on the broken list may have poisoned the control block: that overflow is not real)
+      const int32_t no_poison = -1;
+      LB_HIP(hipMemcpyAsync(&e->ctrl->overflow_step, &no_poison, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+      e->host_flag[0] = -1;
+      fprintf(stderr, "[lbhip] single-launch %s gave up at step %d (spin time-out): resuming there on the multi-launch path\n",
+              e->ctrl_host->persist_error == 2 ? "neighbor build" : "processor", s_bad);
+      if (exec) {
+        (void)hipGraphExecDestroy(exec);
+        exec = nullptr;
+      }
+      if (s_bad > 0)
+        LB_TRY(lbk_load_window_resume(e, traj_dev, T, pred_out_dev, n_steps, s_bad));
+      else
+        LB_TRY(lbk_load_window(e, traj_dev, T, 0, 0));
+      step = s_bad;
+      if (++n_retry > 4) return lb_fail(LB_ERR_STATE, "single-launch paths keep timing out");
+      continue;
+    }
     LB_TRY(lb_check_density(e));
     if (e->ctrl_host->overflow_step < 0) break;
     // (eval) Reallocate neighbors list at step k - rollout.py:139-151.  Every kernel after the

@@ -33,12 +33,13 @@
 // NT: the edge latents are streamed with nontemporal loads / stores (batches whose latents exceed the 256 MiB
 // Infinity Cache); a single trajectory's latents (tens of MB) are read back from the cache by the next layer, so
 // small graphs use plain accesses.
-// GUARD: exhaustive TINY test of the f16x2 range guard on every tile (lb_tile_tiny; +8 % kernel time: lb_math_mode 3 /
-// LB_GUARD=full), else the sampled probe (first tile of every wave).
+// GUARD: 1 (default in guarded mode, round 4) per-ROW TINY test on one k-group of both GEMM operands of every tile
+// (lb_rows_tiny); 2 the same on every k-group plus the tile-wide test (+8 % kernel time: lb_math_mode 3 / LB_GUARD=full);
+// 0 only the sampled probe (first tile of every wave: LB_GUARD=sampled, or unguarded arithmetic).
 // TICKET (round 4): the waves of a workgroup draw their tiles from an LDS ticket counter inside the workgroup's contiguous
 // chunk instead of walking a static stride - the SIMD's issue arbiter prefers its oldest wave, which otherwise finishes its
 // share early and leaves the younger wave to run alone at the end of the launch (k_sg_msg: lb_segnn_msg.hip).
-template <int WPS, bool RELOAD, bool SKIP, int ABL = 0, bool PRIO = false, bool NT = true, bool GUARD = false, bool TICKET = false>
+template <int WPS, bool RELOAD, bool SKIP, int ABL = 0, bool PRIO = false, bool NT = true, int GUARD = 0, bool TICKET = false>
 __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
   constexpr int THREADS = WPS * 256, WAVES = WPS * 4;
   constexpr int NW0 = 4096;
@@ -164,7 +165,8 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
     if constexpr (!(ABL & 8)) {
       lb_gemm16v<true, 4, GUARD>(w1b, acc, acc2, &or_h);
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-      if constexpr (GUARD) guard_tiny |= (int)lb_tile_tiny(or_e) | (int)lb_tile_tiny(or_h);
+      if constexpr (GUARD == 2) guard_tiny |= (int)lb_tile_tiny(or_e) | (int)lb_tile_tiny(or_h);
+      if constexpr (GUARD != 0) guard_tiny |= (int)lb_rows_tiny(or_e) | (int)lb_rows_tiny(or_h);
     } else {
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb)
@@ -326,12 +328,14 @@ int lbk_edge16v(lb_engine* e, const lb_edge16_args& a) {
     else                          \
       LB_E16V__(NT, G, GU, false);\
   } while (0)
-#define LB_E16V(NT, G)        \
-  do {                        \
-    if (e->guard_full)        \
-      LB_E16V_(NT, G, true);  \
-    else                      \
-      LB_E16V_(NT, G, false); \
+#define LB_E16V(NT, G)                           \
+  do {                                           \
+    if (e->guard_full)                           \
+      LB_E16V_(NT, G, 2);                        \
+    else if (e->math_auto && !e->guard_sampled)  \
+      LB_E16V_(NT, G, 1);                        \
+    else                                         \
+      LB_E16V_(NT, G, 0);                        \
   } while (0)
   // Small graphs (one 2.5 k-particle trajectory = ~1000 tiles): a launch is the latency chain
   // "stage 133 KiB of weights -> one tile per wave", so launch no more workgroups than there are tiles for.

@@ -52,6 +52,27 @@ __device__ __forceinline__ bool lb_tile_tiny(uint32_t orv) {
   return !__any((orv & 0x70007000u) != 0u) && __any((orv & 0x7fff7fffu) != 0u);
 }
 
+// Per-ROW test (round 4).  A row (edge / node) whose GEMM operand is uniformly small carries
+// `lo` halves that are fp16 SUBNORMALS: |x - hi - lo| <= 2^-25 absolute, i.e. 2^-25 / max|row| relative to the row -
+// harmless next to a bias, but a following LayerNorm rescales the row to O(1) and the error with it (a row of
+// post-ReLU hiddens ~1e-6 with zero bias came out 3 % off).  The tile-wide test above cannot see one such row among
+// fifteen ordinary ones.  `orv` = OR of the `hi` patterns of the values THIS lane fed for row n = lane & 15 (its 8
+// features of the sampled k-group, or its 32 of the row): exponent bits 14:13 clear on all four lanes of the row <=>
+// every sampled |x| < 2^-7 (error bound 2^-18 = 3.8e-6 of the row maximum above that); an all-zero sample is exact and
+// does not count.  Sampling one k-group: a row that is tiny in all 128 features is tiny in these 32; the converse
+// (a false alarm) costs one step in fp32.
+__device__ __forceinline__ bool lb_rows_tiny(uint32_t orv) {
+  // OR over the four lanes {n, n+16, n+32, n+48} of row n: gfx950 row swaps (v_permlane16_swap exchanges the odd
+  // 16-lane rows of its first operand with the even rows of the second, v_permlane32_swap the upper half of the first
+  // with the lower half of the second; inline asm with the wait states the hazard recogniser cannot add - lb_msplit_dev.h)
+  uint32_t a = orv, b = orv;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  a = b = a | b;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  const uint32_t r = a | b;
+  return __any((r & 0x60006000u) == 0u && (r & 0x7fff7fffu) != 0u);
+}
+
 // hi = fp16(x) (RNE), lo = fp16(x - hi) for 8 values: 4 v_cvt_pk_f16_f32 + 8 v_fma_mix{lo,hi}_f16
 // (the mixed-precision fma evaluates x*1.0 - float(hi) exactly in fp32 and rounds once to fp16).
 // One asm block: the hazard recogniser does not look inside inline asm, so the block ends with the
@@ -86,10 +107,13 @@ __device__ __forceinline__ void lb_split8v(const f32x4& x0, const f32x4& x1, h8&
 // ((p*8 + mbo)*2 + part)*64 f32x4 further.  RELU applies max(x, 0) to v while it is split.
 // GUARD: the fp16 `hi` halves of the B operand are OR-ed into `orv` while they are split (two v_or3 per k-step): the
 // exhaustive TINY test of the range guard (lb_tile_tiny below).
-template <bool RELU, int NP = 4, bool GUARD = false>
+// GUARD: 0 none; 1 the FIRST k-group only (32 of the features of every row: the per-row test lb_rows_tiny, round 4's
+// default - two v_or3 per GEMM); 2 every k-group (lb_tile_tiny / lb_rows_tiny on all features, LB_GUARD=full).
+template <bool RELU, int NP = 4, int GUARD = 0>
 __device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[2 * NP], f32x4 (&acc)[8], uint32_t* orv = nullptr) {
-  auto note = [&](const h8& h) {
-    if constexpr (GUARD) {
+  auto note = [&](const h8& h, bool first = false) {
+    if constexpr (GUARD == 2 || GUARD == 1) {
+      if (GUARD == 1 && !first) return;
       typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
       const u32x4g u = __builtin_bit_cast(u32x4g, h);
       *orv |= (u[0] | u[1]) | (u[2] | u[3]);
@@ -115,7 +139,7 @@ __device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[2 * 
 #pragma unroll
   for (int c = 0; c < 4; ++c) Y[c] = frag(0, c, 0);
   lb_split8v(relu4(v[0]), relu4(v[1]), bh, bl);
-  note(bh);
+  note(bh, true);
   SB();
 #pragma unroll
   for (int blk = 0; blk < 2 * NP; ++blk) {

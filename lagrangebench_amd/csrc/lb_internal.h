@@ -37,6 +37,8 @@ struct lb_ctrl {
   float ln_pad;            // mean = sum / d, var = (sum_128 (x-mean)^2 - pad * mean^2) / d, pad = 128 - d
   int32_t persist_error;   // lb_persist.hip: a grid-barrier spin timed out (the launch gave up; results are invalid)
   int32_t nl_epoch;        // k_nl_small: build counter that tags the per-workgroup edge counts (never 0 mod 2^16)
+  int32_t persist_step;    // first rollout step at which persist_error was raised (0x7fffffff = none): lb_rollout resumes THERE on
+                           // the multi-launch path
   int32_t math_step;       // first rollout step at which a range-guard flag was raised (0x7fffffff = none): lb_rollout
                            // resumes THERE in exact fp32 instead of repeating the rollout
 };
@@ -170,6 +172,9 @@ struct lb_engine {
   int math_auto;       // 1: f16x2 with the range guard - a raised lb_ctrl::math_flags makes the host repeat
                        //    the work in exact-fp32 MFMA arithmetic and stay there (LB_MATH unset);
                        // 0: the mode LB_MATH / lb_math_mode fixed
+  int guard_sampled;   // 1 (LB_GUARD=sampled): only the sampled probe of rounds 2-3 (first tile of every wave); a raised flag then
+                       // repeats the rollout from step 0 (earlier steps may have had unsampled out-of-range tiles)
+  int math_fallbacks = 0;  // steps redone in exact fp32 by the guard since the engine was created (lb_stats)
   int guard_full;      // 1: the wave-per-tile edge kernel tests EVERY tile for the TINY condition (lb_math_mode 3 /
                        //    LB_GUARD=full; +8 % on that kernel); 0: sampled probe.  The M-split kernels always test all.
   float* acc;          // [BN][4] decoder output (dim padded to 4)
@@ -371,7 +376,7 @@ int lbk_node_features_raw(lb_engine* e, float* xnode, int kpad);
 // lb_api.hip: the device-resident step loop shared by the models
 int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* model,
                        const double* traj_dev, int32_t T, int32_t n_steps, double* pred_out_dev,
-                       int32_t* n_realloc_out, int32_t start_step = 0);
+                       int32_t* n_realloc_out, int32_t start_step = 0, int32_t stop_step = -1);
 
 // lb_segnn.hip
 struct lb_segnn;

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
   __shared__ f32x4 sB1[4 * 2 * 64];
   __shared__ f32x4 sB2[4 * 2 * 64];
   __shared__ __attribute__((aligned(16))) f32x2m sRed[16 * 4];
-  __shared__ __attribute__((aligned(16))) int sMx[2][4];
+  __shared__ __attribute__((aligned(16))) int sMx[2][MS_GUARD_WORDS];
   const int poisoned = a.ctrl->overflow_step;
   const int E = a.ctrl->n_edges_total;
   const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
@@ -156,8 +156,8 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
     uint32_t orv;
     ms_stage<false>(sB1, w, lane, ve[0], ve[1], orv, guard.big);
     {
-      const int c = guard.code(orv);
-      if (lane == 0) sMx[0][w] = c;
+      const uint32_t c = guard.code(orv);
+      if (lane < 16) sMx[0][w * 16 + lane] = (int)c;
     }
     // the next tile's loads (and the indices of the one after) go out before this tile's GEMMs
     issue(min(t + wk.stride, wk.q_last));
@@ -170,8 +170,8 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
     uint32_t orv2;
     ms_stage<true>(sB2, w, lane, acc[0], acc[1], orv2, guard.big);
     {
-      const int c = guard.code(orv2);
-      if (lane == 0) sMx[1][w] = c;
+      const uint32_t c = guard.code(orv2);
+      if (lane < 16) sMx[1][w * 16 + lane] = (int)c;
     }
     if (it < 3) MS_STAMP(4 + 8 * it);
     __syncthreads();
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
 __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_enc_ms(lb_ems_args a) {
   __shared__ f32x4 sB2[4 * 2 * 64];
   __shared__ __attribute__((aligned(16))) f32x2m sRed[16 * 4];
-  __shared__ __attribute__((aligned(16))) int sMx[4];
+  __shared__ __attribute__((aligned(16))) int sMx[MS_GUARD_WORDS];
   const int poisoned = a.ctrl->overflow_step;
   const int E = a.ctrl->n_edges_total;
   const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
@@ -289,8 +289,8 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_enc_ms(lb_ems_args a) {
     uint32_t orv;
     ms_stage<true>(sB2, w, lane, acc[0], acc[1], orv, guard.big);
     {
-      const int c = guard.code(orv);
-      if (lane == 0) sMx[w] = c;
+      const uint32_t c = guard.code(orv);
+      if (lane < 16) sMx[w * 16 + lane] = (int)c;
     }
     __syncthreads();
     f32x4 acc2[2] = {b1v[0], b1v[1]};
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
   __shared__ f32x4 sB2[T][4 * 2 * 64];
   __shared__ f32x4 sB3[(PROJ || DEC) ? T : 1][4 * 2 * 64];
   __shared__ __attribute__((aligned(16))) f32x2m sRed[T][16 * 4];
-  __shared__ __attribute__((aligned(16))) int sMx[3][T][4];
+  __shared__ __attribute__((aligned(16))) int sMx[3][T][MS_GUARD_WORDS];
   const int poisoned = a.ctrl->overflow_step;
   const int step = a.ctrl->step;
   const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
@@ -459,8 +459,8 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
       uint32_t orv = 0u, orv2 = 0u;  // the tile's first operand is [rows | aggregated messages]: one code for both
       if (has_x) ms_stage<false>(sB1[i], w, lane, xa[i][0], xa[i][1], orv, guard.big);
       if constexpr (AGG) ms_stage<false>(sB1[i], NKA + w, lane, ag[i][0], ag[i][1], orv2, guard.big);
-      const int c = guard.code(orv | orv2);
-      if (lane == 0) sMx[0][i][w] = c;
+      const uint32_t c = guard.code(orv | orv2);
+      if (lane < 16) sMx[0][i][w * 16 + lane] = (int)c;
     }
     if (it < 2) MS_STAMP(4 + 12 * it);
     __syncthreads();
@@ -477,8 +477,8 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
       guard.tile_codes(sMx[0][i]);
       uint32_t orv;
       ms_stage<true>(sB2[i], w, lane, acc[i][0], acc[i][1], orv, guard.big);
-      const int c = guard.code(orv);
-      if (lane == 0) sMx[1][i][w] = c;
+      const uint32_t c = guard.code(orv);
+      if (lane < 16) sMx[1][i][w * 16 + lane] = (int)c;
     }
     if (it < 2) MS_STAMP(6 + 12 * it);
     __syncthreads();
@@ -514,8 +514,8 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
       if constexpr (PROJ) {
         uint32_t orv;
         ms_stage<false>(sB3[i], w, lane, y[i][0], y[i][1], orv, guard.big);
-        const int c = guard.code(orv);
-        if (lane == 0) sMx[2][i][w] = c;
+        const uint32_t c = guard.code(orv);
+        if (lane < 16) sMx[2][i][w * 16 + lane] = (int)c;
       }
     }
     if (it < 2) MS_STAMP(10 + 12 * it);
@@ -545,8 +545,8 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
         }
         uint32_t orv;
         ms_stage<false>(sB3[i], w, lane, y[i][0], y[i][1], orv, guard.big);
-        const int c = guard.code(orv);
-        if (lane == 0) sMx[2][i][w] = c;
+        const uint32_t c = guard.code(orv);
+        if (lane < 16) sMx[2][i][w * 16 + lane] = (int)c;
       }
       __syncthreads();
       f32x4 hd[T][2];
@@ -561,8 +561,8 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
       for (int i = 0; i < T; ++i) {  // (sB2 / sMx[1] were last read before the LayerNorm barrier)
         uint32_t orv;
         ms_stage<true>(sB2[i], w, lane, hd[i][0], hd[i][1], orv, guard.big);
-        const int c = guard.code(orv);
-        if (lane == 0) sMx[1][i][w] = c;
+        const uint32_t c = guard.code(orv);
+        if (lane < 16) sMx[1][i][w * 16 + lane] = (int)c;
       }
       __syncthreads();
 #pragma unroll

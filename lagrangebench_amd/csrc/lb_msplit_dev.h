@@ -53,6 +53,15 @@ __device__ __forceinline__ float ms_max_g(float x) {
   ms_swap32(a, b);
   return fmaxf(a, b);
 }
+// OR over the four lanes of a row (the range guard's per-row test)
+__device__ __forceinline__ uint32_t ms_or_g(uint32_t x) {
+  float a = __builtin_bit_cast(float, x), b = a;
+  ms_swap16(a, b);
+  const uint32_t y = __builtin_bit_cast(uint32_t, a) | __builtin_bit_cast(uint32_t, b);
+  a = b = __builtin_bit_cast(float, y);
+  ms_swap32(a, b);
+  return __builtin_bit_cast(uint32_t, a) | __builtin_bit_cast(uint32_t, b);
+}
 // max over the whole wave (every lane gets it): rotations inside the 16-lane DPP rows, then the row swaps
 __device__ __forceinline__ float ms_wave_max(float m) {
 #define MS_ROR(k) m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x120 + (k), 0xF, 0xF, false)))
@@ -158,22 +167,22 @@ __device__ __forceinline__ void ms_ln_combine(const f32x2m* red, int n, float in
 }
 
 // running range-guard state of a wave (see the header).  LARGE: `big` = max |x| over every GEMM operand element this
-// wave staged (ms_stage; a value that leaves the fp16 range is seen BEFORE its `hi` becomes inf).  TINY: per tile and
-// operand, the OR of the `hi` bit patterns says whether every element is below 2^-11 (exponent bits 14:12 clear) and
-// not all are zero; the 4 waves hold 32 features each of the tile's rows, so each posts a 2-bit code (1 = something
-// non-zero, 2 = something >= 2^-11) and the tile is TINY iff the OR of the four codes is exactly 1.
+// wave staged (ms_stage; a value that leaves the fp16 range is seen BEFORE its `hi` becomes inf).  TINY, round 4: per
+// ROW of every tile and operand (lb_f16x2.h: lb_rows_tiny has the why) - the OR of the `hi` bit patterns of a row says
+// whether all of its elements are below 2^-7 (exponent bits 14:13 clear) and not all zero; the 4 waves hold 32 features
+// each of the tile's 16 rows, so each posts its 16 per-row ORs (`code`: lanes 0-15 write them) and after the barrier
+// lane n combines the four words of row n (`tile_codes`).
+#define MS_GUARD_WORDS 64  // ints per (operand, tile) slot: [4 waves][16 rows]
 struct ms_guard {
   float big;
   int flags;
-  // this wave's code for one staged operand (wave-uniform; lane 0 writes it to the tile's slot before the barrier)
-  __device__ __forceinline__ int code(uint32_t orv) const {
-    return (__any((orv & 0x70007000u) != 0u) ? 2 : 0) | (__any((orv & 0x7fff7fffu) != 0u) ? 1 : 0);
-  }
-  // after the barrier: the four waves' codes of one operand (`slot`: 4 ints)
+  // this wave's per-row ORs for one staged operand: every lane returns the word of its row n = lane & 15
+  __device__ __forceinline__ uint32_t code(uint32_t orv) const { return ms_or_g(orv); }
+  // after the barrier: the four waves' words of row n = lane & 15 (`slot`: [4][16] ints)
   __device__ __forceinline__ void tile_codes(const int* slot) {
-    typedef int i32x4s __attribute__((ext_vector_type(4)));
-    const i32x4s c = *reinterpret_cast<const i32x4s*>(slot);
-    if (((c[0] | c[1]) | (c[2] | c[3])) == 1) flags |= LB_MATH_TINY;
+    const int n = threadIdx.x & 15;
+    const uint32_t r = (uint32_t)(slot[n] | slot[16 + n]) | (uint32_t)(slot[32 + n] | slot[48 + n]);
+    if ((r & 0x60006000u) == 0u && (r & 0x7fff7fffu) != 0u) flags |= LB_MATH_TINY;
   }
   __device__ __forceinline__ void commit(const lb_ctrl* ctrl, int lane) {
     const float m = ms_wave_max(big);

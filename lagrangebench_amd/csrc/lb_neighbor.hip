@@ -1073,7 +1073,10 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
       ovf |= (int)((v >> 31) & 1);
       occ = max(occ, (int)((v >> 32) & 0xffff));
     }
-    if (timed_out) atomicExch(&ctrl->persist_error, 2);
+    if (timed_out) {
+      atomicExch(&ctrl->persist_error, 2);
+      atomicMin(&ctrl->persist_step, step);
+    }
     for (int off = 32; off > 0; off >>= 1) {
       part += __shfl_xor(part, off);
       ovf |= __shfl_xor(ovf, off);
@@ -1351,7 +1354,10 @@ __global__ void __launch_bounds__(64 * NLM_WAVES) k_nl_mid(lb_geom g, lb_ctrl* _
       ovf |= (int)((v >> 31) & 1);
       occ = max(occ, (int)((v >> 32) & 0xffff));
     }
-    if (timed_out) atomicExch(&ctrl->persist_error, 2);
+    if (timed_out) {
+      atomicExch(&ctrl->persist_error, 2);
+      atomicMin(&ctrl->persist_step, step);
+    }
     for (int off = 32; off > 0; off >>= 1) {
       part += __shfl_xor(part, off);
       ovf |= __shfl_xor(ovf, off);

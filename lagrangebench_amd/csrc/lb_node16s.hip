@@ -211,8 +211,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (NS_SLOTS == 4 ? 1 : 2) : 4
 #pragma unroll
   for (int mb = 0; mb < 8; ++mb) acc2[mb] = vecp[32 + 4 * mb];
   {
+    // per-row TINY test of the hidden row (every tile, one k-group: lb_rows_tiny) - the row the LayerNorm below rescales
     const f32x4 v01[4] = {acc[0], acc[1], acc[2], acc[3]};
-    lb_gemm16v<true, 2>(NS_BUF(C1), v01, acc2);
+    uint32_t or_h = 0;
+    lb_gemm16v<true, 2, 1>(NS_BUF(C1), v01, acc2, &or_h);
+    if (lb_rows_tiny(or_h) && lane == 0) lb_raise_math(a.ctrl, LB_MATH_TINY);
   }
   NS_STEP(C1 + 1);
   // residual: the node row is read a second time (L2 resident), requested before the refill so that

@@ -71,6 +71,7 @@ __device__ __forceinline__ bool ps_grid_barrier(unsigned* bar, unsigned epoch, u
           __hip_atomic_load(&bar[10 * PS_BAR_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         __hip_atomic_store(&bar[10 * PS_BAR_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicExch(&ctrl->persist_error, 1);
+        atomicMin(&ctrl->persist_step, ctrl->step);
         ok = 0;
         break;
       }

@@ -590,6 +590,8 @@ extern "C" int lb_gns_train_read(lb_gns_train* t, int32_t which, float* out_host
   LB_HIP(hipMemcpy(out_host, src, sizeof(float) * n_floats, hipMemcpyDeviceToHost));
   return LB_OK;
 }
+extern "C" int64_t lb_gns_train_step_count(lb_gns_train* t) { return t ? (int64_t)t->step : -1; }
+
 extern "C" int lb_gns_train_write(lb_gns_train* t, int32_t which, const float* in_host, int64_t n_floats, int64_t step) {
   if (!t || !in_host || n_floats != t->n_floats || which < 0 || which > 3) return lb_fail(LB_ERR_ARG, "bad argument");
   float* dst = which == 0 ? t->w : which == 1 ? t->g : which == 2 ? t->m : t->v;

@@ -279,6 +279,11 @@ class RolloutEngine:
         check(self.lib.lb_math_mode(self._h, int(set_mode), C.byref(mode), C.byref(flags)), "lb_math_mode")
         return mode.value, flags.value
 
+    def math_fallbacks(self) -> int:
+        """Steps / stand-alone forwards the range guard has redone in exact fp32 on this engine (the engine returns
+        to guarded f16x2 afterwards: include/lbhip.h: lb_math_fallbacks)."""
+        return int(self.lib.lb_math_fallbacks(self._h))
+
     def set_fused_aggregation(self, on: bool) -> None:
         check(self.lib.lb_set_fused_aggregation(self._h, int(bool(on))), "lb_set_fused_aggregation")
 
@@ -452,6 +457,10 @@ class GnsTrainHandle:
         check(self.engine.lib.lb_gns_train_read(self._h, idx, out.ctypes.data_as(C.POINTER(C.c_float)),
                                                 C.c_int64(out.size)), "lb_gns_train_read")
         return out
+
+    def step_count(self) -> int:
+        """AdamW steps taken on the device (optax's `count`)."""
+        return int(self.engine.lib.lb_gns_train_step_count(self._h))
 
     def write(self, which: str, blob: np.ndarray, step: int = -1) -> None:
         idx = {"weights": 0, "grads": 1, "m": 2, "v": 3}[which]

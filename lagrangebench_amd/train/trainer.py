@@ -56,6 +56,12 @@ class _ShuffledLoader:
 class Trainer:
     def __init__(self, model: GNS, case, data_train, data_valid, cfg_train=None, cfg_eval=None, cfg_logging=None,
                  input_seq_length: int = defaults.model.input_seq_length, seed: int = defaults.seed):
+        if isinstance(model, GNS) and (model._latent_size != 128 or model._blocks_per_step != 2):
+            # fail HERE, before datasets and neighbor lists are set up (csrc/lb_train.hip: the LayerNorm / gather /
+            # concat kernels of the training step are built for 128-wide latents and two Linears per MLP)
+            raise NotImplementedError(
+                f"training is built for GNS-*-128 with num_mlp_layers 2 (got latent_size {model._latent_size}, "
+                f"num_mlp_layers {model._blocks_per_step}); inference runs every size")
         if not isinstance(model, GNS):
             raise NotImplementedError("Trainer: only GNS has a device training step (csrc/lb_train.hip)")
         self.model, self.case, self.input_seq_length = model, case, input_seq_length
@@ -111,7 +117,8 @@ class Trainer:
         th = model.train_handle(case.engine(B), params)   # weights, gradients, AdamW moments: device resident
         if isinstance(opt_state, dict) and "m" in opt_state and "v" in opt_state:
             th.write("m", np.asarray(opt_state["m"], np.float32))
-            th.write("v", np.asarray(opt_state["v"], np.float32), step=int(opt_state.get("step", step)))
+            # `count` = AdamW steps taken (optax's count); checkpoints of round 3 only carried the loop index `step`
+            th.write("v", np.asarray(opt_state["v"], np.float32), step=int(opt_state.get("count", opt_state.get("step", step))))
         o = cfg_train.optimizer
         lw = float(self.loss_weight.get("acc", 1.0))
 
@@ -119,8 +126,10 @@ class Trainer:
             return model.unflatten(th.read("weights"), params)
 
         def opt_state_dict():
+            # count: the device's AdamW step counter - NOT the loop index (it is step + 1 after an update, and differs
+            # again after neighbor-list overflow `continue`s); a resumed run restores it, as optax does from opt_state
             return {"kind": "lagrangebench_amd adamw (flat blobs in GNS.flatten order)", "m": th.read("m"),
-                    "v": th.read("v"), "step": int(step)}
+                    "v": th.read("v"), "step": int(step), "count": th.step_count()}
         if store_ckp is not None:
             os.makedirs(os.path.join(store_ckp, "best"), exist_ok=True)
 

@@ -134,10 +134,10 @@ def _opt_state_to_host(x):
 
 def save_haiku(ckp_dir: str, params, state, opt_state, metadata_ckp) -> None:
     """utils.py:61-96 incl. the best/ copy.  `opt_state.pkl` is always written (the reference's load_haiku opens
-    it unconditionally, utils.py:119-121): here it holds the AdamW state_dict of train/trainer.py (step counters
-    and both moments per leaf, in the key-sorted leaf order of the parameter tree) as numpy arrays, or None.  It
-    is NOT an optax state: a reference run can read params / state of these checkpoints, but restarts its
-    optimiser from scratch."""
+    it unconditionally, utils.py:119-121): here it holds the device AdamW state of train/trainer.py as numpy arrays -
+    {"kind", "m", "v": the two moment blobs (flat, GNS.flatten order), "step": the training-loop index, "count": the
+    AdamW steps taken (optax's count: the bias-correction exponent)} - or None.  It is NOT an optax state: a reference
+    run can read params / state of these checkpoints, but restarts its optimiser from scratch."""
     _os.makedirs(ckp_dir, exist_ok=True)
     save_pytree(ckp_dir, params, "params")
     save_pytree(ckp_dir, state if state is not None else {}, "state")
