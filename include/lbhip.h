@@ -247,8 +247,8 @@ int lb_segnn_forward(lb_engine* eng, lb_segnn* segnn, float* acc_out_dev);
 
 /* Arithmetic of the GNS GEMMs.  Default (LB_MATH unset) = mode 1: every fp32 operand is carried as an fp16
  * hi/lo pair on the fp16 MFMA (fp32-class accuracy, ~5x fewer matrix-pipe cycles than the fp32 MFMA) WITH a
- * range guard: operands >= 2^15 (sampled), operand ROWS whose values all sit below 2^-7 (tested on every tile of
- * the batch edge / node kernels) or tiles below 2^-11 (small-graph kernels), and non-finite accelerations raise
+ * range guard: operands >= 2^15 (sampled), operand ROWS whose values all sit below 2^-11 (tested on every tile of the
+ * batch edge / node kernels and of the small-graph kernels), and non-finite accelerations raise
  * flags; lb_gns_forward / lb_rollout then redo the flagged forward / rollout step in mode 0 and return to mode 1
  * (round 4: not sticky; after LB_GUARD_MAX_FALLBACKS = 3 flagged steps the rest of that rollout runs in mode 0).
  * set_mode: -1 query, 0 exact fp32 MFMA, 1 guarded f16x2, 2 f16x2 without the switch (tests), 3 guarded with

@@ -57,10 +57,13 @@ __device__ __forceinline__ bool lb_tile_tiny(uint32_t orv) {
 // harmless next to a bias, but a following LayerNorm rescales the row to O(1) and the error with it (a row of
 // post-ReLU hiddens ~1e-6 with zero bias came out 3 % off).  The tile-wide test above cannot see one such row among
 // fifteen ordinary ones.  `orv` = OR of the `hi` patterns of the values THIS lane fed for row n = lane & 15 (its 8
-// features of the sampled k-group, or its 32 of the row): exponent bits 14:13 clear on all four lanes of the row <=>
-// every sampled |x| < 2^-7 (error bound 2^-18 = 3.8e-6 of the row maximum above that); an all-zero sample is exact and
-// does not count.  Sampling one k-group: a row that is tiny in all 128 features is tiny in these 32; the converse
-// (a false alarm) costs one step in fp32.
+// features of the sampled k-group, or its 32 of the row): exponent bits 14:12 clear on all four lanes of the row <=>
+// every sampled |x| < 2^-11; an all-zero sample is exact and does not count.  Threshold: above 2^-11 the row's error is
+// <= 2^-14 = 6e-5 of ITS OWN scale, one message among the ~10 a receiver sums - inside the 1e-5 bar on the accelerations;
+// a first version flagged rows below 2^-7 (bound 3.8e-6) and fired on every synthetic rollout in which two particles
+// pass within 0.5 % of the cutoff of each other (their edge-feature row, hence its encoder hidden row, is that small):
+// three fp32 steps per rollout, TGV2D B = 1 0.27 -> 0.30 ms per step.  Sampling one k-group: a row that is tiny in all
+// 128 features is tiny in these 32; the converse (a false alarm) costs one step in fp32.
 __device__ __forceinline__ bool lb_rows_tiny(uint32_t orv) {
   // OR over the four lanes {n, n+16, n+32, n+48} of row n: gfx950 row swaps (v_permlane16_swap exchanges the odd
   // 16-lane rows of its first operand with the even rows of the second, v_permlane32_swap the upper half of the first
@@ -70,7 +73,7 @@ __device__ __forceinline__ bool lb_rows_tiny(uint32_t orv) {
   a = b = a | b;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
   const uint32_t r = a | b;
-  return __any((r & 0x60006000u) == 0u && (r & 0x7fff7fffu) != 0u);
+  return __any((r & 0x70007000u) == 0u && (r & 0x7fff7fffu) != 0u);
 }
 
 // hi = fp16(x) (RNE), lo = fp16(x - hi) for 8 values: 4 v_cvt_pk_f16_f32 + 8 v_fma_mix{lo,hi}_f16
@@ -110,7 +113,7 @@ __device__ __forceinline__ void lb_split8v(const f32x4& x0, const f32x4& x1, h8&
 // GUARD: 0 none; 1 the FIRST k-group only (32 of the features of every row: the per-row test lb_rows_tiny, round 4's
 // default - two v_or3 per GEMM); 2 every k-group (lb_tile_tiny / lb_rows_tiny on all features, LB_GUARD=full).
 template <bool RELU, int NP = 4, int GUARD = 0>
-__device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[2 * NP], f32x4 (&acc)[8], uint32_t* orv = nullptr) {
+__device__ __forceinline__ void lb_gemm16v_r03(lds_cptr wbase, const f32x4 (&v)[2 * NP], f32x4 (&acc)[8], uint32_t* orv = nullptr) {
   auto note = [&](const h8& h, bool first = false) {
     if constexpr (GUARD == 2 || GUARD == 1) {
       if (GUARD == 1 && !first) return;
@@ -181,6 +184,140 @@ __device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[2 * 
       bl = nbl;
     }
     SB();
+  }
+}
+
+
+// ---- round 4: the same block loop with the NEXT operand's split issued one instruction at a time in the shadow of the
+// MFMAs.  tools/issue_bench (profiles/r04_issue_bench.txt): in ONE wave a 16x16x32 f16 MFMA hides two plain VALU
+// instructions or one half-rate one (v_fma_mix*, v_exp, v_rcp) completely (18.3 / 18.0 cycles per slot against 16.5
+// bare); the third plain one costs 4 cycles, every further half-rate one 8.  Round 2-3 issued the split as ONE 12-
+// instruction block between two MFMA phases: ~85 cycles in series with the matrix pipe, four times per GEMM.  Here the
+// 24 MFMAs of k-step p carry, one per slot: [8 integer-max of the ReLU, two per slot] 4 v_cvt_pk_f16_f32, 4
+// v_fma_mixlo_f16, 4 v_fma_mixhi_f16 [, 2 v_or3 of the range guard] of k-step p + 1.  Every filler is its own asm
+// statement pinned behind its MFMA by a sched_barrier; a split result is first read by an MFMA >= 8 instructions later
+// (no VALU -> MFMA wait states needed), mixhi reads the register mixlo wrote 4 slots earlier.
+#ifndef LB_GEMM_INTERLEAVE
+#define LB_GEMM_INTERLEAVE 1
+#endif
+struct lb_split_regs {
+  uint32_t H[4], L[4];
+  f32x4 r0, r1;  // (ReLU'd) operand pair being split
+};
+template <bool RELU, int GUARD>
+__device__ __forceinline__ void lb_split_slot(int s, const f32x4& x0, const f32x4& x1, lb_split_regs& R, uint32_t* orv) {
+  // s = 0 .. 23 (compile-time after unrolling)
+  if (s < 4) {
+    if constexpr (RELU) {  // two integer max per slot
+      const float a = s < 2 ? x0[2 * s] : x1[2 * (s - 2)], b = s < 2 ? x0[2 * s + 1] : x1[2 * (s - 2) + 1];
+      const float ra = __builtin_bit_cast(float, max(__builtin_bit_cast(int, a), 0));
+      const float rb = __builtin_bit_cast(float, max(__builtin_bit_cast(int, b), 0));
+      if (s < 2) {
+        R.r0[2 * s] = ra;
+        R.r0[2 * s + 1] = rb;
+      } else {
+        R.r1[2 * (s - 2)] = ra;
+        R.r1[2 * (s - 2) + 1] = rb;
+      }
+    }
+  } else if (s < 8) {
+    const int i = s - 4;
+    const f32x4& y = i < 2 ? (RELU ? R.r0 : x0) : (RELU ? R.r1 : x1);
+    const float a = y[2 * (i & 1)], b = y[2 * (i & 1) + 1];
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(R.H[i]) : "v"(a), "v"(b));
+  } else if (s < 12) {
+    const int i = s - 8;
+    const f32x4& y = i < 2 ? (RELU ? R.r0 : x0) : (RELU ? R.r1 : x1);
+    const float a = y[2 * (i & 1)];
+    asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(R.L[i]) : "v"(a), "v"(R.H[i]));
+  } else if (s < 16) {
+    const int i = s - 12;
+    const f32x4& y = i < 2 ? (RELU ? R.r0 : x0) : (RELU ? R.r1 : x1);
+    const float b = y[2 * (i & 1) + 1];
+    asm volatile("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(R.L[i]) : "v"(b), "v"(R.H[i]));
+  } else if (s == 16) {
+    if constexpr (GUARD == 2) *orv |= (R.H[0] | R.H[1]) | (R.H[2] | R.H[3]);
+  }
+}
+template <bool RELU, int NP = 4, int GUARD = 0>
+__device__ __forceinline__ void lb_gemm16v(lds_cptr wbase, const f32x4 (&v)[2 * NP], f32x4 (&acc)[8], uint32_t* orv = nullptr) {
+  if constexpr (!LB_GEMM_INTERLEAVE || NP == 1) {
+    lb_gemm16v_r03<RELU, NP, GUARD>(wbase, v, acc, orv);
+    return;
+  } else {
+  auto frag = [&](int p, int mbo, int part) -> h8 {
+    return __builtin_bit_cast(h8, wbase[((p * 8 + mbo) * 2 + part) * 64]);
+  };
+  h8 X[4], Y[4];  // X: lo fragments, Y: hi fragments of the current block (4 output blocks)
+  h8 bh, bl;
+  lb_split_regs R;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) X[c] = frag(0, c, 1);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) Y[c] = frag(0, c, 0);
+  {  // the first operand pair is split up front (nothing to hide it under)
+    f32x4 a0 = v[0], a1 = v[1];
+    if constexpr (RELU) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float f0 = a0[j], f1 = a1[j];
+        a0[j] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, f0), 0));
+        a1[j] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, f1), 0));
+      }
+    }
+    lb_split8v(a0, a1, bh, bl);
+    if constexpr (GUARD != 0) {
+      typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
+      const u32x4g u = __builtin_bit_cast(u32x4g, bh);
+      *orv |= (u[0] | u[1]) | (u[2] | u[3]);
+    }
+  }
+  SB();
+#pragma unroll
+  for (int blk = 0; blk < 2 * NP; ++blk) {
+    const int p = blk >> 1, q = blk & 1;
+    const int np = (blk + 1) >> 1, nq = (blk + 1) & 1;
+    const bool fill = p < NP - 1;       // k-step p + 1 exists: its split rides in this k-step's 24 slots
+    const int s0 = 12 * q;
+    f32x4* a4 = &acc[4 * q];
+    __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(4));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      a4[c] = MFMA16H(X[c], bh, a4[c]);
+      if (fill) lb_split_slot<RELU, GUARD>(s0 + c, v[2 * p + 2], v[2 * p + 3], R, orv);
+      SB();
+    }
+    if (blk < 2 * NP - 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) X[c] = frag(np, 4 * nq + c, 1);
+    }
+    if (blk < 2 * NP - 1)
+      __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(4));
+    else
+      __builtin_amdgcn_s_waitcnt(LB_WAIT_LGKM(0));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      a4[c] = MFMA16H(Y[c], bl, a4[c]);
+      if (fill) lb_split_slot<RELU, GUARD>(s0 + 4 + c, v[2 * p + 2], v[2 * p + 3], R, orv);
+      SB();
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      a4[c] = MFMA16H(Y[c], bh, a4[c]);
+      if (fill) lb_split_slot<RELU, GUARD>(s0 + 8 + c, v[2 * p + 2], v[2 * p + 3], R, orv);
+      SB();
+    }
+    if (blk < 2 * NP - 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Y[c] = frag(np, 4 * nq + c, 0);
+    }
+    if (q == 1 && fill) {  // the split of k-step p + 1 is complete: it becomes the B operand
+      typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+      bh = __builtin_bit_cast(h8, u32x4s{R.H[0], R.H[1], R.H[2], R.H[3]});
+      bl = __builtin_bit_cast(h8, u32x4s{R.L[0], R.L[1], R.L[2], R.L[3]});
+    }
+    SB();
+  }
   }
 }
 

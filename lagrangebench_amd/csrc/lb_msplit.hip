@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
   __shared__ f32x4 sB1[4 * 2 * 64];
   __shared__ f32x4 sB2[4 * 2 * 64];
   __shared__ __attribute__((aligned(16))) f32x2m sRed[16 * 4];
-  __shared__ __attribute__((aligned(16))) int sMx[2][MS_GUARD_WORDS];
+  __shared__ __attribute__((aligned(16))) int sMx[2][2][MS_GUARD_WORDS];
   const int poisoned = a.ctrl->overflow_step;
   const int E = a.ctrl->n_edges_total;
   const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
@@ -144,6 +144,9 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
   }
   ms_guard guard{0.f, 0};
 
+  // (range-guard slots: OR-accumulated per tile, cleared one iteration ahead - see ms_guard)
+  for (int i = tid; i < (int)(sizeof(sMx) / sizeof(int)); i += MS_THREADS) reinterpret_cast<int*>(sMx)[i] = 0;
+  __syncthreads();
   for (int it = 0; it < wk.n_iter; ++it, t += wk.stride) {
     f32x4 ve[2], acc[2];
 #pragma unroll
@@ -155,10 +158,7 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
     if (it < 3) MS_STAMP(1 + 8 * it);
     uint32_t orv;
     ms_stage<false>(sB1, w, lane, ve[0], ve[1], orv, guard.big);
-    {
-      const uint32_t c = guard.code(orv);
-      if (lane < 16) sMx[0][w * 16 + lane] = (int)c;
-    }
+    guard.post(sMx[it & 1][0], orv);
     // the next tile's loads (and the indices of the one after) go out before this tile's GEMMs
     issue(min(t + wk.stride, wk.q_last));
     load_idx(min(t + 2 * wk.stride, wk.q_last));
@@ -166,19 +166,16 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
     __syncthreads();
     if (it < 3) MS_STAMP(3 + 8 * it);
     ms_gemm<4, 2>(sB1, lane, w0h, w0l, acc);
-    guard.tile_codes(sMx[0]);
+    guard.tile_codes(sMx[it & 1][0], sMx[(it & 1) ^ 1][0]);
     uint32_t orv2;
     ms_stage<true>(sB2, w, lane, acc[0], acc[1], orv2, guard.big);
-    {
-      const uint32_t c = guard.code(orv2);
-      if (lane < 16) sMx[1][w * 16 + lane] = (int)c;
-    }
+    guard.post(sMx[it & 1][1], orv2);
     if (it < 3) MS_STAMP(4 + 8 * it);
     __syncthreads();
     if (it < 3) MS_STAMP(5 + 8 * it);
     f32x4 acc2[2] = {b1v[0], b1v[1]};
     ms_gemm<4, 2>(sB2, lane, w1h, w1l, acc2);
-    guard.tile_codes(sMx[1]);
+    guard.tile_codes(sMx[it & 1][1], sMx[(it & 1) ^ 1][1]);
     {
       const f32x2m p = ms_ln_local(acc2[0], acc2[1]);
       if (g == 0) sRed[n * 4 + w] = p;
@@ -238,7 +235,7 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_ms(lb_ems_args a) {
 __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_enc_ms(lb_ems_args a) {
   __shared__ f32x4 sB2[4 * 2 * 64];
   __shared__ __attribute__((aligned(16))) f32x2m sRed[16 * 4];
-  __shared__ __attribute__((aligned(16))) int sMx[MS_GUARD_WORDS];
+  __shared__ __attribute__((aligned(16))) int sMx[2][1][MS_GUARD_WORDS];
   const int poisoned = a.ctrl->overflow_step;
   const int E = a.ctrl->n_edges_total;
   const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
@@ -273,6 +270,9 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_enc_ms(lb_ems_args a) {
   int t = wk.q;
   issue(t);
   ms_guard guard{0.f, 0};
+  // (range-guard slots: OR-accumulated per tile, cleared one iteration ahead - see ms_guard)
+  for (int i = tid; i < (int)(sizeof(sMx) / sizeof(int)); i += MS_THREADS) reinterpret_cast<int*>(sMx)[i] = 0;
+  __syncthreads();
   for (int it = 0; it < wk.n_iter; ++it, t += wk.stride) {
     f32x4 acc[2] = {b0v[0], b0v[1]};
     {
@@ -288,14 +288,11 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_enc_ms(lb_ems_args a) {
     issue(min(t + wk.stride, wk.q_last));
     uint32_t orv;
     ms_stage<true>(sB2, w, lane, acc[0], acc[1], orv, guard.big);
-    {
-      const uint32_t c = guard.code(orv);
-      if (lane < 16) sMx[w * 16 + lane] = (int)c;
-    }
+    guard.post(sMx[it & 1][0], orv);
     __syncthreads();
     f32x4 acc2[2] = {b1v[0], b1v[1]};
     ms_gemm<4, 2>(sB2, lane, w1h, w1l, acc2);
-    guard.tile_codes(sMx);
+    guard.tile_codes(sMx[it & 1][0], sMx[(it & 1) ^ 1][0]);
     {
       const f32x2m p = ms_ln_local(acc2[0], acc2[1]);
       if (g == 0) sRed[n * 4 + w] = p;
@@ -332,7 +329,7 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
   __shared__ f32x4 sB2[T][4 * 2 * 64];
   __shared__ f32x4 sB3[(PROJ || DEC) ? T : 1][4 * 2 * 64];
   __shared__ __attribute__((aligned(16))) f32x2m sRed[T][16 * 4];
-  __shared__ __attribute__((aligned(16))) int sMx[3][T][MS_GUARD_WORDS];
+  __shared__ __attribute__((aligned(16))) int sMx[2][4 * T][MS_GUARD_WORDS];
   const int poisoned = a.ctrl->overflow_step;
   const int step = a.ctrl->step;
   const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
@@ -451,6 +448,9 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
   ms_guard guard{0.f, 0};
 
   MS_STAMP(2);
+  // (range-guard slots: OR-accumulated per tile, cleared one iteration ahead - see ms_guard)
+  for (int i = tid; i < (int)(sizeof(sMx) / sizeof(int)); i += MS_THREADS) reinterpret_cast<int*>(sMx)[i] = 0;
+  __syncthreads();
   for (int it = 0; it < wk.n_iter; ++it, q += wk.stride) {
     if (it > 0) load_rows(q);
     if (it < 2) MS_STAMP(3 + 12 * it);
@@ -459,8 +459,7 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
       uint32_t orv = 0u, orv2 = 0u;  // the tile's first operand is [rows | aggregated messages]: one code for both
       if (has_x) ms_stage<false>(sB1[i], w, lane, xa[i][0], xa[i][1], orv, guard.big);
       if constexpr (AGG) ms_stage<false>(sB1[i], NKA + w, lane, ag[i][0], ag[i][1], orv2, guard.big);
-      const uint32_t c = guard.code(orv | orv2);
-      if (lane < 16) sMx[0][i][w * 16 + lane] = (int)c;
+      guard.post(sMx[it & 1][(0) * T + (i)], orv | orv2);
     }
     if (it < 2) MS_STAMP(4 + 12 * it);
     __syncthreads();
@@ -474,11 +473,10 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
     }
 #pragma unroll
     for (int i = 0; i < T; ++i) {
-      guard.tile_codes(sMx[0][i]);
+      guard.tile_codes(sMx[it & 1][(0) * T + (i)], sMx[(it & 1) ^ 1][(0) * T + (i)]);
       uint32_t orv;
       ms_stage<true>(sB2[i], w, lane, acc[i][0], acc[i][1], orv, guard.big);
-      const uint32_t c = guard.code(orv);
-      if (lane < 16) sMx[1][i][w * 16 + lane] = (int)c;
+      guard.post(sMx[it & 1][(1) * T + (i)], orv);
     }
     if (it < 2) MS_STAMP(6 + 12 * it);
     __syncthreads();
@@ -492,7 +490,7 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
     }
 #pragma unroll
     for (int i = 0; i < T; ++i) {
-      guard.tile_codes(sMx[1][i]);
+      guard.tile_codes(sMx[it & 1][(1) * T + (i)], sMx[(it & 1) ^ 1][(1) * T + (i)]);
       const f32x2m p = ms_ln_local(acc2[i][0], acc2[i][1]);
       if (g == 0) sRed[i][n * 4 + w] = p;
     }
@@ -514,8 +512,7 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
       if constexpr (PROJ) {
         uint32_t orv;
         ms_stage<false>(sB3[i], w, lane, y[i][0], y[i][1], orv, guard.big);
-        const uint32_t c = guard.code(orv);
-        if (lane < 16) sMx[2][i][w * 16 + lane] = (int)c;
+        guard.post(sMx[it & 1][(2) * T + (i)], orv);
       }
     }
     if (it < 2) MS_STAMP(10 + 12 * it);
@@ -524,7 +521,7 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
       if (it < 2) MS_STAMP(11 + 12 * it);
 #pragma unroll
       for (int i = 0; i < T; ++i) {
-        guard.tile_codes(sMx[2][i]);
+        guard.tile_codes(sMx[it & 1][(2) * T + (i)], sMx[(it & 1) ^ 1][(2) * T + (i)]);
         f32x4 accp[4] = {bpv[0], bpv[1], bpv[2], bpv[3]};
         ms_gemm<4, 4>(sB3[i], lane, wph, wpl, accp);
         if (valid[i]) {
@@ -545,14 +542,13 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
         }
         uint32_t orv;
         ms_stage<false>(sB3[i], w, lane, y[i][0], y[i][1], orv, guard.big);
-        const uint32_t c = guard.code(orv);
-        if (lane < 16) sMx[2][i][w * 16 + lane] = (int)c;
+        guard.post(sMx[it & 1][(2) * T + (i)], orv);
       }
       __syncthreads();
       f32x4 hd[T][2];
 #pragma unroll
       for (int i = 0; i < T; ++i) {
-        guard.tile_codes(sMx[2][i]);
+        guard.tile_codes(sMx[it & 1][(2) * T + (i)], sMx[(it & 1) ^ 1][(2) * T + (i)]);
         hd[i][0] = bd0v[0];
         hd[i][1] = bd0v[1];
         ms_gemm<4, 2>(sB3[i], lane, wd0h, wd0l, hd[i]);
@@ -561,13 +557,12 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
       for (int i = 0; i < T; ++i) {  // (sB2 / sMx[1] were last read before the LayerNorm barrier)
         uint32_t orv;
         ms_stage<true>(sB2[i], w, lane, hd[i][0], hd[i][1], orv, guard.big);
-        const uint32_t c = guard.code(orv);
-        if (lane < 16) sMx[1][i][w * 16 + lane] = (int)c;
+        guard.post(sMx[it & 1][(3) * T + (i)], orv);
       }
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < T; ++i) {
-        guard.tile_codes(sMx[1][i]);
+        guard.tile_codes(sMx[it & 1][(3) * T + (i)], sMx[(it & 1) ^ 1][(3) * T + (i)]);
         f32x4 o[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
         ms_gemm<4, 1>(sB2[i], lane, wd1h, wd1l, o);
         if (w == 0 && g == 0 && valid[i]) {

@@ -169,20 +169,23 @@ __device__ __forceinline__ void ms_ln_combine(const f32x2m* red, int n, float in
 // running range-guard state of a wave (see the header).  LARGE: `big` = max |x| over every GEMM operand element this
 // wave staged (ms_stage; a value that leaves the fp16 range is seen BEFORE its `hi` becomes inf).  TINY, round 4: per
 // ROW of every tile and operand (lb_f16x2.h: lb_rows_tiny has the why) - the OR of the `hi` bit patterns of a row says
-// whether all of its elements are below 2^-7 (exponent bits 14:13 clear) and not all zero; the 4 waves hold 32 features
+// whether all of its elements are below 2^-11 (exponent bits 14:12 clear) and not all zero; the 4 waves hold 32 features
 // each of the tile's 16 rows, so each posts its 16 per-row ORs (`code`: lanes 0-15 write them) and after the barrier
 // lane n combines the four words of row n (`tile_codes`).
-#define MS_GUARD_WORDS 64  // ints per (operand, tile) slot: [4 waves][16 rows]
+#define MS_GUARD_WORDS 16  // ints per (parity, operand, tile) slot: one OR word per row
 struct ms_guard {
   float big;
   int flags;
-  // this wave's per-row ORs for one staged operand: every lane returns the word of its row n = lane & 15
-  __device__ __forceinline__ uint32_t code(uint32_t orv) const { return ms_or_g(orv); }
-  // after the barrier: the four waves' words of row n = lane & 15 (`slot`: [4][16] ints)
-  __device__ __forceinline__ void tile_codes(const int* slot) {
-    const int n = threadIdx.x & 15;
-    const uint32_t r = (uint32_t)(slot[n] | slot[16 + n]) | (uint32_t)(slot[32 + n] | slot[48 + n]);
-    if ((r & 0x60006000u) == 0u && (r & 0x7fff7fffu) != 0u) flags |= LB_MATH_TINY;
+  // every lane ORs its word into the slot of its row (LDS atomic: 4 lanes per address; the four waves add theirs) - no
+  // cross-lane reduction, no ballot in the latency chain of the B = 1 launches (a permlane-based version of this test
+  // cost TGV2D-2.5k B = 1 16 %: 0.26 -> 0.30 ms per step)
+  __device__ __forceinline__ void post(int* slot, uint32_t orv) const { atomicOr(&slot[threadIdx.x & 15], (int)orv); }
+  // after the barrier: lane n tests row n; the slot of the OTHER tile parity (last read one iteration ago, next written
+  // one iteration ahead, barriers in between) is cleared for its next use
+  __device__ __forceinline__ void tile_codes(const int* slot, int* slot_other) {
+    const uint32_t r = (uint32_t)slot[threadIdx.x & 15];
+    if ((r & 0x70007000u) == 0u && (r & 0x7fff7fffu) != 0u) flags |= LB_MATH_TINY;
+    if (threadIdx.x < 16) slot_other[threadIdx.x] = 0;
   }
   __device__ __forceinline__ void commit(const lb_ctrl* ctrl, int lane) {
     const float m = ms_wave_max(big);

@@ -44,7 +44,18 @@ static float time_it(F launch, int iters) {
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   // clocks: after an idle gap (the host-side checks) the first ~50 ms run 15 - 20 % slow - warm up for as long as we time
-  for (int i = 0; i < iters * 2; ++i) launch();
+  // clocks: after an idle gap (host-side checks, process start) the GPU needs several hundred ms of work to reach its
+  // sustained clock - the first measurements of a process read up to 40 % slow.  Warm up for ~0.6 s of launches.
+  {
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < 8; ++i) launch();
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms8 = 0;
+    (void)hipEventElapsedTime(&ms8, e0, e1);
+    const int n_warm = (int)(600.0f / (ms8 / 8.0f + 1e-4f));
+    for (int i = 0; i < n_warm && i < 200000; ++i) launch();
+  }
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0, 0);
   for (int i = 0; i < iters; ++i) launch();
