@@ -77,7 +77,7 @@ def per_particle_host_force(fn: Callable):
     return host_fn
 
 
-def force_spec_from_callable(fn: Callable, bounds, n_probe: int = 64):
+def force_spec_from_callable(fn: Callable, bounds, n_probe: int = 64, n_verify: int = 512):
     """Compile a single-position force function into a ForceSpec by probing it on a grid:
     constant -> ForceSpec.constant; one switch along one axis -> ForceSpec.piecewise; otherwise a
     host callable evaluated per particle (slow path)."""
@@ -112,11 +112,31 @@ def force_spec_from_callable(fn: Callable, bounds, n_probe: int = 64):
                 else:
                     hi = m
             split_axis, split_at, f_lo, f_hi = ax, lo, vals[k], vals[k + 1]
-    if const:
-        return ForceSpec.constant(f0)
-    if split_axis is not None and split_axis >= 0:
-        return ForceSpec.piecewise(split_axis, split_at, f_lo, f_hi)
+    # The probes above walk axis-parallel lines through the box centre on a 64-point grid: a force band narrower than
+    # 1/66 of the box, or one that depends on several coordinates, slips through.  Verify the compiled spec on random
+    # points of the whole box (and on points hugging a detected switch) and fall back to the callable on ANY mismatch
+    # (a silently mis-compiled force is worse than the slow path).
+    def compiled(p):
+        if const:
+            return f0
+        return f_hi if p[split_axis] > split_at else f_lo
 
+    spec_ok = const or (split_axis is not None and split_axis >= 0)
+    if spec_ok:
+        rng = np.random.default_rng(0)
+        pts = b[:, 0] + rng.random((n_verify, dim)) * (b[:, 1] - b[:, 0])
+        if not const:
+            near = pts[: n_verify // 4].copy()
+            near[:, split_axis] = split_at + (rng.random(len(near)) - 0.5) * 1e-3 * (b[split_axis, 1] - b[split_axis, 0])
+            pts = np.concatenate([pts, near])
+        for p in pts:
+            if not np.array_equal(np.asarray(fn(p), dtype=np.float64), compiled(p)):
+                spec_ok = False
+                break
+    if spec_ok and const:
+        return ForceSpec.constant(f0)
+    if spec_ok:
+        return ForceSpec.piecewise(split_axis, split_at, f_lo, f_hi)
     return ForceSpec.callable(per_particle_host_force(fn))
 
 

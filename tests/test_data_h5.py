@@ -62,5 +62,19 @@ def test_force_py_is_compiled_to_a_forcespec(tmp_path):
     (tmp_path / "g.py").write_text("import jax.numpy as jnp\n\ndef force_fn(r):\n    return jnp.array([0.0, -1.0])\n")
     spec = force_spec_from_callable(_load_force_fn(str(tmp_path / "g.py")), [[0.0, 5.486], [0.0, 2.12]])
     assert spec.kind == 1 and tuple(spec.f_lo) == tuple(spec.f_hi) == (0.0, -1.0)
+    # a band narrower than the probe grid (1/66 of the box) and a force that depends on two coordinates: the probing
+    # would compile both to a constant - the random-point verification must send them to the host callable instead
+    (tmp_path / "band.py").write_text(
+        "import jax.numpy as jnp\n\n"
+        "def force_fn(r):\n"
+        "    return jnp.where((r[1] > 0.700) & (r[1] < 0.705), jnp.array([5.0, 0.0]), jnp.array([0.0, 0.0]))\n")
+    spec = force_spec_from_callable(_load_force_fn(str(tmp_path / "band.py")), [[0.0, 1.0], [0.0, 1.0]])
+    assert spec.kind == 2, "narrow band mis-compiled"                      # LB_FORCE_BUFFER: evaluated by the callable
+    (tmp_path / "diag.py").write_text(
+        "import jax.numpy as jnp\n\n"
+        "def force_fn(r):\n"
+        "    return jnp.where(r[0] + r[1] > 1.7, jnp.array([0.0, 1.0]), jnp.array([0.0, -1.0]))\n")
+    spec = force_spec_from_callable(_load_force_fn(str(tmp_path / "diag.py")), [[0.0, 1.0], [0.0, 1.0]])
+    assert spec.kind == 2, "two-coordinate force mis-compiled"
     assert get_dataset_name_from_path("/data/2D_TGV_2500_10kevery100") == "tgv2d"
     assert get_dataset_name_from_path("/data/3D_RPF_8000_10kevery10/") == "rpf3d"
