@@ -386,11 +386,12 @@ int lbk_segnn_forward(lb_engine* e, lb_segnn* m);
 void lb_sg_msg_image(const float* ws0, const float* wv0, const float* b0, const float* ws1,
                      const float* wv1, const float* b1, float* out);
 int lb_sg_msg_image_floats(void);
-int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg, bool finish);
+int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg, float* part, int64_t out_bytes,
+                   bool finish);
 void lb_sg_upd_image(const float* ws0, const float* wv0, const float* b0, const float* ws1,
                      const float* wv1, const float* b1, float* out);
 int lb_sg_upd_image_floats(void);
-int lbk_sg_update(lb_engine* e, float* f, const float* agg, const float* nattr, const float* image,
+int lbk_sg_update(lb_engine* e, float* f, const float* agg, const float* part, const float* nattr, const float* image,
                   bool combine_partials);
 
 // lb_segnn_node.hip

@@ -82,7 +82,9 @@ struct lb_segnn {
   float* nodesv;   // [BN][node_stride]
   float* nattr;    // [BN][4]
   float* f;        // [BN][128] hidden state
-  float* agg;      // [BN][128]
+  float* agg;      // [BN][128]; followed in the SAME allocation by
+  float* part;     // [ceil(e_alloc / 16) + 2][2][128]: k_sg_msg's per-tile partial slots (one buffer descriptor)
+  int64_t aggpart_bytes;
   float* tn[2];    // [BN][128] block intermediates
   // edge-sized scratch (regrown with the engine's e_alloc)
   int64_t e_alloc;
@@ -346,6 +348,12 @@ static int sg_ensure_edges(lb_segnn* m) {
   m->eattr = m->msgsv = nullptr;
   LB_TRY(sg_alloc(&m->eattr, (size_t)e->e_alloc * 4));
   LB_TRY(sg_alloc(&m->msgsv, (size_t)e->e_alloc * 16));
+  if (m->agg) (void)hipFree(m->agg);
+  m->agg = nullptr;
+  const size_t n_agg = (size_t)e->BN * 128, n_part = ((size_t)e->e_alloc / 16 + 2) * 2 * 128;
+  LB_TRY(sg_alloc(&m->agg, n_agg + n_part));
+  m->part = m->agg + n_agg;
+  m->aggpart_bytes = (int64_t)(n_agg + n_part) * 4;
   m->e_alloc = e->e_alloc;
   return LB_OK;
 }
@@ -519,7 +527,6 @@ extern "C" int lb_segnn_create(lb_engine* e, const lb_segnn_desc* d, const float
   if (!rc) rc = sg_alloc(&m->nodesv, (size_t)BN * m->node_stride);
   if (!rc) rc = sg_alloc(&m->nattr, (size_t)BN * 4);
   if (!rc) rc = sg_alloc(&m->f, (size_t)BN * 128);
-  if (!rc) rc = sg_alloc(&m->agg, (size_t)BN * 128);
   if (!rc) rc = sg_alloc(&m->tn[0], (size_t)BN * 128);
   if (!rc) rc = sg_alloc(&m->tn[1], (size_t)BN * 128);
   if (rc) {
@@ -585,7 +592,7 @@ int lbk_segnn_forward(lb_engine* e, lb_segnn* m) {
     // message: [f_sender | f_receiver | (rel_disp, rel_dist)] -> gated blocks (segnn.py:280-304)
     if (m->fused_msg) {
       lb_tic(e, LB_T_EDGE_MLP);
-      int rc = lbk_sg_message(e, m->f, m->msg_image[k], m->agg, false);
+      int rc = lbk_sg_message(e, m->f, m->msg_image[k], m->agg, m->part, m->aggpart_bytes, false);
       lb_toc(e);
       if (rc) return rc;
     } else {
@@ -613,7 +620,7 @@ int lbk_segnn_forward(lb_engine* e, lb_segnn* m) {
     // update: [f | agg] -> gated blocks -> linear block -> residual (segnn.py:306-334)
     lb_tic(e, LB_T_NODE_MLP);
     if (m->fused_msg) {
-      int rc = lbk_sg_update(e, m->f, m->agg, m->nattr, m->upd_image[k], true);
+      int rc = lbk_sg_update(e, m->f, m->agg, m->part, m->nattr, m->upd_image[k], true);
       lb_toc(e);
       if (rc) return rc;
       LB_TRY(tap(k + 1));

@@ -66,7 +66,9 @@ struct lb_sg_msg_args {
   const float* f;       // [BN][128] hidden state
   const float* image;   // SGM_IMAGE f32x4 of this layer
   float* agg;           // [BN][128]
-  float* part;          // [ceil(E/16)][2][128]
+  float* part;          // [ceil(E/16)][2][128]; lives in the SAME allocation as agg (one buffer descriptor for the stores)
+  uint32_t part_off;    // byte offset of part from agg
+  uint32_t out_bytes;   // bytes of the agg | part allocation (< 2^31)
   long long* dbg;       // tools/sg_msg_bench (ABL & 32): per wave of workgroup 0, cycles per tile segment
 };
 
@@ -133,6 +135,25 @@ __global__ void __launch_bounds__(WPS * 256, 1) k_sg_msg(lb_sg_msg_args a) {
   const f32x4* ef4 = reinterpret_cast<const f32x4*>(a.efeat);
   int n_iter = 0;
   asm volatile("" : "+v"(s_c), "+v"(r_c));
+  // Memory schedule of a tile (gfx9 has ONE in-order vmcnt for loads and stores): the SENDER rows of tile t + 1 are
+  // requested in the middle of tile t (their registers are free once block 0 is done), i.e. BEFORE tile t's aggregate
+  // stores; the receiver rows, the edge features and the indices of the tile after go out at the top of the tile.  The
+  // stores are raw-buffer stores with the lane's offset pushed out of range where it has nothing to write: no branch
+  // around them, so the compiler counts them exactly and the wait for the sender rows (older than the stores) does not
+  // drain the stores (behind a branch every later wait became vmcnt(0): ~5 us of a 50 us launch, ablation "no stores").
+  const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(a.agg, 0, (int)a.out_bytes, 0x00020000);
+  f32x4 fs[8];
+  auto issue_sender = [&](int s_idx) {
+    const f32x4* ps = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.f) + ((uint32_t)s_idx * 512u + (uint32_t)g * 16u));
+#pragma unroll
+    for (int mb = 0; mb < 2 + 2 * NC; ++mb) fs[mb] = (ABL & 1) ? f32x4{.1f, .2f, (float)s_idx * 1e-6f, (float)mb} : ps[4 * mb];
+  };
+  issue_sender(s_c);
+  f32x4 ef_n = ef4[rowc_of(t) * 2];  // edge features travel with the sender rows (the accumulator start values need them first)
+  // (the first tile's rows are taken delivery of HERE: a wait at the loop header is also executed on the back edge, where
+  // the waitcnt pass would have to assume the preheader's state - nothing younger in flight - and drain the stores)
+  asm volatile("" : "+v"(ef_n), "+v"(fs[0]), "+v"(fs[1]), "+v"(fs[2]), "+v"(fs[3]), "+v"(fs[4]), "+v"(fs[5]));
+  if constexpr (NC == 3) asm volatile("" : "+v"(fs[6]), "+v"(fs[7]));
   long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #define SG_STAMP(i)                                         \
   if constexpr ((ABL & 32) && ((SM >> i) & 1)) {            \
@@ -161,31 +182,21 @@ __global__ void __launch_bounds__(WPS * 256, 1) k_sg_msg(lb_sg_msg_args a) {
       t_next = c_lo + __builtin_amdgcn_readfirstlane(k);
     }
     const int r_cur = r_c;
-    f32x4 fs[8], fr[8];
+    f32x4 fr[8];
     {
       // 32-bit byte offsets from the scalar base (global_load saddr form: no 64-bit address arithmetic per lane;
       // the host refuses node tables beyond 4 GiB)
-      const f32x4* ps = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.f) + ((uint32_t)s_c * 512u + (uint32_t)g * 16u));
       const f32x4* pr = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.f) + ((uint32_t)r_c * 512u + (uint32_t)g * 16u));
-#pragma unroll
-      for (int mb = 0; mb < 2 + 2 * NC; ++mb) fs[mb] = (ABL & 1) ? f32x4{.1f, .2f, (float)s_c * 1e-6f, (float)mb} : ps[4 * mb];
 #pragma unroll
       for (int mb = 0; mb < 2 + 2 * NC; ++mb) fr[mb] = (ABL & 1) ? f32x4{.3f, .1f, (float)r_c * 1e-6f, (float)mb} : pr[4 * mb];
     }
-    // The row gathers go FIRST: they depend only on indices that were delivered a tile ago.  (With the edge-feature
-    // load in front of them hipcc once reused a dead lane of ITS destination as the gathers' address register - a
-    // WAW hazard it resolved with s_waitcnt vmcnt(0): two serialised memory round trips per tile, and a full drain of
-    // the previous tile's stores.)
-    SB();
-    f32x4 ef = ef4[rowc_of(t) * 2];
-    SB();
+    f32x4 ef = ef_n;
     {
       const int64_t rn = rowc_of(min(t_next, c_hi - 1));
       s_c = a.senders[rn];
       r_c = a.receivers[rn];
     }
     int rb = lb_edge_probe(a.receivers, t, lane, E);
-    asm volatile("" : "+v"(ef));  // all four lanes of ef stay allocated until the loads above are issued (same hazard)
     // edge attribute a = Y1 r/|r| (0 for the self edge), message features |r| (rel_dist) and r
     float at[3], dist, dotr, rmag;
     {
@@ -223,6 +234,11 @@ __global__ void __launch_bounds__(WPS * 256, 1) k_sg_msg(lb_sg_msg_args a) {
     } else {
       sg_gate<NC>(S, T, V, at, H);
     }
+    // the next tile's sender rows, into the registers block 0 has just released (see the memory schedule above)
+    asm volatile("" : "+v"(s_c), "+v"(r_c), "+v"(rb));
+    issue_sender(s_c);
+    ef_n = ef4[rowc_of(min(t_next, c_hi - 1)) * 2];
+    SB();
     SG_STAMP(4)  // gate 0
     // ---- block 1: h (x) a -> gate
 #pragma unroll
@@ -235,8 +251,6 @@ __global__ void __launch_bounds__(WPS * 256, 1) k_sg_msg(lb_sg_msg_args a) {
     }
     sg_operand<NC, 4, 4, PRIO, (ABL & 2) != 0>(w1 + (SGM_WS1 - SGM_B1), w1 + (SGM_WT1 - SGM_B1), w1 + (SGM_WV1 - SGM_B1), H, at, S, T, V);
     SG_STAMP(5)  // block 1 operand
-    // take delivery of the next tile's indices while only loads are in flight (in-order vmcnt, see k_edge16v)
-    asm volatile("" : "+v"(s_c), "+v"(r_c), "+v"(rb));
     f32x4 y[8];
     if constexpr (ABL & 4) {
 #pragma unroll
@@ -264,16 +278,16 @@ __global__ void __launch_bounds__(WPS * 256, 1) k_sg_msg(lb_sg_msg_args a) {
 #pragma unroll
     for (int mb = 0; mb < 2 + 2 * NC; mb += 2) lb_scan8(y[mb], y[mb + 1], m1, m2, m4, m8);
     SG_STAMP(7)  // scan
-    if (tail && valid && !(ABL & 16)) {
+    if constexpr (!(ABL & 16)) {
       int slot01;
       const bool complete = lb_seg_complete(rb, rr, segstart, n, t, E, slot01);
-      float* dst = complete ? a.agg + (int64_t)rr * 128 : a.part + ((int64_t)t * 2 + slot01) * 128;
-      f32x4* d4 = reinterpret_cast<f32x4*>(dst) + g;
+      const uint32_t row_off = complete ? (uint32_t)rr * 512u : a.part_off + ((uint32_t)t * 2u + (uint32_t)slot01) * 512u;
+      const uint32_t off = (tail && valid) ? row_off + (uint32_t)g * 16u : 0x80000000u;  // out of range: dropped
+      typedef uint32_t u32x4b __attribute__((ext_vector_type(4)));
 #pragma unroll
-      for (int mb = 0; mb < 2 + 2 * NC; ++mb) d4[4 * mb] = y[mb];
-      if constexpr (NC == 2) {  // consumers outside this file read whole rows
-        d4[24] = f32x4{0.f, 0.f, 0.f, 0.f};
-        d4[28] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int mb = 0; mb < 8; ++mb) {
+        const f32x4 v = mb < 2 + 2 * NC ? y[mb] : f32x4{0.f, 0.f, 0.f, 0.f};  // 2D: consumers outside this file read whole rows
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4b, v), out_rs, (int)off, 64 * mb, 0);
       }
     }
     SG_STAMP(8)  // stores issued
@@ -511,7 +525,8 @@ void lb_sg_msg_image(const float* ws0, const float* wv0, const float* b0, const 
 
 int lb_sg_msg_image_floats(void) { return SGM_IMAGE * 4; }
 
-int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg, bool finish) {
+int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg, float* part, int64_t out_bytes,
+                   bool finish) {
   lb_sg_msg_args a{};
   a.ctrl = e->ctrl;
   a.senders = e->senders;
@@ -520,8 +535,11 @@ int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg,
   a.f = f;
   a.image = image;
   a.agg = agg;
-  a.part = e->part;
+  a.part = part;
   if (e->BN * 512 >= ((int64_t)1 << 32)) return lb_fail(LB_ERR_UNSUPPORTED, "segnn: more than 8 M nodes per engine");
+  if (out_bytes >= ((int64_t)1 << 31) || part < agg) return lb_fail(LB_ERR_UNSUPPORTED, "segnn: aggregate buffer beyond 2 GiB");
+  a.part_off = (uint32_t)((const char*)part - (const char*)agg);
+  a.out_bytes = (uint32_t)out_bytes;
   // no more workgroups than the frozen capacity has tiles for (B = 1: a launch is a latency chain)
   constexpr int WPS = 3;
   const int64_t tiles_cap = ((int64_t)e->e_cap * e->g.B + 15) / 16;
@@ -535,7 +553,7 @@ int lbk_sg_message(lb_engine* e, const float* f, const float* image, float* agg,
   if (finish) {  // consumers other than k_sg_upd want complete rows in agg
     const int nb = (int)((e->BN + 7) / 8);
     hipLaunchKernelGGL(k_sg_agg_finish, dim3(nb), dim3(256), 0, e->stream, e->ctrl, e->BN, e->row_ptr,
-                       e->part, agg);
+                       part, agg);
   }
   LB_HIP(hipGetLastError());
   return LB_OK;
@@ -585,7 +603,7 @@ void lb_sg_upd_image(const float* ws0, const float* wv0, const float* b0, const 
 
 int lb_sg_upd_image_floats(void) { return SGU_IMAGE * 4; }
 
-int lbk_sg_update(lb_engine* e, float* f, const float* agg, const float* nattr, const float* image,
+int lbk_sg_update(lb_engine* e, float* f, const float* agg, const float* part, const float* nattr, const float* image,
                   bool combine_partials) {
   lb_sg_upd_args a{};
   a.ctrl = e->ctrl;
@@ -595,7 +613,7 @@ int lbk_sg_update(lb_engine* e, float* f, const float* agg, const float* nattr, 
   a.nattr = nattr;
   a.image = image;
   a.row_ptr = e->row_ptr;
-  a.part = combine_partials ? e->part : nullptr;
+  a.part = combine_partials ? part : nullptr;
   const int ntiles = (int)((e->BN + 15) / 16);
   const int nb = std::min(256, (ntiles + 7) / 8);
   if (e->g.dim == 2)

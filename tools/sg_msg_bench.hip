@@ -123,8 +123,8 @@ int main(int argc, char** argv) {
   (void)hipMemcpy(def, ef.data(), E * 32, hipMemcpyHostToDevice);
   (void)hipMalloc(&f, N * 512);
   (void)hipMalloc(&f0, N * 512);
-  (void)hipMalloc(&agg, N * 512);
-  (void)hipMalloc(&part, (ntiles + 2) * 1024);
+  (void)hipMalloc(&agg, N * 512 + (ntiles + 2) * 1024);  // agg | part in one allocation (round 4: one buffer descriptor)
+  part = agg + N * 128;
   (void)hipMalloc(&nattr, N * 16);
   std::vector<float> hf((size_t)N * 128), hna((size_t)N * 4);
   for (int64_t i = 0; i < N; ++i) {
@@ -160,6 +160,8 @@ int main(int argc, char** argv) {
   ao.agg = agg; ao.part = part; ao.dim = dim;
   lb_sg_msg_args an{};
   an.ctrl = dc; an.senders = ds; an.receivers = dr; an.efeat = def; an.f = f0; an.image = img_new; an.agg = agg; an.part = part;
+  an.part_off = (uint32_t)(N * 512);
+  an.out_bytes = (uint32_t)(N * 512 + (ntiles + 2) * 1024);
   long long* dbg;
   (void)hipMalloc(&dbg, 16 * 10 * 8);
   (void)hipMemset(dbg, 0, 16 * 10 * 8);
