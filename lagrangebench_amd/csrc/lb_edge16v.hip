@@ -313,7 +313,11 @@ int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a) {
 // Two waves per SIMD, GEMM-phase priority (round 2's measured best; the software-prefetching, second-read and
 // three- / four-wave variants live on in tools/museum/lb_edge16v_r02.hip for tools/edge16v_bench).
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a) {
-  static const bool ticket = getenv("LB_EDGE_TICKET") && getenv("LB_EDGE_TICKET")[0] == '1';
+  // LDS tile tickets (round 4): default on ONE trajectory (a few tiles per wave: the faster - older - wave of a SIMD takes
+  // more of them; LDC3D-8k B = 1 0.619 -> 0.604, TGV3D-8k 0.673 -> 0.663 ms/step), off on batches (neutral: 2.606 vs 2.617 ms
+  // of edge kernels per step on TGV3D x 8 - profiles/r04_ab_edge_ticket.txt).  LB_EDGE_TICKET=0|1 pins it.
+  static const int ticket_env = getenv("LB_EDGE_TICKET") ? atoi(getenv("LB_EDGE_TICKET")) : -1;
+  const bool ticket = ticket_env >= 0 ? ticket_env != 0 : ((int64_t)e->e_cap * e->g.B + 15) / 16 < 12288;
 #define LB_E16V__(NT, G, GU, TK)                                                                        \
   do {                                                                                                  \
     if (a.skip_elat_store)                                                                              \
