@@ -28,7 +28,30 @@ SWITCHES = [
     {"LB_MS_DEC": "0"},                                   # decoder as a launch of its own also behind the M-split node kernel
     {"LB_STEP_FUSE": "0"},                                # node features / integrator as launches of their own
     {"LB_GUARD": "sampled"},                              # rounds 2-3 guard: first tile of every wave only
+    {"LB_EDGE_TICKET": "1", "LB_MSPLIT": "0"},            # LDS tile tickets in the wave-per-tile edge kernel (any size)
+    {"LB_EDGE_TICKET": "0", "LB_MSPLIT": "0"},            # ... and the static strided walk (any size)
+    {"LB_CELLS_ONE": "0", "LB_NL_ONE": "0", "LB_NL_MID": "0"},   # multi-launch cell binning also for one mid-size trajectory
 ]
+
+SEGNN_SWITCHES = [
+    {"LB_SEGNN_NODE": "0"},                               # node prep / embedding / readout / integrator as separate launches
+    {"LB_SEGNN_FUSED": "0"},                              # one kernel per tensor-product block + stand-alone segment_sum
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", SEGNN_SWITCHES, ids=[",".join(f"{k}={v}" for k, v in e.items()) for e in SEGNN_SWITCHES])
+def test_segnn_parity_subset_under_switch(env):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    sel = "(test_segnn_forward_parity and (small2d or small3d or dam2d)) or test_segnn_rollout_parity"
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_segnn.py", "-m", "gpu", "-q", "-x", "-k", sel,
+                        "-p", "no:cacheprovider"], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True,
+                       timeout=900)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-15:])
+    assert r.returncode == 0, f"{env}:\n{tail}"
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail
 
 
 @pytest.mark.gpu
