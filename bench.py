@@ -324,6 +324,7 @@ def main():
     if world == 1 and not args.no_other_configs:
         del pred, traj, handle, eng
         out["other_configs"] = other_configs(device)
+        out["train_step"] = train_step_lines(device)
     # Everything TIMED on the GPU is done.  The CPU-baseline legs run NOW, one after the other, with nothing else on the
     # host (run beside the nested rocprofv3 passes their step times spread 3x); the PMC passes follow.
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -390,6 +391,59 @@ def measure_traffic(args, timeout_s=240):
     except Exception as ex:  # measurement extra: never let it take the bench line down
         log(f"[bench] PMC traffic pass failed ({ex}); using profiles/pmc_traffic.json")
         return None
+
+
+def train_step_lines(device):
+    """SURVEY section 8 row N4, the training step (trainer.py:35-89: value_and_grad of the masked MSE over the batch +
+    optax.adamw), timed like the reference runs it: batch 1 (defaults.py train.batch_size), loss fetched every step.
+    One line per workload: ms per step, particle-steps/s, and the dense-contraction rate against the fp32 MFMA peak (the
+    training path is exact fp32: forward 1x + backward 2x the forward's GEMM flops, on rocBLAS sgemm; everything else -
+    LayerNorm, gathers and their deterministic transposes, AdamW - is hand-written HIP)."""
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    res = []
+    for workload, K in (("tgv2d", 20), ("tgv3d", 10)):
+        try:
+            ds = make_case(workload, n_trajs=1, extra_seq_length=2)
+            dim, isl = len(ds.box), ds.input_seq_length
+            model = GNS(dim, D, 2, 10, 16)
+            node_in, edge_in = gns_widths(ds)
+            params = model.init_params(1234, node_in, edge_in, decoder_scale=1.0)
+            case = hip_case(ds)
+            pos, pt = ds[0]
+            feats, _ = case.allocate_eval((pos[None, :, :isl], pt[None]))
+            eng = feats.engine
+            E = eng.stats()["n_edges_total"]
+            N = len(pt)
+            th = model.train_handle(eng, params)
+            target = torch.randn((1, N, dim), generator=torch.Generator().manual_seed(5)).to(device)
+            for _ in range(3):
+                th.zero_grad()
+                th.loss_grad(target, 1.0)
+                th.adamw_step(1e-4)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(K):
+                th.zero_grad()
+                loss = th.loss_grad(target, 1.0)
+                th.adamw_step(1e-4)
+            torch.cuda.synchronize(device)
+            dt = (time.perf_counter() - t0) / K
+            fwd = 10 * (E * 2 * (3 * D * D + D * D) + N * 2 * (2 * D * D + D * D)) + E * 2 * (8 * D + D * D) \
+                + N * 2 * (eng.node_in + 16 + D) * D + N * 2 * (D * D + D * dim)
+            tf = 3 * fwd / dt / 1e12
+            res.append({"workload": f"{workload} GNS-10-128 training step (B = 1)", "n_particles": int(N), "edges": int(E),
+                        "steps": K, "ms_per_step": 1e3 * dt, "value": N / dt, "unit": "particle-steps/s",
+                        "loss": float(loss), "dtype": "f32",
+                        "roofline": {"kernel": "rocBLAS sgemm (Y = XW, dX = dY W^T, dW += X^T dY)", "bound": "mfma",
+                                     "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                                     "flop_per_step": int(3 * fwd),
+                                     "note": "whole-step rate (GEMMs + everything else) against the fp32 MFMA peak"}})
+            th.close()
+            del eng, feats
+        except Exception as exc:
+            res.append({"workload": workload, "error": repr(exc)[:200]})
+    return res
 
 
 def other_configs(device):

@@ -29,6 +29,8 @@
 
 #include "lb_device.h"
 
+#include <hipcub/hipcub.hpp>  // header-only device radix sort (the sender-sorted edge permutation of the gather's transpose)
+
 #define TD 128  // latent width of the training path (GNS-*-128)
 
 struct lb_train_mlp {
@@ -59,7 +61,14 @@ struct lb_gns_train {
   float* colsum = nullptr;   // partial column sums [blocks][<=128]
   float* node_w = nullptr;   // per node loss weight (0 for kinematic particles)
   double* loss_dev = nullptr;
+  double* loss_part = nullptr;  // one partial per wave of k_mse_grad
   int32_t* cnt_dev = nullptr;  // non-kinematic particles per trajectory
+  // sender-sorted view of the edge list (round 4): the transpose of the [n_s | n_r | e] gather sums, per node, the
+  // gradient rows of the edges it SENDS - in ascending edge order, no atomics, bit-reproducible
+  int32_t *snd_key = nullptr, *snd_perm = nullptr, *iota = nullptr, *snd_key_in = nullptr, *snd_ptr = nullptr;
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  int64_t sort_cap = 0;
 };
 
 static const char* blas_err(rocblas_status s) { return rocblas_status_to_string(s); }
@@ -163,21 +172,49 @@ __global__ void k_gather_edge_in(const float* __restrict__ n, const float* __res
                             : reinterpret_cast<const f32x4*>(el) + e * 32 + (q - 64);
   reinterpret_cast<f32x4*>(xe)[i] = *src;
 }
-// transpose of the gather: dn[snd] += dxe[:, :128] (atomics), dn[rcv] += dxe[:, 128:256] (atomics), de += dxe[:, 256:]
-__global__ void k_scatter_edge_in(const float* __restrict__ dxe, const int32_t* __restrict__ snd,
-                                  const int32_t* __restrict__ rcv, float* __restrict__ dn, float* __restrict__ de,
-                                  int64_t E) {
+// transpose of the gather [n_s | n_r | e] (round 4: deterministic - round 3 used fp32 atomics on dn):
+//   dn[i] += sum over the edges i SENDS  of dxe[e][0:128]     (sender-sorted permutation, ascending edge index)
+//          + sum over the edges i RECEIVES of dxe[e][128:256]  (its CSR row)
+//   de[e] += dxe[e][256:384]
+// one 32-lane group per node, lane q owns the 16-byte chunk q of the 128-wide row
+__global__ void k_scatter_nodes(const float* __restrict__ dxe, const int32_t* __restrict__ snd_ptr,
+                                const int32_t* __restrict__ snd_perm, const int32_t* __restrict__ row_ptr,
+                                float* __restrict__ dn, int64_t N, int64_t E) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= E * 384) return;
-  const int64_t e = i / 384;
-  const int c = (int)(i % 384);
-  const float x = dxe[i];
-  if (c < 128)
-    atomicAdd(&dn[(int64_t)snd[e] * TD + c], x);
-  else if (c < 256)
-    atomicAdd(&dn[(int64_t)rcv[e] * TD + (c - 128)], x);
-  else
-    de[e * TD + (c - 256)] += x;
+  if (i >= N * 32) return;
+  const int64_t r = i / 32;
+  const int q = (int)(i % 32);
+  f32x4 acc = reinterpret_cast<const f32x4*>(dn)[i];
+  const int s0 = snd_ptr[r], s1 = snd_ptr[r + 1];
+  for (int j = s0; j < s1; ++j) acc = acc + reinterpret_cast<const f32x4*>(dxe)[(int64_t)snd_perm[j] * 96 + q];
+  int k0 = row_ptr[r], k1 = row_ptr[r + 1];
+  k0 = k0 < E ? k0 : (int)E;
+  k1 = k1 < E ? k1 : (int)E;
+  for (int k = k0; k < k1; ++k) acc = acc + reinterpret_cast<const f32x4*>(dxe)[(int64_t)k * 96 + 32 + q];
+  reinterpret_cast<f32x4*>(dn)[i] = acc;
+}
+__global__ void k_scatter_edges(const float* __restrict__ dxe, float* __restrict__ de, int64_t E) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E * 32) return;
+  const int64_t e = i / 32;
+  const int q = (int)(i % 32);
+  f32x4* d = reinterpret_cast<f32x4*>(de) + i;
+  *d = *d + reinterpret_cast<const f32x4*>(dxe)[e * 96 + 64 + q];
+}
+__global__ void k_iota(int32_t* __restrict__ x, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = (int32_t)i;
+}
+// snd_ptr[s] = first position of key >= s in the sorted sender keys (lower bound), s = 0 .. N
+__global__ void k_lower_bounds(const int32_t* __restrict__ keys, int64_t E, int64_t N, int32_t* __restrict__ ptr) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > N) return;
+  int64_t lo = 0, hi = E;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < (int32_t)s) lo = mid + 1; else hi = mid;
+  }
+  ptr[s] = (int32_t)lo;
 }
 // xn[i] = [n[i] | agg[i]]
 __global__ void k_concat_node_in(const float* __restrict__ n, const float* __restrict__ agg, float* __restrict__ xn,
@@ -250,7 +287,7 @@ __global__ void k_node_weight(const int32_t* __restrict__ ptype, const int32_t* 
 // loss = (1/B) sum_i w_i * lw * sum_d (pred - target)^2 ; dpred = 2 lw w_i (pred - target)   (gradients SUMMED over b)
 __global__ void k_mse_grad(const float* __restrict__ pred, const float* __restrict__ target,
                            const float* __restrict__ nw, int64_t BN, int dim, float lw, float inv_b,
-                           float* __restrict__ dpred, double* __restrict__ loss) {
+                           float* __restrict__ dpred, double* __restrict__ loss_part) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double l = 0.0;
   if (i < BN) {
@@ -262,18 +299,37 @@ __global__ void k_mse_grad(const float* __restrict__ pred, const float* __restri
     }
   }
   for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
-  if ((threadIdx.x & 63) == 0 && l != 0.0) atomicAdd(loss, l * (double)inv_b);
+  // (round 4: per-wave partials summed in index order by k_loss_finish - the reported loss is bit-reproducible too)
+  if ((threadIdx.x & 63) == 0) loss_part[((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6] = l * (double)inv_b;
 }
-// d embed[type] += sum over nodes of that type of dxnode[:, col0 : col0 + emb]
-__global__ void k_embed_grad(const float* __restrict__ dx, int ld, int col0, int emb, const int32_t* __restrict__ ptype,
-                             int ntypes, int64_t BN, float* __restrict__ gembed) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= BN * emb) return;
-  const int64_t r = i / emb;
-  const int c = (int)(i % emb);
-  int pt = ptype[r];
-  if (pt < 0) pt += ntypes;  // hk.Embed wraps negative ids (padding type -1 -> row 8)
-  atomicAdd(&gembed[(int64_t)pt * emb + c], dx[r * ld + col0 + c]);
+__global__ void k_loss_finish(const double* __restrict__ part, int64_t n, double* __restrict__ loss) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int64_t i = 0; i < n; ++i) s += part[i];
+  *loss += s;
+}
+// d embed[type] += sum over nodes of that type of dxnode[:, col0 : col0 + emb].  Deterministic (round 4; round 3 used fp32
+// atomics): one 256-thread block per type, thread (c, slice) sums column c over the nodes r = slice, slice + S, .. of that
+// type in index order, the S = 256 / emb slice sums are added in slice order.
+__global__ void __launch_bounds__(256) k_embed_grad(const float* __restrict__ dx, int ld, int col0, int emb,
+                                                     const int32_t* __restrict__ ptype, int ntypes, int64_t BN,
+                                                     float* __restrict__ gembed) {
+  __shared__ float s_part[256];
+  const int type = blockIdx.x, c = threadIdx.x % emb, slice = threadIdx.x / emb, S = 256 / emb;
+  float acc = 0.f;
+  if (slice < S)
+    for (int64_t r = slice; r < BN; r += S) {
+      int pt = ptype[r];
+      if (pt < 0) pt += ntypes;  // hk.Embed wraps negative ids (padding type -1 -> row 8)
+      if (pt == type) acc += dx[r * ld + col0 + c];
+    }
+  s_part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < emb) {
+    float t = 0.f;
+    for (int k = 0; k < S; ++k) t += s_part[k * emb + threadIdx.x];
+    gembed[(int64_t)type * emb + threadIdx.x] += t;
+  }
 }
 // optax.adamw(lr, b1, b2, eps, weight_decay): m, v moments, bias correction, decoupled decay (trainer.py:189-193)
 __global__ void k_adamw(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
@@ -404,6 +460,7 @@ static int train_ensure(lb_gns_train* t, int64_t BN, int64_t E) {
   LB_TRY(tr_alloc(&t->agg, (size_t)cn * TD));
   LB_TRY(tr_alloc(&t->colsum, (size_t)(cm / 1024 + 2) * 128));
   LB_TRY(tr_alloc(&t->node_w, (size_t)cn));
+  LB_TRY(tr_alloc(&t->loss_part, (size_t)(cn / 64 + 8)));
   t->cap_n = cn;
   t->cap_e = ce;
   return LB_OK;
@@ -482,7 +539,7 @@ extern "C" void lb_gns_train_destroy(lb_gns_train* t) {
   if (t->blas) (void)rocblas_destroy_handle(t->blas);
   std::vector<void*> bufs = {t->w, t->g, t->m, t->v, t->xnode, t->a_en, t->z_en, t->a_ee, t->z_ee, t->a_d, t->pred,
                              t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->colsum, t->node_w,
-                             t->loss_dev, t->cnt_dev};
+                             t->loss_dev, t->loss_part, t->cnt_dev, t->snd_key, t->snd_perm, t->iota, t->snd_ptr, t->sort_tmp};
   for (auto* v : {&t->nlat, &t->elat, &t->xe, &t->ae, &t->ze, &t->xn, &t->an, &t->zn})
     for (float* p : *v) bufs.push_back(p);
   for (void* b : bufs)
@@ -538,7 +595,31 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
   hipLaunchKernelGGL(k_count_nonkin, GRID1(BN), 0, s, e->ptype, BN, e->g.N, t->cnt_dev);
   hipLaunchKernelGGL(k_node_weight, GRID1(BN), 0, s, e->ptype, t->cnt_dev, BN, e->g.N, t->node_w);
   hipLaunchKernelGGL(k_mse_grad, GRID1(BN), 0, s, t->pred, target_dev, t->node_w, BN, dim, loss_weight, 1.0f / (float)e->g.B,
-                     t->dy, t->loss_dev);
+                     t->dy, t->loss_part);
+  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, s, t->loss_part, (int64_t)((BN + 255) / 256) * 4, t->loss_dev);
+  // ---- sender-sorted view of this step's edge list (stable radix sort of (sender, edge index): ascending edges per sender)
+  if (E) {
+    if (E > t->sort_cap || BN + 1 > t->sort_cap) {
+      LB_HIP(hipStreamSynchronize(s));
+      for (void* b : {(void*)t->snd_key, (void*)t->snd_perm, (void*)t->iota, (void*)t->snd_ptr, t->sort_tmp})
+        if (b) (void)hipFree(b);
+      t->snd_key = t->snd_perm = t->iota = t->snd_ptr = nullptr;
+      t->sort_tmp = nullptr;
+      t->sort_cap = std::max<int64_t>(E + E / 8 + 1024, BN + 2);
+      LB_HIP(hipMalloc((void**)&t->snd_key, sizeof(int32_t) * t->sort_cap));
+      LB_HIP(hipMalloc((void**)&t->snd_perm, sizeof(int32_t) * t->sort_cap));
+      LB_HIP(hipMalloc((void**)&t->iota, sizeof(int32_t) * t->sort_cap));
+      LB_HIP(hipMalloc((void**)&t->snd_ptr, sizeof(int32_t) * t->sort_cap));
+      hipLaunchKernelGGL(k_iota, GRID1(t->sort_cap), 0, s, t->iota, t->sort_cap);
+      t->sort_tmp_bytes = 0;
+      LB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, t->sort_tmp_bytes, e->senders, t->snd_key, t->iota, t->snd_perm,
+                                                (int)t->sort_cap, 0, 32, s));
+      LB_HIP(hipMalloc(&t->sort_tmp, t->sort_tmp_bytes));
+    }
+    size_t bytes = t->sort_tmp_bytes;
+    LB_HIP(hipcub::DeviceRadixSort::SortPairs(t->sort_tmp, bytes, e->senders, t->snd_key, t->iota, t->snd_perm, (int)E, 0, 32, s));
+    hipLaunchKernelGGL(k_lower_bounds, GRID1(BN + 1), 0, s, t->snd_key, E, BN, t->snd_ptr);
+  }
   // ---- backward
   LB_TRY(mlp_bwd(t, t->dec, BN, t->nlat[L], TD, t->a_d, nullptr, t->dy, t->dn));  // dn = d loss / d n_L
   LB_HIP(hipMemsetAsync(t->de, 0, sizeof(float) * std::max<int64_t>(E, 1) * TD, s));  // e_L has no reader
@@ -549,13 +630,16 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
     // edge block: e' feeds agg (gather of dagg over receivers) and e_{k+1} = e_k + e' (de)
     if (E) hipLaunchKernelGGL(k_seg_sum_bwd, GRID1(E * 32), 0, s, t->de, t->dagg, e->receivers, t->dy, E);
     LB_TRY(mlp_bwd(t, t->pe[k], E, t->xe[k], 3 * TD, t->ae[k], t->ze[k], t->dy, t->dx));
-    if (E) hipLaunchKernelGGL(k_scatter_edge_in, GRID1(E * 384), 0, s, t->dx, e->senders, e->receivers, t->dn, t->de, E);
+    if (E) {
+      hipLaunchKernelGGL(k_scatter_nodes, GRID1(BN * 32), 0, s, t->dx, t->snd_ptr, t->snd_perm, e->row_ptr, t->dn, BN, E);
+      hipLaunchKernelGGL(k_scatter_edges, GRID1(E * 32), 0, s, t->dx, t->de, E);
+    }
   }
   LB_TRY(mlp_bwd(t, t->enc_edge, E, e->efeat, 8, t->a_ee, t->z_ee, t->de, nullptr));
   LB_TRY(mlp_bwd(t, t->enc_node, BN, t->xnode, t->kpad, t->a_en, t->z_en, t->dn, has_emb ? t->dx : nullptr));
   if (has_emb)
-    hipLaunchKernelGGL(k_embed_grad, GRID1(BN * emb), 0, s, t->dx, t->kpad, t->desc.node_in, emb, e->ptype,
-                       t->desc.num_particle_types, BN, t->g + t->off_embed);
+    hipLaunchKernelGGL(k_embed_grad, dim3(t->desc.num_particle_types), dim3(256), 0, s, t->dx, t->kpad, t->desc.node_in, emb,
+                       e->ptype, t->desc.num_particle_types, BN, t->g + t->off_embed);
   LB_HIP(hipGetLastError());
   if (loss_out) {
     LB_HIP(hipMemcpyAsync(loss_out, t->loss_dev, sizeof(double), hipMemcpyDeviceToHost, s));

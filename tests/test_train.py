@@ -177,7 +177,14 @@ def test_hip_gradients_match_torch_autograd(name, scale, L, B):
     th = model.train_handle(eng, params)
     th.zero_grad()
     loss_h, pred_h = th.loss_grad(target, 1.0, want_pred=True)
-    g_h = model.unflatten(th.read("grads"), params)
+    g_flat = th.read("grads")
+    g_h = model.unflatten(g_flat, params)
+    # round 4: no floating-point atomics in the training step (sender-sorted gather transpose, ordered loss / embedding
+    # sums): loss and every gradient are bit-reproducible
+    for _ in range(3):
+        th.zero_grad()
+        loss_2, _ = th.loss_grad(target, 1.0, want_pred=True)
+        assert loss_2 == loss_h and np.array_equal(th.read("grads"), g_flat)
 
     feats.materialize()
     dev = eng.device
