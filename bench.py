@@ -117,6 +117,7 @@ def main():
         print(json.dumps({w: cpu_baseline_leg(w, args.mp_steps) for w in args.cpu_baseline_only.split(",")}), flush=True)
         return
 
+    t_start = time.perf_counter()
     from lagrangebench_amd import dist as lbdist
     rank, local_rank, world = lbdist.init()
     cpu_jobs = None
@@ -321,16 +322,20 @@ def main():
             out["f32_exact"] = {"error": repr(exc)[:200]}
         finally:
             eng.math_mode(1)
+    log(f"[bench] headline + f32 sub-run done at {time.perf_counter() - t_start:.1f} s")
     if world == 1 and not args.no_other_configs:
         del pred, traj, handle, eng
         out["other_configs"] = other_configs(device)
+        log(f"[bench] other_configs done at {time.perf_counter() - t_start:.1f} s")
         out["train_step"] = train_step_lines(device)
+        log(f"[bench] train_step done at {time.perf_counter() - t_start:.1f} s")
     # Everything TIMED on the GPU is done.  The CPU-baseline legs run NOW, one after the other, with nothing else on the
     # host (run beside the nested rocprofv3 passes their step times spread 3x); the PMC passes follow.
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_jobs = cpu_baseline_start(args)
         out["cpu_baseline"] = cpu_baseline_collect(cpu_jobs)
         cpu_jobs = None
+        log(f"[bench] cpu_baseline done at {time.perf_counter() - t_start:.1f} s")
     # roofline.traffic measured by THIS run: two nested rocprofv3 passes of the same command (FETCH_SIZE, WRITE_SIZE:
     # the counters do not fit one pass; --kernel-trace + --pmc only), after the timed region; any failure or a
     # missing rocprofv3 falls back to the committed table above
@@ -345,6 +350,8 @@ def main():
                                              "WRITE_SIZE passes (separate), (2*FETCH + WRITE) * 1 KiB per launch")
     if cpu_jobs is not None:
         out["cpu_baseline"] = cpu_baseline_collect(cpu_jobs)
+    out["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
+    log(f"[bench] done at {out['bench_wall_s']} s")
     print(json.dumps(out), flush=True)
 
 
@@ -402,7 +409,7 @@ def train_step_lines(device):
     from lagrangebench_amd.data import make_case
     from lagrangebench_amd.models import GNS
     res = []
-    for workload, K in (("tgv2d", 20), ("tgv3d", 10)):
+    for workload, K in (("tgv2d", 10), ("tgv3d", 5)):
         try:
             ds = make_case(workload, n_trajs=1, extra_seq_length=2)
             dim, isl = len(ds.box), ds.input_seq_length
@@ -417,7 +424,7 @@ def train_step_lines(device):
             N = len(pt)
             th = model.train_handle(eng, params)
             target = torch.randn((1, N, dim), generator=torch.Generator().manual_seed(5)).to(device)
-            for _ in range(3):
+            for _ in range(2):
                 th.zero_grad()
                 th.loss_grad(target, 1.0)
                 th.adamw_step(1e-4)

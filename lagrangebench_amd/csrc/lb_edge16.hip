@@ -200,7 +200,7 @@ __device__ __forceinline__ void lb_gemm16(LD ld, const f32x4 (&v)[NMBK], f32x4 (
   }
 }
 
-// ABL (tools/edge_bench.hip only, 0 in the product): 1 no Ps/Pr gather, 2 no e load, 4 no stores,
+// ABL (ablation harnesses only, 0 in the product): 1 no Ps/Pr gather, 2 no e load, 4 no stores,
 // 8 no LayerNorm, 16 no GEMM2, 32 no GEMM1, 64 no segmented scan.
 template <bool PROC, bool F16, int ABL = 0>
 __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(E16_THREADS, 2) k_edge16(lb_edge16_args a) {
 
 // The fall-back launcher: exact fp32 (LB_MATH=f32 / the range guard's switch), the encoder in fp32, and the f16x2
 // processor with STAND-ALONE aggregation (messages written for k_segment_sum).  The fused f16x2 processor runs on
-// lb_edge16v.hip / lb_msplit.hip; round 1's three-wave k_edge16n is kept in tools/museum/lb_edge16_r01.hip.
+// lb_edge16v.hip / lb_msplit.hip; round 1's three-wave k_edge16n is gone from the tree (round 4; profiles/r01_* have its numbers).
 int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc, bool f16x2) {
   if (proc && f16x2)
     hipLaunchKernelGGL((k_edge16<true, true>), dim3(256), dim3(E16_THREADS), 0, e->stream, a);

@@ -26,7 +26,7 @@
 
 #include "lb_f16x2.h"
 
-// ABL (tools/edge16v_bench.hip only, 0 in the product): 1 no psr gathers, 2 no edge-latent loads,
+// ABL (tools/edge_ab.hip only, 0 in the product): 1 no psr gathers, 2 no edge-latent loads,
 // 4 no stores, 8 no GEMMs, 16 no LayerNorm / scan (epilogue VALU).
 // SKIP: last processor layer - the updated edge latents have no reader (compile-time so that the
 // residual path is branch-free: a store under a branch costs a vmcnt(0) drain at the join).
@@ -311,7 +311,7 @@ int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a) {
 }
 
 // Two waves per SIMD, GEMM-phase priority (round 2's measured best; the software-prefetching, second-read and
-// three- / four-wave variants live on in tools/museum/lb_edge16v_r02.hip for tools/edge16v_bench).
+// three- / four-wave variants were measured in round 2 - profiles/r02_edge16v_bench.txt - and are gone from the tree).
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a) {
   // LDS tile tickets (round 4): default on ONE trajectory (a few tiles per wave: the faster - older - wave of a SIMD takes
   // more of them; LDC3D-8k B = 1 0.619 -> 0.604, TGV3D-8k 0.673 -> 0.663 ms/step), off on batches (neutral: 2.606 vs 2.617 ms
