@@ -136,10 +136,10 @@ __global__ void __launch_bounds__(WPS * 256, WPS) k_edge16v(lb_edge16_args a) {
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb) {
         // streamed once per layer: nontemporal unless the RELOAD variant wants the tile back from L2
-        ve[mb] = (ABL & 2) ? f32x4{1.f, 2.f, (float)t, (float)mb}
+        ve[mb] = (ABL & 2) ? f32x4{1.f, 2.f, (float)(t & 1023), (float)mb}
                            : ((RELOAD || !NT) ? er[64 * mb] : __builtin_nontemporal_load(&er[64 * mb]));
-        p0[mb] = (ABL & 1) ? f32x4{.1f, .2f, (float)s_c, (float)mb} : ps[4 * mb];
-        acc[mb] = (ABL & 1) ? f32x4{.3f, .1f, (float)r_c, (float)mb} : pr[4 * mb];
+        p0[mb] = (ABL & 1) ? f32x4{.1f, .2f, (float)(s_c & 255), (float)mb} : ps[4 * mb];
+        acc[mb] = (ABL & 1) ? f32x4{.3f, .1f, (float)(r_c & 255), (float)mb} : pr[4 * mb];
       }
       const int64_t rn = rowc_of(min(t_next, t_last));
       s_c = a.senders[rn];

@@ -81,6 +81,11 @@ int main(int argc, char** argv) {
     std::vector<float> hw(32768), packed(32768), hv(512);
     for (auto& x : hw) x = (rand() % 2001 - 1000) * 1e-4f;
     for (auto& x : hv) x = 0.5f + (rand() % 1001) * 1e-3f;
+    // LayerNorm scale 1e-3, offset 0: the latents are updated IN PLACE, e += LayerNorm(..), and with an O(1) increment per
+    // launch they leave the fp16 range within a measurement - every wave's range probe then raises the LARGE flag with a
+    // same-address atomic and the launch reads 350 us instead of 250 (the flags are printed per line: they must read 0)
+    for (int i = 128; i < 256; ++i) hv[i] *= 1e-3f;
+    for (int i = 256; i < 384; ++i) hv[i] = 0.f;
     lb_pack_weight16h(hw.data(), 128, 128, 128, packed.data(), 128);
     lb_pack_weight16h(hw.data() + 16384, 128, 128, 128, packed.data() + 16384, 128);
     (void)hipMemcpy(w, packed.data(), 2 * 65536, hipMemcpyHostToDevice);
@@ -109,8 +114,12 @@ int main(int argc, char** argv) {
   (void)hipMemcpy(b.elat, b.elat0, (E + 32) * 512, hipMemcpyDeviceToDevice);
   auto report = [&](const char* name, auto launch) {
     (void)hipMemcpy(b.elat, b.elat0, (E + 32) * 512, hipMemcpyDeviceToDevice);
+    (void)hipMemcpy(dc, &c, sizeof(c), hipMemcpyHostToDevice);  // range-guard flags cleared
     const float us = time_it(launch, iters);
-    printf("%-64s %8.1f us  %5.2f TB/s  frac(8TB/s) %.3f\n", name, us, bytes / us * 1e-6, bytes / us * 1e-6 / 8.0);
+    lb_ctrl cc{};
+    (void)hipMemcpy(&cc, dc, sizeof(cc), hipMemcpyDeviceToHost);
+    printf("%-64s %8.1f us  %5.2f TB/s  frac(8TB/s) %.3f  guard flags %d\n", name, us, bytes / us * 1e-6, bytes / us * 1e-6 / 8.0,
+           cc.math_flags);
     fflush(stdout);
   };
   printf("LB_GEMM_INTERLEAVE=%d\n", (int)LB_GEMM_INTERLEAVE);
@@ -134,6 +143,16 @@ int main(int argc, char** argv) {
   report("  no GEMMs (memory + VALU)", K(false, 8, 1));
   report("  no LayerNorm / scan", K(false, 16, 1));
   report("k_edge16v product (guard rows) AGAIN", K(false, 0, 1));
+  {  // out of place: the latents do not evolve from launch to launch
+    static float* other = nullptr;
+    if (!other) (void)hipMalloc(&other, (E + 32) * 512);
+    a.elat_out = other;
+    report("k_edge16v product, out of place", K(false, 0, 1));
+    a.elat_out = nullptr;
+  }
+#define K3(SKIP, ABL, G) [&] { hipLaunchKernelGGL((k_edge16v<3, false, SKIP, ABL, true, true, G, false>), dim3(256), dim3(768), 0, 0, a); }
+  report("k_edge16v 3 waves per SIMD", K3(false, 0, 1));
+  report("  3 waves, compute only", K3(false, 7, 1));
   }
   return 0;
 }
