@@ -6,15 +6,18 @@
 // (_update: vmap(value_and_grad) over the batch, gradients SUMMED over the batch, loss averaged, optax.adamw);
 // the network is GNS.__call__ of models/gns.py:65-171 (haiku MLP / LayerNorm / Embed, jraph GraphNetwork).
 //
-// Design.  Training is the row next to the hot path, not the hot path: the step is built from plain dense
-// contractions - which go to rocBLAS sgemm (exact fp32; the prompt's rule: library GEMMs for plain GEMMs) - and
-// hand-written HIP kernels for everything that is not a GEMM: gather / concatenation of [n_s | n_r | e] and
-// [n | agg], bias + ReLU, LayerNorm forward and backward (two-pass statistics, one wave per 2 rows), ReLU masking,
-// column sums (bias / LayerNorm parameter gradients) with a two-level deterministic reduction, jraph.segment_sum
-// and its transpose on the receiver-sorted CSR, the sender-side scatter (fp32 atomics: the only non-deterministic
-// summation, as in the reference's XLA scatter), the embedding-table gradient, the masked MSE and its gradient,
-// AdamW over the flat parameter blob.  A batch of B trajectories is one disjoint graph: the per-trajectory losses
-// of _update (gradients summed, loss averaged) are obtained in one pass with a per-node weight 1 / n_nonkinematic(b).
+// Design.  Training is the row next to the hot path, not the hot path.  The two tall-skinny products of every Linear -
+// Y = X W and dX = dY W^T, ~1e5 rows against a <= 384 x 128 matrix - are plain GEMMs and go to rocBLAS sgemm (exact fp32;
+// the library runs them at ~100 TFLOP/s, 65 % of the fp32 MFMA peak).  The THIRD product, dW += X^T dY, is a reduction over
+// ~1e5 rows into a tiny result, which the library ran at 16 TFLOP/s: it is hand-written (k_dw_part: fp32 MFMA, split over
+// the rows, bias column sums folded in, partials combined in a fixed order - 95 TFLOP/s on the 384 x 128 case).
+// Hand-written HIP for everything that is not a GEMM: gather / concatenation of [n_s | n_r | e] and [n | agg], bias + ReLU,
+// LayerNorm forward and backward (the backward keeps the running sums of d scale / d offset in registers, no scratch copy),
+// ReLU masking, jraph.segment_sum and its transpose on the receiver-sorted CSR, the sender-side transpose of the gather
+// through a sender-sorted permutation (stable radix sort: ascending edge order per sender, no atomics), the embedding-table
+// gradient, the masked MSE and its gradient, AdamW over the flat parameter blob.  Every floating-point sum has a fixed
+// order: two runs of a step produce the same bits.  A batch of B trajectories is one disjoint graph: the per-trajectory
+// losses of _update (gradients summed, loss averaged) are obtained in one pass with a per-node weight 1 / n_nonkinematic(b).
 // The graph (receiver-sorted edge list), node / edge features and normalisation are the engine's: the caller runs
 // case.preprocess (noise, neighbor list, features, targets) first, exactly as for inference.
 // Weights live in fp32 in the layout of GNS.flatten (= lb_gns_create's blob): [embed] then per MLP w0 (in x 128),
@@ -58,7 +61,8 @@ struct lb_gns_train {
   float *a_d = nullptr, *pred = nullptr;
   float *dn = nullptr, *de = nullptr, *dy = nullptr, *dz = nullptr, *da = nullptr, *dx = nullptr, *dagg = nullptr;
   float* agg = nullptr;
-  float* colsum = nullptr;   // partial column sums [blocks][<=128]
+  float* colsum = nullptr;   // partial column sums [blocks][<=256]
+  float* dwpart = nullptr;   // k_dw_part partials [DW_MAX_G][385][128]
   float* node_w = nullptr;   // per node loss weight (0 for kinematic particles)
   double* loss_dev = nullptr;
   double* loss_part = nullptr;  // one partial per wave of k_mse_grad
@@ -143,11 +147,11 @@ __global__ void k_relu_bwd(float* __restrict__ da, const float* __restrict__ a, 
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && !(a[i] > 0.f)) da[i] = 0.f;
 }
-// column sums of x (rows x cols, cols <= 128): deterministic two-level reduction (fixed row blocks of 1024 rows)
+// column sums of x (rows x cols, cols <= 128): deterministic two-level reduction (fixed row blocks of 128 rows)
 __global__ void k_colsum_part(const float* __restrict__ x, int64_t rows, int cols, int ld, float* __restrict__ part) {
   const int c = threadIdx.x;
   if (c >= cols) return;
-  const int64_t r0 = (int64_t)blockIdx.x * 1024, r1 = r0 + 1024 < rows ? r0 + 1024 : rows;
+  const int64_t r0 = (int64_t)blockIdx.x * 128, r1 = r0 + 128 < rows ? r0 + 128 : rows;
   float s = 0.f;
   for (int64_t r = r0; r < r1; ++r) s += x[r * ld + c];
   part[(int64_t)blockIdx.x * 128 + c] = s;
@@ -158,6 +162,182 @@ __global__ void k_colsum_fin(const float* __restrict__ part, int nblocks, int co
   float s = 0.f;
   for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * 128 + c];
   out[c] += s;
+}
+// ---- weight gradient (round 4): dW[K x 128] += X^T dY and db[128] += column sums of dY, without the library.
+// rocBLAS ran this contraction - reduction over ~1e5 rows into a 384 x 128 result - at 16 TFLOP/s (660 us per call, 29 %
+// of a TGV3D training step) and the bias sums went through a 128-thread serial loop (another 50 %).  Split over the ROWS:
+// workgroup g owns a contiguous chunk of rows and forms its partial X^T dY on v_mfma_f32_16x16x4_f32 (exact fp32 products,
+// fp32 accumulate); a reduction step is 4 rows (lane (i, kk) works on row r0 + kk).  Wave w = (mh, kq): column half mh
+// (64 columns of dY) x quarter kq of K (32 NA columns of X, NA = ceil(K / 128)).  Operands come straight from global memory
+// with WIDE loads and the MFMA index maps are permuted to fit them: a lane's one 16-byte load of dY[r][64 mh + 4 i .. + 3]
+// is the B operand of FOUR column tiles (tile q holds the columns 64 mh + 4 i + q), its 8-byte load of
+// X[r][c0 + 32 a + 2 i .. + 1] the A operand of TWO row tiles (tile (a, j): rows c0 + 32 a + 2 i + j) - 1 + NA loads per
+// 8 NA MFMAs (a first version with one dword per operand and MFMA ran at 61 TFLOP/s, load-issue bound).  The column sums
+// of dY are the running sums of the B values.  Partials go to part[g][K + 1][128] and are summed over g in ascending order
+// by k_part_reduce: bit-reproducible, no atomics.
+template <int NA>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_dw_part(const float* __restrict__ X, int ldx, int K, const float* __restrict__ dY,
+                                                  int64_t rows, int64_t chunk, float* __restrict__ part) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int mh = w & 1, kq = w >> 1;
+  const int c0 = kq * 32 * NA;
+  const int64_t r_begin = (int64_t)blockIdx.x * chunk, r_end = r_begin + chunk < rows ? r_begin + chunk : rows;
+  f32x4 acc[NA][2][4];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[a][j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+  bool kok[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) kok[a] = c0 + 32 * a + 2 * i < K;  // (K is even: 8, a multiple of 32, ...)
+  // software pipeline: the operands of DEPTH reduction steps are in flight (the compiler does not hoist the loads of an
+  // unrolled loop above the MFMAs of the previous steps; gfx9 returns loads in order, so consuming the oldest slot waits
+  // for exactly that slot)
+  constexpr int DEPTH = NA == 3 ? 4 : 6;
+  f32x4 bq[DEPTH];
+  f32x2 aq[DEPTH][NA];
+  auto fetch = [&](int64_t r0, f32x4& b, f32x2 (&av)[NA]) {
+    const int64_t r = r0 + kk;
+    const bool ok = r < r_end;
+    b = ok ? *reinterpret_cast<const f32x4*>(dY + r * 128 + 64 * mh + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+      av[a] = (ok && kok[a]) ? *reinterpret_cast<const f32x2*>(X + r * ldx + c0 + 32 * a + 2 * i) : f32x2{0.f, 0.f};
+  };
+  if (c0 < K || kq == 0) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) fetch(r_begin + 4 * d, bq[d], aq[d]);
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 4 * DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const f32x4 b = bq[d];
+        f32x2 av[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) av[a] = aq[d][a];
+        fetch(r0 + 4 * (d + DEPTH), bq[d], aq[d]);
+        bs = bs + b;
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[a][j][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], b[q], acc[a][j][q], 0, 0, 0);
+      }
+    }
+  }
+  // D layout: element jj of the tile of lane (i, kk) is (tile row 4 kk + jj, tile column i):
+  //   dW row = c0 + 32 a + 2 (4 kk + jj) + j, column = 64 mh + 4 i + q
+  float* out = part + (int64_t)blockIdx.x * (K + 1) * 128;
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int row = c0 + 32 * a + 2 * (4 * kk + jj) + j;
+        if (row < K)
+          *reinterpret_cast<f32x4*>(out + row * 128 + 64 * mh + 4 * i) =
+              f32x4{acc[a][j][0][jj], acc[a][j][1][jj], acc[a][j][2][jj], acc[a][j][3][jj]};
+      }
+  if (kq == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = bs[q];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      bs[q] = v;
+    }
+    if (kk == 0) *reinterpret_cast<f32x4*>(out + K * 128 + 64 * mh + 4 * i) = bs;
+  }
+}
+// Ordered sum of partials: out e < n0: dst0[e] += sum_g part[g * stride + e]; n0 <= e < n0 + n1: dst1[e - n0] += sum_g
+// part[g * stride + off1 + e - n0].  A 1024-thread block owns 64 outputs x 16 ranges of g (four loads in flight per thread,
+// added in ascending g), the 16 range sums are combined in range order through LDS: the result does not depend on timing.
+__global__ void __launch_bounds__(1024) k_part_reduce(const float* __restrict__ part, int G, int64_t stride, int n0, int n1,
+                                                      int off1, float* __restrict__ dst0, float* __restrict__ dst1) {
+  __shared__ float s_red[16][64];
+  const int c = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + c;
+  const bool ok = e < n0 + n1;
+  const int64_t src = e < n0 ? e : (int64_t)off1 + (e - n0);
+  const int per = (G + 15) / 16, g0 = seg * per, g1 = g0 + per < G ? g0 + per : G;
+  float s = 0.f;
+  if (ok) {
+    int g = g0;
+    for (; g + 4 <= g1; g += 4) {
+      const float v0 = part[(int64_t)g * stride + src], v1 = part[(int64_t)(g + 1) * stride + src];
+      const float v2 = part[(int64_t)(g + 2) * stride + src], v3 = part[(int64_t)(g + 3) * stride + src];
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; g < g1; ++g) s += part[(int64_t)g * stride + src];
+  }
+  s_red[seg][c] = s;
+  __syncthreads();
+  if (seg == 0 && ok) {
+    float v = s_red[0][c];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v += s_red[k][c];
+    if (e < n0) dst0[e] += v; else dst1[e - n0] += v;
+  }
+}
+// LayerNorm backward with the parameter gradients folded in (round 4; k_ln_bwd + two column-sum passes over a scratch copy
+// of dy * zhat before): a workgroup of 4 waves walks LNB_ROWS rows, every lane keeps the running sums of dy * zhat and dy of
+// its two columns, the four waves are combined through LDS in wave order -> part[block][2][128] (k_part_reduce sums the blocks
+// in ascending order).
+#define LNB_ROWS 64
+__global__ void __launch_bounds__(256) k_ln_bwd2(const float* __restrict__ z, const float* __restrict__ sc,
+                                                 const float* __restrict__ dy, float* __restrict__ dz, int64_t rows,
+                                                 float* __restrict__ part) {
+  __shared__ float s_red[4][4][64];
+  const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float sc0 = sc[l], sc1 = sc[64 + l];
+  float ps0 = 0.f, ps1 = 0.f, po0 = 0.f, po1 = 0.f;
+  const int64_t rb = (int64_t)blockIdx.x * LNB_ROWS;
+  for (int it = 0; it < LNB_ROWS / 4; ++it) {
+    const int64_t r = rb + 4 * it + wv;
+    if (r >= rows) break;
+    const float x0 = z[r * TD + l], x1 = z[r * TD + 64 + l];
+    const float g0 = dy[r * TD + l], g1 = dy[r * TD + 64 + l];
+    float s = x0 + x1;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.f / TD);
+    const float d0 = x0 - mean, d1 = x1 - mean;
+    float q = d0 * d0 + d1 * d1;
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rs = 1.0f / sqrtf(q * (1.f / TD) + 1e-5f);
+    const float h0 = d0 * rs, h1 = d1 * rs;
+    const float u0 = g0 * sc0, u1 = g1 * sc1;
+    float a = u0 + u1, b = u0 * h0 + u1 * h1;
+    for (int o = 32; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o);
+      b += __shfl_xor(b, o);
+    }
+    a *= (1.f / TD);
+    b *= (1.f / TD);
+    dz[r * TD + l] = rs * (u0 - a - h0 * b);
+    dz[r * TD + 64 + l] = rs * (u1 - a - h1 * b);
+    ps0 += g0 * h0;
+    ps1 += g1 * h1;
+    po0 += g0;
+    po1 += g1;
+  }
+  s_red[wv][0][l] = ps0;
+  s_red[wv][1][l] = ps1;
+  s_red[wv][2][l] = po0;
+  s_red[wv][3][l] = po1;
+  __syncthreads();
+  const int c = threadIdx.x;  // 0..127 scale columns, 128..255 offset columns
+  const int which = (c >> 6) & 3, ll = c & 63;  // (0: ps0, 1: ps1, 2: po0, 3: po1) x lane = column (c & 127) of its group
+  float v = s_red[0][which][ll];
+  v += s_red[1][which][ll];
+  v += s_red[2][which][ll];
+  v += s_red[3][which][ll];
+  part[(int64_t)blockIdx.x * 256 + c] = v;
 }
 // xe[e] = [n[snd] | n[rcv] | el[e]]  (gns.py:97-100)
 __global__ void k_gather_edge_in(const float* __restrict__ n, const float* __restrict__ el,
@@ -263,17 +443,25 @@ __global__ void k_seg_sum_bwd(const float* __restrict__ base, const float* __res
   if (base) v = v + reinterpret_cast<const f32x4*>(base)[i];
   reinterpret_cast<f32x4*>(out)[i] = v;
 }
-// y += x (n floats)
-__global__ void k_axpy1(float* __restrict__ y, const float* __restrict__ x, int64_t n) {
+// out = a + b (n4 float4s)
+__global__ void k_add2(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, int64_t n4) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) y[i] += x[i];
+  if (i < n4) reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
 }
 // non-kinematic particle count per trajectory (utils.py:28-35) and the per-node loss weight 1 / count
 __global__ void k_count_nonkin(const int32_t* __restrict__ ptype, int64_t BN, int N, int32_t* __restrict__ cnt) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= BN) return;
-  const int pt = ptype[i];
-  if (!(pt == 1 || pt == 2 || pt == -1)) atomicAdd(&cnt[i / N], 1);
+  const bool in = i < BN;
+  const int pt = in ? ptype[i] : 1;
+  const bool nk = in && !(pt == 1 || pt == 2 || pt == -1);
+  const int b = (int)((in ? i : BN - 1) / N);
+  const int b_first = __builtin_amdgcn_readfirstlane(b);
+  if (__all(b == b_first)) {  // the usual case: one integer atomic per wave (integer sums do not depend on the order)
+    const int n = __popcll(__ballot(nk));
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(&cnt[b_first], n);
+  } else if (nk) {
+    atomicAdd(&cnt[b], 1);
+  }
 }
 __global__ void k_node_weight(const int32_t* __restrict__ ptype, const int32_t* __restrict__ cnt, int64_t BN, int N,
                               float* __restrict__ w) {
@@ -309,13 +497,13 @@ __global__ void k_loss_finish(const double* __restrict__ part, int64_t n, double
   *loss += s;
 }
 // d embed[type] += sum over nodes of that type of dxnode[:, col0 : col0 + emb].  Deterministic (round 4; round 3 used fp32
-// atomics): one 256-thread block per type, thread (c, slice) sums column c over the nodes r = slice, slice + S, .. of that
-// type in index order, the S = 256 / emb slice sums are added in slice order.
-__global__ void __launch_bounds__(256) k_embed_grad(const float* __restrict__ dx, int ld, int col0, int emb,
+// atomics): one 1024-thread block per type, thread (c, slice) sums column c over the nodes r = slice, slice + S, .. of that
+// type in index order, the S = 1024 / emb slice sums are added in slice order.
+__global__ void __launch_bounds__(1024) k_embed_grad(const float* __restrict__ dx, int ld, int col0, int emb,
                                                      const int32_t* __restrict__ ptype, int ntypes, int64_t BN,
                                                      float* __restrict__ gembed) {
-  __shared__ float s_part[256];
-  const int type = blockIdx.x, c = threadIdx.x % emb, slice = threadIdx.x / emb, S = 256 / emb;
+  __shared__ float s_part[1024];
+  const int type = blockIdx.x, c = threadIdx.x % emb, slice = threadIdx.x / emb, S = 1024 / emb;
   float acc = 0.f;
   if (slice < S)
     for (int64_t r = slice; r < BN; r += S) {
@@ -374,9 +562,29 @@ static int gemm_tn(lb_gns_train* t, int64_t rows, int M, int K, const float* X, 
                         &beta, dW, M));
   return LB_OK;
 }
+// dW[K x 128] += X^T dY, db[128] += column sums of dY (k_dw_part / k_part_reduce); false = shape not covered (caller falls
+// back to the library call + column sums)
+#define DW_MAX_G 256
+static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx, const float* dY, float* dW, float* db) {
+  if (K > 384 || rows <= 0) return false;
+  int64_t chunk = (rows + DW_MAX_G - 1) / DW_MAX_G;
+  if (chunk < 64) chunk = 64;
+  chunk = (chunk + 3) / 4 * 4;
+  const int G = (int)((rows + chunk - 1) / chunk);
+  hipStream_t s = t->eng->stream;
+  if (K & 1) return false;
+#define DW_GO(NA) hipLaunchKernelGGL((k_dw_part<NA>), dim3(G), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, t->dwpart)
+  if (K <= 128) DW_GO(1);
+  else if (K <= 256) DW_GO(2);
+  else DW_GO(3);
+#undef DW_GO
+  hipLaunchKernelGGL(k_part_reduce, dim3(((K + 1) * 128 + 63) / 64), dim3(1024), 0, s, t->dwpart, G, (int64_t)(K + 1) * 128,
+                     K * 128, 128, K * 128, dW, db);
+  return true;
+}
 static int colsum_add(lb_gns_train* t, const float* x, int64_t rows, int cols, int ld, float* out) {
   if (rows == 0) return LB_OK;
-  const int nb = (int)((rows + 1023) / 1024);
+  const int nb = (int)((rows + 127) / 128);
   hipStream_t s = t->eng->stream;
   hipLaunchKernelGGL(k_colsum_part, dim3(nb), dim3(128), 0, s, x, rows, cols, ld, t->colsum);
   hipLaunchKernelGGL(k_colsum_fin, dim3(1), dim3(128), 0, s, t->colsum, nb, cols, out);
@@ -404,17 +612,22 @@ static int mlp_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const f
   if (rows == 0) return LB_OK;
   const float* dzz = dy;
   if (p.ln) {
-    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, z, t->w + p.lns, dy, t->dz, t->da, rows);
-    LB_TRY(colsum_add(t, t->da, rows, TD, TD, t->g + p.lns));  // d scale = sum dy * zhat
-    LB_TRY(colsum_add(t, dy, rows, TD, TD, t->g + p.lno));     // d offset = sum dy
+    const int nb = (int)((rows + LNB_ROWS - 1) / LNB_ROWS);
+    hipLaunchKernelGGL(k_ln_bwd2, dim3(nb), dim3(256), 0, s, z, t->w + p.lns, dy, t->dz, rows, t->colsum);
+    hipLaunchKernelGGL(k_part_reduce, dim3(4), dim3(1024), 0, s, t->colsum, nb, (int64_t)256, 128, 128, 128, t->g + p.lns,
+                       t->g + p.lno);
     dzz = t->dz;
   }
-  LB_TRY(gemm_tn(t, rows, p.out, TD, a, TD, dzz, t->g + p.w1));
-  LB_TRY(colsum_add(t, dzz, rows, p.out, p.out, t->g + p.b1));
+  if (p.out != TD || !dw_acc(t, rows, TD, a, TD, dzz, t->g + p.w1, t->g + p.b1)) {
+    LB_TRY(gemm_tn(t, rows, p.out, TD, a, TD, dzz, t->g + p.w1));
+    LB_TRY(colsum_add(t, dzz, rows, p.out, p.out, t->g + p.b1));
+  }
   LB_TRY(gemm_nt(t, rows, p.out, TD, dzz, t->w + p.w1, t->da, TD));
   hipLaunchKernelGGL(k_relu_bwd, GRID1(rows * TD), 0, s, t->da, a, rows * TD);
-  LB_TRY(gemm_tn(t, rows, TD, p.in, X, ldx, t->da, t->g + p.w0));
-  LB_TRY(colsum_add(t, t->da, rows, TD, TD, t->g + p.b0));
+  if (!dw_acc(t, rows, p.in, X, ldx, t->da, t->g + p.w0, t->g + p.b0)) {
+    LB_TRY(gemm_tn(t, rows, TD, p.in, X, ldx, t->da, t->g + p.w0));
+    LB_TRY(colsum_add(t, t->da, rows, TD, TD, t->g + p.b0));
+  }
   if (dX) LB_TRY(gemm_nt(t, rows, TD, p.in, t->da, t->w + p.w0, dX, ldx));
   return LB_OK;
 }
@@ -458,7 +671,8 @@ static int train_ensure(lb_gns_train* t, int64_t BN, int64_t E) {
   LB_TRY(tr_alloc(&t->dx, (size_t)cm * 3 * TD));
   LB_TRY(tr_alloc(&t->dagg, (size_t)cn * TD));
   LB_TRY(tr_alloc(&t->agg, (size_t)cn * TD));
-  LB_TRY(tr_alloc(&t->colsum, (size_t)(cm / 1024 + 2) * 128));
+  LB_TRY(tr_alloc(&t->colsum, (size_t)(cm / LNB_ROWS + 2) * 256));
+  if (!t->dwpart) LB_TRY(lb_alloc(&t->dwpart, (size_t)256 * 385 * 128));
   LB_TRY(tr_alloc(&t->node_w, (size_t)cn));
   LB_TRY(tr_alloc(&t->loss_part, (size_t)(cn / 64 + 8)));
   t->cap_n = cn;
@@ -538,7 +752,7 @@ extern "C" void lb_gns_train_destroy(lb_gns_train* t) {
   if (!t) return;
   if (t->blas) (void)rocblas_destroy_handle(t->blas);
   std::vector<void*> bufs = {t->w, t->g, t->m, t->v, t->xnode, t->a_en, t->z_en, t->a_ee, t->z_ee, t->a_d, t->pred,
-                             t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->colsum, t->node_w,
+                             t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->colsum, t->dwpart, t->node_w,
                              t->loss_dev, t->loss_part, t->cnt_dev, t->snd_key, t->snd_perm, t->iota, t->snd_ptr, t->sort_tmp};
   for (auto* v : {&t->nlat, &t->elat, &t->xe, &t->ae, &t->ze, &t->xn, &t->an, &t->zn})
     for (float* p : *v) bufs.push_back(p);
@@ -580,10 +794,7 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
     // e' = LN(MLP(xe)) is both the message and (plus e) the next edge latent: keep e' in dy, then residual
     LB_TRY(mlp_fwd(t, t->pe[k], E, t->xe[k], 3 * TD, t->ae[k], t->ze[k], nullptr, t->dy));
     hipLaunchKernelGGL(k_seg_sum, GRID1(BN * 32), 0, s, e->row_ptr, t->dy, t->agg, BN, E);
-    if (E) {
-      LB_HIP(hipMemcpyAsync(t->elat[k + 1], t->elat[k], sizeof(float) * E * TD, hipMemcpyDeviceToDevice, s));
-      hipLaunchKernelGGL(k_axpy1, GRID1(E * TD), 0, s, t->elat[k + 1], t->dy, E * TD);
-    }
+    if (E) hipLaunchKernelGGL(k_add2, GRID1(E * 32), 0, s, t->elat[k + 1], t->elat[k], t->dy, E * 32);
     hipLaunchKernelGGL(k_concat_node_in, GRID1(BN * 64), 0, s, t->nlat[k], t->agg, t->xn[k], BN);
     LB_TRY(mlp_fwd(t, t->pn[k], BN, t->xn[k], 2 * TD, t->an[k], t->zn[k], t->nlat[k], t->nlat[k + 1]));
   }
@@ -638,7 +849,7 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
   LB_TRY(mlp_bwd(t, t->enc_edge, E, e->efeat, 8, t->a_ee, t->z_ee, t->de, nullptr));
   LB_TRY(mlp_bwd(t, t->enc_node, BN, t->xnode, t->kpad, t->a_en, t->z_en, t->dn, has_emb ? t->dx : nullptr));
   if (has_emb)
-    hipLaunchKernelGGL(k_embed_grad, dim3(t->desc.num_particle_types), dim3(256), 0, s, t->dx, t->kpad, t->desc.node_in, emb,
+    hipLaunchKernelGGL(k_embed_grad, dim3(t->desc.num_particle_types), dim3(1024), 0, s, t->dx, t->kpad, t->desc.node_in, emb,
                        e->ptype, t->desc.num_particle_types, BN, t->g + t->off_embed);
   LB_HIP(hipGetLastError());
   if (loss_out) {
