@@ -243,8 +243,6 @@ def case_builder(
     if not (_is_f32(dtype) or str(dtype) in ("float64", "torch.float64", "<class 'numpy.float64'>") or dtype in (
             np.float64, torch.float64)):
         raise NotImplementedError(f"case_builder: dtype {dtype!r} (float64 and float32 are built)")
-    if _is_f32(dtype) and _force_spec(external_force_fn, metadata.get("bounds")) is not None:
-        raise NotImplementedError("case_builder: dtype=float32 with an external force is not built")
     if cfg_neighbors.multiplier < 1.25:
         warnings.warn(f"cfg_neighbors.multiplier={cfg_neighbors.multiplier} < 1.25 is very low.")
     if cfg_neighbors.backend not in ("jaxmd_vmap", "jaxmd_scan", "hip"):

@@ -182,10 +182,10 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
     g.acc_std[k] = R(d->acc_std[k]);
     g.bound_lo[k] = R(d->bound_lo[k]);
     g.bound_hi[k] = R(d->bound_hi[k]);
-    g.force_lo[k] = d->force_lo[k];
-    g.force_hi[k] = d->force_hi[k];
+    g.force_lo[k] = R(d->force_lo[k]);  // dtype=float32: external_force_fn(position) is evaluated in float32 (features.py:105-107)
+    g.force_hi[k] = R(d->force_hi[k]);
   }
-  g.force_split = d->force_split;
+  g.force_split = R(d->force_split);
   if (use_cells) {
     for (int k = 0; k < d->dim; ++k) {
       const float b32 = (float)d->box[k];

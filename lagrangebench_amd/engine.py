@@ -171,7 +171,10 @@ class RolloutEngine:
     def _refresh_force(self) -> None:
         if self.force is not None and self.force.kind == _lib.LB_FORCE_BUFFER:
             newest = self.read_window()[:, :, -1].reshape(self.B * self.N, self.dim)
-            f = self.force.fn(newest)
+            if self.geometry_f32:  # dtype=float32: the callable sees float32 positions and its result is a float32 array
+                f = self._t(self.force.fn(newest.to(torch.float32)), torch.float32)
+            else:
+                f = self.force.fn(newest)
             f = self._t(f, torch.float64).reshape(self.B, self.N, self.dim)
             check(self.lib.lb_set_force(self._h, ptr(f)), "lb_set_force")
 

@@ -100,15 +100,14 @@ def test_case_test_goldens_on_engine_float32(golden_dir):
     assert np.array_equal(_np(new_pos), _np(new_pos).astype(np.float32).astype(np.float64))
 
 
-@pytest.mark.parametrize("name,scale", [("small2d", 1.0), ("small3d", 1.0), ("tgv2d", 0.6), ("ldc3d", 0.4), ("tgv3d", 0.6)])
+@pytest.mark.parametrize("name,scale", [("small2d", 1.0), ("small3d", 1.0), ("tgv2d", 0.6), ("ldc3d", 0.4), ("tgv3d", 0.6),
+                                        ("rpf2d", 0.5), ("dam2d", 0.4)])
 def test_float32_geometry_bitexact_vs_float32_oracle(name, scale):
     """dtype=float32 (case.py:169): edge list, features and the integrator against the oracle run in float32 -
     bit for bit (the engine rounds every fp64 result to float: for + - * / sqrt that IS the float operation)."""
     _need_gpu()
     from lagrangebench_amd.data import make_case
     ds = make_case(name, n_trajs=1, extra_seq_length=3, scale=scale)
-    if ds.external_force_fn is not None:
-        pytest.skip("float32 geometry with an external force is not built")
     ocase, hcase = oracle_case(ds, dtype=np.float32), hip_case(ds, dtype="float32")
     isl = ds.input_seq_length
     pos, pt = ds[0]
@@ -125,9 +124,10 @@ def test_float32_geometry_bitexact_vs_float32_oracle(name, scale):
     order = np.lexsort((on.idx[1][real], on.idx[0][real]))
     assert np.array_equal(_np(feats["rel_disp"])[:ne].astype(np.float32), of["rel_disp"][real][order])
     assert np.array_equal(_np(feats["rel_dist"])[:ne].astype(np.float32), of["rel_dist"][real][order])
-    for k in ("bound", "vel_mag"):
+    for k in ("bound", "vel_mag", "force"):  # force (round 4): external_force_fn evaluated on the float32 positions
         if k in of:
-            assert np.array_equal(_np(feats[k]).astype(np.float32), of[k]), k
+            assert np.array_equal(_np(feats[k]).astype(np.float32), np.asarray(of[k], np.float32)), k
+    assert ("force" in of) == (ds.external_force_fn is not None)
     # integrator (case.py:230-259) on random normalised accelerations
     acc = np.random.default_rng(2).standard_normal((N, len(ds.box))).astype(np.float32)
     want_pos = ocase.integrate({"acc": acc}, pos[:, :isl].astype(np.float32))
