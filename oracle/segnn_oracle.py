@@ -32,6 +32,27 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
+# Working precision of the restatement: float32 (what the reference computes in).  tests/ switch it to float64
+# (`with precision(np.float64):`) to obtain a yardstick for ELEMENT-WISE errors - the same network, constants and
+# operation order in double precision; the named constants below stay the float32 values the engine also holds.
+F = np.float32
+
+
+class precision:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global F
+        self.prev, F = F, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global F
+        F = self.prev
+        return False
+
+
 Y0 = np.float32(1.0 / (2.0 * np.sqrt(np.pi)))
 Y1 = np.float32(np.sqrt(3.0 / (4.0 * np.pi)))
 INV_SQRT3 = np.float32(1.0 / np.sqrt(3.0))
@@ -61,7 +82,7 @@ class SV:
     """A batch of irreps features with l <= 1: scalars (R, ns) and vectors (R, nv, 3)."""
 
     def __init__(self, s: np.ndarray, v: np.ndarray):
-        self.s, self.v = s.astype(np.float32), v.astype(np.float32)
+        self.s, self.v = s.astype(F), v.astype(F)
 
     @property
     def ns(self):
@@ -82,10 +103,10 @@ def cat(parts: List[SV]) -> List[SV]:
 
 def spherical_harmonics(vec: np.ndarray) -> np.ndarray:
     """(R, 3) -> (R, 4) = [Y0, Y1 * unit vector]  (A2)."""
-    vec = vec.astype(np.float32)
-    nrm = np.sqrt(np.sum(vec * vec, axis=-1, keepdims=True, dtype=np.float32))
-    unit = vec / np.where(nrm == 0, np.float32(1), nrm)
-    return np.concatenate([np.full((len(vec), 1), Y0, np.float32), Y1 * unit], axis=-1).astype(np.float32)
+    vec = vec.astype(F)
+    nrm = np.sqrt(np.sum(vec * vec, axis=-1, keepdims=True, dtype=F))
+    unit = vec / np.where(nrm == 0, F(1), nrm)
+    return np.concatenate([np.full((len(vec), 1), Y0, F), Y1 * unit], axis=-1).astype(F)
 
 
 def tp_inputs(ops: List[SV], attr: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
@@ -93,23 +114,23 @@ def tp_inputs(ops: List[SV], attr: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     scalar channels (R, K) and vector channels (R, K, 3), K = sum(ns + nv).
     Channel order = operand order, within an operand: scalar-derived first, then vector-derived
     (for an e3nn checkpoint the rows of the weights are permuted to this order at import time)."""
-    a0, a = attr[:, :1].astype(np.float32), attr[:, 1:4].astype(np.float32)
+    a0, a = attr[:, :1].astype(F), attr[:, 1:4].astype(F)
     xs, xv = [], []
     for op in ops:
         xs.append(op.s * a0)                                          # 0e x 0e -> 0e
         xs.append(np.einsum("rkc,rc->rk", op.v, a) * INV_SQRT3)       # 1o x 1o -> 0e
         xv.append(op.s[:, :, None] * a[:, None, :])                   # 0e x 1o -> 1o
         xv.append(op.v * a0[:, :, None])                              # 1o x 0e -> 1o
-    return np.concatenate(xs, axis=1).astype(np.float32), np.concatenate(xv, axis=1).astype(np.float32)
+    return np.concatenate(xs, axis=1).astype(F), np.concatenate(xv, axis=1).astype(F)
 
 
 def o3_tensor_product(p: Dict[str, np.ndarray], ops: List[SV], attr: np.ndarray) -> SV:
     """O3TensorProduct (segnn.py:44-128): tensor_product + Linear (A4).  p: ws (K, Ms), wv (K, Mv),
     b (Ms,)."""
     xs, xv = tp_inputs(ops, attr)
-    K = np.float32(xs.shape[1])
-    scale = np.float32(1.0) / np.sqrt(K)
-    s = (xs @ p["ws"]) * scale + p["b"] if p["ws"].shape[1] > 0 else np.zeros((len(xs), 0), np.float32)
+    K = F(xs.shape[1])
+    scale = F(1.0) / np.sqrt(K)
+    s = (xs @ p["ws"]) * scale + p["b"] if p["ws"].shape[1] > 0 else np.zeros((len(xs), 0), F)
     # (R, K, 3) x (K, Mv) -> (R, Mv, 3) as one BLAS product per row block (the c_einsum form of the same contraction
     # took 27 of the 33 s of a DAM2D-size forward)
     v = np.matmul(np.ascontiguousarray(xv.transpose(0, 2, 1)), p["wv"]).transpose(0, 2, 1) * scale
@@ -119,16 +140,16 @@ def o3_tensor_product(p: Dict[str, np.ndarray], ops: List[SV], attr: np.ndarray)
 def gate(x: SV) -> SV:
     """e3nn.gate (A5): x has ns = n_out_scalars + nv scalars; the last nv scalars gate the vectors."""
     n_act = x.ns - x.nv
-    s = C_SILU * _silu(x.s[:, :n_act].astype(np.float32))
-    g = C_SIGMOID * _sigmoid(x.s[:, n_act:].astype(np.float32))
+    s = C_SILU * _silu(x.s[:, :n_act].astype(F))
+    g = C_SIGMOID * _sigmoid(x.s[:, n_act:].astype(F))
     return SV(s, x.v * g[:, :, None])
 
 
 def init_tp(rng: np.random.Generator, K: int, ms: int, mv: int) -> Dict[str, np.ndarray]:
     """uniform_init with weight_std = 1 (A4); biases start at 0 (e3nn Linear default)."""
-    return {"ws": rng.uniform(-1, 1, size=(K, ms)).astype(np.float32),
-            "wv": rng.uniform(-1, 1, size=(K, mv)).astype(np.float32),
-            "b": np.zeros((ms,), np.float32)}
+    return {"ws": rng.uniform(-1, 1, size=(K, ms)).astype(F),
+            "wv": rng.uniform(-1, 1, size=(K, mv)).astype(F),
+            "b": np.zeros((ms,), F)}
 
 
 def weight_balanced_hidden(scalar_units: int) -> int:
@@ -160,7 +181,7 @@ def segnn_init(rng: np.random.Generator, node_ns: int, node_nv: int, num_mp_step
     if random_bias:
         for k, v in p.items():
             if isinstance(v, dict) and v["b"].size:
-                v["b"] = rng.uniform(-0.5, 0.5, size=v["b"].shape).astype(np.float32)
+                v["b"] = rng.uniform(-0.5, 0.5, size=v["b"].shape).astype(F)
     return p
 
 
@@ -171,12 +192,12 @@ def segnn_transform(features: Dict[str, np.ndarray], particle_type: np.ndarray, 
     dim = features["vel_hist"].shape[1] // n_vels
 
     def pad3(x):  # features_2d_to_3d (models/utils.py:118-138)
-        x = np.asarray(x, np.float32)
+        x = np.asarray(x, F)
         if dim == 3:
             return x
-        return np.concatenate([x, np.zeros(x.shape[:-1] + (1,), np.float32)], axis=-1)
+        return np.concatenate([x, np.zeros(x.shape[:-1] + (1,), F)], axis=-1)
 
-    vel_hist = pad3(np.asarray(features["vel_hist"], np.float32).reshape(n, n_vels, dim))
+    vel_hist = pad3(np.asarray(features["vel_hist"], F).reshape(n, n_vels, dim))
     rel_disp = pad3(features["rel_disp"])
     vel = vel_hist.mean(axis=1) if velocity_aggregate == "avg" else vel_hist[:, -1]
     if n_vels == 1:
@@ -185,30 +206,30 @@ def segnn_transform(features: Dict[str, np.ndarray], particle_type: np.ndarray, 
     receivers = np.asarray(features["receivers"]).astype(np.int64)
     real = receivers < n
     senders, receivers, rel_disp = senders[real], receivers[real], rel_disp[real]
-    rel_dist = np.asarray(features["rel_dist"], np.float32)[real]
+    rel_dist = np.asarray(features["rel_dist"], F)[real]
     edge_attr = spherical_harmonics(rel_disp)
     vel_emb = spherical_harmonics(vel)
-    cnt = np.maximum(np.bincount(receivers, minlength=n), 1).astype(np.float32)
-    scat = np.zeros((n, 4), np.float32)
+    cnt = np.maximum(np.bincount(receivers, minlength=n), 1).astype(F)
+    scat = np.zeros((n, 4), F)
     np.add.at(scat, receivers, edge_attr)
     node_attr = vel_emb + scat / cnt[:, None]
     node_attr[:, 0] = 1.0
     vecs = [vel_hist]
     if "bound" in features:
-        b = np.asarray(features["bound"], np.float32)
+        b = np.asarray(features["bound"], F)
         vecs.append(pad3(np.stack([b[:, :dim], b[:, dim:]], axis=1)))
     if "force" in features:
-        vecs.append(pad3(np.asarray(features["force"], np.float32))[:, None, :])
+        vecs.append(pad3(np.asarray(features["force"], F))[:, None, :])
     scal = []
     if "vel_mag" in features:
-        scal.append(np.asarray(features["vel_mag"], np.float32))
+        scal.append(np.asarray(features["vel_mag"], F))
     if not homogeneous:
         pt = np.where(particle_type < 0, particle_type + 9, particle_type)
-        scal.append(np.eye(9, dtype=np.float32)[pt])
-    node = SV(np.concatenate(scal, axis=1) if scal else np.zeros((n, 0), np.float32),
+        scal.append(np.eye(9, dtype=F)[pt])
+    node = SV(np.concatenate(scal, axis=1) if scal else np.zeros((n, 0), F),
               np.concatenate(vecs, axis=1))
     msg = SV(rel_dist.reshape(-1, 1), rel_disp[:, None, :])
-    return node, node_attr.astype(np.float32), edge_attr, msg, senders, receivers, dim
+    return node, node_attr.astype(F), edge_attr, msg, senders, receivers, dim
 
 
 def segnn_apply(p, features, particle_type, n_vels: int, homogeneous: bool, return_latents: bool = False):
@@ -224,8 +245,8 @@ def segnn_apply(p, features, particle_type, n_vels: int, homogeneous: bool, retu
         m: List[SV] = cat([f[senders], f[receivers], msg])
         for i in range(B):
             m = [gate(o3_tensor_product(p[f"layer_{k}/message_{i}"], m, edge_attr))]
-        agg_s = np.zeros((n, m[0].ns), np.float32)
-        agg_v = np.zeros((n, m[0].nv, 3), np.float32)
+        agg_s = np.zeros((n, m[0].ns), F)
+        agg_v = np.zeros((n, m[0].nv, 3), F)
         np.add.at(agg_s, receivers, m[0].s)
         np.add.at(agg_v, receivers, m[0].v)
         x: List[SV] = cat([f, SV(agg_s, agg_v)])
@@ -242,5 +263,5 @@ def segnn_apply(p, features, particle_type, n_vels: int, homogeneous: bool, retu
     if dim == 2:
         acc = acc[:, :2]
     if return_latents:
-        return {"acc": acc.astype(np.float32)}, lat
-    return {"acc": acc.astype(np.float32)}
+        return {"acc": acc.astype(F)}, lat
+    return {"acc": acc.astype(F)}

@@ -9,7 +9,7 @@ import torch
 
 from oracle import lb_oracle as O
 from oracle import segnn_oracle as S
-from tests._common import hip_case, oracle_case, rel_err
+from tests._common import elementwise_stats, hip_case, oracle_case, rel_err
 
 
 def _need_gpu():
@@ -153,6 +153,22 @@ def test_segnn_forward_parity(name, scale, L, mag):
             want = np.concatenate([f.s, f.v[:, :, 0], f.v[:, :, 1], f.v[:, :, 2]], axis=1)
             assert rel_err(got, want) < 1e-5, f"hidden state {k}"
         assert rel_err(acc[b], ref["acc"]) < 1e-5
+        # element-wise (the max-norm lets an entry 100x below the largest be 1e-3 off).  Yardstick =
+        # the same restatement in float64; bar = 4x what the float32 restatement itself achieves against it (f16x2 products
+        # carry 2^-22, fp32 products 2^-24; entries below 1e-3 of the largest are differences of O(1) terms: no float32
+        # evaluation keeps 1e-5 relative there).
+        with S.precision(np.float64):
+            truth = S.segnn_apply(params, of, pt[b], isl - 1, homog)["acc"]
+        assert truth.dtype == np.float64
+        p999_h, max_h, n_h = elementwise_stats(acc[b], truth)
+        p999_o, max_o, _ = elementwise_stats(ref["acc"], truth)
+        print(f"[elementwise segnn {name} b={b}] engine vs f64: p99.9 {p999_h:.2e} max {max_h:.2e} | f32 oracle vs f64: "
+              f"p99.9 {p999_o:.2e} max {max_o:.2e} ({n_h} entries)")
+        # measured (round 4): engine p99.9 8e-6 .. 1.2e-4, float32 restatement 5e-6 .. 7e-5 on the same entries: 1 - 2x on
+        # four cases, 4.4x on small2d (the gates run on v_exp_f32 / v_rcp_f32, ~1 ulp each, the restatement on libm).  The
+        # absolute floors are for that case; all of it is 1e-7 of the largest acceleration in absolute terms.
+        assert p999_h <= max(4.0 * p999_o, 2e-4), (p999_h, p999_o)
+        assert max_h <= max(4.0 * max_o, 5e-4), (max_h, max_o)
     handle.set_tap(False)
 
 
