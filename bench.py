@@ -437,7 +437,8 @@ def train_step_lines(device):
                 th.adamw_step(1e-4)
             torch.cuda.synchronize(device)
             dt = (time.perf_counter() - t0) / K
-            fwd = 10 * (E * 2 * (3 * D * D + D * D) + N * 2 * (2 * D * D + D * D)) + E * 2 * (8 * D + D * D) \
+            # flops EXECUTED (the edge block's first Linear is split: e W_e per edge, n [W_s | W_r] per node)
+            fwd = 10 * (E * 2 * (D * D + D * D) + N * 2 * (2 * D * D) + N * 2 * (2 * D * D + D * D)) + E * 2 * (8 * D + D * D) \
                 + N * 2 * (eng.node_in + 16 + D) * D + N * 2 * (D * D + D * dim)
             tf = 3 * fwd / dt / 1e12
             res.append({"workload": f"{workload} GNS-10-128 training step (B = 1)", "n_particles": int(N), "edges": int(E),

@@ -11,7 +11,8 @@
 // the library runs them at ~100 TFLOP/s, 65 % of the fp32 MFMA peak).  The THIRD product, dW += X^T dY, is a reduction over
 // ~1e5 rows into a tiny result, which the library ran at 16 TFLOP/s: it is hand-written (k_dw_part: fp32 MFMA, split over
 // the rows, bias column sums folded in, partials combined in a fixed order - 95 TFLOP/s on the 384 x 128 case).
-// Hand-written HIP for everything that is not a GEMM: gather / concatenation of [n_s | n_r | e] and [n | agg], bias + ReLU,
+// The edge block never forms [n_s | n_r | e]: its first Linear is split by rows of W0 into two node-sized products and one
+// edge-sized one (k_edge_pre / k_edge_dP).  Hand-written HIP for everything that is not a GEMM: [n | agg], bias + ReLU,
 // LayerNorm forward and backward (the backward keeps the running sums of d scale / d offset in registers, no scratch copy),
 // ReLU masking, jraph.segment_sum and its transpose on the receiver-sorted CSR, the sender-side transpose of the gather
 // through a sender-sorted permutation (stable radix sort: ascending edge order per sender, no atomics), the embedding-table
@@ -57,12 +58,13 @@ struct lb_gns_train {
   int64_t cap_n = 0, cap_e = 0;
   float *xnode = nullptr, *a_en = nullptr, *z_en = nullptr, *a_ee = nullptr, *z_ee = nullptr;
   std::vector<float*> nlat, elat;            // [L+1] node / edge latents entering layer k
-  std::vector<float*> xe, ae, ze, xn, an, zn;  // per layer: concat input, post-ReLU hidden, pre-LayerNorm output
+  std::vector<float*> ae, ze, xn, an, zn;  // per layer: post-ReLU hidden, pre-LayerNorm output; node block: concat input
   float *a_d = nullptr, *pred = nullptr;
   float *dn = nullptr, *de = nullptr, *dy = nullptr, *dz = nullptr, *da = nullptr, *dx = nullptr, *dagg = nullptr;
   float* agg = nullptr;
   float* colsum = nullptr;   // partial column sums [blocks][<=256]
   float* dwpart = nullptr;   // k_dw_part partials [DW_MAX_G][385][128]
+  float* proj = nullptr;     // edge block: [n W_s ; n W_r] (2 x cap_n x 128), reused for their gradients
   float* node_w = nullptr;   // per node loss weight (0 for kinematic particles)
   double* loss_dev = nullptr;
   double* loss_part = nullptr;  // one partial per wave of k_mse_grad
@@ -339,47 +341,44 @@ __global__ void __launch_bounds__(256) k_ln_bwd2(const float* __restrict__ z, co
   v += s_red[3][which][ll];
   part[(int64_t)blockIdx.x * 256 + c] = v;
 }
-// xe[e] = [n[snd] | n[rcv] | el[e]]  (gns.py:97-100)
-__global__ void k_gather_edge_in(const float* __restrict__ n, const float* __restrict__ el,
-                                 const int32_t* __restrict__ snd, const int32_t* __restrict__ rcv,
-                                 float* __restrict__ xe, int64_t E) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= E * 96) return;
-  const int64_t e = i / 96;
-  const int q = (int)(i % 96);  // f32x4 chunk of the 384-wide row
-  const f32x4* src = q < 32 ? reinterpret_cast<const f32x4*>(n) + (int64_t)snd[e] * 32 + q
-                   : q < 64 ? reinterpret_cast<const f32x4*>(n) + (int64_t)rcv[e] * 32 + (q - 32)
-                            : reinterpret_cast<const f32x4*>(el) + e * 32 + (q - 64);
-  reinterpret_cast<f32x4*>(xe)[i] = *src;
-}
-// transpose of the gather [n_s | n_r | e] (round 4: deterministic - round 3 used fp32 atomics on dn):
-//   dn[i] += sum over the edges i SENDS  of dxe[e][0:128]     (sender-sorted permutation, ascending edge index)
-//          + sum over the edges i RECEIVES of dxe[e][128:256]  (its CSR row)
-//   de[e] += dxe[e][256:384]
-// one 32-lane group per node, lane q owns the 16-byte chunk q of the 128-wide row
-__global__ void k_scatter_nodes(const float* __restrict__ dxe, const int32_t* __restrict__ snd_ptr,
-                                const int32_t* __restrict__ snd_perm, const int32_t* __restrict__ row_ptr,
-                                float* __restrict__ dn, int64_t N, int64_t E) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * 32) return;
-  const int64_t r = i / 32;
-  const int q = (int)(i % 32);
-  f32x4 acc = reinterpret_cast<const f32x4*>(dn)[i];
-  const int s0 = snd_ptr[r], s1 = snd_ptr[r + 1];
-  for (int j = s0; j < s1; ++j) acc = acc + reinterpret_cast<const f32x4*>(dxe)[(int64_t)snd_perm[j] * 96 + q];
-  int k0 = row_ptr[r], k1 = row_ptr[r + 1];
-  k0 = k0 < E ? k0 : (int)E;
-  k1 = k1 < E ? k1 : (int)E;
-  for (int k = k0; k < k1; ++k) acc = acc + reinterpret_cast<const f32x4*>(dxe)[(int64_t)k * 96 + 32 + q];
-  reinterpret_cast<f32x4*>(dn)[i] = acc;
-}
-__global__ void k_scatter_edges(const float* __restrict__ dxe, float* __restrict__ de, int64_t E) {
+// Edge block, first Linear, without the concatenation (round 4, as the inference kernels do it): W0 = [W_s ; W_r ; W_e] by
+// rows, so  [n_s | n_r | e] W0 = (n W_s)[snd] + (n W_r)[rcv] + e W_e  - the two node-sized products are formed once per NODE
+// (N rows) instead of once per EDGE (E ~ 14 N rows): the edge block's first Linear costs a third of the flops, forward
+// and backward, and the E x 384 concatenated inputs are never stored.
+//   a[e] = relu(a[e] + Ps[snd[e]] + Pr[rcv[e]] + b0)        (a holds e W_e on entry, Ps = n W_s, Pr = n W_r)
+__global__ void k_edge_pre(float* __restrict__ a, const float* __restrict__ Ps, const float* __restrict__ Pr,
+                           const int32_t* __restrict__ snd, const int32_t* __restrict__ rcv, const float* __restrict__ b0,
+                           int64_t E) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= E * 32) return;
   const int64_t e = i / 32;
   const int q = (int)(i % 32);
-  f32x4* d = reinterpret_cast<f32x4*>(de) + i;
-  *d = *d + reinterpret_cast<const f32x4*>(dxe)[e * 96 + 64 + q];
+  f32x4 v = reinterpret_cast<const f32x4*>(a)[i];
+  v = v + reinterpret_cast<const f32x4*>(Ps)[(int64_t)snd[e] * 32 + q];
+  v = v + reinterpret_cast<const f32x4*>(Pr)[(int64_t)rcv[e] * 32 + q];
+  v = v + reinterpret_cast<const f32x4*>(b0)[q];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+  reinterpret_cast<f32x4*>(a)[i] = v;
+}
+// its transpose: dPs[i] = sum over the edges i SENDS of da[e] (sender-sorted permutation, ascending edge index),
+// dPr[i] = sum over the edges i RECEIVES (its CSR row).  One 32-lane group per node, no atomics.
+__global__ void k_edge_dP(const float* __restrict__ da, const int32_t* __restrict__ snd_ptr, const int32_t* __restrict__ snd_perm,
+                          const int32_t* __restrict__ row_ptr, float* __restrict__ dPs, float* __restrict__ dPr, int64_t N,
+                          int64_t E) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * 32) return;
+  const int64_t r = i / 32;
+  const int q = (int)(i % 32);
+  f32x4 as = {0.f, 0.f, 0.f, 0.f}, ar = {0.f, 0.f, 0.f, 0.f};
+  const int s0 = snd_ptr[r], s1 = snd_ptr[r + 1];
+  for (int j = s0; j < s1; ++j) as = as + reinterpret_cast<const f32x4*>(da)[(int64_t)snd_perm[j] * 32 + q];
+  int k0 = row_ptr[r], k1 = row_ptr[r + 1];
+  k0 = k0 < E ? k0 : (int)E;
+  k1 = k1 < E ? k1 : (int)E;
+  for (int k = k0; k < k1; ++k) ar = ar + reinterpret_cast<const f32x4*>(da)[(int64_t)k * 32 + q];
+  reinterpret_cast<f32x4*>(dPs)[i] = as;
+  reinterpret_cast<f32x4*>(dPr)[i] = ar;
 }
 __global__ void k_iota(int32_t* __restrict__ x, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -546,12 +545,13 @@ static int gemm_nn(lb_gns_train* t, int64_t rows, int M, int K, const float* X, 
                         &beta, Y, ldy));
   return LB_OK;
 }
-// dX[rows x K] (ldx) = dY[rows x M] * W^T
-static int gemm_nt(lb_gns_train* t, int64_t rows, int M, int K, const float* dY, const float* W, float* dX, int ldx) {
-  const float alpha = 1.f, beta = 0.f;
+// dX[rows x K] (ldx) = dY[rows x M] (ldy) * W^T (+ beta * dX)
+static int gemm_nt(lb_gns_train* t, int64_t rows, int M, int K, const float* dY, const float* W, float* dX, int ldx,
+                   float beta = 0.f, int ldy = 0) {
+  const float alpha = 1.f;
   if (rows == 0) return LB_OK;
-  LB_BLAS(rocblas_sgemm(t->blas, rocblas_operation_transpose, rocblas_operation_none, K, (int)rows, M, &alpha, W, M, dY, M,
-                        &beta, dX, ldx));
+  LB_BLAS(rocblas_sgemm(t->blas, rocblas_operation_transpose, rocblas_operation_none, K, (int)rows, M, &alpha, W, M, dY,
+                        ldy ? ldy : M, &beta, dX, ldx));
   return LB_OK;
 }
 // dW[K x M] += X^T[K x rows] * dY[rows x M]
@@ -578,8 +578,9 @@ static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx
   else if (K <= 256) DW_GO(2);
   else DW_GO(3);
 #undef DW_GO
-  hipLaunchKernelGGL(k_part_reduce, dim3(((K + 1) * 128 + 63) / 64), dim3(1024), 0, s, t->dwpart, G, (int64_t)(K + 1) * 128,
-                     K * 128, 128, K * 128, dW, db);
+  const int nb1 = db ? 128 : 0;
+  hipLaunchKernelGGL(k_part_reduce, dim3((K * 128 + nb1 + 63) / 64), dim3(1024), 0, s, t->dwpart, G, (int64_t)(K + 1) * 128,
+                     K * 128, nb1, K * 128, dW, db);
   return true;
 }
 static int colsum_add(lb_gns_train* t, const float* x, int64_t rows, int cols, int ld, float* out) {
@@ -591,12 +592,30 @@ static int colsum_add(lb_gns_train* t, const float* x, int64_t rows, int cols, i
   return LB_OK;
 }
 
+static int mlp_fwd_tail(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, float* a, float* z, const float* resid, float* y);
 // forward of one MLP block: X (rows x in, ldx) -> a = relu(X W0 + b0) -> z = a W1 + b1 -> [LayerNorm (+ resid)] -> y
 static int mlp_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* X, int ldx, float* a, float* z,
                    const float* resid, float* y) {
   hipStream_t s = t->eng->stream;
   LB_TRY(gemm_nn(t, rows, TD, p.in, X, ldx, t->w + p.w0, a, TD));
   if (rows) hipLaunchKernelGGL(k_bias_act, GRID1(rows * TD), 0, s, a, t->w + p.b0, rows, TD, 1);
+  return mlp_fwd_tail(t, p, rows, a, z, resid, y);
+}
+// forward of the edge block (gns.py:86-101) without the concatenated input: see k_edge_pre
+static int edge_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t E, int64_t BN, const float* n, const float* el, float* a,
+                    float* z, float* y) {
+  hipStream_t s = t->eng->stream;
+  lb_engine* e = t->eng;
+  float *Ps = t->proj, *Pr = t->proj + (size_t)BN * TD;
+  LB_TRY(gemm_nn(t, BN, TD, TD, n, TD, t->w + p.w0, Ps, TD));
+  LB_TRY(gemm_nn(t, BN, TD, TD, n, TD, t->w + p.w0 + (size_t)TD * TD, Pr, TD));
+  LB_TRY(gemm_nn(t, E, TD, TD, el, TD, t->w + p.w0 + (size_t)2 * TD * TD, a, TD));
+  if (E) hipLaunchKernelGGL(k_edge_pre, GRID1(E * 32), 0, s, a, Ps, Pr, e->senders, e->receivers, t->w + p.b0, E);
+  return mlp_fwd_tail(t, p, E, a, z, nullptr, y);
+}
+static int mlp_fwd_tail(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, float* a, float* z, const float* resid,
+                        float* y) {
+  hipStream_t s = t->eng->stream;
   float* zz = p.ln ? z : y;
   LB_TRY(gemm_nn(t, rows, p.out, TD, a, TD, t->w + p.w1, zz, p.out));
   if (rows) hipLaunchKernelGGL(k_bias_act, GRID1(rows * p.out), 0, s, zz, t->w + p.b1, rows, p.out, 0);
@@ -606,8 +625,8 @@ static int mlp_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const f
 }
 // backward of one MLP block.  dy: gradient w.r.t. the block's output BEFORE the residual add (rows x out);
 // produces parameter gradients (accumulated) and, if dX != null, dX (rows x in, ld = ldx).  Scratch: t->dz, t->da.
-static int mlp_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* X, int ldx, const float* a,
-                   const float* z, const float* dy, float* dX) {
+// first part (shared with the edge block): LayerNorm and second Linear backward, ReLU mask -> t->da = d loss / d (X W0 + b0)
+static int mlp_bwd_head(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* a, const float* z, const float* dy) {
   hipStream_t s = t->eng->stream;
   if (rows == 0) return LB_OK;
   const float* dzz = dy;
@@ -624,11 +643,39 @@ static int mlp_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const f
   }
   LB_TRY(gemm_nt(t, rows, p.out, TD, dzz, t->w + p.w1, t->da, TD));
   hipLaunchKernelGGL(k_relu_bwd, GRID1(rows * TD), 0, s, t->da, a, rows * TD);
+  return LB_OK;
+}
+static int mlp_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* X, int ldx, const float* a,
+                   const float* z, const float* dy, float* dX) {
+  if (rows == 0) return LB_OK;
+  LB_TRY(mlp_bwd_head(t, p, rows, a, z, dy));
   if (!dw_acc(t, rows, p.in, X, ldx, t->da, t->g + p.w0, t->g + p.b0)) {
     LB_TRY(gemm_tn(t, rows, TD, p.in, X, ldx, t->da, t->g + p.w0));
     LB_TRY(colsum_add(t, t->da, rows, TD, TD, t->g + p.b0));
   }
   if (dX) LB_TRY(gemm_nt(t, rows, TD, p.in, t->da, t->w + p.w0, dX, ldx));
+  return LB_OK;
+}
+
+// backward of the edge block: parameter gradients, de += d loss / d e_k, dn += the node-side terms (see k_edge_pre / k_edge_dP)
+static int edge_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t E, int64_t BN, const float* n, const float* el,
+                    const float* a, const float* z, const float* dy, float* de, float* dn) {
+  if (E == 0) return LB_OK;
+  hipStream_t s = t->eng->stream;
+  lb_engine* e = t->eng;
+  LB_TRY(mlp_bwd_head(t, p, E, a, z, dy));  // -> t->da (E x 128)
+  const float *Ws = t->w + p.w0, *Wr = Ws + (size_t)TD * TD, *We = Wr + (size_t)TD * TD;
+  float *gWs = t->g + p.w0, *gWr = gWs + (size_t)TD * TD, *gWe = gWr + (size_t)TD * TD;
+  // edge rows: dW_e += e^T da, db0 += column sums of da, de += da W_e^T
+  if (!dw_acc(t, E, TD, el, TD, t->da, gWe, t->g + p.b0)) return lb_fail(LB_ERR_STATE, "dw_acc refused the edge block");
+  LB_TRY(gemm_nt(t, E, TD, TD, t->da, We, de, TD, 1.f));
+  // node rows: dP = transpose of the two gathers, then dW_s += n^T dPs, dW_r += n^T dPr, dn += dPs W_s^T + dPr W_r^T
+  float *dPs = t->proj, *dPr = t->proj + (size_t)BN * TD;
+  hipLaunchKernelGGL(k_edge_dP, GRID1(BN * 32), 0, s, t->da, t->snd_ptr, t->snd_perm, e->row_ptr, dPs, dPr, BN, E);
+  if (!dw_acc(t, BN, TD, n, TD, dPs, gWs, nullptr) || !dw_acc(t, BN, TD, n, TD, dPr, gWr, nullptr))
+    return lb_fail(LB_ERR_STATE, "dw_acc refused the edge block");
+  LB_TRY(gemm_nt(t, BN, TD, TD, dPs, Ws, dn, TD, 1.f));
+  LB_TRY(gemm_nt(t, BN, TD, TD, dPr, Wr, dn, TD, 1.f));
   return LB_OK;
 }
 
@@ -653,7 +700,6 @@ static int train_ensure(lb_gns_train* t, int64_t BN, int64_t E) {
     LB_TRY(tr_alloc(&t->elat[k], (size_t)ce * TD));
   }
   for (int k = 0; k < L; ++k) {
-    LB_TRY(tr_alloc(&t->xe[k], (size_t)ce * 3 * TD));
     LB_TRY(tr_alloc(&t->ae[k], (size_t)ce * TD));
     LB_TRY(tr_alloc(&t->ze[k], (size_t)ce * TD));
     LB_TRY(tr_alloc(&t->xn[k], (size_t)cn * 2 * TD));
@@ -668,11 +714,12 @@ static int train_ensure(lb_gns_train* t, int64_t BN, int64_t E) {
   LB_TRY(tr_alloc(&t->dy, (size_t)cm * TD));
   LB_TRY(tr_alloc(&t->dz, (size_t)cm * TD));
   LB_TRY(tr_alloc(&t->da, (size_t)cm * TD));
-  LB_TRY(tr_alloc(&t->dx, (size_t)cm * 3 * TD));
+  LB_TRY(tr_alloc(&t->dx, (size_t)cn * std::max(3 * TD, t->kpad)));
   LB_TRY(tr_alloc(&t->dagg, (size_t)cn * TD));
   LB_TRY(tr_alloc(&t->agg, (size_t)cn * TD));
   LB_TRY(tr_alloc(&t->colsum, (size_t)(cm / LNB_ROWS + 2) * 256));
   if (!t->dwpart) LB_TRY(lb_alloc(&t->dwpart, (size_t)256 * 385 * 128));
+  LB_TRY(tr_alloc(&t->proj, (size_t)cn * 2 * TD));
   LB_TRY(tr_alloc(&t->node_w, (size_t)cn));
   LB_TRY(tr_alloc(&t->loss_part, (size_t)(cn / 64 + 8)));
   t->cap_n = cn;
@@ -728,7 +775,7 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
   t->n_floats = o;
   t->nlat.assign(L + 1, nullptr);
   t->elat.assign(L + 1, nullptr);
-  t->xe.assign(L, nullptr); t->ae.assign(L, nullptr); t->ze.assign(L, nullptr);
+  t->ae.assign(L, nullptr); t->ze.assign(L, nullptr);
   t->xn.assign(L, nullptr); t->an.assign(L, nullptr); t->zn.assign(L, nullptr);
   int rc = LB_OK;
   for (float** p : {&t->w, &t->g, &t->m, &t->v})
@@ -752,9 +799,9 @@ extern "C" void lb_gns_train_destroy(lb_gns_train* t) {
   if (!t) return;
   if (t->blas) (void)rocblas_destroy_handle(t->blas);
   std::vector<void*> bufs = {t->w, t->g, t->m, t->v, t->xnode, t->a_en, t->z_en, t->a_ee, t->z_ee, t->a_d, t->pred,
-                             t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->colsum, t->dwpart, t->node_w,
+                             t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->colsum, t->dwpart, t->proj, t->node_w,
                              t->loss_dev, t->loss_part, t->cnt_dev, t->snd_key, t->snd_perm, t->iota, t->snd_ptr, t->sort_tmp};
-  for (auto* v : {&t->nlat, &t->elat, &t->xe, &t->ae, &t->ze, &t->xn, &t->an, &t->zn})
+  for (auto* v : {&t->nlat, &t->elat, &t->ae, &t->ze, &t->xn, &t->an, &t->zn})
     for (float* p : *v) bufs.push_back(p);
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -790,9 +837,8 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
   LB_TRY(mlp_fwd(t, t->enc_node, BN, t->xnode, t->kpad, t->a_en, t->z_en, nullptr, t->nlat[0]));
   LB_TRY(mlp_fwd(t, t->enc_edge, E, e->efeat, 8, t->a_ee, t->z_ee, nullptr, t->elat[0]));
   for (int k = 0; k < L; ++k) {
-    if (E) hipLaunchKernelGGL(k_gather_edge_in, GRID1(E * 96), 0, s, t->nlat[k], t->elat[k], e->senders, e->receivers, t->xe[k], E);
-    // e' = LN(MLP(xe)) is both the message and (plus e) the next edge latent: keep e' in dy, then residual
-    LB_TRY(mlp_fwd(t, t->pe[k], E, t->xe[k], 3 * TD, t->ae[k], t->ze[k], nullptr, t->dy));
+    // e' = LN(MLP([n_s | n_r | e])) is both the message and (plus e) the next edge latent: keep e' in dy, then residual
+    LB_TRY(edge_fwd(t, t->pe[k], E, BN, t->nlat[k], t->elat[k], t->ae[k], t->ze[k], t->dy));
     hipLaunchKernelGGL(k_seg_sum, GRID1(BN * 32), 0, s, e->row_ptr, t->dy, t->agg, BN, E);
     if (E) hipLaunchKernelGGL(k_add2, GRID1(E * 32), 0, s, t->elat[k + 1], t->elat[k], t->dy, E * 32);
     hipLaunchKernelGGL(k_concat_node_in, GRID1(BN * 64), 0, s, t->nlat[k], t->agg, t->xn[k], BN);
@@ -840,11 +886,7 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
     hipLaunchKernelGGL(k_split_node_in, GRID1(BN * 256), 0, s, t->dx, t->dn, t->dagg, BN);
     // edge block: e' feeds agg (gather of dagg over receivers) and e_{k+1} = e_k + e' (de)
     if (E) hipLaunchKernelGGL(k_seg_sum_bwd, GRID1(E * 32), 0, s, t->de, t->dagg, e->receivers, t->dy, E);
-    LB_TRY(mlp_bwd(t, t->pe[k], E, t->xe[k], 3 * TD, t->ae[k], t->ze[k], t->dy, t->dx));
-    if (E) {
-      hipLaunchKernelGGL(k_scatter_nodes, GRID1(BN * 32), 0, s, t->dx, t->snd_ptr, t->snd_perm, e->row_ptr, t->dn, BN, E);
-      hipLaunchKernelGGL(k_scatter_edges, GRID1(E * 32), 0, s, t->dx, t->de, E);
-    }
+    LB_TRY(edge_bwd(t, t->pe[k], E, BN, t->nlat[k], t->elat[k], t->ae[k], t->ze[k], t->dy, t->de, t->dn));
   }
   LB_TRY(mlp_bwd(t, t->enc_edge, E, e->efeat, 8, t->a_ee, t->z_ee, t->de, nullptr));
   LB_TRY(mlp_bwd(t, t->enc_node, BN, t->xnode, t->kpad, t->a_en, t->z_en, t->dn, has_emb ? t->dx : nullptr));
