@@ -79,10 +79,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        # rocBLAS: the plain dense contractions of the TRAINING step (csrc/lb_train.hip); nothing on the rollout path
+        # no library besides the HIP runtime at link time: rocBLAS (two plain GEMM shapes of the TRAINING step) is dlopen-ed
+        # by csrc/lb_train.hip when the first training handle is created; the rpath lets that find the ROCm copy
         libdir = os.path.join(_rocm_root(), "lib")
         run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs +
-            ["-L" + libdir, "-lrocblas", "-Wl,-rpath," + libdir])
+            ["-ldl", "-Wl,-rpath," + libdir])
     return LIB
 
 

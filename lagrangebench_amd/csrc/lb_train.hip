@@ -77,7 +77,46 @@ struct lb_gns_train {
   int64_t sort_cap = 0;
 };
 
-static const char* blas_err(rocblas_status s) { return rocblas_status_to_string(s); }
+// rocBLAS is bound at run time, when the first training handle is created (a link-time -lrocblas made every
+// inference-only process load the library and tied the build to one ROCm prefix): dlopen by soname, the five entry points
+// the training step uses resolved by name; the header above supplies the types only.
+#include <dlfcn.h>
+namespace {
+struct lb_blas_api {
+  void* lib = nullptr;
+  rocblas_status (*create_handle)(rocblas_handle*) = nullptr;
+  rocblas_status (*destroy_handle)(rocblas_handle) = nullptr;
+  rocblas_status (*set_stream)(rocblas_handle, hipStream_t) = nullptr;
+  rocblas_status (*sgemm)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int,
+                          const float*, const float*, rocblas_int, const float*, rocblas_int, const float*, float*,
+                          rocblas_int) = nullptr;
+  const char* (*status_to_string)(rocblas_status) = nullptr;
+};
+lb_blas_api g_blas;
+const char* lb_blas_load() {  // nullptr = ready, else what failed
+  if (g_blas.lib) return nullptr;
+  void* h = nullptr;
+  for (const char* name : {"librocblas.so", "librocblas.so.5", "librocblas.so.4", "/opt/rocm/lib/librocblas.so"}) {
+    h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (h) break;
+  }
+  if (!h) return "librocblas.so could not be loaded (the training step's Y = XW / dX = dY W^T products run on rocBLAS)";
+  lb_blas_api a;
+  a.create_handle = (decltype(a.create_handle))dlsym(h, "rocblas_create_handle");
+  a.destroy_handle = (decltype(a.destroy_handle))dlsym(h, "rocblas_destroy_handle");
+  a.set_stream = (decltype(a.set_stream))dlsym(h, "rocblas_set_stream");
+  a.sgemm = (decltype(a.sgemm))dlsym(h, "rocblas_sgemm");
+  a.status_to_string = (decltype(a.status_to_string))dlsym(h, "rocblas_status_to_string");
+  if (!a.create_handle || !a.destroy_handle || !a.set_stream || !a.sgemm || !a.status_to_string) {
+    dlclose(h);
+    return "librocblas.so lacks one of rocblas_create_handle / destroy_handle / set_stream / sgemm / status_to_string";
+  }
+  a.lib = h;
+  g_blas = a;
+  return nullptr;
+}
+}  // namespace
+static const char* blas_err(rocblas_status s) { return g_blas.status_to_string(s); }
 #define LB_BLAS(call)                                                                            \
   do {                                                                                           \
     rocblas_status _s = (call);                                                                  \
@@ -541,7 +580,7 @@ static int gemm_nn(lb_gns_train* t, int64_t rows, int M, int K, const float* X, 
                    int ldy, float beta = 0.f) {
   const float alpha = 1.f;
   if (rows == 0) return LB_OK;
-  LB_BLAS(rocblas_sgemm(t->blas, rocblas_operation_none, rocblas_operation_none, M, (int)rows, K, &alpha, W, M, X, ldx,
+  LB_BLAS(g_blas.sgemm(t->blas, rocblas_operation_none, rocblas_operation_none, M, (int)rows, K, &alpha, W, M, X, ldx,
                         &beta, Y, ldy));
   return LB_OK;
 }
@@ -550,7 +589,7 @@ static int gemm_nt(lb_gns_train* t, int64_t rows, int M, int K, const float* dY,
                    float beta = 0.f, int ldy = 0) {
   const float alpha = 1.f;
   if (rows == 0) return LB_OK;
-  LB_BLAS(rocblas_sgemm(t->blas, rocblas_operation_transpose, rocblas_operation_none, K, (int)rows, M, &alpha, W, M, dY,
+  LB_BLAS(g_blas.sgemm(t->blas, rocblas_operation_transpose, rocblas_operation_none, K, (int)rows, M, &alpha, W, M, dY,
                         ldy ? ldy : M, &beta, dX, ldx));
   return LB_OK;
 }
@@ -558,7 +597,7 @@ static int gemm_nt(lb_gns_train* t, int64_t rows, int M, int K, const float* dY,
 static int gemm_tn(lb_gns_train* t, int64_t rows, int M, int K, const float* X, int ldx, const float* dY, float* dW) {
   const float alpha = 1.f, beta = 1.f;
   if (rows == 0) return LB_OK;
-  LB_BLAS(rocblas_sgemm(t->blas, rocblas_operation_none, rocblas_operation_transpose, M, K, (int)rows, &alpha, dY, M, X, ldx,
+  LB_BLAS(g_blas.sgemm(t->blas, rocblas_operation_none, rocblas_operation_transpose, M, K, (int)rows, &alpha, dY, M, X, ldx,
                         &beta, dW, M));
   return LB_OK;
 }
@@ -782,7 +821,11 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
     if (!rc) rc = lb_alloc(p, (size_t)o);
   if (!rc) rc = lb_alloc(&t->loss_dev, 1);
   if (!rc) rc = lb_alloc(&t->cnt_dev, (size_t)e->g.B);
-  if (!rc && rocblas_create_handle(&t->blas) != rocblas_status_success) rc = lb_fail(LB_ERR_HIP, "rocblas_create_handle failed");
+  if (!rc) {
+    const char* why = lb_blas_load();
+    if (why) rc = lb_fail(LB_ERR_HIP, "%s", why);
+  }
+  if (!rc && g_blas.create_handle(&t->blas) != rocblas_status_success) rc = lb_fail(LB_ERR_HIP, "rocblas_create_handle failed");
   if (!rc && (hipMemcpy(t->w, w, sizeof(float) * o, hipMemcpyHostToDevice) != hipSuccess ||
               hipMemset(t->g, 0, sizeof(float) * o) != hipSuccess || hipMemset(t->m, 0, sizeof(float) * o) != hipSuccess ||
               hipMemset(t->v, 0, sizeof(float) * o) != hipSuccess))
@@ -797,7 +840,7 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
 
 extern "C" void lb_gns_train_destroy(lb_gns_train* t) {
   if (!t) return;
-  if (t->blas) (void)rocblas_destroy_handle(t->blas);
+  if (t->blas) (void)g_blas.destroy_handle(t->blas);
   std::vector<void*> bufs = {t->w, t->g, t->m, t->v, t->xnode, t->a_en, t->z_en, t->a_ee, t->z_ee, t->a_d, t->pred,
                              t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->colsum, t->dwpart, t->proj, t->node_w,
                              t->loss_dev, t->loss_part, t->cnt_dev, t->snd_key, t->snd_perm, t->iota, t->snd_ptr, t->sort_tmp};
@@ -817,7 +860,7 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
   lb_engine* e = t->eng;
   if (e->e_cap <= 0) return lb_fail(LB_ERR_STATE, "lb_gns_train_loss_grad before lb_nl_allocate");
   hipStream_t s = e->stream;
-  LB_BLAS(rocblas_set_stream(t->blas, s));
+  LB_BLAS(g_blas.set_stream(t->blas, s));
   LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, s));
   LB_HIP(hipStreamSynchronize(s));
   if (e->ctrl_host->overflow_step >= 0) return lb_fail(LB_ERR_STATE, "neighbor list overflowed: re-allocate first");

@@ -24,6 +24,6 @@ with ThreadPoolExecutor(max_workers=4) as ex:
     objs = list(ex.map(one, B.SOURCES))
 libdir = os.path.join(B._rocm_root(), "lib")
 subprocess.check_call([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", os.path.join(out, "liblbhip.so")] + objs +
-                      ["-L" + libdir, "-lrocblas", "-Wl,-rpath," + libdir])
+                      ["-ldl", "-Wl,-rpath," + libdir])
 print("built", os.path.join(out, "liblbhip.so"))
 PY
