@@ -184,16 +184,12 @@ __global__ void __launch_bounds__(LB_SMALL_T)
   extern __shared__ int s_cnt[];  // [ncell_tot]
   __shared__ int s_scan[LB_SMALL_T];
   __shared__ int s_max;
-  if (ctrl->overflow_step >= 0) return;
-  const int tid = threadIdx.x;
-  if (tid == 0) {
-    ctrl->max_deg = 0;
-    ctrl->row_overflow = 0;
-    s_max = 0;
-  }
-  for (int c = tid; c < ncell_tot; c += LB_SMALL_T) s_cnt[c] = 0;
-  __syncthreads();
+  // (one workgroup on one CU: the launch is a chain of dependent round trips - the control block is read ONCE, the position
+  // loads are in flight while the counts are zeroed)
+  const int poisoned = ctrl->overflow_step;
   const int step = ctrl->step;
+  if (poisoned >= 0) return;
+  const int tid = threadIdx.x;
   int gcs[PER], rk[PER];
   double pos[PER][3];
 #pragma unroll
@@ -203,6 +199,13 @@ __global__ void __launch_bounds__(LB_SMALL_T)
 #pragma unroll
     for (int d = 0; d < 3; ++d) pos[k][d] = d < g.dim ? lb_pos(win, g, BN, step, g.isl - 1, d, gc) : 0.0;
   }
+  if (tid == 0) {
+    ctrl->max_deg = 0;
+    ctrl->row_overflow = 0;
+    s_max = 0;
+  }
+  for (int c = tid; c < ncell_tot; c += LB_SMALL_T) s_cnt[c] = 0;
+  __syncthreads();
   float inv_cs[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) inv_cs[d] = d < g.dim ? (float)(1.0 / g.cell_size[d]) : 0.f;
@@ -249,7 +252,9 @@ __global__ void __launch_bounds__(LB_SMALL_T)
     if ((tid & 63) >= o) incl += v;
   }
   if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
-  if (mx > 0) atomicMax(&s_max, mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));  // one LDS atomic per wave (1024 on one address: ~3 us)
+  if ((tid & 63) == 0 && mx > 0) atomicMax(&s_max, mx);
   __syncthreads();
   int wbase = 0, total = 0;
 #pragma unroll
@@ -264,13 +269,13 @@ __global__ void __launch_bounds__(LB_SMALL_T)
     if (c < ncell_tot) {
       const int v = s_cnt[c];
       s_cnt[c] = run;  // the counts become the cell starts
-      cell_start[c] = run;
       run += v;
     }
   }
   if (tid == LB_SMALL_T - 1) cell_start[ncell_tot] = total;
   if (tid == 0) ctrl->max_cell_occ = s_max;
   __syncthreads();
+  for (int c = tid; c < ncell_tot; c += LB_SMALL_T) cell_start[c] = s_cnt[c];  // coalesced (thread t owned t*per .. : stride per)
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int64_t gi = tid + (int64_t)LB_SMALL_T * k;
