@@ -133,12 +133,13 @@ __global__ void k_bias_act(float* __restrict__ y, const float* __restrict__ b, i
 }
 // LayerNorm forward over 128 columns: z (pre, bias already added) -> y = scale * zhat + offset [+ resid]; 64 lanes
 // own one row, 2 columns each
-__global__ void k_ln_fwd(const float* __restrict__ z, const float* __restrict__ sc, const float* __restrict__ of,
-                         const float* __restrict__ resid, float* __restrict__ y, int64_t rows) {
+__global__ void k_ln_fwd(const float* __restrict__ z, const float* __restrict__ b1, const float* __restrict__ sc,
+                         const float* __restrict__ of, const float* __restrict__ resid, float* __restrict__ y, int64_t rows) {
   const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int l = threadIdx.x & 63;
   if (r >= rows) return;
-  const float x0 = z[r * TD + l], x1 = z[r * TD + 64 + l];
+  // z = a W1 as the GEMM left it: the second Linear's bias is added here (and in k_ln_bwd2), not in a pass of its own
+  const float x0 = z[r * TD + l] + b1[l], x1 = z[r * TD + 64 + l] + b1[64 + l];
   float s = x0 + x1;
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   const float mean = s * (1.f / TD);
@@ -153,35 +154,6 @@ __global__ void k_ln_fwd(const float* __restrict__ z, const float* __restrict__ 
   }
   y[r * TD + l] = y0;
   y[r * TD + 64 + l] = y1;
-}
-// LayerNorm backward: dy, z -> dz; also writes dy * zhat into t (for d scale), d offset = column sum of dy
-__global__ void k_ln_bwd(const float* __restrict__ z, const float* __restrict__ sc, const float* __restrict__ dy,
-                         float* __restrict__ dz, float* __restrict__ t, int64_t rows) {
-  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int l = threadIdx.x & 63;
-  if (r >= rows) return;
-  const float x0 = z[r * TD + l], x1 = z[r * TD + 64 + l];
-  float s = x0 + x1;
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s * (1.f / TD);
-  const float d0 = x0 - mean, d1 = x1 - mean;
-  float q = d0 * d0 + d1 * d1;
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  const float rs = 1.0f / sqrtf(q * (1.f / TD) + 1e-5f);
-  const float h0 = d0 * rs, h1 = d1 * rs;
-  const float g0 = dy[r * TD + l], g1 = dy[r * TD + 64 + l];
-  const float u0 = g0 * sc[l], u1 = g1 * sc[64 + l];
-  float a = u0 + u1, b = u0 * h0 + u1 * h1;
-  for (int o = 32; o > 0; o >>= 1) {
-    a += __shfl_xor(a, o);
-    b += __shfl_xor(b, o);
-  }
-  a *= (1.f / TD);
-  b *= (1.f / TD);
-  dz[r * TD + l] = rs * (u0 - a - h0 * b);
-  dz[r * TD + 64 + l] = rs * (u1 - a - h1 * b);
-  t[r * TD + l] = g0 * h0;
-  t[r * TD + 64 + l] = g1 * h1;
 }
 // da *= (a > 0)
 __global__ void k_relu_bwd(float* __restrict__ da, const float* __restrict__ a, int64_t n) {
@@ -331,18 +303,18 @@ __global__ void __launch_bounds__(1024) k_part_reduce(const float* __restrict__ 
 // its two columns, the four waves are combined through LDS in wave order -> part[block][2][128] (k_part_reduce sums the blocks
 // in ascending order).
 #define LNB_ROWS 64
-__global__ void __launch_bounds__(256) k_ln_bwd2(const float* __restrict__ z, const float* __restrict__ sc,
-                                                 const float* __restrict__ dy, float* __restrict__ dz, int64_t rows,
-                                                 float* __restrict__ part) {
+__global__ void __launch_bounds__(256) k_ln_bwd2(const float* __restrict__ z, const float* __restrict__ b1,
+                                                 const float* __restrict__ sc, const float* __restrict__ dy,
+                                                 float* __restrict__ dz, int64_t rows, float* __restrict__ part) {
   __shared__ float s_red[4][4][64];
   const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const float sc0 = sc[l], sc1 = sc[64 + l];
+  const float sc0 = sc[l], sc1 = sc[64 + l], bb0 = b1[l], bb1 = b1[64 + l];
   float ps0 = 0.f, ps1 = 0.f, po0 = 0.f, po1 = 0.f;
   const int64_t rb = (int64_t)blockIdx.x * LNB_ROWS;
   for (int it = 0; it < LNB_ROWS / 4; ++it) {
     const int64_t r = rb + 4 * it + wv;
     if (r >= rows) break;
-    const float x0 = z[r * TD + l], x1 = z[r * TD + 64 + l];
+    const float x0 = z[r * TD + l] + bb0, x1 = z[r * TD + 64 + l] + bb1;
     const float g0 = dy[r * TD + l], g1 = dy[r * TD + 64 + l];
     float s = x0 + x1;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -657,9 +629,10 @@ static int mlp_fwd_tail(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, fl
   hipStream_t s = t->eng->stream;
   float* zz = p.ln ? z : y;
   LB_TRY(gemm_nn(t, rows, p.out, TD, a, TD, t->w + p.w1, zz, p.out));
-  if (rows) hipLaunchKernelGGL(k_bias_act, GRID1(rows * p.out), 0, s, zz, t->w + p.b1, rows, p.out, 0);
+  if (rows && !p.ln) hipLaunchKernelGGL(k_bias_act, GRID1(rows * p.out), 0, s, zz, t->w + p.b1, rows, p.out, 0);
   if (p.ln && rows)
-    hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, z, t->w + p.lns, t->w + p.lno, resid, y, rows);
+    hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, z, t->w + p.b1, t->w + p.lns, t->w + p.lno, resid,
+                       y, rows);
   return LB_OK;
 }
 // backward of one MLP block.  dy: gradient w.r.t. the block's output BEFORE the residual add (rows x out);
@@ -671,7 +644,7 @@ static int mlp_bwd_head(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, co
   const float* dzz = dy;
   if (p.ln) {
     const int nb = (int)((rows + LNB_ROWS - 1) / LNB_ROWS);
-    hipLaunchKernelGGL(k_ln_bwd2, dim3(nb), dim3(256), 0, s, z, t->w + p.lns, dy, t->dz, rows, t->colsum);
+    hipLaunchKernelGGL(k_ln_bwd2, dim3(nb), dim3(256), 0, s, z, t->w + p.b1, t->w + p.lns, dy, t->dz, rows, t->colsum);
     hipLaunchKernelGGL(k_part_reduce, dim3(4), dim3(1024), 0, s, t->colsum, nb, (int64_t)256, 128, 128, 128, t->g + p.lns,
                        t->g + p.lno);
     dzz = t->dz;
