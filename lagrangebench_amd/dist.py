@@ -57,6 +57,9 @@ def pin_rank_to_cores(local_rank: int, local_world: int) -> Optional[List[int]]:
 
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, local_rank, world = env_world()
+    # the host driver supports dmabuf IPC only: without this RCCL fails with hipIpcGetMemHandle: invalid argument
+    # (already exported on the benchmark boxes; kept here for environments that build their own)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1:
         pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     # LB_DIST_FORCE_INIT=1: initialise the process group even for one rank (smoke test of the RCCL path on a one-GPU box)
