@@ -135,6 +135,7 @@ struct lb_engine {
   int32_t* cell_count; // [B*ncells]
   int32_t* cell_start; // [B*ncells+1]
   int32_t* cell_fill;  // [B*ncells]
+  bool cells_traj_ready = false;  // k_cells_traj: cell_count[0 .. B] hold its occupancy slots + arrival ticket, zeroed
   int32_t* cell_part;  // [BN] particle ids grouped by cell
   int32_t* deg;        // [BN]
   lb_feat_job feat_job{};    // rollout step: node features ride along with the neighbor search (xnode == null: no job)

@@ -289,6 +289,133 @@ __global__ void __launch_bounds__(LB_SMALL_T)
   }
 }
 
+// Batches (round 4): binning of trajectory b by workgroup b, ONE launch instead of memset + count + two scan passes + fill
+// (five launches, ~35 us of kernels + their dependency gaps per step).  Trajectories are independent here: every trajectory
+// has exactly N particles, so its cells start at slot b * N of the cell-sorted arrays and no prefix crosses workgroups.
+// k_cells_small's arithmetic (same cell coordinates, arbitrary order inside a cell - the rows are sorted by sender id later).
+// The per-trajectory maximum occupancy goes to occ[b]; the workgroup that finishes last (ticket counter occ[B], left at 0)
+// publishes the maximum to the control block.
+template <int PER>
+__global__ void __launch_bounds__(LB_SMALL_T)
+    k_cells_traj(lb_geom g, int64_t BN, const double* __restrict__ win, lb_ctrl* __restrict__ ctrl,
+                 int32_t* __restrict__ cell_of, int32_t* __restrict__ cell_start, int32_t* __restrict__ cell_part,
+                 double* __restrict__ cpos, int32_t* __restrict__ occ) {
+  extern __shared__ int s_cnt[];  // [g.ncells]
+  __shared__ int s_scan[LB_SMALL_T / 64];
+  __shared__ int s_max, s_last;
+  const int poisoned = ctrl->overflow_step;
+  const int step = ctrl->step;
+  if (poisoned >= 0) return;
+  const int tid = threadIdx.x, b = blockIdx.x, N = g.N, nc = g.ncells;
+  const int64_t p0 = (int64_t)b * N;
+  int lcs[PER], rk[PER];
+  double pos[PER][3];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {  // all position loads of a thread in flight together
+    const int li = tid + LB_SMALL_T * k;
+    const int64_t gi = p0 + (li < N ? li : N - 1);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pos[k][d] = d < g.dim ? lb_pos(win, g, BN, step, g.isl - 1, d, gi) : 0.0;
+  }
+  if (tid == 0) {
+    s_max = 0;
+    if (b == 0) {
+      ctrl->max_deg = 0;
+      ctrl->row_overflow = 0;
+    }
+  }
+  for (int c = tid; c < nc; c += LB_SMALL_T) s_cnt[c] = 0;
+  __syncthreads();
+  float inv_cs[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) inv_cs[d] = d < g.dim ? (float)(1.0 / g.cell_size[d]) : 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int li = tid + LB_SMALL_T * k;
+    lcs[k] = -1;
+    rk[k] = 0;
+    if (li < N) {
+      int h = 0, mult = 1;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (d < g.dim) {
+          const int c = g.f32 ? lb_cell_coord<true>(pos[k][d], inv_cs[d], g.cell_size[d], g.ncell[d])
+                              : lb_cell_coord<false>(pos[k][d], inv_cs[d], g.cell_size[d], g.ncell[d]);
+          h += c * mult;
+          mult *= g.ncell[d];
+        }
+      }
+      cell_of[p0 + li] = b * nc + h;
+      lcs[k] = h;
+      rk[k] = atomicAdd(&s_cnt[h], 1);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the counts: thread t owns the cells [t*per, (t+1)*per)
+  const int per = (nc + LB_SMALL_T - 1) / LB_SMALL_T;
+  const int c_lo = tid * per;
+  int sum = 0, mx = 0;
+  for (int j = 0; j < per; ++j) {
+    const int c = c_lo + j;
+    const int v = c < nc ? s_cnt[c] : 0;
+    sum += v;
+    mx = max(mx, v);
+  }
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if ((tid & 63) >= o) incl += v;
+  }
+  if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+  if ((tid & 63) == 0 && mx > 0) atomicMax(&s_max, mx);
+  __syncthreads();
+  int wbase = 0;
+#pragma unroll
+  for (int w = 0; w < LB_SMALL_T / 64; ++w)
+    if (w < (tid >> 6)) wbase += s_scan[w];
+  int run = (int)p0 + wbase + incl - sum;  // global slot of the trajectory's first particle + local start
+  for (int j = 0; j < per; ++j) {
+    const int c = c_lo + j;
+    if (c < nc) {
+      const int v = s_cnt[c];
+      s_cnt[c] = run;  // the counts become the cell starts
+      run += v;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < nc; c += LB_SMALL_T) cell_start[(int64_t)b * nc + c] = s_cnt[c];
+  if (b == (int)gridDim.x - 1 && tid == 0) cell_start[(int64_t)gridDim.x * nc] = (int32_t)BN;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int li = tid + LB_SMALL_T * k;
+    if (li < N) {
+      const int slot = s_cnt[lcs[k]] + rk[k];
+      cell_part[slot] = (int32_t)(p0 + li);
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        if (d < g.dim) cpos[(int64_t)d * BN + slot] = pos[k][d];
+    }
+  }
+  // maximum occupancy over the batch: last workgroup to arrive combines (integers: the order does not matter)
+  if (tid == 0) {
+    __hip_atomic_store(&occ[b], s_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    const int ticket = atomicAdd(&occ[gridDim.x], 1);
+    s_last = ticket == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last && tid == 0) {
+    __threadfence();
+    int m = 0;
+    for (int i = 0; i < (int)gridDim.x; ++i) m = max(m, __hip_atomic_load(&occ[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    ctrl->max_cell_occ = m;
+    __hip_atomic_store(&occ[gridDim.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // -------------------------------------------------------------------------- stencil search
 struct lb_nl_args {
   const int32_t* cell_of;   // [BN] global cell id of each particle
@@ -1642,9 +1769,28 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   // (one mid-size trajectory that the single-launch builds above refused, e.g. DAM2D: binning still in one launch)
   static const bool cells1_ok = !(getenv("LB_CELLS_ONE") && getenv("LB_CELLS_ONE")[0] == '0');
   const bool mid_cells = cells1_ok && small_ok && frozen && g.B == 1 && BN <= LB_CELLS1_N && ncell_tot <= LB_CELLS1_NCELL;
+  // batches: one workgroup per trajectory, one launch (LB_CELLS_TRAJ=0: the five-launch counting sort)
+  static const bool cells_traj_ok = !(getenv("LB_CELLS_TRAJ") && getenv("LB_CELLS_TRAJ")[0] == '0');
+  // (measured, profiles/r04_ab_cells_traj.txt: 2.5 k particles x 8 23.1 -> 17.5 us, 5.7 k x 8 27.7 -> 22.7 us, 8 k x 8 30.8 -> 32.5 us -
+  // one workgroup per trajectory is bound by its scattered stores from ONE CU; above 6 k particles the five launches stay)
+  const bool traj_cells = cells_traj_ok && frozen && !small_cells && g.B > 1 && g.use_cell_list && g.N <= 6144 &&
+                          g.ncells <= LB_CELLS1_NCELL;
   if (small_cells) {
     hipLaunchKernelGGL((k_cells_small<LB_SMALL_N / LB_SMALL_T>), dim3(1), dim3(LB_SMALL_T), sizeof(int) * (size_t)ncell_tot, s, g,
                        BN, e->win, e->ctrl, e->cell_of, e->cell_start, e->cell_part, e->cpos, ncell_tot);
+  } else if (traj_cells) {
+    static bool raised_t = false;
+    if (!raised_t) {
+      (void)hipFuncSetAttribute((const void*)k_cells_traj<LB_CELLS1_PER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                sizeof(int) * LB_CELLS1_NCELL);
+      raised_t = true;
+    }
+    if (!e->cells_traj_ready) {  // occ[0 .. B] (max occupancy per trajectory, arrival ticket) live in the unused cell_count
+      LB_HIP(hipMemsetAsync(e->cell_count, 0, sizeof(int32_t) * (size_t)(g.B + 1), s));
+      e->cells_traj_ready = true;
+    }
+    hipLaunchKernelGGL((k_cells_traj<LB_CELLS1_PER>), dim3(g.B), dim3(LB_SMALL_T), sizeof(int) * (size_t)g.ncells, s, g, BN,
+                       e->win, e->ctrl, e->cell_of, e->cell_start, e->cell_part, e->cpos, e->cell_count);
   } else if (mid_cells) {
     static bool raised = false;
     if (!raised) {
@@ -1655,6 +1801,7 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
     hipLaunchKernelGGL((k_cells_small<LB_CELLS1_PER>), dim3(1), dim3(LB_SMALL_T), sizeof(int) * (size_t)ncell_tot, s, g, BN,
                        e->win, e->ctrl, e->cell_of, e->cell_start, e->cell_part, e->cpos, ncell_tot);
   } else {
+    e->cells_traj_ready = false;  // (the counting sort uses cell_count: k_cells_traj's occ[] must be zeroed again after it)
     LB_HIP(hipMemsetAsync(e->cell_count, 0, sizeof(int32_t) * 2 * (size_t)ncell_tot, s));
     // (max_cell_occ, max_deg, row_overflow are reset by k_cell_count)
     const int nb = (int)((BN + 255) / 256);

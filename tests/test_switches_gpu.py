@@ -24,6 +24,7 @@ SWITCHES = [
     {"LB_EDGE32": "1", "LB_MSPLIT": "0"},                 # processor edge kernel on 32-edge tiles (32x32x16 MFMA)
     {"LB_NODE_T2": "2", "LB_MSPLIT": "0"},                # node kernel with two tiles per wave and weight chunk
     {"LB_NODE_Q": "2", "LB_MSPLIT": "0"},                 # node kernel with the four-slot ring of 16 KiB chunks (k_node16q)
+    {"LB_CELLS_TRAJ": "0"},                               # batches: five-launch counting sort instead of one workgroup per trajectory
     {"LB_NL_ONE": "0"},                                   # four-launch neighbor build also for one small trajectory
     {"LB_NL_ONE": "0", "LB_NL_CSCAN": "0"},               # ... and degree scan / finish / compaction as separate launches
     {"LB_MS_DEC": "0"},                                   # decoder as a launch of its own also behind the M-split node kernel
