@@ -223,6 +223,38 @@ def test_single_trajectory_update_path_bitexact(name, scale):
     assert int(eng.nl_flags()[0]) == 1
 
 
+@pytest.mark.parametrize("name,scale,B", [("tgv2d", 1.0, 3), ("dam2d", 1.0, 2), ("rpf2d", 1.0, 4)])
+def test_batched_update_path_bitexact(name, scale, B):
+    """Batches of mid-size trajectories (more than 4096 particles in total, at most 6144 each): the UPDATE path bins every
+    trajectory with its own workgroup in one launch (k_cells_traj, round 4).  Edge lists, edge counts and edge features of
+    an update on a later frame equal the oracle's preprocess_eval bit for bit, trajectory by trajectory."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    ds = make_case(name, n_trajs=B, extra_seq_length=3, scale=scale)
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    isl = ds.input_seq_length
+    pos = np.stack([ds[b][0] for b in range(B)])
+    pt = np.stack([ds[b][1] for b in range(B)])
+    N = pos.shape[1]
+    assert B * N > 4096 and N <= 6144
+    _, nbrs = hcase.allocate_eval((pos[:, :, :isl], pt))
+    ons = [ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))[1] for b in range(B)]
+    for shift in (1, 2):
+        feats, nbrs = hcase.preprocess_eval((pos[:, :, shift:shift + isl], pt), nbrs)
+        assert not bool(nbrs.did_buffer_overflow.any())
+        idx_all, ne_all = _np(nbrs.idx), _np(nbrs.n_edges)
+        rd, rdist = _np(feats["rel_disp"]), _np(feats["rel_dist"])
+        for b in range(B):
+            of, ons[b] = ocase.preprocess_eval((pos[b][:, shift:shift + isl].astype(np.float64), pt[b]), ons[b])
+            want = O.canonical_edges(ons[b].idx, N)
+            ne = want.shape[1]
+            assert int(ne_all[b]) == ne and (idx_all[b][:, :ne] == want).all(), f"{name} b={b} shift={shift}"
+            real = ons[b].idx[0] < N
+            order = np.lexsort((ons[b].idx[1][real], ons[b].idx[0][real]))
+            assert np.array_equal(rd[b][:ne], of["rel_disp"][real][order])
+            assert np.array_equal(rdist[b][:ne], of["rel_dist"][real][order])
+
+
 @pytest.mark.parametrize("name,scale", CASES)
 def test_neighbors_and_features_bitexact(name, scale):
     _need_gpu()
