@@ -47,7 +47,10 @@ struct lb_gns_train {
   lb_gns_desc desc;
   lb_engine* eng;
   rocblas_handle blas = nullptr;
-  int64_t n_floats = 0;
+  int64_t n_floats = 0;   // floats of the DEVICE blobs (latent padded to 128)
+  int64_t n_compact = 0;  // floats of the caller's blob (GNS.flatten with the model's latent size)
+  int lat = TD;           // the model's latent size (<= 128)
+  std::vector<int64_t> cmap;  // caller index -> device index (empty: identity, latent 128)
   float *w = nullptr, *g = nullptr, *m = nullptr, *v = nullptr;  // weights, gradients, AdamW moments
   int64_t off_embed = 0;
   lb_train_mlp enc_node, enc_edge, dec;
@@ -133,8 +136,12 @@ __global__ void k_bias_act(float* __restrict__ y, const float* __restrict__ b, i
 }
 // LayerNorm forward over 128 columns: z (pre, bias already added) -> y = scale * zhat + offset [+ resid]; 64 lanes
 // own one row, 2 columns each
+// (d < 128: latents narrower than the 128-wide rows - weights, biases and LayerNorm parameters are zero in the padded
+// columns, so those columns of z are 0: mean = sum / d, variance = (sum_128 (x - mean)^2 - (128 - d) mean^2) / d, and the
+// padded outputs are scale 0 x .. + offset 0 = 0)
 __global__ void k_ln_fwd(const float* __restrict__ z, const float* __restrict__ b1, const float* __restrict__ sc,
-                         const float* __restrict__ of, const float* __restrict__ resid, float* __restrict__ y, int64_t rows) {
+                         const float* __restrict__ of, const float* __restrict__ resid, float* __restrict__ y, int64_t rows,
+                         int d) {
   const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int l = threadIdx.x & 63;
   if (r >= rows) return;
@@ -142,11 +149,13 @@ __global__ void k_ln_fwd(const float* __restrict__ z, const float* __restrict__ 
   const float x0 = z[r * TD + l] + b1[l], x1 = z[r * TD + 64 + l] + b1[64 + l];
   float s = x0 + x1;
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s * (1.f / TD);
+  const float inv_d = 1.f / (float)d;
+  const float mean = s * inv_d;
   const float d0 = x0 - mean, d1 = x1 - mean;
   float q = d0 * d0 + d1 * d1;
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  const float rs = 1.0f / sqrtf(q * (1.f / TD) + 1e-5f);
+  q -= (float)(TD - d) * mean * mean;
+  const float rs = 1.0f / sqrtf(q * inv_d + 1e-5f);
   float y0 = sc[l] * (d0 * rs) + of[l], y1 = sc[64 + l] * (d1 * rs) + of[64 + l];
   if (resid) {
     y0 += resid[r * TD + l];
@@ -305,11 +314,13 @@ __global__ void __launch_bounds__(1024) k_part_reduce(const float* __restrict__ 
 #define LNB_ROWS 64
 __global__ void __launch_bounds__(256) k_ln_bwd2(const float* __restrict__ z, const float* __restrict__ b1,
                                                  const float* __restrict__ sc, const float* __restrict__ dy,
-                                                 float* __restrict__ dz, int64_t rows, float* __restrict__ part) {
+                                                 float* __restrict__ dz, int64_t rows, float* __restrict__ part, int d) {
   __shared__ float s_red[4][4][64];
   const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float sc0 = sc[l], sc1 = sc[64 + l], bb0 = b1[l], bb1 = b1[64 + l];
   float ps0 = 0.f, ps1 = 0.f, po0 = 0.f, po1 = 0.f;
+  const float inv_d = 1.f / (float)d;
+  const bool real0 = l < d, real1 = 64 + l < d;
   const int64_t rb = (int64_t)blockIdx.x * LNB_ROWS;
   for (int it = 0; it < LNB_ROWS / 4; ++it) {
     const int64_t r = rb + 4 * it + wv;
@@ -318,11 +329,12 @@ __global__ void __launch_bounds__(256) k_ln_bwd2(const float* __restrict__ z, co
     const float g0 = dy[r * TD + l], g1 = dy[r * TD + 64 + l];
     float s = x0 + x1;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s * (1.f / TD);
+    const float mean = s * inv_d;
     const float d0 = x0 - mean, d1 = x1 - mean;
     float q = d0 * d0 + d1 * d1;
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rs = 1.0f / sqrtf(q * (1.f / TD) + 1e-5f);
+    q -= (float)(TD - d) * mean * mean;
+    const float rs = 1.0f / sqrtf(q * inv_d + 1e-5f);
     const float h0 = d0 * rs, h1 = d1 * rs;
     const float u0 = g0 * sc0, u1 = g1 * sc1;
     float a = u0 + u1, b = u0 * h0 + u1 * h1;
@@ -330,10 +342,10 @@ __global__ void __launch_bounds__(256) k_ln_bwd2(const float* __restrict__ z, co
       a += __shfl_xor(a, o);
       b += __shfl_xor(b, o);
     }
-    a *= (1.f / TD);
-    b *= (1.f / TD);
-    dz[r * TD + l] = rs * (u0 - a - h0 * b);
-    dz[r * TD + 64 + l] = rs * (u1 - a - h1 * b);
+    a *= inv_d;
+    b *= inv_d;
+    dz[r * TD + l] = real0 ? rs * (u0 - a - h0 * b) : 0.f;   // (u is 0 in the padded columns: they add nothing to a, b)
+    dz[r * TD + 64 + l] = real1 ? rs * (u1 - a - h1 * b) : 0.f;
     ps0 += g0 * h0;
     ps1 += g1 * h1;
     po0 += g0;
@@ -632,7 +644,7 @@ static int mlp_fwd_tail(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, fl
   if (rows && !p.ln) hipLaunchKernelGGL(k_bias_act, GRID1(rows * p.out), 0, s, zz, t->w + p.b1, rows, p.out, 0);
   if (p.ln && rows)
     hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, z, t->w + p.b1, t->w + p.lns, t->w + p.lno, resid,
-                       y, rows);
+                       y, rows, t->lat);
   return LB_OK;
 }
 // backward of one MLP block.  dy: gradient w.r.t. the block's output BEFORE the residual add (rows x out);
@@ -644,7 +656,7 @@ static int mlp_bwd_head(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, co
   const float* dzz = dy;
   if (p.ln) {
     const int nb = (int)((rows + LNB_ROWS - 1) / LNB_ROWS);
-    hipLaunchKernelGGL(k_ln_bwd2, dim3(nb), dim3(256), 0, s, z, t->w + p.b1, t->w + p.lns, dy, t->dz, rows, t->colsum);
+    hipLaunchKernelGGL(k_ln_bwd2, dim3(nb), dim3(256), 0, s, z, t->w + p.b1, t->w + p.lns, dy, t->dz, rows, t->colsum, t->lat);
     hipLaunchKernelGGL(k_part_reduce, dim3(4), dim3(1024), 0, s, t->colsum, nb, (int64_t)256, 128, 128, 128, t->g + p.lns,
                        t->g + p.lno);
     dzz = t->dz;
@@ -743,8 +755,8 @@ static int train_ensure(lb_gns_train* t, int64_t BN, int64_t E) {
 extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const float* w, int64_t n_floats,
                                    lb_gns_train** out) {
   if (!e || !d || !w || !out) return lb_fail(LB_ERR_ARG, "null argument");
-  if (d->latent_size != TD || d->blocks_per_step != 2)
-    return lb_fail(LB_ERR_UNSUPPORTED, "training path: latent_size 128 and num_mlp_layers 2 are built");
+  if (d->latent_size < 4 || d->latent_size > TD || d->blocks_per_step != 2)
+    return lb_fail(LB_ERR_UNSUPPORTED, "training path: latent_size <= 128 and num_mlp_layers 2 are built");
   if (d->out_dim != e->g.dim || d->node_in != e->g.node_in || d->edge_in != e->g.dim + 1)
     return lb_fail(LB_ERR_ARG, "model widths do not match the case");
   const int L = d->num_mp_steps;
@@ -780,11 +792,46 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
     t->pn.push_back(mlp(2 * TD, TD, true));
   }
   t->dec = mlp(TD, d->out_dim, false);
-  if (o != n_floats) {
+  // Latents narrower than 128 (round 4; GNS-5-64 of docs/pages/baselines.rst): the device blobs keep the 128-wide layout with
+  // zeros in the padded rows / columns - they stay zero under the step (a padded hidden unit is relu(0) = 0, so its weight
+  // gradients vanish; padded LayerNorm columns are masked in k_ln_bwd2; AdamW of (w, g, m, v) = 0 is 0) - and the caller's
+  // blob (GNS.flatten with the model's latent size) is scattered into / gathered from it through an index map.
+  const int lat = d->latent_size;
+  t->lat = lat;
+  int64_t oc = has_emb ? (int64_t)d->num_particle_types * emb : 0;
+  if (lat != TD) t->cmap.reserve((size_t)o);
+  for (int64_t i = 0; i < oc && lat != TD; ++i) t->cmap.push_back(i);  // embedding table: as is
+  auto map_mlp = [&](const lb_train_mlp& p, int in_c, int nblk, int out_c) {
+    // in_c caller rows of w0: nblk blocks of `lat` latent rows (row j of block q -> device row 128 q + j), or plain rows (nblk 0)
+    if (lat != TD) {
+      for (int r = 0; r < in_c; ++r) {
+        const int rp = nblk ? (r / lat) * TD + (r % lat) : r;
+        for (int c = 0; c < lat; ++c) t->cmap.push_back(p.w0 + (int64_t)rp * TD + c);
+      }
+      for (int c = 0; c < lat; ++c) t->cmap.push_back(p.b0 + c);
+      for (int r = 0; r < lat; ++r)
+        for (int c = 0; c < out_c; ++c) t->cmap.push_back(p.w1 + (int64_t)r * p.out + c);
+      for (int c = 0; c < out_c; ++c) t->cmap.push_back(p.b1 + c);
+      if (p.ln) {
+        for (int c = 0; c < out_c; ++c) t->cmap.push_back(p.lns + c);
+        for (int c = 0; c < out_c; ++c) t->cmap.push_back(p.lno + c);
+      }
+    }
+    oc += (int64_t)in_c * lat + lat + (int64_t)lat * out_c + out_c + (p.ln ? 2 * out_c : 0);
+  };
+  map_mlp(t->enc_node, t->nin, 0, lat);
+  map_mlp(t->enc_edge, d->edge_in, 0, lat);
+  for (int k = 0; k < L; ++k) {
+    map_mlp(t->pe[k], 3 * lat, 3, lat);
+    map_mlp(t->pn[k], 2 * lat, 2, lat);
+  }
+  map_mlp(t->dec, lat, 1, d->out_dim);
+  if (oc != n_floats) {
     delete t;
-    return lb_fail(LB_ERR_ARG, "weight blob has %lld floats, expected %lld", (long long)n_floats, (long long)o);
+    return lb_fail(LB_ERR_ARG, "weight blob has %lld floats, expected %lld", (long long)n_floats, (long long)oc);
   }
   t->n_floats = o;
+  t->n_compact = oc;
   t->nlat.assign(L + 1, nullptr);
   t->elat.assign(L + 1, nullptr);
   t->ae.assign(L, nullptr); t->ze.assign(L, nullptr);
@@ -799,10 +846,19 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
     if (why) rc = lb_fail(LB_ERR_HIP, "%s", why);
   }
   if (!rc && g_blas.create_handle(&t->blas) != rocblas_status_success) rc = lb_fail(LB_ERR_HIP, "rocblas_create_handle failed");
-  if (!rc && (hipMemcpy(t->w, w, sizeof(float) * o, hipMemcpyHostToDevice) != hipSuccess ||
-              hipMemset(t->g, 0, sizeof(float) * o) != hipSuccess || hipMemset(t->m, 0, sizeof(float) * o) != hipSuccess ||
-              hipMemset(t->v, 0, sizeof(float) * o) != hipSuccess))
-    rc = lb_fail(LB_ERR_HIP, "weight upload failed");
+  if (!rc) {
+    std::vector<float> padded;
+    const float* src = w;
+    if (!t->cmap.empty()) {
+      padded.assign((size_t)o, 0.f);
+      for (int64_t i = 0; i < oc; ++i) padded[(size_t)t->cmap[(size_t)i]] = w[i];
+      src = padded.data();
+    }
+    if (hipMemcpy(t->w, src, sizeof(float) * o, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(t->g, 0, sizeof(float) * o) != hipSuccess || hipMemset(t->m, 0, sizeof(float) * o) != hipSuccess ||
+        hipMemset(t->v, 0, sizeof(float) * o) != hipSuccess)
+      rc = lb_fail(LB_ERR_HIP, "weight upload failed");
+  }
   if (rc) {
     lb_gns_train_destroy(t);
     return rc;
@@ -937,19 +993,31 @@ extern "C" int lb_adamw_step(lb_gns_train* t, float lr, float b1, float b2, floa
 
 // which: 0 weights, 1 gradients, 2 first moment, 3 second moment (flat blob, GNS.flatten order)
 extern "C" int lb_gns_train_read(lb_gns_train* t, int32_t which, float* out_host, int64_t n_floats) {
-  if (!t || !out_host || n_floats != t->n_floats || which < 0 || which > 3) return lb_fail(LB_ERR_ARG, "bad argument");
+  if (!t || !out_host || n_floats != t->n_compact || which < 0 || which > 3) return lb_fail(LB_ERR_ARG, "bad argument");
   const float* src = which == 0 ? t->w : which == 1 ? t->g : which == 2 ? t->m : t->v;
   LB_HIP(hipStreamSynchronize(t->eng->stream));
-  LB_HIP(hipMemcpy(out_host, src, sizeof(float) * n_floats, hipMemcpyDeviceToHost));
+  if (t->cmap.empty()) {
+    LB_HIP(hipMemcpy(out_host, src, sizeof(float) * n_floats, hipMemcpyDeviceToHost));
+  } else {
+    std::vector<float> padded((size_t)t->n_floats);
+    LB_HIP(hipMemcpy(padded.data(), src, sizeof(float) * t->n_floats, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n_floats; ++i) out_host[i] = padded[(size_t)t->cmap[(size_t)i]];
+  }
   return LB_OK;
 }
 extern "C" int64_t lb_gns_train_step_count(lb_gns_train* t) { return t ? (int64_t)t->step : -1; }
 
 extern "C" int lb_gns_train_write(lb_gns_train* t, int32_t which, const float* in_host, int64_t n_floats, int64_t step) {
-  if (!t || !in_host || n_floats != t->n_floats || which < 0 || which > 3) return lb_fail(LB_ERR_ARG, "bad argument");
+  if (!t || !in_host || n_floats != t->n_compact || which < 0 || which > 3) return lb_fail(LB_ERR_ARG, "bad argument");
   float* dst = which == 0 ? t->w : which == 1 ? t->g : which == 2 ? t->m : t->v;
   LB_HIP(hipStreamSynchronize(t->eng->stream));
-  LB_HIP(hipMemcpy(dst, in_host, sizeof(float) * n_floats, hipMemcpyHostToDevice));
+  if (t->cmap.empty()) {
+    LB_HIP(hipMemcpy(dst, in_host, sizeof(float) * n_floats, hipMemcpyHostToDevice));
+  } else {
+    std::vector<float> padded((size_t)t->n_floats, 0.f);
+    for (int64_t i = 0; i < n_floats; ++i) padded[(size_t)t->cmap[(size_t)i]] = in_host[i];
+    LB_HIP(hipMemcpy(dst, padded.data(), sizeof(float) * t->n_floats, hipMemcpyHostToDevice));
+  }
   if (step >= 0) t->step = step;
   return LB_OK;
 }

@@ -56,12 +56,12 @@ class _ShuffledLoader:
 class Trainer:
     def __init__(self, model: GNS, case, data_train, data_valid, cfg_train=None, cfg_eval=None, cfg_logging=None,
                  input_seq_length: int = defaults.model.input_seq_length, seed: int = defaults.seed):
-        if isinstance(model, GNS) and (model._latent_size != 128 or model._blocks_per_step != 2):
-            # fail HERE, before datasets and neighbor lists are set up (csrc/lb_train.hip: the LayerNorm / gather /
-            # concat kernels of the training step are built for 128-wide latents and two Linears per MLP)
+        if isinstance(model, GNS) and (not 4 <= model._latent_size <= 128 or model._blocks_per_step != 2):
+            # fail HERE, before datasets and neighbor lists are set up (csrc/lb_train.hip: the training step runs on
+            # 128-wide rows - narrower latents are zero-padded - and two Linears per MLP)
             raise NotImplementedError(
-                f"training is built for GNS-*-128 with num_mlp_layers 2 (got latent_size {model._latent_size}, "
-                f"num_mlp_layers {model._blocks_per_step}); inference runs every size")
+                f"training is built for GNS with latent_size <= 128 and num_mlp_layers 2 (got latent_size "
+                f"{model._latent_size}, num_mlp_layers {model._blocks_per_step}); inference runs every size")
         if not isinstance(model, GNS):
             raise NotImplementedError("Trainer: only GNS has a device training step (csrc/lb_train.hip)")
         self.model, self.case, self.input_seq_length = model, case, input_seq_length

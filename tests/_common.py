@@ -39,14 +39,14 @@ def feature_widths(ds, isl=None):
     return node_in, dim + 1
 
 
-def make_params(ds, num_mp_steps=10, seed=1234, decoder_scale=0.01, random_affine=True):
+def make_params(ds, num_mp_steps=10, seed=1234, decoder_scale=0.01, random_affine=True, latent_size=128):
     """Haiku-default weights from default_rng(seed); decoder output layer scaled so a random
     net does not blow the neighbor count up.  random_affine additionally randomises biases and
     LayerNorm scale/offset so those code paths are exercised (defaults are 0 / 1 / 0)."""
     node_in, edge_in = feature_widths(ds)
     dim = len(ds.box)
     rng = np.random.default_rng(seed)
-    p = O.gns_init(rng, node_in=node_in, edge_in=edge_in, particle_dimension=dim,
+    p = O.gns_init(rng, node_in=node_in, edge_in=edge_in, particle_dimension=dim, latent_size=latent_size,
                    num_mp_steps=num_mp_steps, decoder_scale=decoder_scale)
     if random_affine:
         r2 = np.random.default_rng(seed + 1)

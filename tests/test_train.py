@@ -151,9 +151,10 @@ def test_torch_forward_on_engine_graph_equals_hip_forward():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,scale,L,B", [("small2d", 1.0, 3, 2), ("small3d", 1.0, 2, 1), ("tgv2d", 0.6, 10, 2),
-                                            ("ldc3d", 0.4, 2, 2)])
-def test_hip_gradients_match_torch_autograd(name, scale, L, B):
+@pytest.mark.parametrize("name,scale,L,B,latent", [("small2d", 1.0, 3, 2, 128), ("small3d", 1.0, 2, 1, 128),
+                                                   ("tgv2d", 0.6, 10, 2, 128), ("ldc3d", 0.4, 2, 2, 128),
+                                                   ("small2d", 1.0, 5, 2, 64), ("small3d", 1.0, 2, 2, 40)])
+def test_hip_gradients_match_torch_autograd(name, scale, L, B, latent):
     """the hand-written backward (csrc/lb_train.hip: lb_gns_train_loss_grad) against torch
     autograd of the checker network (oracle/gns_torch.py, itself checked against the oracle and finite differences
     above) on engine-built graphs: loss and every parameter gradient of _mse (trainer.py:35-60), gradients summed and
@@ -169,8 +170,9 @@ def test_hip_gradients_match_torch_autograd(name, scale, L, B):
     isl, dim = ds.input_seq_length, len(ds.box)
     pos = np.stack([ds[b][0] for b in range(B)])
     pt = np.stack([ds[b][1] for b in range(B)])
-    params = make_params(ds, num_mp_steps=L, decoder_scale=1.0)
-    model = GNS(dim, 128, 2, L, 16)
+    # latent < 128 (round 4: GNS-5-64 of the reference's baselines): the device step runs 128-wide with zero padding
+    params = make_params(ds, num_mp_steps=L, decoder_scale=1.0, latent_size=latent)
+    model = GNS(dim, latent, 2, L, 16)
     feats, _ = hcase.allocate_eval((pos[:, :, :isl], pt))
     eng = feats.engine
     target = torch.randn((B, pos.shape[1], dim), generator=torch.Generator().manual_seed(5))
