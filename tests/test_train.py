@@ -275,7 +275,7 @@ def test_trainer_lowers_the_loss_and_runner_mode_all(tmp_path):
     assert set(p2) == set(params)
     # the runner route of the reference's runner_test
     cfg = {"mode": "all", "dataset": {"src": str(ds_dir), "name": "lj3d"},
-           "model": {"name": "gns", "num_mp_steps": 1, "input_seq_length": isl},
+           "model": {"name": "gns", "num_mp_steps": 1, "input_seq_length": isl, "latent_dim": 64},  # (a narrow latent: round 4)
            "train": {"step_max": 12, "batch_size": 1, "pushforward": {"steps": [-1], "unrolls": [0], "probs": [1]}},
            "logging": {"log_steps": 5, "eval_steps": 5, "ckp_dir": str(tmp_path / "ckp2"), "run_name": "r"},
            "eval": {"n_rollout_steps": 5, "train": {"n_trajs": 1, "metrics": ["mse"]},
