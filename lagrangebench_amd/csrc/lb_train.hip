@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(1024) k_embed_grad(const float* __restrict__ d
     }
   s_part[threadIdx.x] = acc;
   __syncthreads();
-  if (threadIdx.x < emb) {
+  if ((int)threadIdx.x < emb) {
     float t = 0.f;
     for (int k = 0; k < S; ++k) t += s_part[k * emb + threadIdx.x];
     gembed[(int64_t)type * emb + threadIdx.x] += t;
