@@ -164,6 +164,7 @@ def main():
     # timed region: EXACTLY K steps between barrier + synchronize on both sides, max over ranks; repeated
     # `--repeats` times (same rollout, same inputs) - value / ms_per_step are the MEDIAN repeat, all repeats listed
     dts, n_realloc = [], 0
+    eng.edge_accounting(reset=True)   # every neighbor-list build from here on adds its real edge count (device side)
     for _ in range(max(1, args.repeats)):
         lbdist.barrier(device)
         t0 = time.perf_counter()
@@ -173,8 +174,10 @@ def main():
         n_realloc += nr
     dt = float(np.median(dts))
     dist_info = lbdist.group_info(device)
+    acct = eng.edge_accounting(reset=True)   # edges of the builds of the timed repeats (every repeat = the same K steps)
     st = eng.stats()
-    E_tot = st["n_edges_total"]
+    E_last = st["n_edges_total"]             # the LAST step's list (what the engine still holds)
+    fallbacks_timed = eng.math_fallbacks()
 
     # gather the per-trajectory MSE vectors over RCCL (the only collective of the job)
     tgt = traj[:, :, ds.input_seq_length:ds.input_seq_length + K].permute(0, 2, 1, 3).contiguous()
@@ -186,11 +189,16 @@ def main():
     eng.timers_reset()
     eng.rollout(handle, traj, K)
     tm = eng.timers()
+    acct_tm = eng.edge_accounting(reset=True)
+    # E of a launch AVERAGED over the K steps the timers cover (the rollout's E drifts, the launch times are
+    # averages over all K steps - bytes and flops per launch must use the mean E of those steps, not the last step's)
+    E_tot = acct_tm["mean"]
     fused = tm["aggregate"][1] == 0
     if fused:
         # aggregation is fused into the edge kernel on the hot path: time the stand-alone
         # jraph.segment_sum kernel (lb_segment_sum) on the same receiver-sorted list separately
-        msg = torch.randn((E_tot, D), dtype=torch.float32, device=device)
+        # (that list is the LAST step's: its bytes use E_last)
+        msg = torch.randn((E_last, D), dtype=torch.float32, device=device)
         eng.segment_sum(msg)
         eng.timers_reset()
         for _ in range(20):
@@ -218,13 +226,13 @@ def main():
     #   + aggregated messages written once (N*512)
     # SURVEY 8d counts E*(2*D*4+8) + N*2*D*4 (= E*1032 + N*1024); the N*512 of aggregated messages the
     # kernel also writes are left out of `achieved` (conservative) and listed under bytes_incl_agg
-    edge_bytes = E_tot * (2 * D * 4 + 8) + BN * (2 * D * 4)
+    edge_bytes = int(round(E_tot * (2 * D * 4 + 8))) + BN * (2 * D * 4)
     edge_bytes_incl_agg = edge_bytes + BN * D * 4
     gbs_edge = edge_bytes / (us_edge * 1e-6) / 1e9
     # flops: algorithmic (reference formulation) 2*4*D*D per edge; executed products
     # 2*2*D*D per edge (sender/receiver part projected per node), x3 MFMA passes in f16x2
-    flop_algo = E_tot * 2 * 4 * D * D
-    flop_prod = E_tot * 2 * 2 * D * D
+    flop_algo = int(round(E_tot * 2 * 4 * D * D))
+    flop_prod = int(round(E_tot * 2 * 2 * D * D))
     if math_mode == "f16x2":
         mfma = {"dtype": "f16 (x3 split passes)", "achieved": 3 * flop_prod / (us_edge * 1e-6) / 1e12,
                 "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s"}
@@ -240,7 +248,7 @@ def main():
     last_variant = None
     if n_last > 0:
         us_last = 1e3 * ms_last / n_last
-        last_bytes = E_tot * (D * 4 + 8) + BN * (2 * D * 4)
+        last_bytes = int(round(E_tot * (D * 4 + 8))) + BN * (2 * D * 4)
         last_variant = {"kernel": kern + " [last layer: SKIP = no edge-latent store]", "us_per_launch": us_last,
                         "launches": int(n_last), "bytes_per_launch": last_bytes,
                         "achieved": last_bytes / (us_last * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -253,6 +261,8 @@ def main():
                 "traffic": pmc_traffic(pmc_key, args.workload, B),
                 "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured by this run)",
                 "us_per_launch": us_edge, "launches": int(n_edge), "bytes_per_launch": edge_bytes,
+                "edges_per_launch_mean": round(E_tot, 1), "tiles_per_launch_mean": round(E_tot / 16, 1),
+                "bytes_formula": "E_mean * (2*128*4 + 8) + B*N * 2*128*4  (SURVEY 8d; E_mean = mean real E of the timed steps)",
                 "bytes_incl_agg": edge_bytes_incl_agg, "mfma": mfma, "node_kernel": eng.kernel_names()["node"]}
     else:
         roof = {"kernel": kern, "bound": "mfma", "achieved": mfma["achieved"], "peak": mfma["peak"],
@@ -261,7 +271,7 @@ def main():
                 "node_kernel": eng.kernel_names()["node"],
                 "us_per_launch": us_edge, "launches": int(n_edge), "flop_per_launch_executed": flop_prod,
                 "hbm": {"achieved": gbs_edge, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_edge / HBM_PEAK_GBS}}
-    agg_bytes = E_tot * (D * 4 + 4) + BN * D * 4  # E*516 + N*512
+    agg_bytes = E_last * (D * 4 + 4) + BN * D * 4  # E*516 + N*512 (the stand-alone kernel ran on the last step's list)
     gbs_agg = agg_bytes / (us_agg * 1e-6) / 1e9
     breakdown = {k: round(v[0] / K, 4) for k, v in tm.items() if v[1] > 0 and not (fused and k == "aggregate")}
 
@@ -284,7 +294,13 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload} GNS-{L}-{D} inference rollout, neighbor list rebuilt every step",
-            "n_particles": int(N), "batch_per_gpu": B, "edges_per_traj": int(E_tot // B),
+            "n_particles": int(N), "batch_per_gpu": B, "edges_per_traj": int(round(E_tot / B)),
+            "edges_per_traj_first": int(acct_tm["first"] // B), "edges_per_traj_mean": round(E_tot / B, 1),
+            "edges_per_traj_last": int(E_last // B), "edges_per_traj_mean_timed_repeats": round(acct["mean"] / B, 1),
+            "edges_note": ("per-launch bytes / flops of every roofline object use the MEAN real E of the K steps the HIP-event "
+                           "timers cover (device-side sum over the neighbor-list builds, lb_edge_accounting); the synthetic "
+                           "rollout is not stationary - see `stationary` for the same engine at SURVEY 8d's neighbour count"),
+            "math_fallbacks": int(fallbacks_timed),
             "input_seq_length": ds.input_seq_length, "geometry_dtype": "f64", "network_math": math_mode,
             "weights": "haiku-default init (seed 1234), decoder x0.01", "n_realloc": int(n_realloc),
         },
@@ -327,6 +343,12 @@ def main():
         del pred, traj, handle, eng
         out["other_configs"] = other_configs(device)
         log(f"[bench] other_configs done at {time.perf_counter() - t_start:.1f} s")
+        out["stationary"] = {"lines": other_configs(device, STATIONARY_PLAN, repeats=3),
+                             "note": ("same engine, same weights, trajectories whose neighbour count does not drift over the "
+                                      "rollout (vel_amp 0.03: TGV3D holds ~14.4 neighbours per particle, SURVEY 8d quotes 13.1 "
+                                      "for the dataset); `value` of the headline line stays on the drifting workload of rounds "
+                                      "1-4 (13.6 -> 18.5 -> 17.1 per particle, mean 16.2) for comparability")}
+        log(f"[bench] stationary lines done at {time.perf_counter() - t_start:.1f} s")
         out["train_step"] = train_step_lines(device)
         log(f"[bench] train_step done at {time.perf_counter() - t_start:.1f} s")
     # Everything TIMED on the GPU is done.  The CPU-baseline legs run NOW, one after the other, with nothing else on the
@@ -376,7 +398,8 @@ def measure_traffic(args, timeout_s=240):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="lbpmc_", dir="/tmp")
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                   "--no-cpu-baseline", "--no-other-configs", "--no-pmc", "--steps", "5", "--warmup", "10",
+                   "--no-cpu-baseline", "--no-other-configs", "--no-pmc", "--no-f32", "--repeats", "1",
+                   "--steps", str(args.steps), "--warmup", str(args.warmup),   # the SAME steps as the timed region: same mean E
                    "--workload", args.workload, "--batch", str(args.batch), "--mp-steps", str(args.mp_steps),
                    "--model", args.model]
             p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
@@ -455,18 +478,26 @@ def train_step_lines(device):
     return res
 
 
-def other_configs(device):
+OTHER_PLAN = [("tgv2d", "gns", 1, 20, 1.0), ("tgv2d", "gns", 8, 20, 1.0), ("rpf2d", "gns", 1, 400, 1.0),
+              ("tgv3d", "gns", 1, 20, 1.0), ("ldc3d", "gns", 1, 20, 1.0), ("ldc3d", "gns", 8, 20, 1.0),
+              ("dam2d", "segnn", 1, 20, 1.0), ("dam2d", "segnn", 8, 20, 1.0)]
+# the headline workload (and config 5) on trajectories whose neighbour count does NOT drift over the rollout: velocities
+# scaled down so that the ballistic rollout of untrained weights stays within half a spacing of the lattice
+# (lagrangebench_amd/data/synthetic.py: vel_amp); TGV3D then holds 14.4 neighbours per particle over all steps
+STATIONARY_PLAN = [("tgv3d", "gns", 8, 20, 0.03), ("tgv3d", "gns", 1, 20, 0.03), ("dam2d", "segnn", 8, 20, 0.03)]
+
+
+def other_configs(device, plan=None, repeats=1):
     """Short runs of the other BASELINE.json configs (configs[0], [1], [3], [4]) so that the driver's
     single bench line carries them too: same step definition and timing (barrier + synchronize on both
-    sides of K steps, inputs resident), one line per (workload, batch)."""
+    sides of K steps, inputs resident), one line per (workload, batch).  Also used for the `stationary` lines
+    (STATIONARY_PLAN; `repeats` timed regions, the median reported)."""
     from lagrangebench_amd.data import make_case
     from lagrangebench_amd.models import GNS, SEGNN, node_irreps
     res = []
-    plan = [("tgv2d", "gns", 1, 20), ("tgv2d", "gns", 8, 20), ("rpf2d", "gns", 1, 400), ("tgv3d", "gns", 1, 20),
-            ("ldc3d", "gns", 1, 20), ("ldc3d", "gns", 8, 20), ("dam2d", "segnn", 1, 20), ("dam2d", "segnn", 8, 20)]
-    for workload, kind, B, K in plan:
+    for workload, kind, B, K, vel_amp in (plan or OTHER_PLAN):
         try:
-            ds = make_case(workload, n_trajs=B, extra_seq_length=K)
+            ds = make_case(workload, n_trajs=B, extra_seq_length=K, vel_amp=vel_amp)
             dim, isl = len(ds.box), ds.input_seq_length
             if kind == "gns":
                 model = GNS(dim, D, 2, 10, 16)
@@ -488,38 +519,58 @@ def other_configs(device):
             traj = eng.prepare_traj(pos)
             handle = model.handle(eng, params)
             eng.rollout(handle, traj, K)  # warm-up: same rollout (capacities grown)
-            torch.cuda.synchronize(device)
-            t0 = time.perf_counter()
-            eng.rollout(handle, traj, K)
-            torch.cuda.synchronize(device)
-            dt = time.perf_counter() - t0
+            dts = []
+            for _ in range(max(1, repeats)):
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                _, n_realloc = eng.rollout(handle, traj, K)
+                torch.cuda.synchronize(device)
+                dts.append(time.perf_counter() - t0)
+            dt = float(np.median(dts))
             N = pos.shape[1]
             entry = {"workload": f"{workload} {'GNS-10-128' if kind == 'gns' else 'SEGNN-10-64'}", "n_particles": int(N),
                      "batch": B, "steps": K, "ms_per_step": round(1e3 * dt / K, 4),
-                     "value": B * N * K / dt, "unit": "particle-steps/s"}
+                     "value": B * N * K / dt, "unit": "particle-steps/s", "n_realloc": int(n_realloc),
+                     "math_fallbacks": int(eng.math_fallbacks())}
+            if vel_amp != 1.0:
+                entry["vel_amp"] = vel_amp
+            if repeats > 1:
+                entry["ms_per_step_all"] = [round(1e3 * x / K, 4) for x in dts]
             # this entry's own roofline: the processor edge (GNS) / message (SEGNN) kernel on the engine's HIP-event
             # timers over min(K, 20) more steps
             try:
                 Kt = min(K, 20)
-                E_tot = eng.stats()["n_edges_total"]
                 eng.timers_enable(True)
                 eng.timers_reset()
+                eng.edge_accounting(reset=True)
                 eng.rollout(handle, traj, Kt)
                 tm = eng.timers()
                 eng.timers_enable(False)
+                acct = eng.edge_accounting(reset=True)
+                E_tot = acct["mean"]   # mean real E of the Kt steps the timers cover (not the last step's)
+                entry["edges_per_traj"] = {"first": int(acct["first"] // B), "mean": round(E_tot / B, 1),
+                                           "last": int(acct["last"] // B)}
                 ms_e, n_e = tm["edge_mlp"]
                 if n_e == 0 and tm.get("processor", (0, 0))[1] > 0:  # persistent launch: one layer's share (edge + node)
                     ms_e, n_e = tm["processor"][0], tm["processor"][1] * 10
                 us = 1e3 * ms_e / max(n_e, 1)
                 if kind == "gns":
-                    byts = E_tot * (2 * D * 4 + 8) + B * N * (2 * D * 4)
+                    byts = int(round(E_tot * (2 * D * 4 + 8))) + B * N * (2 * D * 4)
                     entry["roofline"] = {"kernel": eng.kernel_names()["edge"], "node_kernel": eng.kernel_names()["node"],
                                          "bound": "hbm", "us_per_launch": round(us, 2), "bytes_per_launch": int(byts),
                                          "achieved": byts / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": byts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                         "note": "B = 1 graphs are launch-latency bound, not bandwidth bound"}
+                                         "note": ("B = 1 graphs are launch-latency bound, not bandwidth bound" if B == 1 else
+                                                  "bytes from the mean real E of the timed steps")}
+                    ms_l, n_l = tm.get("edge_mlp_last", (0.0, 0))
+                    if n_l > 0:
+                        us_l = 1e3 * ms_l / n_l
+                        byts_l = int(round(E_tot * (D * 4 + 8))) + B * N * (2 * D * 4)
+                        entry["roofline"]["last_layer_variant"] = {
+                            "us_per_launch": round(us_l, 2), "bytes_per_launch": byts_l,
+                            "frac": byts_l / (us_l * 1e-6) / 1e9 / HBM_PEAK_GBS}
                 else:
-                    fl = sg_msg_flops(E_tot, len(ds.box))
+                    fl = int(round(sg_msg_flops(E_tot, len(ds.box))))
                     entry["roofline"] = {"kernel": "k_sg_msg (gather + 2 gated TP blocks + segment_sum, f16x2)",
                                          "bound": "mfma", "us_per_launch": round(us, 2),
                                          "achieved": fl / (us * 1e-6) / 1e12, "peak": MFMA_F16_PEAK_TF,
@@ -567,38 +618,43 @@ def run_segnn(args, rank, world, device):
     pred, n_realloc = eng.rollout(handle, traj, K)
     lbdist.barrier(device)
     dt = lbdist.max_over_ranks(time.perf_counter() - t0, device)
-    E_tot = eng.stats()["n_edges_total"]
+    E_last = eng.stats()["n_edges_total"]
     eng.timers_enable(True)
     eng.timers_reset()
+    eng.edge_accounting(reset=True)
     eng.rollout(handle, traj, K)
     tm = eng.timers()
     eng.timers_enable(False)
+    acct_tm = eng.edge_accounting(reset=True)
+    E_tot = acct_tm["mean"]   # mean real E of the K steps the timers cover
     if rank != 0:
         return
     ms_msg, n_msg = tm["edge_mlp"]  # one record per layer = the two gated message blocks
     us_msg = 1e3 * ms_msg / max(n_msg, 1)
     C = 32
     fused = tm["aggregate"][1] == 0
-    flop_algo = E_tot * 2 * (130 + 64) * (2 * C + 3 * C)   # reference formulation: TP + Linear, two blocks
+    flop_algo = int(round(E_tot * 2 * (130 + 64) * (2 * C + 3 * C)))   # reference formulation: TP + Linear, two blocks
     if fused:
         # k_sg_msg (f16x2): products actually executed per edge (s W_v^s computed once instead of 3x):
         # block 0: 128x64 + 64x32 + 3*64x32, block 1: 64x64 + 32x32 + 3*32x32; x3 split passes
         # (round 4: the vector products run on `dim` components - in 2D the z component is identically zero in the
         # reference too and is skipped: 126 instead of 144 MFMAs per 16-edge tile)
-        flop_exec = sg_msg_flops(E_tot, len(ds.box))
+        flop_exec = int(round(sg_msg_flops(E_tot, len(ds.box))))
         peak, kname = MFMA_F16_PEAK_TF, "k_sg_msg (gather + 2 gated TP blocks + segment_sum, f16x2)"
-        msg_bytes = E_tot * (2 * 512 + 40) + B * N * 512   # two node rows per edge (L2/MALL), one row per receiver
+        msg_bytes = int(round(E_tot * (2 * 512 + 40))) + B * N * 512   # two node rows per edge (L2/MALL), one row per receiver
     else:
-        flop_exec = E_tot * 2 * (136 + 64) * (2 * C + 3 * C)    # K padded to 136 / 64, fp32 MFMA
+        flop_exec = int(round(E_tot * 2 * (136 + 64) * (2 * C + 3 * C)))    # K padded to 136 / 64, fp32 MFMA
         peak, kname = MFMA_F32_PEAK_TF, "k_sg_tp<GATE> x2 (message blocks of one layer, fp32 MFMA)"
-        msg_bytes = E_tot * (2 * 512 + 512 + 512 + 512 + 16 + 64 + 8)
+        msg_bytes = int(round(E_tot * (2 * 512 + 512 + 512 + 512 + 16 + 64 + 8)))
     tf = flop_exec / (us_msg * 1e-6) / 1e12
     out = {
         "metric": "rollout particle-steps/sec", "value": world * B * N * K / dt, "unit": "particle-steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload} SEGNN-{L}-64 (lmax 1) inference rollout, neighbor list rebuilt every step",
-                   "n_particles": int(N), "batch_per_gpu": B, "edges_per_traj": int(E_tot // B),
+                   "n_particles": int(N), "batch_per_gpu": B, "edges_per_traj": int(round(E_tot / B)),
+                   "edges_per_traj_first": int(acct_tm["first"] // B), "edges_per_traj_mean": round(E_tot / B, 1),
+                   "edges_per_traj_last": int(E_last // B),
                    "input_seq_length": isl, "geometry_dtype": "f64", "network_math": "f32",
                    "weights": "U(-1,1) e3nn-style init (seed 1234), output x0.01", "n_realloc": int(n_realloc)},
         "steps_per_s_per_traj": K / dt,

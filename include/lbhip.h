@@ -259,6 +259,17 @@ int lb_math_mode(lb_engine* eng, int32_t set_mode, int32_t* mode_out, int32_t* f
 /* Steps (or stand-alone forwards) the range guard has redone in exact fp32 since the engine was created. */
 int32_t lb_math_fallbacks(lb_engine* eng);
 
+/* What the per-tile guard covers (mode 1): LARGE / NaN - the sampled probe (first tile of every wave) on every GEMM operand,
+ * plus the decoder's output test on every row; TINY rows - the edge latents and the hidden layer of k_edge16v, every operand
+ * of the M-split kernels, the hidden layer of k_node16s.  NOT row-tested: the first operand [node latents | aggregated
+ * messages] of k_node16s (its rows are LayerNorm outputs, |x| = O(1), plus sums of them).  A flagged step is redone in fp32
+ * and the steps before it are kept; with LB_GUARD=sampled (probe only) the rollout restarts from step 0 instead.
+ *
+ * Test hook: the NEXT lb_rollout behaves as if the guard had raised `flags` (LB_MATH_* bits: 1 large, 2 tiny, 4 non-finite)
+ * at rollout step `step` (one-shot; step < 0 disarms).  Lets a test drive the redo-one-step-in-fp32 / resume-in-f16x2
+ * path on healthy weights and compare the result with the oracle.  No reference counterpart. */
+int lb_debug_inject_guard(lb_engine* eng, int32_t flags, int32_t step);
+
 /* Debug/parity tap: hidden node state after the embedding and after each layer,
  * ((num_mp_steps+1), B*N, 128) fp32 rows [s(32) | vx(32) | vy(32) | vz(32)], or NULL. */
 int lb_segnn_set_tap(lb_segnn* segnn, float* hidden_out_dev);
@@ -316,6 +327,14 @@ int lb_timer_get(lb_engine* eng, int32_t cls, double* ms_out, int64_t* launches_
 
 /* Current totals: real edges over all trajectories, E_cap, cell capacity (host-synchronous). */
 int lb_stats(lb_engine* eng, int64_t* n_edges_total, int32_t* e_cap, int32_t* cell_capacity);
+
+/* Edge accounting for measurements: every neighbor-list build (allocate or update, each rollout step is one) adds its real
+ * edge count (all B trajectories, before clamping to the capacity) to a device-side sum.  sum_edges / n_builds = the MEAN
+ * E of the steps run since the last reset - what a per-launch byte or flop count averaged over a rollout must use
+ * (SURVEY 8d "use real E"; a rollout's E drifts).  first_edges / last_edges: the first build after the reset and the
+ * latest one.  reset != 0 zeroes the sums after reading.  Host-synchronous.  No reference counterpart. */
+int lb_edge_accounting(lb_engine* eng, int64_t* sum_edges, int64_t* n_builds, int64_t* first_edges, int64_t* last_edges,
+                       int32_t reset);
 
 /* Which kernels a GNS forward of this engine runs on at its CURRENT size / arithmetic mode, as
  * "edge=<kernel>;node=<kernel>" (NUL-terminated, truncated to cap): the network kernels are picked by graph size

@@ -75,6 +75,7 @@ _SIGS = {
     "lb_gns_set_tap": (C.c_int, [_P, _P]),
     "lb_math_mode": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lb_math_fallbacks": (C.c_int32, [_P]),
+    "lb_debug_inject_guard": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "lb_integrate": (C.c_int, [_P, _P, _P, _P, C.c_int32]),
     "lb_case_integrate": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P]),
     "lb_rollout": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_int32)]),
@@ -89,6 +90,8 @@ _SIGS = {
     "lb_timer_name": (C.c_char_p, [C.c_int32]),
     "lb_timer_get": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "lb_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "lb_edge_accounting": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64), C.c_int32]),
     "lb_kernel_names": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "lb_gns_train_create": (C.c_int, [_P, C.POINTER(GnsDesc), C.POINTER(C.c_float), C.c_int64, C.POINTER(_P)]),
     "lb_gns_train_destroy": (None, [_P]),

@@ -271,7 +271,7 @@ extern "C" void lb_engine_destroy(lb_engine* e) {
                   e->cell_part, e->deg, e->nl_wg_sum, e->row_ptr, e->scan_part, e->cpos, e->tmp_send, e->tmp_feat, e->tmp_feat64,
                   e->senders, e->receivers, e->efeat, e->efeat64,
                   e->overflow, e->nedges_b, e->xnode, e->nlat, e->agg, e->psr, e->elat, e->msg,
-                  e->part, e->acc, e->blocks_done, e->persist_bar};
+                  e->part, e->acc, e->blocks_done};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->ctrl_host) (void)hipHostFree(e->ctrl_host);
@@ -344,12 +344,6 @@ static int lb_check_density(lb_engine* e) {
     (void)hipMemsetAsync(&e->ctrl->persist_error, 0, sizeof(int32_t), e->stream);
     return lb_fail(LB_ERR_STATE, "single-launch neighbor build: a predecessor workgroup's edge count never arrived; "
                                  "results of this call are invalid, the engine now uses the multi-launch build");
-  }
-  if (e->ctrl_host->persist_error) {
-    e->persist_off = true;  // stay on the multi-launch path from now on
-    (void)hipMemsetAsync(&e->ctrl->persist_error, 0, sizeof(int32_t), e->stream);
-    return lb_fail(LB_ERR_STATE, "persistent processor launch: a grid-barrier spin timed out (workgroups not co-resident?); "
-                                 "results of this call are invalid, the engine now uses the multi-launch path");
   }
   if (e->ctrl_host->density_error)
     return lb_fail(LB_ERR_DENSITY,
@@ -470,6 +464,22 @@ extern "C" int lb_stats(lb_engine* e, int64_t* n_edges_total, int32_t* e_cap, in
   return LB_OK;
 }
 
+extern "C" int lb_edge_accounting(lb_engine* e, int64_t* sum_edges, int64_t* n_builds, int64_t* first_edges,
+                                  int64_t* last_edges, int32_t reset) {
+  if (!e) return lb_fail(LB_ERR_ARG, "null engine");
+  LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, e->stream));
+  LB_HIP(hipStreamSynchronize(e->stream));
+  if (sum_edges) *sum_edges = e->ctrl_host->acct_sum;
+  if (n_builds) *n_builds = e->ctrl_host->acct_builds;
+  if (first_edges) *first_edges = e->ctrl_host->acct_first;
+  if (last_edges) *last_edges = e->ctrl_host->n_edges_unclamped;
+  if (reset) {
+    LB_HIP(hipMemsetAsync(&e->ctrl->acct_builds, 0, sizeof(int32_t) * 2 + sizeof(int64_t), e->stream));
+    LB_HIP(hipStreamSynchronize(e->stream));
+  }
+  return LB_OK;
+}
+
 extern "C" int lb_segment_sum(lb_engine* e, const float* msg_dev, float* out_dev, int32_t D) {
   if (!e || !msg_dev || !out_dev) return lb_fail(LB_ERR_ARG, "null argument");
   lb_tic(e, LB_T_AGGREGATE);
@@ -586,11 +596,6 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     lb_pack_weight16h(src, K, M, Kp, tmp.data(), Mp);
     return put(tmp.data(), tmp.size());
   };
-  auto put_packed32h = [&](const float* src) -> size_t {  // D x D, 32-edge-tile fragment order (lb_edge32.hip)
-    std::vector<float> tmp((size_t)D * D);
-    lb_pack_weight32h(src, D, D, tmp.data());
-    return put(tmp.data(), tmp.size());
-  };
   auto put_packed = [&](const float* src, int K, int M, int Kp, int Mp) -> size_t {
     std::vector<float> tmp((size_t)Kp * Mp);
     lb_pack_weight(src, K, M, Kp, Mp, tmp.data());
@@ -646,7 +651,7 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
   const size_t o_ee_w1_16 = put_packed16(p_enc_edge + (size_t)d->edge_in * D + D, D, D, D);
   const size_t o_ee_w0_16h = put_packed16h(p_enc_edge, d->edge_in, D, 32);
   const size_t o_ee_w1_16h = put_packed16h(p_enc_edge + (size_t)d->edge_in * D + D, D, D, D);
-  std::vector<size_t> o_pe_w0_16(L), o_pe_w1_16(L), o_pe_w0_16h(L), o_pe_w1_16h(L), o_pe_w0_32h(L), o_pe_w1_32h(L);
+  std::vector<size_t> o_pe_w0_16(L), o_pe_w1_16(L), o_pe_w0_16h(L), o_pe_w1_16h(L);
   std::vector<Off> o_pe(L), o_pn(L);
   std::vector<size_t> o_pw(L), o_pb(L);
   for (int k = 0; k < L; ++k) {
@@ -677,12 +682,10 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     o.w0 = put_packed(w0 + (size_t)2 * D * D, D, D, D, D);  // edge rows only
     o_pe_w0_16[k] = put_packed16(w0 + (size_t)2 * D * D, D, D, D);
     o_pe_w0_16h[k] = put_packed16h(w0 + (size_t)2 * D * D, D, D, D);
-    o_pe_w0_32h[k] = put_packed32h(w0 + (size_t)2 * D * D);
     o.b0 = put(b0, D);
     p += (size_t)3 * D * D + D;
     o_pe_w1_16[k] = put_packed16(p, D, D, D);
     o_pe_w1_16h[k] = put_packed16h(p, D, D, D);
-    o_pe_w1_32h[k] = put_packed32h(p);
     o.w1 = put_packed(p, D, D, D, D); p += (size_t)D * D;
     o.b1 = put(p, D); p += D;
     o.ln = true;
@@ -827,35 +830,12 @@ extern "C" int lb_gns_create(lb_engine* e, const lb_gns_desc* d, const float* w,
     g->proj_w_h2.push_back(g->blob + o_pw_h2[k]);
     g->proc_edge_w0_16h.push_back(g->blob + o_pe_w0_16h[k]);
     g->proc_edge_w1_16h.push_back(g->blob + o_pe_w1_16h[k]);
-    g->proc_edge_w0_32h.push_back(g->blob + o_pe_w0_32h[k]);
-    g->proc_edge_w1_32h.push_back(g->blob + o_pe_w1_32h[k]);
   }
   g->ms_enc_node = g->blob + o_ms_enc_node;
   g->ms_enc_edge = g->blob + o_ms_enc_edge;
   for (int k = 0; k < L; ++k) {
     g->ms_proc_edge.push_back(g->blob + o_ms_pe[k]);
     g->ms_proc_node.push_back(g->blob + o_ms_pn[k]);
-  }
-  if (L > 0) {
-    std::vector<lb_persist_layer> tab(L);
-    for (int k = 0; k < L; ++k) {
-      lb_persist_layer& t = tab[k];
-      t.we = g->ms_proc_edge[k];
-      t.b1e = g->blob + o_pe[k].b1;
-      t.lnse = g->blob + o_pe[k].lns;
-      t.lnoe = g->blob + o_pe[k].lno;
-      t.wn = g->ms_proc_node[k];
-      t.b0n = g->blob + o_pn[k].b0;
-      t.b1n = g->blob + o_pn[k].b1;
-      t.lnsn = g->blob + o_pn[k].lns;
-      t.lnon = g->blob + o_pn[k].lno;
-      t.bp = (k + 1 < L) ? g->blob + o_pb[k + 1] : nullptr;
-    }
-    if (hipMalloc(&g->persist_layers, sizeof(lb_persist_layer) * L) != hipSuccess ||
-        hipMemcpy(g->persist_layers, tab.data(), sizeof(lb_persist_layer) * L, hipMemcpyHostToDevice) != hipSuccess) {
-      lb_gns_destroy(g);
-      return lb_fail(LB_ERR_HIP, "persistent-processor layer table upload failed");
-    }
   }
   g->dec_unscale = dec_unscale;
   g->dec_w0_h = g->blob + o_dec_w0_h;
@@ -908,7 +888,6 @@ int lb_gns_bind(lb_engine* e, lb_gns* g) {
 extern "C" void lb_gns_destroy(lb_gns* g) {
   if (!g) return;
   if (g->eng && g->eng->bound_model == g) g->eng->bound_model = nullptr;
-  if (g->persist_layers) (void)hipFree(g->persist_layers);
   if (g->blob) (void)hipFree(g->blob);
   for (float* b : g->gen_hn)
     if (b) (void)hipFree(b);
@@ -936,14 +915,17 @@ __global__ void k_acc_export(int64_t BN, int dim, const float* __restrict__ acc4
 }
 
 // f16x2 range guard, host side: read (and clear) the flags the kernels raised since the last check.
-// Returns 1 when the engine was in guarded f16x2 mode and has just been switched to exact fp32 - the
-// caller then repeats its work; the switch is sticky for the engine.
-static int lb_math_check(lb_engine* e, int* switched, int* flagged_step = nullptr) {
+// *switched = 1 when the engine was in guarded f16x2 mode and has just been put on exact fp32 - the caller then
+// repeats its work and sets f16x2 back afterwards (not sticky).  Called with the engine already on fp32 it only
+// clears the flags (the fp32 decoder raises LB_MATH_NONFINITE too) and reports them through flags_out.
+static int lb_math_check(lb_engine* e, int* switched, int* flagged_step = nullptr, int* flags_out = nullptr) {
   *switched = 0;
+  if (flags_out) *flags_out = 0;
   LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, e->stream));
   LB_HIP(hipStreamSynchronize(e->stream));
   const int flags = e->ctrl_host->math_flags;
   if (!flags) return LB_OK;
+  if (flags_out) *flags_out = flags;
   if (flagged_step) *flagged_step = e->ctrl_host->math_step;
   {
     const int32_t reset[1] = {LB_MATH_NO_STEP};
@@ -981,6 +963,15 @@ extern "C" int lb_math_mode(lb_engine* e, int32_t set_mode, int32_t* mode_out, i
 
 extern "C" int32_t lb_math_fallbacks(lb_engine* e) { return e ? e->math_fallbacks : 0; }
 
+extern "C" int lb_debug_inject_guard(lb_engine* e, int32_t flags, int32_t step) {
+  if (!e) return lb_fail(LB_ERR_ARG, "null engine");
+  if (step >= 0 && !(flags & (LB_MATH_LARGE | LB_MATH_TINY | LB_MATH_NONFINITE)))
+    return lb_fail(LB_ERR_ARG, "flags must carry at least one LB_MATH_* bit");
+  e->debug_guard_flags = flags;
+  e->debug_guard_step = step < 0 ? -1 : step;
+  return LB_OK;
+}
+
 extern "C" int lb_gns_forward(lb_engine* e, lb_gns* g, float* acc_out_dev) {
   if (!e || !g) return lb_fail(LB_ERR_ARG, "null argument");
   if (g->eng != e) return lb_fail(LB_ERR_ARG, "model was created for another engine");
@@ -993,7 +984,9 @@ extern "C" int lb_gns_forward(lb_engine* e, lb_gns* g, float* acc_out_dev) {
     LB_TRY(lb_math_check(e, &switched));
     if (switched) {  // this forward again in exact fp32; the engine returns to guarded f16x2 (round 4: not sticky)
       ++e->math_fallbacks;
-      const int rc = lbk_gns_forward(e, g);
+      int rc = lbk_gns_forward(e, g);
+      int sw2 = 0;
+      if (!rc) rc = lb_math_check(e, &sw2);  // (engine on fp32: only clears what the fp32 decoder may have raised)
       e->f16x2 = 1;
       if (rc) return rc;
     }
@@ -1046,16 +1039,16 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
     // again.  Steps before the flagged one are valid f16x2 work only if every tile was tested: with LB_GUARD=sampled
     // (first tile of every wave, rounds 2-3) the rollout is repeated from step 0 instead.
     static const int max_fb = getenv("LB_GUARD_MAX_FALLBACKS") ? atoi(getenv("LB_GUARD_MAX_FALLBACKS")) : 3;
-#ifdef LB_TEST_HOOKS
-    // LB_TEST_RESUME_AT=k (tests only, library built with -DLB_TEST_HOOKS): behave as if the guard had fired at step k
-    static const int force_at = getenv("LB_TEST_RESUME_AT") ? atoi(getenv("LB_TEST_RESUME_AT")) : -1;
-    if (force_at >= 0 && force_at < n_steps) {
-      const int32_t inj[2] = {LB_MATH_TINY, force_at};
-      LB_HIP(hipMemcpyAsync(&e->ctrl->math_flags, &inj[0], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-      LB_HIP(hipMemcpyAsync(&e->ctrl->math_step, &inj[1], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-      LB_HIP(hipStreamSynchronize(e->stream));
+    if (e->debug_guard_step >= 0) {
+      // lb_debug_inject_guard (tests): behave as if the guard had fired at that step of THIS rollout; one-shot
+      if (e->debug_guard_step < n_steps) {
+        const int32_t inj[2] = {e->debug_guard_flags, e->debug_guard_step};
+        LB_HIP(hipMemcpyAsync(&e->ctrl->math_flags, &inj[0], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        LB_HIP(hipMemcpyAsync(&e->ctrl->math_step, &inj[1], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        LB_HIP(hipStreamSynchronize(e->stream));
+      }
+      e->debug_guard_step = -1;
     }
-#endif
     int rc = LB_OK;
     for (int fallbacks = 0;;) {
       int switched = 0, s0 = 0;
@@ -1067,7 +1060,20 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
       e->math_fallbacks += rest ? n_steps - s0 : 1;
       rc = lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, &n2, s0, rest ? -1 : s0 + 1);
       if (n_realloc_out) *n_realloc_out += n2;
+      if (rc) break;
+      // Flags raised by the fp32 work itself (its decoder reports non-finite accelerations too) are final - there is no
+      // better arithmetic to fall back to.  They are cleared here so that neither this loop nor the next call sees a
+      // stale flag, and a step that flags again in fp32 is not retried: the rest of the rollout runs in fp32.
+      int sw2 = 0, f32_flags = 0;
+      rc = lb_math_check(e, &sw2, nullptr, &f32_flags);
       if (rc || rest) break;
+      if (f32_flags) {
+        e->math_fallbacks += n_steps - (s0 + 1);
+        rc = lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, &n2, s0 + 1, -1);
+        if (n_realloc_out) *n_realloc_out += n2;
+        if (!rc) rc = lb_math_check(e, &sw2);
+        break;
+      }
       e->f16x2 = 1;                 // back to guarded f16x2 behind the flagged step
       rc = lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, &n2, s0 + 1);
       if (n_realloc_out) *n_realloc_out += n2;
@@ -1172,21 +1178,24 @@ int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* mo
     LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, e->stream));
     LB_HIP(hipStreamSynchronize(e->stream));
     if (e->ctrl_host->persist_error) {
-      // A bounded spin of a single-launch neighbor build (2) or of the persistent processor (1) timed out - a busy or
-      // shared GPU can starve a predecessor workgroup.  Everything from that step on is invalid, nothing before it:
+      // A bounded spin of a single-launch neighbor build timed out - a busy or shared GPU can starve a predecessor
+      // workgroup.  Everything from that step on is invalid, nothing before it:
       // the engine leaves that path and the rollout RESUMES at the recorded step on the multi-launch path (ADVICE r03;
       // round 3 surfaced LB_ERR_STATE here although the fall-back was one flag away).
-      if (e->ctrl_host->persist_error == 2) e->nl_one_off = true; else e->persist_off = true;
+      e->nl_one_off = true;
       const int s_bad = std::max(start_step, std::min(e->ctrl_host->persist_step, last - 1));
       const int32_t reset[2] = {0, LB_MATH_NO_STEP};
       LB_HIP(hipMemcpyAsync(&e->ctrl->persist_error, &reset[0], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
       LB_HIP(hipMemcpyAsync(&e->ctrl->persist_step, &reset[1], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+      // (... and may have raised the range guard on garbage latents: those flags are not real either)
+      LB_HIP(hipMemcpyAsync(&e->ctrl->math_flags, &reset[0], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+      LB_HIP(hipMemcpyAsync(&e->ctrl->math_step, &reset[1], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
       // (the steps computed on the broken list may have poisoned the control block: that overflow is not real)
       const int32_t no_poison = -1;
       LB_HIP(hipMemcpyAsync(&e->ctrl->overflow_step, &no_poison, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
       e->host_flag[0] = -1;
-      fprintf(stderr, "[lbhip] single-launch %s gave up at step %d (spin time-out): resuming there on the multi-launch path\n",
-              e->ctrl_host->persist_error == 2 ? "neighbor build" : "processor", s_bad);
+      fprintf(stderr, "[lbhip] single-launch neighbor build gave up at step %d (spin time-out): resuming there on the multi-launch path\n",
+              s_bad);
       if (exec) {
         (void)hipGraphExecDestroy(exec);
         exec = nullptr;

@@ -311,17 +311,6 @@ static bool lb_use_msplit_edge(const lb_engine* e) {
   if (env == 1) return true;
   return ((int64_t)e->e_cap * e->g.B + 15) / 16 <= max_tiles;
 }
-// All message-passing layers in one persistent launch (lb_persist.hip): OPT-IN (LB_PERSIST=1, graphs up to
-// LB_PERSIST_MAX_TILES 16-edge tiles).  Measured in round 3 (profiles/r03_persist.txt): a grid barrier with the
-// write-through / acquire hand-off costs ~4.5 us and a layer needs two, and one 512-register workgroup per CU walks
-// its 4-5 edge tiles one after the other - 27.8 us per layer on TGV2D-2.5k against 22.4 us for the two M-split
-// launches, so the multi-launch path stays the default.
-static bool lb_use_persist(const lb_engine* e) {
-  static const int env = getenv("LB_PERSIST") ? atoi(getenv("LB_PERSIST")) : 0;
-  static const int64_t max_tiles = getenv("LB_PERSIST_MAX_TILES") ? atoll(getenv("LB_PERSIST_MAX_TILES")) : 3072;
-  if (!e->f16x2 || !e->fused_agg || e->persist_off || e->BN > 16384 || env != 1) return false;
-  return ((int64_t)e->e_cap * e->g.B + 15) / 16 <= max_tiles;
-}
 static bool lb_use_msplit_node(const lb_engine* e) {
   static const int64_t max_nodes = getenv("LB_MS_MAX_NODES") ? atoll(getenv("LB_MS_MAX_NODES")) : 16384;
   const int env = lb_msplit_env();
@@ -332,11 +321,6 @@ static bool lb_use_msplit_node(const lb_engine* e) {
 
 extern "C" int lb_kernel_names(lb_engine* e, char* out, int32_t cap) {
   if (!e || !out || cap < 1) return lb_fail(LB_ERR_ARG, "null argument");
-  if (lb_use_persist(e)) {
-    snprintf(out, (size_t)cap, "edge=k_gns_persist (all layers in one launch: M-split edge + node phases, f16x2);"
-                               "node=k_gns_persist (same launch)");
-    return LB_OK;
-  }
   const char* edge = !e->f16x2 ? "k_edge16<PROC,f32>"
                      : !e->fused_agg ? "k_edge16<PROC,f16x2> + k_segment_sum"
                      : lb_use_msplit_edge(e) ? "k_edge_ms (M-split, f16x2, fused segment_sum)"
@@ -349,11 +333,8 @@ extern "C" int lb_kernel_names(lb_engine* e, char* out, int32_t cap) {
 int lbk_gns_forward(lb_engine* e, lb_gns* g) {
   LB_TRY(lb_gns_bind(e, g));
   if (g->generic) return lbk_gns_forward_generic(e, g);
-  // LB_MS_PARTS (debug / ablation): bit 0 encoder node, 1 encoder edge, 2 processor edge, 3 processor node
-  static const int ms_parts = getenv("LB_MS_PARTS") ? atoi(getenv("LB_MS_PARTS")) : 15;
   const bool ms_e = lb_use_msplit_edge(e), ms_n = lb_use_msplit_node(e);
-  const bool ms_en = ms_n && (ms_parts & 1), ms_ee = ms_e && (ms_parts & 2);
-  const bool ms_pe = ms_e && (ms_parts & 4), ms_pn = ms_n && (ms_parts & 8);
+  const bool ms_en = ms_n, ms_ee = ms_e, ms_pe = ms_e, ms_pn = ms_n;
   hipStream_t s = e->stream;
   const int64_t BN = e->BN;
   const int ntile_n = (int)((BN + LB_TILE - 1) / LB_TILE);
@@ -475,44 +456,8 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
   if (rc) return rc;
   if (g->tap) LB_HIP(hipMemcpyAsync(g->tap, e->nlat, sizeof(float) * BN * LB_D, hipMemcpyDeviceToDevice, s));
 
-  // ---- processor.  Small graphs: all L layers in ONE persistent launch (lb_persist.hip)
-  bool persist = false;
-  static const bool persist_tap = getenv("LB_PERSIST_TAP") && getenv("LB_PERSIST_TAP")[0] == '1';  // debug: tap[L] only
-  if (L > 0 && (!g->tap || persist_tap) && g->persist_layers) persist = lb_use_persist(e);
-  if (persist && !e->persist_bar) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8) {
-      e->persist_grid = (cus > 256 ? 256 : cus) / 8 * 8;  // one 512-register workgroup per CU, all co-resident
-      if (getenv("LB_PERSIST_GRID")) e->persist_grid = std::max(8, std::min(e->persist_grid, atoi(getenv("LB_PERSIST_GRID")) / 8 * 8));
-      if (lb_alloc(&e->persist_bar, (size_t)32 * 12)) e->persist_grid = 0;
-    }
-    if (e->persist_grid <= 0) e->persist_off = true;
-  }
-  if (persist && e->persist_grid > 0) {
-    lb_persist_args pa{};
-    pa.ctrl = e->ctrl;
-    pa.senders = e->senders;
-    pa.receivers = e->receivers;
-    pa.row_ptr = e->row_ptr;
-    pa.elat = e->elat;
-    pa.psr = e->psr;
-    pa.agg = e->agg;
-    pa.part = e->part;
-    pa.nlat = e->nlat;
-    pa.n_rows = BN;
-    pa.L = L;
-    pa.layers = (const lb_persist_layer*)g->persist_layers;
-    pa.bar = e->persist_bar;
-    pa.grid = e->persist_grid;
-    lb_tic_single(e, LB_T_PROCESSOR);
-    rc = lbk_gns_persist(e, pa);
-    lb_toc(e);
-    if (rc) return rc;
-    if (g->tap)
-      LB_HIP(hipMemcpyAsync(g->tap + (size_t)L * BN * LB_D, e->nlat, sizeof(float) * BN * LB_D, hipMemcpyDeviceToDevice, s));
-  }
-  for (int k = 0; k < L && !(persist && e->persist_grid > 0); ++k) {
+  // ---- processor
+  for (int k = 0; k < L; ++k) {
     const lb_mlp_w& pe = g->proc_edge[k];
     const bool skip = (k == L - 1) && e->fused_agg && !g->tap;  // the last layer's edge latents have no reader
     lb_tic_single(e, skip ? LB_T_EDGE_LAST : LB_T_EDGE_MLP);
@@ -549,15 +494,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       b.agg = e->agg;
       b.part = e->part;
       b.skip_elat_store = skip;
-      // LB_EDGE32=1: 32-edge tiles on the 32x32x16 MFMA (lb_edge32.hip)
-      static const bool edge32 = getenv("LB_EDGE32") && getenv("LB_EDGE32")[0] == '1';
-      if (e->f16x2 && e->fused_agg && edge32) {
-        b.w0p = g->proc_edge_w0_32h[k];
-        b.w1p = g->proc_edge_w1_32h[k];
-        rc = lbk_edge32(e, b);
-      } else {
-        rc = (e->f16x2 && e->fused_agg) ? lbk_edge16v(e, b) : lbk_edge16(e, b, true, e->f16x2 != 0);
-      }
+      rc = (e->f16x2 && e->fused_agg) ? lbk_edge16v(e, b) : lbk_edge16(e, b, true, e->f16x2 != 0);
     }
     lb_toc(e);
     if (rc) return rc;

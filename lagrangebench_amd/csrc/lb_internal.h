@@ -35,13 +35,22 @@ struct lb_ctrl {
                            // 4 = non-finite accelerations; checked by the host at its sync points
   float ln_inv_d;          // LayerNorm over a latent narrower than the 128-wide tiles (zero-padded weights):
   float ln_pad;            // mean = sum / d, var = (sum_128 (x-mean)^2 - pad * mean^2) / d, pad = 128 - d
-  int32_t persist_error;   // lb_persist.hip: a grid-barrier spin timed out (the launch gave up; results are invalid)
+  int32_t persist_error;   // 2: a single-launch neighbor build (k_nl_small / k_nl_mid) gave up a bounded spin; results are invalid
   int32_t nl_epoch;        // k_nl_small: build counter that tags the per-workgroup edge counts (never 0 mod 2^16)
   int32_t persist_step;    // first rollout step at which persist_error was raised (0x7fffffff = none): lb_rollout resumes THERE on
                            // the multi-launch path
   int32_t math_step;       // first rollout step at which a range-guard flag was raised (0x7fffffff = none): lb_rollout
                            // resumes THERE in exact fp32 instead of repeating the rollout
+  int32_t acct_builds;     // lb_edge_accounting: neighbor-list builds since the last reset,
+  int32_t acct_first;      // the first of them's edge count,
+  int64_t acct_sum;        // and the sum of their (unclamped) edge counts
 };
+// every finisher of a neighbor-list build calls this from ONE thread, next to its n_edges_unclamped store
+__device__ __forceinline__ void lb_acct_edges(lb_ctrl* ctrl, int total) {
+  if (ctrl->acct_builds == 0) ctrl->acct_first = total;
+  ctrl->acct_builds += 1;
+  ctrl->acct_sum += total;
+}
 #define LB_MATH_NO_STEP 0x7fffffff
 #define LB_MATH_LARGE 1
 #define LB_MATH_TINY 2
@@ -176,12 +185,11 @@ struct lb_engine {
   int guard_sampled;   // 1 (LB_GUARD=sampled): only the sampled probe of rounds 2-3 (first tile of every wave); a raised flag then
                        // repeats the rollout from step 0 (earlier steps may have had unsampled out-of-range tiles)
   int math_fallbacks = 0;  // steps redone in exact fp32 by the guard since the engine was created (lb_stats)
+  int debug_guard_step = -1;   // lb_debug_inject_guard: the next lb_rollout behaves as if the guard fired at this step
+  int debug_guard_flags = 0;
   int guard_full;      // 1: the wave-per-tile edge kernel tests EVERY tile for the TINY condition (lb_math_mode 3 /
                        //    LB_GUARD=full; +8 % on that kernel); 0: sampled probe.  The M-split kernels always test all.
   float* acc;          // [BN][4] decoder output (dim padded to 4)
-  unsigned* persist_bar = nullptr;    // grid-barrier words of the persistent processor launch (lb_persist.hip)
-  int persist_grid = 0;               // workgroups of that launch (= CUs, multiple of 8); 0 = not usable
-  bool persist_off = false;           // a barrier timed out once: the engine stays on the multi-launch path
   const void* bound_model = nullptr;  // the lb_gns whose per-model constants (LayerNorm width, node row stride) are
                                       // currently in the control block / geometry: lb_gns_bind
 
@@ -271,7 +279,6 @@ struct lb_gns {
   const float* enc_edge_w0_16h;                // f16x2 (hi|lo) packings
   const float* enc_edge_w1_16h;
   std::vector<const float*> proc_edge_w0_16h, proc_edge_w1_16h;
-  std::vector<const float*> proc_edge_w0_32h, proc_edge_w1_32h;  // 32-edge-tile fragment order (lb_edge32.hip)
   // f16x2 node-MLP packings: w0 (Kpad x 128), w1 (128 x 128), projection (128 x 256)
   const float* enc_node_w0_h;
   const float* enc_node_w1_h;
@@ -290,7 +297,6 @@ struct lb_gns {
   const float* ms_enc_node = nullptr;
   const float* ms_enc_edge = nullptr;
   std::vector<const float*> ms_proc_edge, ms_proc_node;
-  void* persist_layers = nullptr;  // device array of lb_persist_layer[L] (lb_persist.hip)
   // num_mlp_layers != 2 (lb_gns_generic.hip): one packed 128x128 Linear per input block, both packings
   bool generic = false;
   lb_gen_mlp g_enc_node, g_enc_edge, g_dec;
@@ -427,9 +433,6 @@ void lb_pack_weight16h(const float* w, int K, int M, int Kpad, float* out, int M
 int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const float* w1h,
                 const float* wph2, int npa, int npb, bool resid);
 int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc, bool f16x2);
-// lb_edge32.hip: the processor edge kernel on 32-edge tiles (w0p / w1p: lb_pack_weight32h images)
-void lb_pack_weight32h(const float* w, int K, int M, float* out);
-int lbk_edge32(lb_engine* e, const lb_edge16_args& a);
 // lb_edge16v.hip: processor edge kernel (f16x2, fused aggregation, two waves per SIMD)
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a);
 int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a);

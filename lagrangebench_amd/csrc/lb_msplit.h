@@ -17,7 +17,7 @@ struct lb_ems_args {      // edge kernels
   float* agg;             // [BN][128] rows complete inside one tile
   float* part;            // [tiles][2][128] segments cut by a tile boundary
   int skip_elat_store;    // last processor layer: the updated edge latents have no reader
-  long long* dbg;         // LB_MS_DBG=1: shader-clock stamps of workgroup 0 (null in the product path)
+  long long* dbg;         // -DLB_MS_STAMPS builds: shader-clock stamps of workgroup 0 (null in the product path)
 };
 
 struct lb_nms_args {      // node kernel
@@ -44,41 +44,10 @@ struct lb_nms_args {      // node kernel
   float* acc_out;         // [rows][4]
   int32_t out_dim;
   lb_integ_job integ;     // on = 0: stand-alone forward
-  long long* dbg;         // LB_MS_DBG=1: shader-clock stamps of workgroup 0 (null in the product path)
-};
-
-struct lb_persist_layer {  // device pointers of one message-passing layer (lb_persist.hip)
-  const float* we;         // lb_pack_ms images [W0 edge rows | W1]
-  const float* b1e;
-  const float* lnse;
-  const float* lnoe;
-  const float* wn;         // [W0 (nlat | agg) | W1 | projection of layer k+1]
-  const float* b0n;
-  const float* b1n;
-  const float* lnsn;
-  const float* lnon;
-  const float* bp;         // [256] projection bias of layer k+1 (null on the last layer)
-};
-
-struct lb_persist_args {
-  lb_ctrl* ctrl;
-  const int32_t* senders;
-  const int32_t* receivers;
-  const int32_t* row_ptr;
-  float* elat;
-  float* psr;
-  float* agg;
-  float* part;
-  float* nlat;
-  int64_t n_rows;
-  int L;
-  const lb_persist_layer* layers;  // [L], device
-  unsigned* bar;                   // grid-barrier words (zeroed before every launch)
-  int grid;                        // workgroups = CUs used (multiple of 8)
+  long long* dbg;         // -DLB_MS_STAMPS builds: shader-clock stamps of workgroup 0 (null in the product path)
 };
 
 void lb_pack_ms(const float* w, int K, int M, int nkb, int npw, bool perm, float* out);
 int lbk_edge_ms(lb_engine* e, const lb_ems_args& a);
 int lbk_edge_enc_ms(lb_engine* e, const lb_ems_args& a);
 int lbk_node_ms(lb_engine* e, const lb_nms_args& a, int nka, bool agg, bool resid, bool proj, bool dec = false);
-int lbk_gns_persist(lb_engine* e, const lb_persist_args& a);

@@ -599,9 +599,13 @@ __global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geo
 
 // =========================================================================================== launchers
 // one tile per workgroup and iteration; two edge workgroups / one node workgroup per CU
-// LB_MS_DBG=1: every launch is followed by a device sync and a dump of workgroup 0's stamps (debug only)
+// -DLB_MS_STAMPS builds only: every launch is followed by a device sync and a dump of workgroup 0's stamps
 static long long* ms_dbg_buf() {
-  static const bool on = getenv("LB_MS_DBG") && getenv("LB_MS_DBG")[0] == '1';
+#ifdef LB_MS_STAMPS
+  static const bool on = true;
+#else
+  static const bool on = false;
+#endif
   static long long* buf = nullptr;
   if (on && !buf) {
     if (hipMalloc((void**)&buf, 32 * sizeof(long long)) != hipSuccess) buf = nullptr;
@@ -653,8 +657,7 @@ int lbk_node_ms(lb_engine* e, const lb_nms_args& a_in, int nka, bool agg, bool r
   a.dbg = ms_dbg_buf();
   const int64_t tiles = (a.n_rows + 15) / 16;
   // more than one tile per CU: two tiles per iteration (both tiles' loads in flight together)
-  static const int t_env = getenv("LB_MS_NODE_T") ? atoi(getenv("LB_MS_NODE_T")) : 0;
-  const bool t2 = t_env ? t_env == 2 : tiles > 256;
+  const bool t2 = tiles > 256;
   const dim3 grid(ms_grid(t2 ? (tiles + 1) / 2 : tiles, 1)), block(MS_THREADS);
   if (dec) {  // last processor layer + decoder (+ integrator)
     if (!(nka == 4 && agg && resid && !proj)) return lb_fail(LB_ERR_UNSUPPORTED, "k_node_ms<DEC>: processor shape only");

@@ -1,4 +1,4 @@
-// lb_msplit_dev.h - device helpers of the M-split kernels (lb_msplit.hip, lb_persist.hip): fp16 hi/lo staging of a
+// lb_msplit_dev.h - device helpers of the M-split kernels (lb_msplit.hip): fp16 hi/lo staging of a
 // tile's activations as MFMA B fragments in LDS, register-resident weight fragments, the cross-wave LayerNorm
 // combine, DPP / permlane reductions, the exhaustive range guard, the XCD-aware unit walk.
 #pragma once
@@ -10,7 +10,7 @@ typedef float f32x2m __attribute__((ext_vector_type(2)));
 typedef _Float16 h2m __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2m __attribute__((ext_vector_type(2)));
 
-// Built with -DLB_MS_STAMPS (debug builds only; LB_MS_DBG=1 then prints them): wave 0 of workgroup 0 stamps the shader
+// Built with -DLB_MS_STAMPS (debug builds only; every launch then prints them): wave 0 of workgroup 0 stamps the shader
 // clock at phase boundaries.  Not in the product library: the run-time test alone cost ~60 scalar instructions and nine
 // exec-mask round trips per tile.
 #ifdef LB_MS_STAMPS
@@ -193,61 +193,6 @@ struct ms_guard {
     if (!(m < 32768.f)) f |= LB_MATH_LARGE;  // close to the fp16 range, inf
     const bool any_large = __any(f & LB_MATH_LARGE), any_tiny = __any(f & LB_MATH_TINY);
     f = (any_large ? LB_MATH_LARGE : 0) | (any_tiny ? LB_MATH_TINY : 0);
-    if (lane == 0 && f) lb_raise_math(ctrl, f);
-  }
-};
-
-// ---- round-3a forms of the staging / range-guard helpers, kept for the persistent kernel (lb_persist.hip) only: at its
-// 256 VGPR + 240 AGPR budget the inline-asm forms of round 3b (ms_stage / ms_guard above) gave rollouts that are off by
-// 1e-4 on two-trajectory batches (tests/test_switches_gpu.py, LB_PERSIST=1) - not understood, so the opt-in kernel keeps
-// the compiler-visible arithmetic it was validated with.
-// 8 values (this wave's two output blocks of one row) -> fp16 hi (RNE) and lo = fp16(x - hi), as one B-fragment
-// k-block entry: elements 0-3 from block c = 0, 4-7 from c = 1
-template <bool RELU>
-__device__ __forceinline__ void ps_split8(const f32x4& x0, const f32x4& x1, h8& hi, h8& lo) {
-  f32x2m a[4] = {{x0[0], x0[1]}, {x0[2], x0[3]}, {x1[0], x1[1]}, {x1[2], x1[3]}};
-  h2m hh[4], ll[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (RELU) a[i] = f32x2m{fmaxf(a[i][0], 0.f), fmaxf(a[i][1], 0.f)};
-    hh[i] = __builtin_convertvector(a[i], h2m);
-    ll[i] = __builtin_convertvector(a[i] - __builtin_convertvector(hh[i], f32x2m), h2m);
-  }
-  hi = h8{hh[0][0], hh[0][1], hh[1][0], hh[1][1], hh[2][0], hh[2][1], hh[3][0], hh[3][1]};
-  lo = h8{ll[0][0], ll[0][1], ll[1][0], ll[1][1], ll[2][0], ll[2][1], ll[3][0], ll[3][1]};
-}
-
-// write this wave's 32 features x 16 rows (C layout) as k-block kb of a tile's B-fragment image [kb][part][lane]
-template <bool RELU>
-__device__ __forceinline__ void ps_stage(f32x4* img, int kb, int lane, const f32x4& x0, const f32x4& x1) {
-  h8 hi, lo;
-  ps_split8<RELU>(x0, x1, hi, lo);
-  img[(kb * 2 + 0) * 64 + lane] = __builtin_bit_cast(f32x4, hi);
-  img[(kb * 2 + 1) * 64 + lane] = __builtin_bit_cast(f32x4, lo);
-}
-
-// running range-guard state of a wave (see the header)
-struct ps_guard {
-  float big;  // max |x| over every operand seen
-  int flags;
-  __device__ __forceinline__ float see(const f32x4& x0, const f32x4& x1) {
-    const float m = fmaxf(ms_absmax4(x0), ms_absmax4(x1));
-    big = fmaxf(big, m);
-    if (!(m == m)) flags |= LB_MATH_LARGE;  // NaN
-    return m;
-  }
-  // tile-wide maximum of an operand, combined over the 4 waves through `slot` (4 floats, written before a barrier)
-  __device__ __forceinline__ void tile_max(const float* slot) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(slot);
-    const float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
-    if (m > 0.f && m < 0.0009765625f) flags |= LB_MATH_TINY;
-  }
-  __device__ __forceinline__ void commit(const lb_ctrl* ctrl, int lane) {
-    const float m = ms_wave_max(big);
-    int f = flags;
-    if (!(m < 32768.f)) f |= LB_MATH_LARGE;  // close to the fp16 range, inf
-    const bool any_nan = __any(f & LB_MATH_LARGE), any_tiny = __any(f & LB_MATH_TINY);
-    f = (any_nan ? LB_MATH_LARGE : 0) | (any_tiny ? LB_MATH_TINY : 0);
     if (lane == 0 && f) lb_raise_math(ctrl, f);
   }
 };

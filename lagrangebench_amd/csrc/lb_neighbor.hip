@@ -889,6 +889,7 @@ __global__ void __launch_bounds__(256)
     }
     row_ptr[BN] = total;
     ctrl->n_edges_unclamped = total;
+    lb_acct_edges(ctrl, total);
     ctrl->n_edges_total = (int)min((int64_t)total, e_alloc);
     if ((any || (int64_t)total > e_alloc) && ctrl->overflow_step < 0) {
       ctrl->overflow_step = ctrl->step;
@@ -923,6 +924,7 @@ __device__ __forceinline__ void lb_row_finish_body(const lb_geom& g, const int32
   if (threadIdx.x == 0) {
     const int total = row_ptr[n];
     ctrl->n_edges_unclamped = total;
+    lb_acct_edges(ctrl, total);
     ctrl->n_edges_total = (int)min((int64_t)total, e_alloc);
     if (frozen && (*s_any || (int64_t)total > e_alloc) && ctrl->overflow_step < 0) {
       ctrl->overflow_step = ctrl->step;
@@ -1020,7 +1022,7 @@ struct lb_nls_args {
   int32_t e_cap, cell_capacity, npad;
   int32_t* host_flag;
   lb_feat_job feat;  // node features of this step: every wave writes the row of its receiver (xnode == null: no job)
-  long long* dbg;  // LB_NLS_DBG=1: [3 workgroups][8] wall-clock stamps (first, middle, last workgroup)
+  long long* dbg;  // -DLB_MS_STAMPS builds: [3 workgroups][8] wall-clock stamps (first, middle, last workgroup)
 };
 #define NLS_STAMP(k)                                                                                       \
   do {                                                                                                     \
@@ -1269,6 +1271,7 @@ __global__ void __launch_bounds__(NLS_THREADS) k_nl_small(lb_geom g, lb_ctrl* __
     a.overflow[0] = ov;
     ctrl->max_cell_occ = max_occ;
     ctrl->n_edges_unclamped = total;
+    lb_acct_edges(ctrl, total);
     ctrl->n_edges_total = (int)min((int64_t)total, a.e_alloc);
     if ((ov || (int64_t)total > a.e_alloc) && ctrl->overflow_step < 0) {
       ctrl->overflow_step = step;
@@ -1551,6 +1554,7 @@ __global__ void __launch_bounds__(64 * NLM_WAVES) k_nl_mid(lb_geom g, lb_ctrl* _
     a.overflow[0] = ov;
     ctrl->max_cell_occ = max_occ;
     ctrl->n_edges_unclamped = total;
+    lb_acct_edges(ctrl, total);
     ctrl->n_edges_total = (int)min((int64_t)total, a.e_alloc);
     if ((ov || (int64_t)total > a.e_alloc) && ctrl->overflow_step < 0) {
       ctrl->overflow_step = step;
@@ -1669,7 +1673,11 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
     a.cell_capacity = e->cell_capacity;
     a.npad = nls_npad;
     a.host_flag = e->host_flag_dev;
-    static const bool nls_dbg = getenv("LB_NLS_DBG") && getenv("LB_NLS_DBG")[0] == '1';
+#ifdef LB_MS_STAMPS  // debug builds only: wall-clock stamps of three workgroups
+    static const bool nls_dbg = true;
+#else
+    static const bool nls_dbg = false;
+#endif
     static long long* dbg_dev = nullptr;
     if (nls_dbg && !dbg_dev) LB_HIP(hipMalloc((void**)&dbg_dev, sizeof(long long) * 32));
     a.dbg = nls_dbg ? dbg_dev : nullptr;

@@ -306,444 +306,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (NS_SLOTS == 4 ? 1 : 2) : 4
 #undef NS_STEP
 #undef NS_REFILL
 
-// ---------------------------------------------------------------------------------------------------------
-// k_node16s2 (round 3): the processor shape (4 + 4 k-steps, residual) with TWO 16-node tiles per
-// wave and weight chunk.  One 8-wave workgroup per CU owns 16 tiles: the 320 KiB of weights cross L2 -> LDS once per CU
-// instead of twice (82 instead of 164 MB per launch), every chunk barrier serves two tiles, and the two tiles' MFMA
-// chains interleave inside a step.  232 VGPRs, two waves per SIMD, no scratch.
-// MEASURED (TGV3D-8k x 8, bench.py timer class node_mlp): 55.2 us per launch (five steps of 64 KiB; ten steps of
-// 32 KiB: 56.8) against 50.5 us for k_node16s<.., 8, 2> - SLOWER, like the 16-wave workgroup of round 2.  Neither the
-// weight traffic (halved) nor the number of chunk steps (halved again) is what bounds the launch.  What does: it moves
-// ~2.6 - 3 KB per node through HBM (latents + aggregates in, latents + projections out: 165 - 200 MB = 33 - 40 us at the
-// 5 TB/s this access pattern gets), and since the launch is ONE round of workgroups every workgroup loads, multiplies and
-// stores at the same time as all the others - memory and matrix phases do not overlap across the chip; two
-// 8-tile workgroups per CU drifting out of phase (the default) recover some of that, one 16-tile workgroup does not.
-// Parity green (tests/test_switches_gpu.py).  Opt-in: LB_NODE_T2=1.
-template <bool PROJ>
-__global__ void __launch_bounds__(512, 2)
-    k_node16s2(lb_node_args a, const f32x4* __restrict__ w0h, const f32x4* __restrict__ w1h,
-               const f32x4* __restrict__ wph) {
-  // 64 KiB chunks (two of the 32 KiB chunks of k_node16s, which are consecutive in the packed images) through a
-  // two-slot 128 KiB ring: FIVE steps - W0 rows of the latents, W0 rows of the aggregates, W1, projection halves
-  constexpr int NW = 8, T = 2, CH = 2 * NS_CHUNK;
-  extern __shared__ f32x4 sB2[];  // [2][CH] ring, then 192 vectors
-  f32x4* const sP = sB2 + 2 * CH;
-  if (a.ctrl->overflow_step >= 0) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, g = lane >> 4;
-  constexpr int n_chunks = 3 + (PROJ ? 2 : 0);
-  if (tid < 128) {
-    const float* src = tid < 32 ? a.b0 : (tid < 64 ? a.b1 : (tid < 96 ? a.ln_s : a.ln_o));
-    sP[tid] = reinterpret_cast<const f32x4*>(src)[tid & 31];
-  } else if (tid < 192) {
-    sP[tid] = (PROJ && a.bp) ? reinterpret_cast<const f32x4*>(a.bp)[tid - 128] : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  auto issue_chunk = [&](int c) {
-    const f32x4* src = c < 2 ? w0h + (size_t)c * CH : (c == 2 ? w1h : wph + (size_t)(c - 3) * CH);
-    f32x4* slot = sB2 + (c & 1) * CH;
-#pragma unroll
-    for (int i = 0; i < CH / 64 / NW; ++i) {
-      const int piece = wave + NW * i;
-      const uint32_t voff = (uint32_t)(piece * 64 + lane) * 16u;
-      const uint32_t lo = (uint32_t)(uintptr_t)(lds_ptr)(slot + piece * 64);
-      asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lo) : "memory");
-    }
-  };
-  // step c: chunk c has landed (it is the oldest outstanding group; everything issued later - the other slot's refill
-  // and this step's own data loads - may stay in flight: vmcnt counts in order)
-#define NS2_STEP(c, later_ops)                                                     \
-  do {                                                                             \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(later_ops) : "memory");               \
-    if constexpr ((c) == 0) {                                                      \
-      __syncthreads();                                                             \
-    } else {                                                                       \
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");              \
-    }                                                                              \
-  } while (0)
-  int64_t row[T], rowc[T];
-  bool valid[T];
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    row[i] = (((int64_t)blockIdx.x * NW + wave) * T + i) * 16 + n;
-    valid[i] = row[i] < a.n_rows;
-    rowc[i] = valid[i] ? row[i] : a.n_rows - 1;
-  }
-  // data first (rows + CSR bounds), then the two ring slots: a wait for the rows must not cover the weights
-  f32x4 va[T][8];
-  int k0[T], k1[T];
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    const f32x4* xr = reinterpret_cast<const f32x4*>(a.xin) + rowc[i] * 32 + g;
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) va[i][mb] = xr[4 * mb];
-    k0[i] = k1[i] = 0;
-    if (a.fused) {
-      k0[i] = a.row_ptr[rowc[i]];
-      k1[i] = a.row_ptr[rowc[i] + 1];
-    }
-  }
-  issue_chunk(0);
-  issue_chunk(1);
-  const lds_cptr buf0 = (lds_cptr)(sB2 + lane), buf1 = (lds_cptr)(sB2 + CH + lane);
-  const lds_cptr vecp = (lds_cptr)(sP + g);
-  const bool probe = wave == 0;
-  f32x4 acc[T][8], h0[T][4], h1[T][4];
-  // ---- step 0: W0, latent rows
-  NS2_STEP(0, 8);  // (chunk 1's eight pieces may still be in flight)
-  if (probe) lb_range_probe(a.ctrl, va[0], 8);
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    lb_load_agg_half<0>(a, rowc[i], g, k0[i], k1[i], h0[i]);
-    lb_load_agg_half<4>(a, rowc[i], g, k0[i], k1[i], h1[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) acc[i][mb] = vecp[4 * mb];
-    const f32x4 v01[4] = {va[i][0], va[i][1], va[i][2], va[i][3]};
-    lb_gemm16v<false, 2>(buf0, v01, acc[i]);
-    const f32x4 v23[4] = {va[i][4], va[i][5], va[i][6], va[i][7]};
-    lb_gemm16v<false, 2>(buf0 + NS_CHUNK, v23, acc[i]);
-  }
-  // ---- step 1: W0, aggregated messages
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // chunk 1 + the aggregates
-  issue_chunk(2);  // slot 0 is free: W1
-  if (probe) {
-    lb_range_probe(a.ctrl, h0[0], 4);
-    lb_range_probe(a.ctrl, h1[0], 4);
-  }
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    lb_gemm16v<false, 2>(buf1, h0[i], acc[i]);
-    lb_gemm16v<false, 2>(buf1 + NS_CHUNK, h1[i], acc[i]);
-  }
-  if (probe) lb_range_probe(a.ctrl, acc[0], 8);
-  // ---- step 2: W1 (ReLU folded into the operand split); the residual rows are requested behind the refill
-  f32x4 acc2[T][8], res[T][8];
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  if constexpr (PROJ) issue_chunk(3);  // slot 1 is free
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    const f32x4* xr = reinterpret_cast<const f32x4*>(a.xin) + rowc[i] * 32 + g;
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) res[i][mb] = xr[4 * mb];
-  }
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) acc2[i][mb] = vecp[32 + 4 * mb];
-    const f32x4 v01[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-    lb_gemm16v<true, 2>(buf0, v01, acc2[i]);
-    const f32x4 v23[4] = {acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
-    lb_gemm16v<true, 2>(buf0 + NS_CHUNK, v23, acc2[i]);
-  }
-  f32x4 y[T][8];
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    lb_layernorm16(acc2[i], vecp + 64, vecp + 96, y[i], a.ctrl->ln_inv_d, a.ctrl->ln_pad);
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) y[i][mb] = lb_pk_add(res[i][mb], y[i][mb]);
-  }
-  if (probe) lb_range_probe(a.ctrl, y[0], 8);
-  if constexpr (PROJ) {
-    // ---- steps 3, 4: projection halves [Ws | Wr]
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (half == 0) {
-        issue_chunk(4);  // slot 0 is free
-        // the node latents go out behind the refill (their drain is waited for with the next chunk, not before it)
-#pragma unroll
-        for (int i = 0; i < T; ++i)
-          if (valid[i]) {
-            f32x4* nr = reinterpret_cast<f32x4*>(a.nlat) + row[i] * 32 + g;
-#pragma unroll
-            for (int mb = 0; mb < 8; ++mb) nr[4 * mb] = y[i][mb];
-          }
-      }
-      const lds_cptr bp = half == 0 ? buf1 : buf0;
-#pragma unroll
-      for (int i = 0; i < T; ++i) {
-        f32x4 accp[8];
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) accp[mb] = vecp[128 + 32 * half + 4 * mb];
-        const f32x4 v01[4] = {y[i][0], y[i][1], y[i][2], y[i][3]};
-        lb_gemm16v<false, 2>(bp, v01, accp);
-        const f32x4 v23[4] = {y[i][4], y[i][5], y[i][6], y[i][7]};
-        lb_gemm16v<false, 2>(bp + NS_CHUNK, v23, accp);
-        if (valid[i]) {
-          f32x4* pr = reinterpret_cast<f32x4*>(a.psr) + row[i] * 64 + 32 * half + g;
-#pragma unroll
-          for (int mb = 0; mb < 8; ++mb) pr[4 * mb] = accp[mb];
-        }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < T; ++i)
-      if (valid[i]) {
-        f32x4* nr = reinterpret_cast<f32x4*>(a.nlat) + row[i] * 32 + g;
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) nr[4 * mb] = y[i][mb];
-      }
-  }
-  (void)n_chunks;
-}
-#undef NS2_STEP
-
-// ---------------------------------------------------------------------------------------------------------
-// k_node16q (round 4; opt-in LB_NODE_Q=1 - built, bit-identical, NOT faster: see the launcher): the
-// processor shape of k_node16s with a DEEPER weight ring in the same LDS -
-// four slots of 16 KiB (one 32-wide k-step x 8 output blocks x hi|lo) instead of two of 32 KiB.  With two slots the refill
-// of a slot can only be issued one chunk step (~1.3 us of MFMA time per SIMD) before it is needed - less than the
-// L2 -> LDS latency under load, so every one of the ten steps waited for its weights (ablation: "weight stream 20 us" of a
-// 52 us launch, nothing overlapping).  Here chunk c + 3 is requested at step c: three steps of MFMA work cover its flight.
-// The in-order vmcnt makes that work only with EXACT waits: at step c the wave allows exactly the operations it has issued
-// after chunk c's pieces to stay outstanding (nq_wait: later refills, residual-row loads, the stores of the node latents /
-// projections - all issued unconditionally, the stores as raw-buffer stores whose bounds check drops the rows behind
-// n_rows, so that every wave has the same count).  Twenty steps, one barrier each.
-// Same tiles, operand order and arithmetic as k_node16s: bit-identical results.
-template <bool PROJ>
-__host__ __device__ constexpr int nq_ops_before_refill(int s) {  // issued by step s between its barrier and its refill
-  return (s == 10 || s == 11) ? 4 : 0;   // residual rows (two halves); aggregated-message loads (steps 2, 4): a data-
-                                         // dependent number, counted as 0 - they are summed as they arrive, which drains
-                                         // the counter anyway (splitting request and sum costs 16 VGPRs: spills at 128)
-}
-template <bool PROJ>
-__host__ __device__ constexpr int nq_ops_after_refill(int s) {   // issued by step s after its refill
-  return s == 11 ? 8 : ((PROJ && s == 15) ? 8 : 0);  // node-latent stores; first projection half
-}
-template <bool PROJ>
-__host__ __device__ constexpr int nq_refill(int s) { return (s >= 1 && s + 3 < (PROJ ? 20 : 12)) ? 2 : 0; }
-template <bool PROJ>
-__host__ __device__ constexpr int nq_wait(int c) {
-  int n = 0;
-  if (c < 4) {
-    n = (3 - c) * 2 + 8;  // the later prologue chunks, the eight row loads
-    for (int s = 0; s < c; ++s) n += nq_ops_before_refill<PROJ>(s) + nq_refill<PROJ>(s) + nq_ops_after_refill<PROJ>(s);
-  } else {
-    n = nq_ops_after_refill<PROJ>(c - 3);
-    for (int s = c - 2; s < c; ++s) n += nq_ops_before_refill<PROJ>(s) + nq_refill<PROJ>(s) + nq_ops_after_refill<PROJ>(s);
-  }
-  return n;
-}
-#define NQ_CHUNK 1024  // f32x4 per chunk (16 KiB)
-template <bool PROJ>
-__global__ void __launch_bounds__(512, 4)
-    k_node16q(lb_node_args a, const f32x4* __restrict__ w0h, const f32x4* __restrict__ w1h, const f32x4* __restrict__ wph) {
-  __shared__ f32x4 sB[4][NQ_CHUNK];
-  __shared__ f32x4 sP[192];  // [0,32) b0, [32,64) b1, [64,96) ln_s, [96,128) ln_o, [128,192) bp
-  if (a.ctrl->overflow_step >= 0) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, g = lane >> 4;
-  constexpr int n_chunks = PROJ ? 20 : 12;
-  constexpr int C1 = 8, CP = 12;
-  const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;  // (read here: behind the chunk requests the load's wait would drain them)
-  {  // bias / LayerNorm vectors -> LDS, branch-free (a load under a branch left a vmcnt(0) behind the chunk requests below:
-     // the register allocator reused its destination) and complete BEFORE the first chunk is requested
-    const bool has_bp = PROJ && a.bp;
-    const float* src = tid < 32 ? a.b0 : (tid < 64 ? a.b1 : (tid < 96 ? a.ln_s : (tid < 128 || !has_bp ? a.ln_o : a.bp)));
-    const int idx = (tid < 128 || !has_bp) ? (tid & 31) : ((tid - 128) & 63);
-    f32x4 v = reinterpret_cast<const f32x4*>(src)[idx];
-    if (tid >= 128 && !has_bp) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid < 192) sP[tid] = v;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  auto issue_chunk = [&](int c) {
-    const f32x4* src = c < C1 ? w0h + (size_t)c * NQ_CHUNK : (c < CP ? w1h + (size_t)(c - C1) * NQ_CHUNK : wph + (size_t)(c - CP) * NQ_CHUNK);
-    f32x4* slot = sB[c & 3];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int piece = wave + 8 * i;  // 1 KiB per wave instruction
-      const uint32_t voff = (uint32_t)(piece * 64 + lane) * 16u;
-      const uint32_t lo = (uint32_t)(uintptr_t)(lds_ptr)(slot + piece * 64);
-      asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lo) : "memory");
-    }
-  };
-#define NQ_STEP(c)                                                            \
-  do {                                                                        \
-    constexpr int nw_ = nq_wait<PROJ>(c);                                     \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(nw_) : "memory");                \
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           \
-  } while (0)
-#define NQ_REFILL(c)                                                          \
-  do {                                                                        \
-    if constexpr ((c) >= 1 && (c) + 3 < n_chunks) issue_chunk((c) + 3);       \
-  } while (0)
-#define NQ_BUF(c) lane_b[(c) & 3]
-  issue_chunk(0);
-  issue_chunk(1);
-  issue_chunk(2);
-  issue_chunk(3);
-  const int64_t row = ((int64_t)blockIdx.x * 8 + wave) * 16 + n;
-  const int64_t rowc = row < a.n_rows ? row : a.n_rows - 1;
-  lds_cptr lane_b[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) lane_b[i] = (lds_cptr)(sB[i] + lane);
-  const lds_cptr vecp = (lds_cptr)(sP + g);
-  // stores through buffer descriptors: rows behind n_rows fall outside num_records and are dropped by the bounds check
-  const __amdgpu_buffer_rsrc_t nl_rs = __builtin_amdgcn_make_buffer_rsrc(a.nlat, 0, (int)(a.n_rows * 512), 0x00020000);
-  const __amdgpu_buffer_rsrc_t ps_rs = __builtin_amdgcn_make_buffer_rsrc(a.psr, 0, (int)(a.n_rows * 1024), 0x00020000);
-  typedef uint32_t u32x4b __attribute__((ext_vector_type(4)));
-  f32x4 va[8];
-  int k0 = 0, k1 = 0;
-  {
-    const f32x4* xr = reinterpret_cast<const f32x4*>(a.xin) + rowc * 32 + g;
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) va[mb] = xr[4 * mb];
-    if (a.fused) {
-      k0 = a.row_ptr[rowc];
-      k1 = a.row_ptr[rowc + 1];
-    }
-  }
-  const bool probe = wave == 0;
-  f32x4 acc[8], h0[4], h1[4];
-  // ---- GEMM1 over [node latents | aggregated messages]: one k-step per chunk
-  NQ_STEP(0);
-  if (probe) lb_range_probe(a.ctrl, va, 8);
-#pragma unroll
-  for (int mb = 0; mb < 8; ++mb) acc[mb] = vecp[4 * mb];
-  {
-    const f32x4 v[2] = {va[0], va[1]};
-    lb_gemm16v<false, 1>(NQ_BUF(0), v, acc);
-  }
-  NQ_STEP(1);
-  NQ_REFILL(1);
-  {
-    const f32x4 v[2] = {va[2], va[3]};
-    lb_gemm16v<false, 1>(NQ_BUF(1), v, acc);
-  }
-  NQ_STEP(2);
-  lb_load_agg_half<0>(a, rowc, g, k0, k1, h0);  // into the registers va[0..3] released
-  NQ_REFILL(2);
-  {
-    const f32x4 v[2] = {va[4], va[5]};
-    lb_gemm16v<false, 1>(NQ_BUF(2), v, acc);
-  }
-  NQ_STEP(3);
-  NQ_REFILL(3);
-  {
-    const f32x4 v[2] = {va[6], va[7]};
-    lb_gemm16v<false, 1>(NQ_BUF(3), v, acc);
-  }
-  NQ_STEP(4);
-  lb_load_agg_half<4>(a, rowc, g, k0, k1, h1);
-  NQ_REFILL(4);
-  {
-    const f32x4 v[2] = {h0[0], h0[1]};
-    lb_gemm16v<false, 1>(NQ_BUF(4), v, acc);
-  }
-  NQ_STEP(5);
-  NQ_REFILL(5);
-  if (probe) lb_range_probe(a.ctrl, h0, 4);
-  {
-    const f32x4 v[2] = {h0[2], h0[3]};
-    lb_gemm16v<false, 1>(NQ_BUF(5), v, acc);
-  }
-  NQ_STEP(6);
-  NQ_REFILL(6);
-  if (probe) lb_range_probe(a.ctrl, h1, 4);
-  {
-    const f32x4 v[2] = {h1[0], h1[1]};
-    lb_gemm16v<false, 1>(NQ_BUF(6), v, acc);
-  }
-  NQ_STEP(7);
-  NQ_REFILL(7);
-  {
-    const f32x4 v[2] = {h1[2], h1[3]};
-    lb_gemm16v<false, 1>(NQ_BUF(7), v, acc);
-  }
-  if (probe) lb_range_probe(a.ctrl, acc, 8);
-  // ---- GEMM2 (ReLU folded into the operand split)
-  f32x4 acc2[8];
-  NQ_STEP(8);
-  NQ_REFILL(8);
-#pragma unroll
-  for (int mb = 0; mb < 8; ++mb) acc2[mb] = vecp[32 + 4 * mb];
-  {
-    const f32x4 v[2] = {acc[0], acc[1]};
-    uint32_t or_h = 0;
-    lb_gemm16v<true, 1, 1>(NQ_BUF(8), v, acc2, &or_h);  // per-row TINY test of the hidden row (lb_rows_tiny)
-    if (lb_rows_tiny(or_h) && lane == 0) lb_raise_math(a.ctrl, LB_MATH_TINY);
-  }
-  NQ_STEP(9);
-  NQ_REFILL(9);
-  {
-    const f32x4 v[2] = {acc[2], acc[3]};
-    lb_gemm16v<true, 1>(NQ_BUF(9), v, acc2);
-  }
-  NQ_STEP(10);
-  f32x4 res[8];
-  const f32x4* xr = reinterpret_cast<const f32x4*>(a.xin) + rowc * 32 + g;
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb) res[mb] = xr[4 * mb];  // residual: second read of the node row (L2), registers of acc[0..3]
-  NQ_REFILL(10);
-  {
-    const f32x4 v[2] = {acc[4], acc[5]};
-    lb_gemm16v<true, 1>(NQ_BUF(10), v, acc2);
-  }
-  NQ_STEP(11);
-#pragma unroll
-  for (int mb = 4; mb < 8; ++mb) res[mb] = xr[4 * mb];
-  {
-    const f32x4 v[2] = {acc[6], acc[7]};
-    lb_gemm16v<true, 1>(NQ_BUF(11), v, acc2);
-  }
-  // ---- LayerNorm + residual
-  f32x4 y[8];
-  lb_layernorm16(acc2, vecp + 64, vecp + 96, y, ln_inv_d, ln_pad);
-#pragma unroll
-  for (int mb = 0; mb < 8; ++mb) y[mb] = lb_pk_add(res[mb], y[mb]);
-  // this step's refill goes out HERE: the compiler's wait for the residual rows above does not know the chunk requests and
-  // would drain one issued before it (same position in the operation order as far as nq_wait is concerned: rows, refill, stores)
-  NQ_REFILL(11);
-  if (probe) lb_range_probe(a.ctrl, y, 8);
-  {
-    const uint32_t off = (uint32_t)row * 512u + (uint32_t)g * 16u;
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4b, y[mb]), nl_rs, (int)off, 64 * mb, 0);
-  }
-  // ---- projection for the next edge MLP: psr = y @ [Ws | Wr] + [0 | b0_next], one 128-wide half at a time
-  if constexpr (PROJ) {
-#define NQ_PROJ_STEP(c, i0)                                      \
-  NQ_STEP(c);                                                    \
-  NQ_REFILL(c);                                                  \
-  {                                                              \
-    const f32x4 v[2] = {y[i0], y[i0 + 1]};                       \
-    lb_gemm16v<false, 1>(NQ_BUF(c), v, accp);                    \
-  }
-    {
-      f32x4 accp[8];
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) accp[mb] = vecp[128 + 4 * mb];
-      NQ_PROJ_STEP(12, 0)
-      NQ_PROJ_STEP(13, 2)
-      NQ_PROJ_STEP(14, 4)
-      NQ_PROJ_STEP(15, 6)
-      const uint32_t off = (uint32_t)row * 1024u + (uint32_t)g * 16u;
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4b, accp[mb]), ps_rs, (int)off, 64 * mb, 0);
-    }
-    {
-      f32x4 accp[8];
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) accp[mb] = vecp[128 + 32 + 4 * mb];
-      NQ_PROJ_STEP(16, 0)
-      NQ_PROJ_STEP(17, 2)
-      NQ_PROJ_STEP(18, 4)
-      NQ_PROJ_STEP(19, 6)
-      const uint32_t off = (uint32_t)row * 1024u + 512u + (uint32_t)g * 16u;
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4b, accp[mb]), ps_rs, (int)off, 64 * mb, 0);
-    }
-#undef NQ_PROJ_STEP
-  }
-#undef NQ_STEP
-#undef NQ_REFILL
-#undef NQ_BUF
-}
+// (round 5: the two measured-slower variants of this kernel left the tree - k_node16s2, two tiles per wave and weight chunk,
+// 55 - 57 vs 50.5 us per launch, profiles/r02_node16s_ablation.txt / DESIGN.md section 4; k_node16q, a four-slot ring of
+// 16 KiB chunks with exact in-order vmcnt waits, 51.4 vs 50.6 us, profiles/r04_node_q_ab.txt.  git history has both.)
 
 int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const float* w1h, const float* wph2,
                 int npa, int npb, bool resid) {
@@ -773,36 +338,7 @@ int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const flo
     else                               \
       LB_NS_W(A, B, R, false);         \
   } while (0)
-  // LB_NODE_T2=1: two tiles per wave and weight chunk (k_node16s2) for the processor shape on batches
-  static const int node_q = getenv("LB_NODE_Q") ? atoi(getenv("LB_NODE_Q")) : 0;  // 1: batches, 2: also small launches (tests)
-  static const int t2 = getenv("LB_NODE_T2") ? atoi(getenv("LB_NODE_T2")) : 0;  // 2: also on small launches (tests)
-  if (t2 && npa == 4 && npb == 4 && resid && (nw == 8 || t2 == 2)) {
-    dim3 grid2((unsigned)((tiles + 15) / 16)), block2(512);
-    const size_t lds2 = sizeof(f32x4) * (4 * NS_CHUNK + 192);  // 128 KiB ring + the bias / LayerNorm vectors
-    static bool raised = false;
-    if (!raised) {
-      (void)hipFuncSetAttribute((const void*)k_node16s2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-      (void)hipFuncSetAttribute((const void*)k_node16s2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-      raised = true;
-    }
-    if (e->ext_armed && !e->ext_used) {
-      if (proj)
-        hipExtLaunchKernelGGL((k_node16s2<true>), grid2, block2, lds2, e->stream, e->trecs.back().a, e->trecs.back().b, 0, a, w0, w1, wp);
-      else
-        hipExtLaunchKernelGGL((k_node16s2<false>), grid2, block2, lds2, e->stream, e->trecs.back().a, e->trecs.back().b, 0, a, w0, w1, wp);
-      e->ext_used = true;
-    } else if (proj) {
-      hipLaunchKernelGGL((k_node16s2<true>), grid2, block2, lds2, e->stream, a, w0, w1, wp);
-    } else {
-      hipLaunchKernelGGL((k_node16s2<false>), grid2, block2, lds2, e->stream, a, w0, w1, wp);
-    }
-  } else if (npa == 4 && npb == 4 && resid && proj && ((node_q && nw == 8) || node_q == 2) && a.n_rows < (1 << 21)) {
-    // round 4, opt-in (LB_NODE_Q=1): four-slot ring of 16 KiB chunks (k_node16q) - parity green, measured 1.5 % SLOWER than
-    // the two-slot kernel (TGV3D x 8: 51.4 vs 50.6 us per launch, profiles/r04_node_q_ab.txt); the last layer (no projection)
-    // stays on k_node16s
-    dim3 gridq((unsigned)((tiles + 7) / 8));
-    LB_LAUNCH_TIMED(e, (k_node16q<true>), gridq, dim3(512), a, w0, w1, wp);
-  } else if (npa == 4 && npb == 4 && resid)
+  if (npa == 4 && npb == 4 && resid)
     LB_NS_P(4, 4, true);
   else if (npa == 1 && npb == 0 && !resid)
     LB_NS_P(1, 0, false);

@@ -102,9 +102,14 @@ def _tgv3d_field():
 
 
 def make_case(name: str, n_trajs: int = 1, extra_seq_length: int = 20, input_seq_length: int = 6,
-              scale: float = 1.0) -> SyntheticDataset:
+              scale: float = 1.0, vel_amp: float = 1.0) -> SyntheticDataset:
     """name in {tgv2d, rpf2d, tgv3d, ldc3d, dam2d, small2d, small3d}.  ``scale`` multiplies the
-    lattice counts per side (tests use small2d / small3d or scale < 1)."""
+    lattice counts per side (tests use small2d / small3d or scale < 1).  ``vel_amp`` multiplies the per-frame
+    displacement of the analytic advection (and its jitter): a rollout with UNTRAINED weights is ballistic
+    (x' = x + (x - x_prev) + ~0), so at the datasets' velocity scale (vel_amp 1) a 20-step rollout compresses the lattice
+    and the neighbour count drifts (TGV3D: 13.6 -> 18.5 -> 17 per particle); ``vel_amp`` ~ 0.03 keeps the particles
+    within half a spacing of their lattice sites over 40 steps, i.e. the neighbour count at the datasets' own value
+    (13.1 per particle for TGV3D) - bench.py's `stationary` line."""
     name = name.lower()
     isl = input_seq_length
     T = isl + extra_seq_length
@@ -125,7 +130,7 @@ def make_case(name: str, n_trajs: int = 1, extra_seq_length: int = 20, input_seq
             rng = np.random.default_rng(i)
             p0 = np.mod(_lattice(c, dx) + rng.normal(0, 0.1 * dx, size=(c[0] * c[1], 2)), box)
             pt = np.zeros(len(p0), np.int32)
-            return _advect(p0, pt, T, box, [True] * 2, field, 1.4 * vel_std, rng, jitter=0.01 * dx), pt
+            return _advect(p0, pt, T, box, [True] * 2, field, 1.4 * vel_std * vel_amp, rng, jitter=0.01 * dx * vel_amp), pt
 
         return SyntheticDataset(name, md, isl, extra_seq_length, n_trajs, make)
 
@@ -147,7 +152,7 @@ def make_case(name: str, n_trajs: int = 1, extra_seq_length: int = 20, input_seq
             rng = np.random.default_rng(i)
             p0 = np.mod(_lattice(c, dx) + rng.normal(0, 0.1 * dx, size=(c[0] * c[1], 2)), box)
             pt = np.zeros(len(p0), np.int32)
-            return _advect(p0, pt, T, box, [True] * 2, field, 1.4 * vel_std, rng, jitter=0.01 * dx), pt
+            return _advect(p0, pt, T, box, [True] * 2, field, 1.4 * vel_std * vel_amp, rng, jitter=0.01 * dx * vel_amp), pt
 
         return SyntheticDataset(name, md, isl, extra_seq_length, n_trajs, make, force=force, force_numpy=fnp)
 
@@ -166,7 +171,7 @@ def make_case(name: str, n_trajs: int = 1, extra_seq_length: int = 20, input_seq
             rng = np.random.default_rng(i)
             p0 = np.mod(_lattice(c, dx) + rng.normal(0, 0.1 * dx, size=(n, 3)), box)
             pt = np.zeros(n, np.int32)
-            return _advect(p0, pt, T, box, [True] * 3, field, 1.4 * vel_std, rng, jitter=0.01 * dx), pt
+            return _advect(p0, pt, T, box, [True] * 3, field, 1.4 * vel_std * vel_amp, rng, jitter=0.01 * dx * vel_amp), pt
 
         return SyntheticDataset(name, md, isl, extra_seq_length, n_trajs, make)
 
@@ -196,8 +201,8 @@ def make_case(name: str, n_trajs: int = 1, extra_seq_length: int = 20, input_seq
             fl = ptype0 == 0
             p0[fl] += rng.normal(0, 0.08 * dx, size=(int(fl.sum()), 3))
             p0 = np.mod(p0, box)
-            return _advect(p0, ptype0, T, box, [True] * 3, field, 1.2 * vel_std, rng,
-                           moving_vel=np.array([0.09 * dx / (1.0 / 24.0), 0.0, 0.0]), jitter=0.01 * dx), ptype0.copy()
+            return _advect(p0, ptype0, T, box, [True] * 3, field, 1.2 * vel_std * vel_amp, rng,
+                           moving_vel=np.array([0.09 * dx / (1.0 / 24.0), 0.0, 0.0]), jitter=0.01 * dx * vel_amp), ptype0.copy()
 
         return SyntheticDataset(name, md, isl, extra_seq_length, n_trajs, make, multiplier=2.0)
 
@@ -236,7 +241,7 @@ def make_case(name: str, n_trajs: int = 1, extra_seq_length: int = 20, input_seq
             p0[fl] += rng.normal(0, 0.08 * dx, size=(int(fl.sum()), 2))
             p0[fl, 1] = np.maximum(p0[fl, 1], 1.6 * dx)
             p0 = np.mod(p0, box)
-            tr = _advect(p0, ptype0, T, box, [True, True], field, 1.0 * vel_std, rng, jitter=0.01 * dx)
+            tr = _advect(p0, ptype0, T, box, [True, True], field, 1.0 * vel_std * vel_amp, rng, jitter=0.01 * dx * vel_amp)
             # keep the fluid above the floor (no real pressure solve here)
             tr[fl, :, 1] = np.maximum(tr[fl, :, 1], np.float32(1.3 * dx))
             return tr, ptype0.copy()

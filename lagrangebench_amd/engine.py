@@ -211,6 +211,15 @@ class RolloutEngine:
         check(self.lib.lb_stats(self._h, C.byref(n), C.byref(ec), C.byref(cc)), "lb_stats")
         return {"n_edges_total": n.value, "e_cap": ec.value, "cell_capacity": cc.value}
 
+    def edge_accounting(self, reset: bool = False) -> Dict[str, float]:
+        """Edge counts of the neighbor-list builds since the last reset (include/lbhip.h: lb_edge_accounting):
+        mean / first / last real E over all B trajectories, and the number of builds."""
+        s, n, f, l = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        check(self.lib.lb_edge_accounting(self._h, C.byref(s), C.byref(n), C.byref(f), C.byref(l), int(bool(reset))),
+              "lb_edge_accounting")
+        return {"sum": s.value, "builds": n.value, "first": f.value, "last": l.value,
+                "mean": s.value / n.value if n.value else float(l.value)}
+
     # ------------------------------------------------------------------ features
 
     def kernel_names(self) -> dict:
@@ -286,6 +295,11 @@ class RolloutEngine:
         """Steps / stand-alone forwards the range guard has redone in exact fp32 on this engine (the engine returns
         to guarded f16x2 afterwards: include/lbhip.h: lb_math_fallbacks)."""
         return int(self.lib.lb_math_fallbacks(self._h))
+
+    def debug_inject_guard(self, flags: int, step: int) -> None:
+        """Test hook: the next rollout behaves as if the range guard had raised `flags` at rollout step `step`
+        (include/lbhip.h: lb_debug_inject_guard)."""
+        check(self.lib.lb_debug_inject_guard(self._h, int(flags), int(step)), "lb_debug_inject_guard")
 
     def set_fused_aggregation(self, on: bool) -> None:
         check(self.lib.lb_set_fused_aggregation(self._h, int(bool(on))), "lb_set_fused_aggregation")

@@ -7,6 +7,7 @@ bit-exact vs the oracle (same operation order, no FMA contraction); network outp
 """
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -886,6 +887,81 @@ def test_f16x2_range_guard_falls_back_to_fp32(kind):
     p_roll["decoder/linear_1"]["w"] *= np.float32(1e-6 if kind == "large" else 1.0)
     pred, _ = e4.rollout(model.handle(e4, p_roll), pos[None].astype(np.float64), 2)
     assert e4.math_fallbacks() >= 1 and e4.math_mode()[0] == 1 and torch.isfinite(pred).all()
+
+
+@pytest.mark.parametrize("mode", ["resume", "cap", "nonfinite_in_fp32", "sampled"])
+def test_guard_loop_resume_matches_oracle(mode):
+    """lb_rollout's guard loop - ONE flagged step redone in exact fp32, guarded f16x2 resumed
+    behind it, at most LB_GUARD_MAX_FALLBACKS (3) times, the rest in fp32 - driven on HEALTHY weights through the
+    lb_debug_inject_guard hook and checked against the oracle: a clean f16x2 continuation behind a redone step with
+    s0 > 0 and several steps left."""
+    _need_gpu()
+    if os.environ.get("LB_MATH") or os.environ.get("LB_GUARD"):
+        pytest.skip("LB_MATH / LB_GUARD pin the arithmetic or the guard: this test drives the default loop")
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    L, n_steps, k = 3, 8, 3
+    ds = make_case("small3d", n_trajs=2, extra_seq_length=n_steps)
+    params = make_params(ds, num_mp_steps=L)
+    model = GNS(3, 128, 2, L, 16)
+    hcase = hip_case(ds)
+    pos = np.stack([ds[0][0], ds[1][0]]).astype(np.float64)
+    pt = np.stack([ds[0][1], ds[1][1]])
+    preds_o, _ = _oracle_rollout(ds, params, L, n_steps, [0, 1])
+    tol = 1e-6 * float(ds.metadata["dx"])
+    eng = hcase.engine(2)
+    eng.set_particle_type(pt)
+    handle = model.handle(eng, params)
+    clean, _ = eng.rollout(handle, pos, n_steps)
+    assert eng.math_fallbacks() == 0 and eng.math_mode() == (1, 0)
+    assert np.abs(_np(clean) - preds_o).max() < tol
+    if mode == "resume":
+        eng.debug_inject_guard(2, k)                       # LB_MATH_TINY "raised" at step k
+        pred, _ = eng.rollout(handle, pos, n_steps)
+        assert eng.math_fallbacks() == 1                   # exactly one step redone
+        assert eng.math_mode() == (1, 0)                   # back in guarded f16x2, no stale flag
+        p = _np(pred)
+        assert np.abs(p - preds_o).max() < tol
+        # the steps before the flagged one are the f16x2 run's, bit for bit; the redone step is fp32 work and differs
+        assert np.array_equal(p[:, :k], _np(clean)[:, :k])
+        # one-shot: the next rollout is clean again
+        again, _ = eng.rollout(handle, pos, n_steps)
+        assert eng.math_fallbacks() == 1 and np.array_equal(_np(again), _np(clean))
+    elif mode == "cap":
+        # a flag at the LAST step: redone in fp32, nothing left to resume (rest == true path with one step)
+        eng.debug_inject_guard(1, n_steps - 1)
+        pred, _ = eng.rollout(handle, pos, n_steps)
+        assert eng.math_fallbacks() == 1 and eng.math_mode() == (1, 0)
+        assert np.abs(_np(pred) - preds_o).max() < tol
+        # a flag at step 0: the whole rollout behind it runs in f16x2 again
+        eng.debug_inject_guard(2, 0)
+        pred, _ = eng.rollout(handle, pos, n_steps)
+        assert eng.math_fallbacks() == 2 and eng.math_mode() == (1, 0)
+        assert np.abs(_np(pred) - preds_o).max() < tol
+    elif mode == "nonfinite_in_fp32":
+        # LB_MATH_NONFINITE at step k: the step is redone in fp32 (finite there on healthy weights), flags come back clear
+        eng.debug_inject_guard(4, k)
+        pred, _ = eng.rollout(handle, pos, n_steps)
+        assert eng.math_fallbacks() == 1 and eng.math_mode() == (1, 0)
+        assert np.abs(_np(pred) - preds_o).max() < tol
+    else:
+        # LB_GUARD=sampled engines restart from step 0 in fp32: needs its own process (the switch is read once)
+        import subprocess
+        code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+                "from tests._common import hip_case, make_params\n"
+                "from lagrangebench_amd.data import make_case\n"
+                "from lagrangebench_amd.models import GNS\n"
+                "ds = make_case('small3d', n_trajs=1, extra_seq_length=6); p = make_params(ds, num_mp_steps=2)\n"
+                "m = GNS(3, 128, 2, 2, 16); e = hip_case(ds).engine(1); e.set_particle_type(ds[0][1][None])\n"
+                "h = m.handle(e, p); pos = ds[0][0][None].astype(np.float64)\n"
+                "a, _ = e.rollout(h, pos, 6); e.debug_inject_guard(2, 3); b, _ = e.rollout(h, pos, 6)\n"
+                "e.math_mode(0); c, _ = e.rollout(h, pos, 6)\n"
+                "assert e.math_fallbacks() == 6, e.math_fallbacks()\n"
+                "assert np.array_equal(b.cpu().numpy(), c.cpu().numpy())\n"
+                "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LB_GUARD="sampled"), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("name,batch,layer", [("tgv3d", 3, 1), ("small3d", 1, 0)], ids=["batch_kernels", "msplit_kernels"])

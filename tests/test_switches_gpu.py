@@ -1,6 +1,7 @@
-"""Every environment switch that selects another kernel family or schedule and SURVIVED the round-3 clean-up must stay
-correct: the forward / rollout parity subset of tests/test_gpu_parity.py is re-run in a subprocess under each of them
-(the switches are read once per process).  INTEGRATION.md section 3 lists them."""
+"""Every environment switch that selects another kernel family or schedule and SURVIVED the round-5 clean-up must stay
+correct: the forward / rollout parity subset of tests/test_gpu_parity.py is re-run in a subprocess under each GROUP of
+compatible switches (the switches are read once per process; round 5 grouped them - one subprocess per switch cost the
+GPU suite ~8 minutes).  INTEGRATION.md section 3 lists them."""
 import os
 import subprocess
 import sys
@@ -12,27 +13,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SWITCHES = [
     {"LB_MATH": "f32"},                                   # exact-fp32 MFMA kernels (the range guard's fall-back)
     {"LB_FUSED_AGG": "0"},                                # stand-alone jraph.segment_sum
-    {"LB_MSPLIT": "0"},                                   # wave-per-tile kernels also on small graphs
+    {"LB_MSPLIT": "0", "LB_GUARD": "full", "LB_EDGE_TICKET": "1"},   # wave-per-tile kernels also on small graphs, every tile
+                                                          # range-tested, LDS tile tickets at any size
+    {"LB_MSPLIT": "0", "LB_EDGE_TICKET": "0", "LB_EDGE_NT_MIN_TILES": "0"},  # ... static strided walk, nontemporal streams
     {"LB_MSPLIT": "1"},                                   # M-split kernels also on large graphs
-    {"LB_MSPLIT": "1", "LB_MS_NODE_T": "2"},              # ... with two node tiles per iteration
-    {"LB_SMALL_FUSED": "0", "LB_NL_KERNEL": "wave"},      # multi-launch cell binning, wave-per-receiver search
-    {"LB_NL_KERNEL": "cell"},                             # workgroup-per-cell search
-    {"LB_GRAPH": "1"},                                    # hipGraph replay of the step
-    {"LB_EDGE_NT_MIN_TILES": "0"},                        # nontemporal edge-latent streams also on small graphs
-    {"LB_GUARD": "full", "LB_MSPLIT": "0"},               # every tile of the wave-per-tile edge kernel range-tested
-    {"LB_PERSIST": "1"},                                  # all message-passing layers in one persistent launch
-    {"LB_EDGE32": "1", "LB_MSPLIT": "0"},                 # processor edge kernel on 32-edge tiles (32x32x16 MFMA)
-    {"LB_NODE_T2": "2", "LB_MSPLIT": "0"},                # node kernel with two tiles per wave and weight chunk
-    {"LB_NODE_Q": "2", "LB_MSPLIT": "0"},                 # node kernel with the four-slot ring of 16 KiB chunks (k_node16q)
-    {"LB_CELLS_TRAJ": "0"},                               # batches: five-launch counting sort instead of one workgroup per trajectory
-    {"LB_NL_ONE": "0"},                                   # four-launch neighbor build also for one small trajectory
-    {"LB_NL_ONE": "0", "LB_NL_CSCAN": "0"},               # ... and degree scan / finish / compaction as separate launches
-    {"LB_MS_DEC": "0"},                                   # decoder as a launch of its own also behind the M-split node kernel
-    {"LB_STEP_FUSE": "0"},                                # node features / integrator as launches of their own
+    {"LB_NL_KERNEL": "cell", "LB_GRAPH": "1"},            # workgroup-per-cell search; hipGraph replay of the step
     {"LB_GUARD": "sampled"},                              # rounds 2-3 guard: first tile of every wave only
-    {"LB_EDGE_TICKET": "1", "LB_MSPLIT": "0"},            # LDS tile tickets in the wave-per-tile edge kernel (any size)
-    {"LB_EDGE_TICKET": "0", "LB_MSPLIT": "0"},            # ... and the static strided walk (any size)
-    {"LB_CELLS_ONE": "0", "LB_NL_ONE": "0", "LB_NL_MID": "0"},   # multi-launch cell binning also for one mid-size trajectory
+    # every launch-fusion of rounds 2-4 switched off together (each unfused path is also the default at larger sizes):
+    # multi-launch cell binning / neighbor build / degree scan + compaction, wave-per-receiver search, decoder and
+    # node features / integrator as launches of their own
+    {"LB_SMALL_FUSED": "0", "LB_NL_KERNEL": "wave", "LB_CELLS_TRAJ": "0", "LB_CELLS_ONE": "0", "LB_NL_ONE": "0",
+     "LB_NL_MID": "0", "LB_NL_CSCAN": "0", "LB_MS_DEC": "0", "LB_STEP_FUSE": "0"},
 ]
 
 SEGNN_SWITCHES = [
