@@ -17,13 +17,17 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liblbhip.so")
-SOURCES = ["lb_api.hip", "lb_neighbor.hip", "lb_state.hip", "lb_gns.hip", "lb_edge16.hip", "lb_segnn.hip", "lb_segnn_msg.hip", "lb_segnn_node.hip", "lb_sinkhorn.hip", "lb_edge16v.hip", "lb_node16s.hip", "lb_gns_generic.hip", "lb_msplit.hip", "lb_train.hip"]
+SOURCES = ["lb_api.hip", "lb_neighbor.hip", "lb_state.hip", "lb_gns.hip", "lb_edge16.hip", "lb_segnn.hip", "lb_segnn_msg.hip", "lb_segnn_node.hip", "lb_sinkhorn.hip", "lb_edge16v.hip", "lb_edge16w.hip", "lb_node16s.hip", "lb_gns_generic.hip", "lb_msplit.hip", "lb_train.hip"]
 HEADERS = ["lb_internal.h", "lb_device.h", "lb_f16x2.h", "lb_segnn_dev.h", "lb_features.h", "lb_msplit.h", "lb_msplit_dev.h", os.path.join("..", "..", "include", "lbhip.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
 # per-file extras.  lb_edge16v.hip: the SLP vectoriser packs the LayerNorm / scan arithmetic into
 # v_pk_*_f32 pairs, which need register-pair shuffles (v_mov) and cannot carry a DPP operand.
-EXTRA_FLAGS = {"lb_edge16v.hip": ["-fno-slp-vectorize"], "lb_node16s.hip": ["-fno-slp-vectorize"],
+# lb_edge16w.hip: its GEMM loop carries ~280 micro-operations of the previous tile's epilogue as compile-time-indexed fillers;
+# the fully unrolled body exceeds LLVM's default size cap for `#pragma unroll` (16 k instructions) and without the unroll the
+# register arrays become scratch memory.
+EXTRA_FLAGS = {"lb_edge16v.hip": ["-fno-slp-vectorize"],
+               "lb_edge16w.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=10000000"], "lb_node16s.hip": ["-fno-slp-vectorize"],
                "lb_gns_generic.hip": ["-fno-slp-vectorize"], "lb_segnn_msg.hip": ["-fno-slp-vectorize"], "lb_segnn_node.hip": ["-fno-slp-vectorize"], "lb_msplit.hip": ["-fno-slp-vectorize"]}
 
 

@@ -271,7 +271,7 @@ extern "C" void lb_engine_destroy(lb_engine* e) {
                   e->cell_part, e->deg, e->nl_wg_sum, e->row_ptr, e->scan_part, e->cpos, e->tmp_send, e->tmp_feat, e->tmp_feat64,
                   e->senders, e->receivers, e->efeat, e->efeat64,
                   e->overflow, e->nedges_b, e->xnode, e->nlat, e->agg, e->psr, e->elat, e->msg,
-                  e->part, e->acc, e->blocks_done};
+                  e->acc, e->blocks_done};  // (e->part lives inside the e->agg allocation)
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->ctrl_host) (void)hipHostFree(e->ctrl_host);
@@ -282,19 +282,33 @@ extern "C" void lb_engine_destroy(lb_engine* e) {
   delete e;
 }
 
+// Aggregated messages [BN][128] and the partial sums of the receivers a tile (chunk) boundary cuts [tiles + 2][2][128] in ONE
+// allocation: the fused segment_sum of the edge kernels stores both through one buffer resource with branch-free
+// raw-buffer stores (a lane with nothing to write has its offset pushed out of range).  Contents are transient (one layer).
+int lb_alloc_aggpart(lb_engine* e) {
+  if (e->agg) (void)hipFree(e->agg);
+  e->agg = e->part = nullptr;
+  const size_t n_agg = (size_t)e->BN * LB_D, n_part = (size_t)(e->e_alloc / 16 + 2) * 2 * LB_D;
+  LB_TRY(lb_alloc(&e->agg, n_agg + n_part));
+  e->part = e->agg + n_agg;
+  e->aggpart_bytes = (int64_t)(n_agg + n_part) * (int64_t)sizeof(float);
+  return LB_OK;
+}
+
 // Edge-sized buffers grow geometrically; contents are not preserved (rebuilt every step).
 int lb_ensure_edges(lb_engine* e, int64_t need) {
   if (need <= e->e_alloc && e->senders) return LB_OK;
   LB_HIP(hipStreamSynchronize(e->stream));
   int64_t n = std::max<int64_t>(need + need / 8 + 1024, 4096);
-  void* old[] = {e->senders, e->receivers, e->efeat, e->efeat64, e->elat, e->msg, e->part};
+  void* old[] = {e->senders, e->receivers, e->efeat, e->efeat64, e->elat, e->msg};
   for (void* b : old)
     if (b) (void)hipFree(b);
   e->senders = e->receivers = nullptr;
   e->efeat = nullptr;
   e->efeat64 = nullptr;
-  e->elat = e->msg = e->part = nullptr;
-  LB_TRY(lb_alloc(&e->part, (size_t)(n / 16 + 2) * 2 * LB_D));  // sized for the 16-row tiles
+  e->elat = e->msg = nullptr;
+  e->e_alloc = n;
+  LB_TRY(lb_alloc_aggpart(e));  // agg | part (sized for the 16-row tiles of the new capacity)
   LB_TRY(lb_alloc(&e->senders, (size_t)n));
   LB_TRY(lb_alloc(&e->receivers, (size_t)n));
   // (kernels may gather through index rows past the current edge count before they know it: keep every row a valid id)
@@ -870,7 +884,7 @@ int lb_ensure_node_scratch(lb_engine* e) {
   const int64_t BN = e->BN;
   if (!e->xnode) LB_TRY(lb_alloc(&e->xnode, (size_t)BN * LB_D));  // widest node input row
   if (!e->nlat) LB_TRY(lb_alloc(&e->nlat, (size_t)BN * LB_D));
-  if (!e->agg) LB_TRY(lb_alloc(&e->agg, (size_t)BN * LB_D));
+  if (!e->agg) LB_TRY(lb_alloc_aggpart(e));
   if (!e->psr) LB_TRY(lb_alloc(&e->psr, (size_t)BN * 2 * LB_D));
   return LB_OK;
 }

@@ -311,6 +311,11 @@ static bool lb_use_msplit_edge(const lb_engine* e) {
   if (env == 1) return true;
   return ((int64_t)e->e_cap * e->g.B + 15) / 16 <= max_tiles;
 }
+static bool lb_use_edge_w(const lb_engine* e) {
+  static const bool edge_w = !(getenv("LB_EDGE_W") && getenv("LB_EDGE_W")[0] == '0');
+  return edge_w && !e->guard_full && e->aggpart_bytes < ((int64_t)1 << 31) &&
+         (int64_t)(e->e_alloc + 32) * 512 < ((int64_t)1 << 32) && e->BN * 1024 < ((int64_t)1 << 32);  // 32-bit byte offsets
+}
 static bool lb_use_msplit_node(const lb_engine* e) {
   static const int64_t max_nodes = getenv("LB_MS_MAX_NODES") ? atoll(getenv("LB_MS_MAX_NODES")) : 16384;
   const int env = lb_msplit_env();
@@ -324,7 +329,8 @@ extern "C" int lb_kernel_names(lb_engine* e, char* out, int32_t cap) {
   const char* edge = !e->f16x2 ? "k_edge16<PROC,f32>"
                      : !e->fused_agg ? "k_edge16<PROC,f16x2> + k_segment_sum"
                      : lb_use_msplit_edge(e) ? "k_edge_ms (M-split, f16x2, fused segment_sum)"
-                                             : "k_edge16v<2 waves/SIMD, resident latents, GEMM-phase priority> (PROC, f16x2, fused segment_sum)";
+                     : lb_use_edge_w(e) ? "k_edge16w<2 waves/SIMD, resident latents; last layer: deferred epilogue> (PROC, f16x2, fused segment_sum)"
+                                        : "k_edge16v<2 waves/SIMD, resident latents, GEMM-phase priority> (PROC, f16x2, fused segment_sum)";
   const char* node = !e->f16x2 ? "k_node_mlp<f32>" : lb_use_msplit_node(e) ? "k_node_ms (M-split, f16x2)" : "k_node16s (f16x2)";
   snprintf(out, (size_t)cap, "edge=%s;node=%s", edge, node);
   return LB_OK;
@@ -493,8 +499,14 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       b.row_ptr = e->row_ptr;
       b.agg = e->agg;
       b.part = e->part;
+      b.aggpart_bytes = e->aggpart_bytes;
       b.skip_elat_store = skip;
-      rc = (e->f16x2 && e->fused_agg) ? lbk_edge16v(e, b) : lbk_edge16(e, b, true, e->f16x2 != 0);
+      // round 5: k_edge16w (deferred epilogue: the previous tile's scan / aggregate stores ride in the MFMA slots) unless
+      // LB_EDGE_W=0, the engine range-tests every k-group (LB_GUARD=full: k_edge16v's GUARD 2), or agg | part >= 2 GiB
+      if (e->f16x2 && e->fused_agg)
+        rc = lb_use_edge_w(e) ? lbk_edge16w(e, b) : lbk_edge16v(e, b);
+      else
+        rc = lbk_edge16(e, b, true, e->f16x2 != 0);
     }
     lb_toc(e);
     if (rc) return rc;

@@ -176,7 +176,8 @@ struct lb_engine {
   float* psr;          // [BN][2D]  projections of the node latents for the edge MLP
   float* elat;         // [e_alloc][D]
   float* msg;          // [e_alloc][D]   (stand-alone segment_sum path only)
-  float* part;         // [e_alloc/32+1][2][D] partial sums of receivers cut by a tile boundary
+  float* part;         // [e_alloc/16+2][2][D] partial sums of receivers cut by a tile boundary: inside the agg allocation
+  int64_t aggpart_bytes = 0;  // bytes of that allocation (agg | part)
   int fused_agg;       // 1: aggregation fused into the edge kernel (default), 0: msg + k_segment_sum
   int f16x2;           // 1: GEMMs in fp16 hi/lo split arithmetic on the fp16 MFMA (fp32-class accuracy)
   int math_auto;       // 1: f16x2 with the range guard - a raised lb_ctrl::math_flags makes the host repeat
@@ -229,7 +230,10 @@ struct lb_edge16_args {  // lb_edge16.hip
   int fused;
   const int32_t* row_ptr;
   float* agg;
-  float* part;         // [ceil(E/16)][2][128]
+  float* part;         // [ceil(E/16)][2][128]; = agg + BN*128 (one allocation of aggpart_bytes bytes)
+  int64_t aggpart_bytes;
+  int reverse;         // k_edge16w: every XCD walks its range of tiles from the end (odd layers: the latents the layer before
+                       // wrote last are still in the 256 MiB Infinity Cache)
   int skip_elat_store; // last processor layer: the updated edge latents have no reader
 };
 
@@ -351,6 +355,7 @@ void lb_tic_single(lb_engine* e, int cls);
 
 // lb_api.hip
 int lb_ensure_edges(lb_engine* e, int64_t need);
+int lb_alloc_aggpart(lb_engine* e);
 
 // lb_neighbor.hip
 int lbk_nl_build(lb_engine* e, bool want_efeat64);
@@ -435,4 +440,6 @@ int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const flo
 int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc, bool f16x2);
 // lb_edge16v.hip: processor edge kernel (f16x2, fused aggregation, two waves per SIMD)
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a);
+// lb_edge16w.hip: the same kernel with the deferred epilogue (round 5); bit-identical results
+int lbk_edge16w(lb_engine* e, const lb_edge16_args& a);
 int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a);
