@@ -416,7 +416,15 @@ def test_fused_rollout_parity(name, scale, L, n_steps):
     hcase = hip_case(ds)
     out = infer(model, hcase, ds, params=params, cfg_eval_infer={"batch_size": 2, "metrics": ["mse", "mae"]},
                 n_rollout_steps=n_steps)
-    preds_o, metrics_o = _oracle_rollout(ds, params, L, n_steps, [0, 1])
+    if name == "tgv2d":   # the full-size case: 44 s of NumPy oracle - from tests/golden/oracle_fullsize/ when its inputs match
+        from tests import _fullsize_oracle as FO
+        pos2 = np.stack([ds[0][0], ds[1][0]])
+        fix, hit = FO.cached("gns_roll_np_tgv2d_b2", FO._hash_inputs(pos2, ds[0][1]) + FO.params_hash(params),
+                             lambda: FO.gns_rollout(ds, params, L, n_steps, traj_ids=(0, 1), use_torch=False))
+        print(f"[fused rollout tgv2d] oracle from the {'fixture' if hit else 'LIVE oracle'}")
+        metrics_o = [{"mse": fix["mse"][b]} for b in range(2)]
+    else:
+        preds_o, metrics_o = _oracle_rollout(ds, params, L, n_steps, [0, 1])
     for b in range(2):
         m = out[f"rollout_{b}"]
         mse_h, mse_o = _np(m["mse"]), metrics_o[b]["mse"]

@@ -31,10 +31,11 @@ def main():
         names = {r[0]: r[1] for r in c.execute(f"select id, display_name from {t['rocpd_info_kernel_symbol']}")}
         disp = list(c.execute(f"select kernel_id, start, end, event_id from {t['rocpd_kernel_dispatch']}"))
         stat = defaultdict(list)
-        ev2k = {}
+        ev2k, ev2d = {}, {}
         for kid, s, e, ev in disp:
             stat[names.get(kid, str(kid))].append(e - s)
             ev2k[ev] = names.get(kid, str(kid))
+            ev2d[ev] = e - s
         tot = sum(sum(v) for v in stat.values()) or 1
         print(f"== {db}")
         print("(avg_real_us / real: launches of at least 20 % of the kernel's median duration, i.e. without the "
@@ -50,14 +51,15 @@ def main():
         if pmc_names:
             acc = defaultdict(lambda: defaultdict(float))
             cnt = defaultdict(set)
+            med = {k: sorted(v)[len(v) // 2] for k, v in stat.items()}
             for ev, pid, val in c.execute(f"select event_id, pmc_id, value from {t['rocpd_pmc_event']}"):
                 k = ev2k.get(ev)
-                if k is None:
+                if k is None or ev2d[ev] < 0.2 * med[k]:   # (round 5: REAL launches only, like avg_real_us)
                     continue
                 acc[k][pmc_names[pid]] += val
                 cnt[k].add(ev)
             cols = sorted(set(pmc_names.values()))
-            print(f"-- PMC, average per launch (summed over instances): {', '.join(cols)}")
+            print(f"-- PMC, average per REAL launch (summed over instances): {', '.join(cols)}")
             for k in sorted(acc, key=lambda kk: -sum(stat[kk])):
                 n = len(cnt[k])
                 vals = "  ".join(f"{cname}={acc[k][cname]/n:.4g}" for cname in cols)
