@@ -344,7 +344,7 @@ __device__ __forceinline__ void ew_gemm(lds_cptr wbase, const f32x4 (&v)[8], f32
 //      Registers: the next tile's latents (32) live through both GEMMs - 2 waves per SIMD still fit without DEFER 2's
 //      travelling latents (storing variant: DEFER <= 1).
 // ABL (tools/edge_ab.hip only): 1 the deferred part in one piece ahead of the GEMMs (debug), 2 GEMM-phase priority.
-template <bool SKIP, bool NT, int GUARD, bool TICKET, int DEFER = 1, int ABL = 0, int WPS = 2, int PF = 0>
+template <bool SKIP, bool NT, int GUARD, bool TICKET, int DEFER = 1, int ABL = 0, int WPS = 2, int PF = 0, int WALK = 0>
 __global__ void __launch_bounds__(WPS * 256, 1) k_edge16w(lb_edge16_args a) {
   static_assert(PF == 0 || PF == 2, "PF: 0 or 2");
   static_assert(!(PF == 2 && DEFER == 2 && !SKIP), "DEEP prefetch overwrites the previous tile's latents");
@@ -389,6 +389,12 @@ __global__ void __launch_bounds__(WPS * 256, 1) k_edge16w(lb_edge16_args a) {
   // a.reverse: the XCD's range [t_lo0, t_hi) is walked from its end (the walk position tw still runs upwards)
   const int t_lo0 = (int)(((int64_t)ntiles * xcd) >> 3);
   const int rev_sum = a.reverse ? t_lo0 + t_hi - 1 : 0;
+  if constexpr (WALK == 1) {  // (experiment) every wave owns a CONTIGUOUS chunk of its XCD's range instead of a stride
+    const int slot = (blockIdx.x >> 3) * WAVES + wave, nslot = (gridDim.x >> 3) * WAVES, ntx = t_hi - t_lo0;
+    t = t_lo0 + (int)(((int64_t)ntx * slot) / nslot);
+    t_hi = t_lo0 + (int)(((int64_t)ntx * (slot + 1)) / nslot);
+    stride = 1;
+  }
   auto tmap = [&](int tw) -> int { return a.reverse ? rev_sum - tw : tw; };
   int s_c = 0, r_c = 0;
   if (t < t_hi) {

@@ -249,6 +249,10 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(vec + 128, z.data(), 1024, hipMemcpyHostToDevice);
   }
   for (int round = 0; round < 2; ++round) {
+  report("k_edge16w<loads at top, defer nothing>, contiguous chunk per wave",
+         [&] { hipLaunchKernelGGL((k_edge16w<false, true, 1, false, 0, 0, 2, 0, 1>), dim3(256), dim3(512), 0, 0, a); });
+  report("k_edge16w<loads at top, defer all> last layer, contiguous chunk per wave",
+         [&] { hipLaunchKernelGGL((k_edge16w<true, true, 1, false, 2, 0, 2, 0, 1>), dim3(256), dim3(512), 0, 0, a); });
   report("k_edge16w<deep prefetch, defer nothing>", KW(false, 1, 0, 0, 2, 2));
   report("k_edge16w<deep prefetch, defer nothing, GEMM priority>", KW(false, 1, 0, 2, 2, 2));
   report("k_edge16w<loads at top, defer nothing>", KW(false, 1, 0, 0, 2, 0));
