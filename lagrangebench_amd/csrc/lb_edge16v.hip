@@ -312,29 +312,9 @@ int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a) {
 
 // Two waves per SIMD, GEMM-phase priority (round 2's measured best; the software-prefetching, second-read and
 // three- / four-wave variants were measured in round 2 - profiles/r02_edge16v_bench.txt - and are gone from the tree).
-// (round-5 experiment) FOUR waves per SIMD with the second read of the latents (128 VGPRs): on ONE trajectory a wave has
-// 3 - 4 tiles and the launch is rounds x per-tile latency - more resident waves = fewer rounds.  LB_EDGE_WPS4=1, small graphs only.
-int lbk_edge16v_wps4(lb_engine* e, const lb_edge16_args& a) {
-  const int64_t tiles_cap = ((int64_t)e->e_cap * e->g.B + 15) / 16;
-  int64_t g = (tiles_cap + 15) / 16;
-  g = (g + 7) / 8 * 8;
-  const int grid = (int)(g < 8 ? 8 : (g > 256 ? 256 : g));
-  const bool guard = e->math_auto && !e->guard_sampled;
-  if (a.skip_elat_store) {
-    if (guard)
-      LB_LAUNCH_TIMED(e, (k_edge16v<4, true, true, 0, false, false, 1, true>), dim3(grid), dim3(1024), a);
-    else
-      LB_LAUNCH_TIMED(e, (k_edge16v<4, true, true, 0, false, false, 0, true>), dim3(grid), dim3(1024), a);
-  } else {
-    if (guard)
-      LB_LAUNCH_TIMED(e, (k_edge16v<4, true, false, 0, false, false, 1, true>), dim3(grid), dim3(1024), a);
-    else
-      LB_LAUNCH_TIMED(e, (k_edge16v<4, true, false, 0, false, false, 0, true>), dim3(grid), dim3(1024), a);
-  }
-  LB_HIP(hipGetLastError());
-  return LB_OK;
-}
-
+// (round 5: FOUR waves per SIMD with the second read of the latents - k_edge16v<4, true, ..>, 128 VGPRs - measured on ONE
+// trajectory, where a wave has 3 - 4 tiles and fewer rounds might have paid: TGV3D-8k B = 1 42.4 us per launch against 36.4,
+// 0.668 vs 0.615 ms per step; not kept.)
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a) {
   // LDS tile tickets (round 4): default on ONE trajectory (a few tiles per wave: the faster - older - wave of a SIMD takes
   // more of them; LDC3D-8k B = 1 0.619 -> 0.604, TGV3D-8k 0.673 -> 0.663 ms/step), off on batches (neutral: 2.606 vs 2.617 ms

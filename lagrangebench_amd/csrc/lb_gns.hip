@@ -503,10 +503,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       b.skip_elat_store = skip;
       // round 5: k_edge16w (deferred epilogue: the previous tile's scan / aggregate stores ride in the MFMA slots) unless
       // LB_EDGE_W=0, the engine range-tests every k-group (LB_GUARD=full: k_edge16v's GUARD 2), or agg | part >= 2 GiB
-      static const bool wps4 = getenv("LB_EDGE_WPS4") && getenv("LB_EDGE_WPS4")[0] == '1';
-      if (e->f16x2 && e->fused_agg && wps4 && !e->guard_full && ((int64_t)e->e_cap * e->g.B + 15) / 16 < 12288)
-        rc = lbk_edge16v_wps4(e, b);
-      else if (e->f16x2 && e->fused_agg)
+      if (e->f16x2 && e->fused_agg)
         rc = lb_use_edge_w(e) ? lbk_edge16w(e, b) : lbk_edge16v(e, b);
       else
         rc = lbk_edge16(e, b, true, e->f16x2 != 0);

@@ -440,7 +440,6 @@ int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const flo
 int lbk_edge16(lb_engine* e, const lb_edge16_args& a, bool proc, bool f16x2);
 // lb_edge16v.hip: processor edge kernel (f16x2, fused aggregation, two waves per SIMD)
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a);
-int lbk_edge16v_wps4(lb_engine* e, const lb_edge16_args& a);
 // lb_edge16w.hip: the same kernel with the deferred epilogue (round 5); bit-identical results
 int lbk_edge16w(lb_engine* e, const lb_edge16_args& a);
 int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a);
