@@ -270,7 +270,7 @@ extern "C" void lb_engine_destroy(lb_engine* e) {
   void* bufs[] = {e->win, e->ptype, e->force, e->ctrl, e->cell_of, e->cell_count, e->cell_start,
                   e->cell_part, e->deg, e->nl_wg_sum, e->row_ptr, e->scan_part, e->cpos, e->tmp_send, e->tmp_feat, e->tmp_feat64,
                   e->senders, e->receivers, e->efeat, e->efeat64,
-                  e->overflow, e->nedges_b, e->xnode, e->nlat, e->agg, e->psr, e->psr2, e->elat, e->msg,
+                  e->overflow, e->nedges_b, e->xnode, e->nlat, e->agg, e->psr, e->elat, e->msg,
                   e->acc, e->blocks_done};  // (e->part lives inside the e->agg allocation)
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -288,8 +288,7 @@ extern "C" void lb_engine_destroy(lb_engine* e) {
 int lb_alloc_aggpart(lb_engine* e) {
   if (e->agg) (void)hipFree(e->agg);
   e->agg = e->part = nullptr;
-  // (+ BN / 16 + 2 tiles: the owner layout of the single-trajectory path has one partly filled tile per node tile)
-  const size_t n_agg = (size_t)e->BN * LB_D, n_part = (size_t)(e->e_alloc / 16 + e->BN / 16 + 4) * 2 * LB_D;
+  const size_t n_agg = (size_t)e->BN * LB_D, n_part = (size_t)(e->e_alloc / 16 + 2) * 2 * LB_D;
   LB_TRY(lb_alloc(&e->agg, n_agg + n_part));
   e->part = e->agg + n_agg;
   e->aggpart_bytes = (int64_t)(n_agg + n_part) * (int64_t)sizeof(float);
@@ -317,7 +316,7 @@ int lb_ensure_edges(lb_engine* e, int64_t need) {
   LB_HIP(hipMemsetAsync(e->receivers, 0, sizeof(int32_t) * (size_t)n, e->stream));
   LB_TRY(lb_alloc(&e->efeat, (size_t)n * 8));
   LB_TRY(lb_alloc(&e->efeat64, (size_t)n * 4));
-  LB_TRY(lb_alloc(&e->elat, (size_t)(n + e->BN + 64) * LB_D));  // tile-blocked in the 16-row kernels: pad to a tile (+ the owner layout's partly filled tiles)
+  LB_TRY(lb_alloc(&e->elat, (size_t)(n + 32) * LB_D));  // tile-blocked in the 16-row kernels: pad to a tile
   LB_TRY(lb_alloc(&e->msg, (size_t)(n + 32) * LB_D));  // also the second edge-latent buffer of the ping-pong
   e->e_alloc = n;
   return LB_OK;
@@ -887,7 +886,6 @@ int lb_ensure_node_scratch(lb_engine* e) {
   if (!e->nlat) LB_TRY(lb_alloc(&e->nlat, (size_t)BN * LB_D));
   if (!e->agg) LB_TRY(lb_alloc_aggpart(e));
   if (!e->psr) LB_TRY(lb_alloc(&e->psr, (size_t)BN * 2 * LB_D));
-  if (!e->psr2 && BN <= 16384) LB_TRY(lb_alloc(&e->psr2, (size_t)BN * 2 * LB_D));
   return LB_OK;
 }
 

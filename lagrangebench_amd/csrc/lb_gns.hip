@@ -316,14 +316,6 @@ static bool lb_use_edge_w(const lb_engine* e) {
   return edge_w && !e->guard_full && e->aggpart_bytes < ((int64_t)1 << 31) &&
          (int64_t)(e->e_alloc + 32) * 512 < ((int64_t)1 << 32) && e->BN * 1024 < ((int64_t)1 << 32);  // 32-bit byte offsets
 }
-static bool lb_use_msplit_node(const lb_engine* e);
-// Owner-layout path (round 5, lb_msplit.hip: k_layer_own): one launch per message-passing layer on graphs the M-split node
-// kernel serves (single trajectories).  LB_OWN=0 restores the two launches per layer.
-static bool lb_use_own(const lb_engine* e) {
-  static const bool on = !(getenv("LB_OWN") && getenv("LB_OWN")[0] == '0');
-  return on && e->f16x2 && e->fused_agg && !e->guard_full && e->psr2 && lb_use_msplit_node(e) &&
-         e->aggpart_bytes < ((int64_t)1 << 31);
-}
 static bool lb_use_msplit_node(const lb_engine* e) {
   static const int64_t max_nodes = getenv("LB_MS_MAX_NODES") ? atoll(getenv("LB_MS_MAX_NODES")) : 16384;
   const int env = lb_msplit_env();
@@ -334,11 +326,6 @@ static bool lb_use_msplit_node(const lb_engine* e) {
 
 extern "C" int lb_kernel_names(lb_engine* e, char* out, int32_t cap) {
   if (!e || !out || cap < 1) return lb_fail(LB_ERR_ARG, "null argument");
-  if (lb_use_own(e)) {
-    snprintf(out, (size_t)cap, "edge=k_layer_own (edge + node phase of a layer in one launch, owner tiles, f16x2);"
-                               "node=k_layer_own (same launch)");
-    return LB_OK;
-  }
   const char* edge = !e->f16x2 ? "k_edge16<PROC,f32>"
                      : !e->fused_agg ? "k_edge16<PROC,f16x2> + k_segment_sum"
                      : lb_use_msplit_edge(e) ? "k_edge_ms (M-split, f16x2, fused segment_sum)"
@@ -372,12 +359,8 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
   // k_node16s (nodes).  Exact fp32 (LB_MATH=f32, or the range guard's fall-back): k_edge16<*, f32> and the 32-row
   // k_node_mlp.  Stand-alone aggregation (lb_set_fused_aggregation(0)): k_edge16 writes the messages, k_segment_sum
   // adds them up.
-  const bool own = lb_use_own(e);
-  float* const pbuf[2] = {e->psr, own ? e->psr2 : e->psr};  // own: layer k reads pbuf[k & 1], writes pbuf[(k + 1) & 1]
-  float* psr_out = e->psr;
   auto node_mlp = [&](const lb_mlp_w& w, const float* xin, int kq, bool with_agg, bool resid, int next,
-                      const float* ms_img, const float* w0h, const float* w1h, bool ms, bool dec = false,
-                      lb_nms_args* nms_out = nullptr) -> int {
+                      const float* ms_img, const float* w0h, const float* w1h, bool ms, bool dec = false) -> int {
     const bool proj = next < L;
     lb_node_args a{};
     a.ctrl = e->ctrl;
@@ -393,7 +376,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
     a.ln_o = w.ln_o;
     a.wpp = proj ? g->proj_w[next] : nullptr;
     a.bp = proj ? g->proj_b[next] : nullptr;
-    a.psr = psr_out;
+    a.psr = e->psr;
     a.fused = e->fused_agg;
     a.tile_shift = 4;
     a.row_ptr = e->row_ptr;
@@ -414,7 +397,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       m.ln_s = a.ln_s;
       m.ln_o = a.ln_o;
       m.bp = a.bp;
-      m.psr = psr_out;
+      m.psr = e->psr;
       if (dec) {  // last layer: decoder (+ integrator in a rollout step) in the same launch
         m.bd0 = g->dec.b0;
         m.bd1 = g->dec.b1;
@@ -425,10 +408,6 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
           m.integ = e->integ_job;
           e->integ_done = true;
         }
-      }
-      if (nms_out) {  // (owner-layout path: the caller launches the fused layer kernel with this argument block)
-        *nms_out = m;
-        return LB_OK;
       }
       return lbk_node_ms(e, m, kq / 4, with_agg, resid, proj, dec);
     }
@@ -455,19 +434,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
 
   bool decoded = false;  // the decoder ran inside the last layer's node launch
   lb_tic(e, LB_T_ENC_EDGE);
-  if (own) {
-    lb_edge16_args b{};
-    b.ctrl = e->ctrl;
-    b.efeat = e->efeat;
-    b.elat = e->elat;
-    b.w0p = g->enc_edge_w0_16h;
-    b.b0 = g->enc_edge.b0;
-    b.w1p = g->enc_edge_w1_16h;
-    b.b1 = g->enc_edge.b1;
-    b.ln_s = g->enc_edge.ln_s;
-    b.ln_o = g->enc_edge.ln_o;
-    rc = lbk_edge_enc_own(e, b);
-  } else if (ms_ee) {
+  if (ms_ee) {
     lb_ems_args m{};
     m.ctrl = e->ctrl;
     m.efeat = e->efeat;
@@ -499,40 +466,6 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
   for (int k = 0; k < L; ++k) {
     const lb_mlp_w& pe = g->proc_edge[k];
     const bool skip = (k == L - 1) && e->fused_agg && !g->tap;  // the last layer's edge latents have no reader
-    if (own) {  // edge phase + node phase of layer k in ONE launch (k_layer_own)
-      static const bool ms_dec_ok2 = !(getenv("LB_MS_DEC") && getenv("LB_MS_DEC")[0] == '0');
-      const bool with_dec = ms_dec_ok2 && k == L - 1 && g->desc.out_dim <= 4;
-      lb_edge16_args b{};
-      b.ctrl = e->ctrl;
-      b.senders = e->senders;
-      b.receivers = e->receivers;
-      b.elat = e->elat;
-      b.psr = pbuf[k & 1];
-      b.w0p = g->proc_edge_w0_16h[k];
-      b.w1p = g->proc_edge_w1_16h[k];
-      b.b1 = pe.b1;
-      b.ln_s = pe.ln_s;
-      b.ln_o = pe.ln_o;
-      b.fused = 1;
-      b.row_ptr = e->row_ptr;
-      b.agg = e->agg;
-      b.part = e->part;
-      b.aggpart_bytes = e->aggpart_bytes;
-      b.skip_elat_store = skip;
-      lb_nms_args m{};
-      psr_out = pbuf[(k + 1) & 1];
-      rc = node_mlp(g->proc_node[k], e->nlat, 16, true, true, k + 1, g->ms_proc_node[k], nullptr, nullptr, true, with_dec, &m);
-      if (rc) return rc;
-      lb_tic_single(e, skip ? LB_T_EDGE_LAST : LB_T_EDGE_MLP);
-      rc = lbk_layer_own(e, b, m, k + 1 < L, with_dec);
-      lb_toc(e);
-      if (rc) return rc;
-      decoded = with_dec;
-      if (g->tap)
-        LB_HIP(hipMemcpyAsync(g->tap + (size_t)(k + 1) * BN * LB_D, e->nlat, sizeof(float) * BN * LB_D,
-                              hipMemcpyDeviceToDevice, s));
-      continue;
-    }
     lb_tic_single(e, skip ? LB_T_EDGE_LAST : LB_T_EDGE_MLP);
     if (ms_pe) {
       lb_ems_args m{};

@@ -174,7 +174,6 @@ struct lb_engine {
   float* nlat;         // [BN][D]
   float* agg;          // [BN][D]
   float* psr;          // [BN][2D]  projections of the node latents for the edge MLP
-  float* psr2 = nullptr;  // second buffer of the owner-layout path (a fused layer reads one and writes the other)
   float* elat;         // [e_alloc][D]
   float* msg;          // [e_alloc][D]   (stand-alone segment_sum path only)
   float* part;         // [e_alloc/16+2][2][D] partial sums of receivers cut by a tile boundary: inside the agg allocation

@@ -48,9 +48,6 @@ struct lb_nms_args {      // node kernel
 };
 
 void lb_pack_ms(const float* w, int K, int M, int nkb, int npw, bool perm, float* out);
-// owner-layout kernels (round 5): encoder edge MLP into owner tiles; one processor layer (edge + node phase) per launch
-int lbk_edge_enc_own(lb_engine* e, const lb_edge16_args& a);
-int lbk_layer_own(lb_engine* e, const lb_edge16_args& ea, const lb_nms_args& na, bool proj, bool dec);
 int lbk_edge_ms(lb_engine* e, const lb_ems_args& a);
 int lbk_edge_enc_ms(lb_engine* e, const lb_ems_args& a);
 int lbk_node_ms(lb_engine* e, const lb_nms_args& a, int nka, bool agg, bool resid, bool proj, bool dec = false);

@@ -321,43 +321,15 @@ __global__ void __launch_bounds__(MS_THREADS, 2) k_edge_enc_ms(lb_ems_args a) {
 // projection: 320 registers of weights (one wave per SIMD, 512 registers each).  T tiles of 16 nodes per iteration
 // (their loads are in flight together; the weights are reused from registers).
 // DEC (last layer, no projection): decoder MLP + (rollout step) integrator in the epilogue - one launch less per step.
-// Round 5: the body is a device function over caller-provided LDS (ms_node_smem) so that the fused layer kernel of
-// lb_own.hip - edge phase + node phase of one message-passing layer in ONE launch - can run it behind its edge phase
-// in the LDS the edge weights occupied.  OWN (that kernel): the partial-sum slots are indexed by OWNER tiles - the
-// 16-edge tiles of a node tile's own edge range, slot (row_ptr[16 q] >> 4) + q + j (lb_own.hip) - instead of the global
-// 16-edge tiles.
-template <int NKA, bool AGG, int T, bool PD>
-struct ms_node_smem {
-  static constexpr int NK0 = NKA + (AGG ? 4 : 0);
-  f32x4 (*sB1)[NK0 * 2 * 64];
-  f32x4 (*sB2)[4 * 2 * 64];
-  f32x4 (*sB3)[4 * 2 * 64];
-  f32x2m (*sRed)[16 * 4];
-  int (*sMx)[4 * T][MS_GUARD_WORDS];
-  static constexpr int f32x4_count = T * NK0 * 128 + T * 512 + (PD ? T : 1) * 512 + T * 32 + 2 * 4 * T * MS_GUARD_WORDS / 4;
-  __device__ __forceinline__ void carve(f32x4* base) {
-    sB1 = reinterpret_cast<f32x4(*)[NK0 * 2 * 64]>(base);
-    base += T * NK0 * 128;
-    sB2 = reinterpret_cast<f32x4(*)[4 * 2 * 64]>(base);
-    base += T * 512;
-    sB3 = reinterpret_cast<f32x4(*)[4 * 2 * 64]>(base);
-    base += (PD ? T : 1) * 512;
-    sRed = reinterpret_cast<f32x2m(*)[16 * 4]>(base);
-    base += T * 32;
-    sMx = reinterpret_cast<int(*)[4 * T][MS_GUARD_WORDS]>(base);
-  }
-};
-
-template <int NKA, bool AGG, bool RESID, bool PROJ, int T, bool DEC, bool OWN = false>
-__device__ __forceinline__ void ms_node_body(const lb_nms_args& a, const lb_geom& geom,
-                                             const ms_node_smem<NKA, AGG, T, (PROJ || DEC)>& sm) {
+template <int NKA, bool AGG, bool RESID, bool PROJ, int T, bool DEC = false>
+__global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geom geom) {
   static_assert(!(DEC && PROJ), "the decoder follows the LAST layer");
   constexpr int NK0 = NKA + (AGG ? 4 : 0);
-  auto& sB1 = sm.sB1;
-  auto& sB2 = sm.sB2;
-  auto& sB3 = sm.sB3;
-  auto& sRed = sm.sRed;
-  auto& sMx = sm.sMx;
+  __shared__ f32x4 sB1[T][NK0 * 2 * 64];
+  __shared__ f32x4 sB2[T][4 * 2 * 64];
+  __shared__ f32x4 sB3[(PROJ || DEC) ? T : 1][4 * 2 * 64];
+  __shared__ __attribute__((aligned(16))) f32x2m sRed[T][16 * 4];
+  __shared__ __attribute__((aligned(16))) int sMx[2][4 * T][MS_GUARD_WORDS];
   const int poisoned = a.ctrl->overflow_step;
   const int step = a.ctrl->step;
   const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
@@ -416,20 +388,12 @@ __device__ __forceinline__ void ms_node_body(const lb_nms_args& a, const lb_geom
         } else {
           // one source when the receiver's CSR row lies inside one 16-edge tile (agg[r]), else the per-tile
           // partial slots in tile order (epilogues of k_edge_ms / k_edge16v)
-          // OWN: tiles counted from the node tile's first edge R0, slots shifted by (R0 >> 4) + node tile
-          int r0 = 0, sbase = 0;
-          if constexpr (OWN) {
-            const int64_t qt = (int64_t)q * T + i;
-            r0 = a.row_ptr[qt * 16];
-            sbase = (r0 >> 4) + (int)qt;
-          }
-          const int t0 = (k0[i] - r0) >> 4, t1 = (k1[i] - 1 - r0) >> 4;
+          const int t0 = k0[i] >> 4, t1 = (k1[i] - 1) >> 4;
           const bool single = t0 == t1;
           const int nsrc = (k1[i] <= k0[i]) ? 0 : (single ? 1 : t1 - t0 + 1);
           const int kk0 = k0[i];
           auto slot_of = [&](int tt) -> const f32x4* {
-            const float* src = single ? a.agg + rc * 128
-                                      : a.part + ((int64_t)(sbase + tt) * 2 + (kk0 <= r0 + (tt << 4) ? 0 : 1)) * 128;
+            const float* src = single ? a.agg + rc * 128 : a.part + ((int64_t)tt * 2 + (kk0 <= (tt << 4) ? 0 : 1)) * 128;
             return reinterpret_cast<const f32x4*>(src) + 8 * w + g;
           };
           // the first two sources together (a row of ~7-17 edges usually straddles at most one tile boundary)
@@ -485,7 +449,7 @@ __device__ __forceinline__ void ms_node_body(const lb_nms_args& a, const lb_geom
 
   MS_STAMP(2);
   // (range-guard slots: OR-accumulated per tile, cleared one iteration ahead - see ms_guard)
-  for (int i = tid; i < 2 * 4 * T * MS_GUARD_WORDS; i += MS_THREADS) reinterpret_cast<int*>(sMx)[i] = 0;
+  for (int i = tid; i < (int)(sizeof(sMx) / sizeof(int)); i += MS_THREADS) reinterpret_cast<int*>(sMx)[i] = 0;
   __syncthreads();
   for (int it = 0; it < wk.n_iter; ++it, q += wk.stride) {
     if (it > 0) load_rows(q);
@@ -633,15 +597,6 @@ __device__ __forceinline__ void ms_node_body(const lb_nms_args& a, const lb_geom
   MS_STAMP(31);
 }
 
-template <int NKA, bool AGG, bool RESID, bool PROJ, int T, bool DEC = false>
-__global__ void __launch_bounds__(MS_THREADS, 1) k_node_ms(lb_nms_args a, lb_geom geom) {
-  using SM = ms_node_smem<NKA, AGG, T, (PROJ || DEC)>;
-  __shared__ f32x4 smem[SM::f32x4_count];
-  SM sm;
-  sm.carve(smem);
-  ms_node_body<NKA, AGG, RESID, PROJ, T, DEC>(a, geom, sm);
-}
-
 // =========================================================================================== launchers
 // one tile per workgroup and iteration; two edge workgroups / one node workgroup per CU
 // -DLB_MS_STAMPS builds only: every launch is followed by a device sync and a dump of workgroup 0's stamps
@@ -739,245 +694,6 @@ int lbk_node_ms(lb_engine* e, const lb_nms_args& a_in, int nka, bool agg, bool r
     return lb_fail(LB_ERR_UNSUPPORTED, "k_node_ms<%d,%d,%d> not instantiated", nka, (int)agg, (int)resid);
 #undef LB_NMS
   ms_dbg_dump("node", a.dbg);
-  LB_HIP(hipGetLastError());
-  return LB_OK;
-}
-
-// =========================================================================================== owner-layout kernels (round 5)
-// ONE LAUNCH PER MESSAGE-PASSING LAYER for single trajectories.  The edge list is CSR by receiver,
-// so a workgroup that owns the 16 receivers of node tile q also owns every edge that aggregates into them: edge MLP ->
-// segment sums -> node MLP -> next projection need no kernel boundary in between, only the gathered SENDER projections
-// cross workgroups, at the launch boundary (double-buffered: a layer reads psr[k & 1] and writes psr[(k + 1) & 1]).
-// 24 launches per rollout step become 13.
-// Owner tiles.  The 16-edge tiles of the edge latents are aligned to the node tile's own edge range instead of to the
-// global edge index: node tile q (edges R0 = row_ptr[16 q] .. R1 = row_ptr[16 q + 16]) has c = ceil((R1 - R0) / 16)
-// tiles, tile j holds the edges R0 + 16 j .. + 15 (the last one partly filled) and lives in slot (R0 >> 4) + q + j of
-// the tile-blocked latents and of the partial-sum slots - a closed form, no scan: slots of consecutive node tiles do not
-// overlap because ceil(cnt / 16) <= floor((R0 % 16 + cnt) / 16) + 1, and there are at most E / 16 + BN / 16 + 1 of them
-// (lb_api.hip sizes the buffers for that).  A receiver's edges never cross a node tile's range, so the segment rule of
-// the batch kernels (complete rows -> agg[r], the <= 2 segments a tile boundary cuts -> part[slot][0 | 1], combined by
-// the node phase in tile order) carries over with the origin moved to R0.
-// The edge phase is k_edge16v's per-tile body (the whole tile in one wave, both matrices in LDS, chained registers);
-// the node phase is ms_node_body (M-split, weights in registers) in the LDS the edge weights occupied.
-struct own_tiles {  // one node tile's owner tiles
-  int R0, R1, c, S;
-  __device__ __forceinline__ void init(const int32_t* __restrict__ row_ptr, int64_t q, int64_t n_rows) {
-    const int64_t r1 = (q + 1) * 16 < n_rows ? (q + 1) * 16 : n_rows;
-    R0 = row_ptr[q * 16];
-    R1 = row_ptr[r1];
-    c = (R1 - R0 + 15) >> 4;
-    S = (R0 >> 4) + (int)q;
-  }
-};
-
-// Encoder edge MLP (gns.py:73-84) into the owner layout: k_edge_enc16v's tile body, node tiles over the workgroups,
-// a node tile's owner tiles over the 8 waves.
-__global__ void __launch_bounds__(512, 2) k_edge_enc_own(lb_edge16_args a, const int32_t* __restrict__ row_ptr, int64_t n_rows) {
-  constexpr int THREADS = 512, WAVES = 8, NW0 = 1024;
-  __shared__ f32x4 sW[NW0 + 4096 + 128];  // W0 | W1 | b1 | ln scale | ln offset | b0
-  const int poisoned = a.ctrl->overflow_step;
-  const int tid = threadIdx.x;
-  {
-    const f32x4* g0 = reinterpret_cast<const f32x4*>(a.w0p);
-    const f32x4* g1 = reinterpret_cast<const f32x4*>(a.w1p);
-    for (int i = tid; i < NW0; i += THREADS) sW[i] = g0[i];
-    for (int i = tid; i < 4096; i += THREADS) sW[NW0 + i] = g1[i];
-    if (tid < 128) {
-      const float* src = tid < 32 ? a.b1 : (tid < 64 ? a.ln_s : (tid < 96 ? a.ln_o : a.b0));
-      sW[NW0 + 4096 + tid] = reinterpret_cast<const f32x4*>(src)[tid & 31];
-    }
-  }
-  if (poisoned >= 0) return;
-  __syncthreads();
-  const float ln_inv_d = a.ctrl->ln_inv_d, ln_pad = a.ctrl->ln_pad;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, g = lane >> 4;
-  ms_walk wk;
-  if (!wk.init((int)((n_rows + 15) >> 4))) return;
-  const lds_cptr w0b = (lds_cptr)(sW + lane), w1b = (lds_cptr)(sW + NW0 + lane);
-  const lds_cptr vecb = (lds_cptr)(sW + NW0 + 4096 + g);
-  const f32x4* ef4 = reinterpret_cast<const f32x4*>(a.efeat);
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  bool first = true;
-  int q = wk.q;
-  for (int it = 0; it < wk.n_iter; ++it, q += wk.stride) {
-    own_tiles ot;
-    ot.init(row_ptr, q, n_rows);
-    for (int j = wave; j < ot.c; j += WAVES) {
-      const int row = ot.R0 + 16 * j + n;
-      const int64_t rc = row < ot.R1 ? row : ot.R1 - 1;
-      const f32x4 f = ef4[rc * 2 + (g & 1)];
-      const f32x4 v2[2] = {g < 2 ? f : zero, zero};
-      f32x4 acc[8], acc2[8];
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) acc[mb] = vecb[96 + 4 * mb];
-      lb_gemm16v<false, 1>(w0b, v2, acc);
-      if (first) lb_range_probe(a.ctrl, acc, 8);
-      first = false;
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) acc2[mb] = vecb[4 * mb];
-      lb_gemm16v<true>(w1b, acc, acc2);
-      f32x4 y[8];
-      lb_layernorm16<true>(acc2, vecb + 32, vecb + 64, y, ln_inv_d, ln_pad);
-      f32x4* ew = reinterpret_cast<f32x4*>(a.elat) + (int64_t)(ot.S + j) * 512 + lane;
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) ew[64 * mb] = y[mb];
-    }
-  }
-}
-
-// One processor layer (gns.py:83-124) in one launch: edge phase over the owner tiles of this workgroup's node tiles
-// (4 waves, a tile each), then the node phase on those node tiles.  SKIP: last layer (no edge-latent store);
-// PROJ: the next layer's projection; DEC: decoder (+ integrator of a rollout step) in the epilogue.
-template <bool SKIP, bool PROJ, bool DEC, int GUARD>
-__global__ void __launch_bounds__(MS_THREADS, 1) k_layer_own(lb_edge16_args ea, lb_nms_args na, lb_geom geom) {
-  constexpr int NW0 = 4096;
-  using SM = ms_node_smem<4, true, 1, (PROJ || DEC)>;
-  static_assert(SM::f32x4_count <= NW0 + 4096 + 96, "the node phase lives in the edge weights' LDS");
-  __shared__ f32x4 sW[NW0 + 4096 + 96];
-  const int poisoned = ea.ctrl->overflow_step;
-  const float ln_inv_d = ea.ctrl->ln_inv_d, ln_pad = ea.ctrl->ln_pad;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, g = lane >> 4;
-  ms_walk wk;
-  const bool has_work = wk.init((int)((na.n_rows + 15) >> 4));
-  SM sm;
-  sm.carve(sW);
-  if (poisoned >= 0 || !has_work) {  // (the node body does the idle workgroup's share of the step bookkeeping)
-    ms_node_body<4, true, true, PROJ, 1, DEC, true>(na, geom, sm);
-    return;
-  }
-  {
-    const f32x4* g0 = reinterpret_cast<const f32x4*>(ea.w0p);
-    const f32x4* g1 = reinterpret_cast<const f32x4*>(ea.w1p);
-    for (int i = tid; i < NW0; i += MS_THREADS) sW[i] = g0[i];
-    for (int i = tid; i < 4096; i += MS_THREADS) sW[NW0 + i] = g1[i];
-    if (tid < 96) {
-      const float* src = tid < 32 ? ea.b1 : (tid < 64 ? ea.ln_s : ea.ln_o);
-      sW[NW0 + 4096 + tid] = reinterpret_cast<const f32x4*>(src)[tid & 31];
-    }
-  }
-  __syncthreads();
-  {
-    uint32_t off0 = (uint32_t)(uintptr_t)(lds_cptr)(sW + lane);
-    uint32_t off1 = (uint32_t)(uintptr_t)(lds_cptr)(sW + NW0 + lane);
-    uint32_t off2 = (uint32_t)(uintptr_t)(lds_cptr)(sW + NW0 + 4096 + g);
-    asm volatile("" : "+v"(off0), "+v"(off1), "+v"(off2));
-    const lds_cptr w0b = (lds_cptr)(uintptr_t)off0, w1b = (lds_cptr)(uintptr_t)off1, vecb = (lds_cptr)(uintptr_t)off2;
-    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(ea.agg, 0, (int)ea.aggpart_bytes, 0x00020000);
-    const uint32_t part_off = (uint32_t)((const char*)ea.part - (const char*)ea.agg);
-    const f32x4* psr4 = reinterpret_cast<const f32x4*>(ea.psr);
-    typedef uint32_t u32x4o __attribute__((ext_vector_type(4)));
-    int guard_tiny = 0;
-    bool first = true;
-    int q = wk.q;
-    for (int it = 0; it < wk.n_iter; ++it, q += wk.stride) {
-      own_tiles ot;
-      ot.init(ea.row_ptr, q, na.n_rows);
-      for (int j = wave; j < ot.c; j += MS_WAVES) {
-        const int e0 = ot.R0 + 16 * j, row = e0 + n;
-        const bool valid = row < ot.R1;
-        const int rowc = valid ? row : ot.R1 - 1;
-        const int s_c = ea.senders[rowc], r_c = ea.receivers[rowc];
-        // receivers of the edge just before / after the tile INSIDE the node tile's range (lane parity 0 / 1)
-        int pi = (lane & 1) ? e0 + 16 : e0 - 1;
-        pi = pi < ot.R0 ? ot.R0 : (pi < ot.R1 ? pi : ot.R1 - 1);
-        const int rb = ea.receivers[pi];
-        const int slot = ot.S + j;
-        f32x4 ve[8], acc[8], p0[8];
-        {
-          const f32x4* er = reinterpret_cast<const f32x4*>(ea.elat) + (int64_t)slot * 512 + lane;
-          const f32x4* ps = psr4 + (int64_t)s_c * 64 + g;
-          const f32x4* pr = psr4 + (int64_t)r_c * 64 + 32 + g;
-#pragma unroll
-          for (int mb = 0; mb < 8; ++mb) {
-            ve[mb] = er[64 * mb];
-            acc[mb] = pr[4 * mb];
-            p0[mb] = ps[4 * mb];
-          }
-        }
-        if (first) lb_range_probe(ea.ctrl, ve, 8);
-        uint32_t or_e = 0, or_h = 0;
-        lb_gemm16v<false, 4, GUARD>(w0b, ve, acc, &or_e);
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) acc[mb] = lb_pk_add(acc[mb], p0[mb]);
-        if (first) lb_range_probe(ea.ctrl, acc, 8);
-        first = false;
-        f32x4 acc2[8];
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) acc2[mb] = vecb[4 * mb];
-        lb_gemm16v<true, 4, GUARD>(w1b, acc, acc2, &or_h);
-        if constexpr (GUARD != 0) guard_tiny |= (int)lb_rows_tiny(or_e) | (int)lb_rows_tiny(or_h);
-        f32x4 y[8];
-        lb_layernorm16<true>(acc2, vecb + 32, vecb + 64, y, ln_inv_d, ln_pad);
-        if constexpr (!SKIP) {
-          f32x4* ew = reinterpret_cast<f32x4*>(ea.elat) + (int64_t)slot * 512 + lane;
-#pragma unroll
-          for (int mb = 0; mb < 8; ++mb) ew[64 * mb] = lb_pk_add(ve[mb], y[mb]);
-        }
-        // fused jraph.segment_sum: segmented scan inside each 16-lane DPP row (rows past R1: copies of the node tile's
-        // last edge, each its own segment, above every valid lane, never stored)
-        const int rr = valid ? r_c : (-1 - n);
-        const int r_prev = __builtin_amdgcn_update_dpp(-2, rr, 0x111, 0xF, 0xF, false);
-        const bool head = (n == 0) || (rr != r_prev);
-        const unsigned H = (unsigned)(__ballot(head) & 0xffffull);
-        const int segstart = 31 - __clz(H & ((2u << n) - 1u));
-        const bool tail = (n == 15) || ((H >> (n + 1)) & 1u);
-        const float m1 = (n >= 1 && segstart <= n - 1) ? 1.f : 0.f, m2 = (n >= 2 && segstart <= n - 2) ? 1.f : 0.f;
-        const float m4 = (n >= 4 && segstart <= n - 4) ? 1.f : 0.f, m8 = (n >= 8 && segstart <= n - 8) ? 1.f : 0.f;
-#pragma unroll
-        for (int mb = 0; mb < 8; mb += 2) lb_scan8(y[mb], y[mb + 1], m1, m2, m4, m8);
-        {
-          const int r_before = __builtin_amdgcn_readlane(rb, 0), r_after = __builtin_amdgcn_readlane(rb, 1);
-          const bool starts_before = segstart == 0 && j > 0 && r_before == rr;
-          const bool ends_after = n == 15 && e0 + 16 < ot.R1 && r_after == rr;
-          const int slot01 = segstart == 0 ? 0 : 1;
-          const uint32_t row_off = (!starts_before && !ends_after) ? (uint32_t)rr * 512u
-                                                                  : part_off + ((uint32_t)slot * 2u + (uint32_t)slot01) * 512u;
-          const uint32_t off = (tail && valid) ? row_off + (uint32_t)g * 16u : 0x80000000u;  // out of range: dropped
-#pragma unroll
-          for (int mb = 0; mb < 8; ++mb)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4o, y[mb]), out_rs, (int)off, 64 * mb, 0);
-        }
-      }
-    }
-    if (guard_tiny && lane == 0) lb_raise_math(ea.ctrl, LB_MATH_TINY);
-  }
-  // the aggregates of this workgroup's node tiles are complete: every wave's stores are visible to the workgroup behind
-  // the barrier (workgroup-scope release / acquire), and the edge weights' LDS is free for the node phase
-  __syncthreads();
-  ms_node_body<4, true, true, PROJ, 1, DEC, true>(na, geom, sm);
-}
-
-int lbk_edge_enc_own(lb_engine* e, const lb_edge16_args& a) {
-  const int64_t tiles = (e->BN + 15) / 16;
-  hipLaunchKernelGGL(k_edge_enc_own, dim3(ms_grid(tiles, 2)), dim3(512), 0, e->stream, a, e->row_ptr, e->BN);
-  LB_HIP(hipGetLastError());
-  return LB_OK;
-}
-
-int lbk_layer_own(lb_engine* e, const lb_edge16_args& ea, const lb_nms_args& na_in, bool proj, bool dec) {
-  lb_nms_args na = na_in;
-  na.dbg = nullptr;
-  const int64_t tiles = (na.n_rows + 15) / 16;
-  const dim3 grid(ms_grid(tiles, 1)), block(MS_THREADS);
-  const bool guard = e->math_auto && !e->guard_sampled;
-  if (dec && proj) return lb_fail(LB_ERR_ARG, "k_layer_own: the decoder follows the last layer");
-#define LB_OWN_GO(SK, PR, DE)                                                            \
-  do {                                                                                   \
-    if (guard)                                                                           \
-      LB_LAUNCH_TIMED(e, (k_layer_own<SK, PR, DE, 1>), grid, block, ea, na, e->g);       \
-    else                                                                                 \
-      LB_LAUNCH_TIMED(e, (k_layer_own<SK, PR, DE, 0>), grid, block, ea, na, e->g);       \
-  } while (0)
-  if (proj) {
-    if (ea.skip_elat_store) LB_OWN_GO(true, true, false); else LB_OWN_GO(false, true, false);
-  } else if (dec) {
-    if (ea.skip_elat_store) LB_OWN_GO(true, false, true); else LB_OWN_GO(false, false, true);
-  } else {
-    if (ea.skip_elat_store) LB_OWN_GO(true, false, false); else LB_OWN_GO(false, false, false);
-  }
-#undef LB_OWN_GO
   LB_HIP(hipGetLastError());
   return LB_OK;
 }
