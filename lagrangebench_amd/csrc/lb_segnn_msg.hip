@@ -69,12 +69,12 @@ struct lb_sg_msg_args {
   float* part;          // [ceil(E/16)][2][128]; lives in the SAME allocation as agg (one buffer descriptor for the stores)
   uint32_t part_off;    // byte offset of part from agg
   uint32_t out_bytes;   // bytes of the agg | part allocation (< 2^31)
-  long long* dbg;       // tools/sg_msg_bench (ABL & 32): per wave of workgroup 0, cycles per tile segment
+  long long* dbg;       // ABL & 32 (round 4's tools/sg_msg_bench, commit 9d3d71e): per wave of workgroup 0, cycles per tile segment
 };
 
 // WPS waves per SIMD (one workgroup of WPS * 256 threads per CU); each wave loads its own tile (only the
 // next tile's two indices travel ahead) and the other waves of the SIMD hide the latency.
-// ABL (tools/sg_msg_bench.hip only, 0 in the product): 1 no row gathers, 2 no MFMAs, 4 no gates, 8 no scan, 16 no stores.
+// ABL (round 4's tools/sg_msg_bench.hip - removed with the museum kernel it cross-checked, commit 9d3d71e has it; 0 in the product): 1 no row gathers, 2 no MFMAs, 4 no gates, 8 no scan, 16 no stores.
 template <int DIM, int WPS, bool PRIO, int ABL = 0, int SM = 0x1ff>
 __global__ void __launch_bounds__(WPS * 256, 1) k_sg_msg(lb_sg_msg_args a) {
   constexpr int NT = WPS * 256, WAVES = WPS * 4, NC = DIM;
