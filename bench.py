@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--shuffle", action="store_true",
                     help="randomly permute the particle ids (memory-locality ablation; default: lattice order)")
     ap.add_argument("--cpu-steps", type=int, default=5)
-    ap.add_argument("--repeats", type=int, default=5,
+    ap.add_argument("--repeats", type=int, default=15,
                     help="the K-step timed region is repeated this many times; value / ms_per_step = the median")
     ap.add_argument("--cpu-baseline-only", default=None, metavar="WORKLOAD",
                     help="(internal) run only the CPU baseline leg of WORKLOAD and print its JSON object")
