@@ -427,8 +427,9 @@ def train_step_lines(device):
     """SURVEY section 8 row N4, the training step (trainer.py:35-89: value_and_grad of the masked MSE over the batch +
     optax.adamw), timed like the reference runs it: batch 1 (defaults.py train.batch_size), loss fetched every step.
     One line per workload: ms per step, particle-steps/s, and the dense-contraction rate against the fp32 MFMA peak (the
-    training path is exact fp32: forward 1x + backward 2x the forward's GEMM flops; Y = XW and dX = dY W^T on rocBLAS
-    sgemm, dW += X^T dY on the hand-written fp32-MFMA k_dw_part; everything else - LayerNorm, gathers and their
+    training path is exact fp32: forward 1x + backward 2x the forward's GEMM flops; Y = XW and dX = dY W^T on the
+    hand-written k_lin32f (fp32 MFMA, epilogues fused; rocBLAS sgemm until round 4), dW += X^T dY on the hand-written
+    fp32-MFMA k_dw_part; everything else - LayerNorm, gathers and their
     deterministic transposes, AdamW - is hand-written HIP)."""
     from lagrangebench_amd.data import make_case
     from lagrangebench_amd.models import GNS
@@ -467,7 +468,7 @@ def train_step_lines(device):
             res.append({"workload": f"{workload} GNS-10-128 training step (B = 1)", "n_particles": int(N), "edges": int(E),
                         "steps": K, "ms_per_step": 1e3 * dt, "value": N / dt, "unit": "particle-steps/s",
                         "loss": float(loss), "dtype": "f32",
-                        "roofline": {"kernel": "rocBLAS sgemm (Y = XW, dX = dY W^T) + k_dw_part (dW += X^T dY, fp32 MFMA)", "bound": "mfma",
+                        "roofline": {"kernel": "k_lin32 (Y = XW, dX = dY W^T) + k_dw_part (dW += X^T dY): v_mfma_f32_16x16x4_f32, no library GEMM", "bound": "mfma",
                                      "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
                                      "flop_per_step": int(3 * fwd),
                                      "note": "whole-step rate (GEMMs + everything else) against the fp32 MFMA peak"}})

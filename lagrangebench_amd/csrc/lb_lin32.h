@@ -1,0 +1,248 @@
+// lb_lin32.h - the training step's tall-skinny fp32 products without the library (round 5; device code, included by
+// lb_train.hip and by tools/lin_bench.hip):  Y[rows x NO] = X[rows x NR] * Wop[NR x NO]  with the elementwise neighbours of
+// the product in the epilogue.  Wop = W (Y = X W: forward) or W^T (dX = dY W^T: backward); rows ~1e4 .. 1e5, NR, NO <= 256.
+// Reference: the Linear layers of hk.nets.MLP inside GNS (models/gns.py:65-171) under value_and_grad (train/trainer.py:63-89).
+//
+// rocBLAS ran these at 60 - 94 TFLOP/s and every elementwise pass behind them (bias + ReLU, ReLU mask, the "+=" of a gradient
+// with two producers) was a launch of its own over the same E x 128 array.
+//
+// Layout.  One wave per 16-row tile on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate), 8 waves per workgroup,
+// ONE workgroup per CU (2 waves per SIMD, 256 VGPRs each), the whole operand matrix in LDS in MFMA A-fragment order:
+// f32x4 entry ((j * NOB + mb) * 64 + lane) holds, for i = 0 .. 3, Wop[16 j + 4 (lane >> 4) + i][16 mb + (lane & 15)] - one
+// ds_read_b128 feeds the four k-steps (j, i) of output block mb.  The fragment order is produced ONCE per training step for all
+// weight matrices by k_pack_w (both orientations; the weights only change in the optimiser): the workgroups then stage LDS with
+// a flat, fully vectorised copy (a first version built the fragments inside k_lin32 from the row-major matrix with scalar
+// loads: 512 workgroups x 32 dependent L2 round trips to the same 64 KiB - 10 us of a 40 us launch, 55 us on edge-sized calls
+// where rocBLAS took 29).
+// The B operand comes straight from global memory: lane (n, kq) loads X[row n][16 j + 4 kq .. + 3] (16 bytes) and uses element
+// i in k-step (j, i) - the four k of an MFMA are then {16 j + 4 kq + i}, a permutation the A fragments follow.
+// k_lin32f (the shapes that matter: NR a multiple of 128, NO = 128) keeps a RING of eight such loads in flight per lane -
+// the fragment j + 8 of the sequence (tile, j), crossing into the wave's next tile - and fetches what the epilogue reads
+// (ReLU mask, previous Y) at the top of the tile: 8 - 16 KiB in flight per wave, so the HBM side (64 - 96 MB per edge-sized
+// call) overlaps the 256 MFMAs of a tile instead of being waited for one k-group at a time.
+// D layout: lane (n, g) holds out[row n][16 mb + 4 g + jj]: one 16-byte store per block and lane.
+// Epilogue (all optional): + bias[m]; ReLU; * (mask[row][m] > 0) (ReLU backward); += the previous Y (beta = 1).
+// Every sum has a fixed order: bit-reproducible, and independent of which kernel (k_lin32 / k_lin32f) or grid ran it.
+#pragma once
+#include "lb_device.h"
+
+struct lb_lin_args {
+  const float* X;
+  int ldx, NR;
+  const float* Wp;      // the operand in fragment order (k_pack_w): NJ * NOB * 64 f32x4
+  int NJ;               // ceil(NR / 16)
+  float* Y;
+  int ldy, NO;
+  int64_t rows;
+  const float* bias;    // [NO] or null
+  int relu;
+  const float* mask;    // [rows][ldm] or null: y *= (mask > 0)
+  int ldm;
+  int accum;            // y += Y
+};
+
+struct lb_pack_ent {    // one operand matrix of k_pack_w
+  int64_t src, dst;     // float offsets into the weight blob / the packed blob
+  int NR, NO, ldw, trans;  // trans = 0: Wop[k][m] = W[k * ldw + m]; 1: Wop[k][m] = W[m * ldw + k]
+  int NJ, NOB;
+};
+
+// weight blob -> fragment order, zero padded; grid (blocks, entries)
+__global__ void __launch_bounds__(256) k_pack_w(const float* __restrict__ w, float* __restrict__ wp,
+                                                const lb_pack_ent* __restrict__ tab) {
+  const lb_pack_ent e = tab[blockIdx.y];
+  const int total = e.NJ * e.NOB * 256;
+  const float* src = w + e.src;
+  float* dst = wp + e.dst;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int i = idx & 3, ln = (idx >> 2) & 63, q = idx >> 8;
+    const int mb = q % e.NOB, j = q / e.NOB;
+    const int k = 16 * j + 4 * (ln >> 4) + i, m = 16 * mb + (ln & 15);
+    float v = 0.f;
+    if (k < e.NR && m < e.NO) v = e.trans ? src[(int64_t)m * e.ldw + k] : src[(int64_t)k * e.ldw + m];
+    dst[idx] = v;
+  }
+}
+
+// flat copy of the packed operand into LDS (n4 f32x4), four loads in flight per thread
+__device__ __forceinline__ void lb_lin_stage(f32x4* sW, const float* Wp, int n4, int tid) {
+  const f32x4* src = reinterpret_cast<const f32x4*>(Wp);
+  int idx = tid;
+  for (; idx + 3 * 512 < n4; idx += 4 * 512) {
+    const f32x4 v0 = src[idx], v1 = src[idx + 512], v2 = src[idx + 1024], v3 = src[idx + 1536];
+    sW[idx] = v0;
+    sW[idx + 512] = v1;
+    sW[idx + 1024] = v2;
+    sW[idx + 1536] = v3;
+  }
+  for (; idx < n4; idx += 512) sW[idx] = src[idx];
+}
+
+// ---- generic shapes (any NR, NO <= 16 NOB, unaligned rows): one k-group of X ahead
+template <int NOB>
+__global__ void __launch_bounds__(512) k_lin32(lb_lin_args a) {
+  extern __shared__ f32x4 sWl[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const int NJ = a.NJ;
+  lb_lin_stage(sWl, a.Wp, NJ * NOB * 64, tid);
+  __syncthreads();
+  const int64_t ntiles = (a.rows + 15) >> 4;
+  const bool x_vec = (a.ldx & 3) == 0 && (a.NR & 15) == 0;            // whole 16-byte loads stay inside the row
+  const bool y_vec = (a.ldy & 3) == 0 && (a.NO & 3) == 0;
+  for (int64_t t = (int64_t)wave * gridDim.x + blockIdx.x; t < ntiles; t += (int64_t)gridDim.x * 8) {
+    const int64_t row = t * 16 + n, rowc = row < a.rows ? row : a.rows - 1;
+    const float* xr = a.X + rowc * a.ldx;
+    f32x4 acc[NOB];
+#pragma unroll
+    for (int mb = 0; mb < NOB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load_x = [&](int j) -> f32x4 {
+      const int c = 16 * j + 4 * kq;
+      if (x_vec) return *reinterpret_cast<const f32x4*>(xr + c);
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = c + i < a.NR ? xr[c + i] : 0.f;
+      return v;
+    };
+    f32x4 xn = load_x(0);
+    for (int j = 0; j < NJ; ++j) {
+      const f32x4 x = xn;
+      if (j + 1 < NJ) xn = load_x(j + 1);
+      f32x4 wv[NOB];
+#pragma unroll
+      for (int mb = 0; mb < NOB; ++mb) wv[mb] = sWl[(j * NOB + mb) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int mb = 0; mb < NOB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[mb][i], x[i], acc[mb], 0, 0, 0);
+    }
+    if (row < a.rows) {
+#pragma unroll
+      for (int mb = 0; mb < NOB; ++mb) {
+        const int m0 = 16 * mb + 4 * kq;
+        if (m0 >= a.NO) continue;
+        f32x4 y = acc[mb];
+        if (a.bias) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) y[jj] += m0 + jj < a.NO ? a.bias[m0 + jj] : 0.f;
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) y[jj] = fmaxf(y[jj], 0.f);
+        }
+        if (a.mask) {
+          const float* mr = a.mask + row * a.ldm + m0;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) y[jj] = (m0 + jj < a.NO && mr[jj] > 0.f) ? y[jj] : 0.f;
+        }
+        float* yr = a.Y + row * a.ldy + m0;
+        if (y_vec) {
+          f32x4* y4 = reinterpret_cast<f32x4*>(yr);
+          *y4 = a.accum ? *y4 + y : y;
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            if (m0 + jj < a.NO) yr[jj] = a.accum ? yr[jj] + y[jj] : y[jj];
+        }
+      }
+    }
+  }
+}
+
+// ---- the shapes that matter: NR % 128 == 0, NO == 128, ldx % 4 == 0, ldy % 4 == 0.  EPI: 0 none, 1 ReLU mask, 2 accumulate
+// Software pipeline (the compiler neither double-buffers the LDS reads nor keeps the global loads where they are written: it
+// sinks all eight of a chunk behind the chunk's last MFMA, which exposes the latency of the first one): per k-group the LDS
+// reads of the NEXT group are issued first, then the 32 MFMAs of this group, then the ring slot is refilled; sched_barriers pin
+// the three parts.
+template <int EPI>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lin32f(lb_lin_args a) {
+  constexpr int NOB = 8;
+  extern __shared__ f32x4 sWl[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const int NJ = a.NJ, nch = NJ >> 3;
+  const int64_t ntiles = (a.rows + 15) >> 4, tstep = (int64_t)gridDim.x * 8;
+  int64_t t = (int64_t)wave * gridDim.x + blockIdx.x;
+  auto row_ptr = [&](int64_t tt) -> const float* {
+    int64_t r = tt * 16 + n;
+    r = r < a.rows ? r : a.rows - 1;
+    return a.X + r * a.ldx + 4 * kq;
+  };
+  // the first eight fragments (and the bias) are requested before the operand is staged
+  const float* xr = row_ptr(t);
+  f32x4 ring[8];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) ring[jj] = *reinterpret_cast<const f32x4*>(xr + 16 * jj);
+  const bool has_bias = a.bias != nullptr;
+  f32x4 bv[NOB];
+#pragma unroll
+  for (int mb = 0; mb < NOB; ++mb)
+    bv[mb] = has_bias ? *reinterpret_cast<const f32x4*>(a.bias + 16 * mb + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  lb_lin_stage(sWl, a.Wp, NJ * NOB * 64, tid);
+  __syncthreads();
+  const f32x4* sw0 = sWl + lane;
+  f32x4 wv[2][NOB];
+#pragma unroll
+  for (int mb = 0; mb < NOB; ++mb) wv[0][mb] = sw0[mb * 64];
+  for (; t < ntiles; t += tstep) {
+    const int64_t row = t * 16 + n;
+    const bool live = row < a.rows;
+    const int64_t rowc = live ? row : a.rows - 1;
+    const float* xnext = row_ptr(t + tstep);
+    f32x4 ep[NOB];
+    if (EPI == 1) {
+      const float* mr = a.mask + rowc * a.ldm + 4 * kq;
+#pragma unroll
+      for (int mb = 0; mb < NOB; ++mb) ep[mb] = *reinterpret_cast<const f32x4*>(mr + 16 * mb);
+    } else if (EPI == 2) {
+      const float* yo = a.Y + rowc * a.ldy + 4 * kq;
+#pragma unroll
+      for (int mb = 0; mb < NOB; ++mb) ep[mb] = *reinterpret_cast<const f32x4*>(yo + 16 * mb);
+    }
+    f32x4 acc[NOB];
+#pragma unroll
+    for (int mb = 0; mb < NOB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int jc = 0; jc < nch; ++jc) {
+      const bool more = jc + 1 < nch;
+      const float* nx = more ? xr + 128 * (jc + 1) : xnext;
+      const f32x4* sw = sw0 + (jc * 8 * NOB) * 64;
+      const f32x4* swn = more ? sw + 8 * NOB * 64 : sw0;  // the k-group behind this chunk's last: next chunk / next tile
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const f32x4* sn = jj < 7 ? sw + (jj + 1) * NOB * 64 : swn;
+#pragma unroll
+        for (int mb = 0; mb < NOB; ++mb) wv[(jj + 1) & 1][mb] = sn[mb * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 x = ring[jj];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int mb = 0; mb < NOB; ++mb)
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[jj & 1][mb][i], x[i], acc[mb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ring[jj] = *reinterpret_cast<const f32x4*>(nx + 16 * jj);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (live) {
+      float* yr = a.Y + row * a.ldy + 4 * kq;
+#pragma unroll
+      for (int mb = 0; mb < NOB; ++mb) {
+        f32x4 y = acc[mb];
+        if (has_bias) y = y + bv[mb];
+        if (a.relu) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) y[jj] = fmaxf(y[jj], 0.f);
+        }
+        if (EPI == 1) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) y[jj] = ep[mb][jj] > 0.f ? y[jj] : 0.f;
+        } else if (EPI == 2) {
+          y = ep[mb] + y;
+        }
+        *reinterpret_cast<f32x4*>(yr + 16 * mb) = y;
+      }
+    }
+    xr = xnext;
+  }
+}

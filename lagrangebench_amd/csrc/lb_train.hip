@@ -6,11 +6,14 @@
 // (_update: vmap(value_and_grad) over the batch, gradients SUMMED over the batch, loss averaged, optax.adamw);
 // the network is GNS.__call__ of models/gns.py:65-171 (haiku MLP / LayerNorm / Embed, jraph GraphNetwork).
 //
-// Design.  Training is the row next to the hot path, not the hot path.  The two tall-skinny products of every Linear -
-// Y = X W and dX = dY W^T, ~1e5 rows against a <= 384 x 128 matrix - are plain GEMMs and go to rocBLAS sgemm (exact fp32;
-// the library runs them at ~100 TFLOP/s, 65 % of the fp32 MFMA peak).  The THIRD product, dW += X^T dY, is a reduction over
-// ~1e5 rows into a tiny result, which the library ran at 16 TFLOP/s: it is hand-written (k_dw_part: fp32 MFMA, split over
-// the rows, bias column sums folded in, partials combined in a fixed order - 95 TFLOP/s on the 384 x 128 case).
+// Design.  Training is the row next to the hot path, not the hot path.  Round 5: no library GEMM is left.  The two tall-skinny
+// products of every Linear - Y = X W and dX = dY W^T, ~1e5 rows against a <= 256 x 128 matrix - run on k_lin32f (lb_lin32.h:
+// one wave per 16-row tile, v_mfma_f32_16x16x4_f32, the operand matrix in LDS in fragment order, packed once per step by
+// k_pack_w) with their elementwise neighbours in the epilogue (bias + ReLU forward, ReLU mask backward, "+=" for gradients
+// with two producers); rounds 3 - 4 sent them to rocBLAS sgemm (dlopen-ed) and paid a launch per elementwise pass.  The THIRD
+// product, dW += X^T dY, is a reduction over ~1e5 rows into a tiny result, which the library ran at 16 TFLOP/s: hand-written
+// since round 4 (k_dw_part: fp32 MFMA, split over the rows, bias column sums folded in, partials combined in a fixed order -
+// 95 TFLOP/s on the 384 x 128 case; k_dw_narrow for the decoder's 128 x dim matrix).
 // The edge block never forms [n_s | n_r | e]: its first Linear is split by rows of W0 into two node-sized products and one
 // edge-sized one (k_edge_pre / k_edge_dP).  Hand-written HIP for everything that is not a GEMM: [n | agg], bias + ReLU,
 // LayerNorm forward and backward (the backward keeps the running sums of d scale / d offset in registers, no scratch copy),
@@ -24,7 +27,6 @@
 // Weights live in fp32 in the layout of GNS.flatten (= lb_gns_create's blob): [embed] then per MLP w0 (in x 128),
 // b0, w1 (128 x out), b1 [, LayerNorm scale, offset]; gradients and both AdamW moments use the same layout.
 #include <math.h>
-#include <rocblas/rocblas.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -32,6 +34,7 @@
 #include <vector>
 
 #include "lb_device.h"
+#include "lb_lin32.h"
 
 #include <hipcub/hipcub.hpp>  // header-only device radix sort (the sender-sorted edge permutation of the gather's transpose)
 
@@ -46,7 +49,6 @@ struct lb_train_mlp {
 struct lb_gns_train {
   lb_gns_desc desc;
   lb_engine* eng;
-  rocblas_handle blas = nullptr;
   int64_t n_floats = 0;   // floats of the DEVICE blobs (latent padded to 128)
   int64_t n_compact = 0;  // floats of the caller's blob (GNS.flatten with the model's latent size)
   int lat = TD;           // the model's latent size (<= 128)
@@ -78,53 +80,14 @@ struct lb_gns_train {
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   int64_t sort_cap = 0;
+  // the operand matrices of k_lin32 in MFMA fragment order (lb_lin32.h): registered at their first use, re-packed from the
+  // weight blob at the top of every lb_gns_train_loss_grad (one launch)
+  std::vector<lb_pack_ent> pack_tab;
+  lb_pack_ent* pack_dev = nullptr;
+  float* wpack = nullptr;
+  int64_t wpack_floats = 0, wpack_cap = 0;
 };
-
-// rocBLAS is bound at run time, when the first training handle is created (a link-time -lrocblas made every
-// inference-only process load the library and tied the build to one ROCm prefix): dlopen by soname, the five entry points
-// the training step uses resolved by name; the header above supplies the types only.
-#include <dlfcn.h>
-namespace {
-struct lb_blas_api {
-  void* lib = nullptr;
-  rocblas_status (*create_handle)(rocblas_handle*) = nullptr;
-  rocblas_status (*destroy_handle)(rocblas_handle) = nullptr;
-  rocblas_status (*set_stream)(rocblas_handle, hipStream_t) = nullptr;
-  rocblas_status (*sgemm)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int,
-                          const float*, const float*, rocblas_int, const float*, rocblas_int, const float*, float*,
-                          rocblas_int) = nullptr;
-  const char* (*status_to_string)(rocblas_status) = nullptr;
-};
-lb_blas_api g_blas;
-const char* lb_blas_load() {  // nullptr = ready, else what failed
-  if (g_blas.lib) return nullptr;
-  void* h = nullptr;
-  for (const char* name : {"librocblas.so", "librocblas.so.5", "librocblas.so.4", "/opt/rocm/lib/librocblas.so"}) {
-    h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-    if (h) break;
-  }
-  if (!h) return "librocblas.so could not be loaded (the training step's Y = XW / dX = dY W^T products run on rocBLAS)";
-  lb_blas_api a;
-  a.create_handle = (decltype(a.create_handle))dlsym(h, "rocblas_create_handle");
-  a.destroy_handle = (decltype(a.destroy_handle))dlsym(h, "rocblas_destroy_handle");
-  a.set_stream = (decltype(a.set_stream))dlsym(h, "rocblas_set_stream");
-  a.sgemm = (decltype(a.sgemm))dlsym(h, "rocblas_sgemm");
-  a.status_to_string = (decltype(a.status_to_string))dlsym(h, "rocblas_status_to_string");
-  if (!a.create_handle || !a.destroy_handle || !a.set_stream || !a.sgemm || !a.status_to_string) {
-    dlclose(h);
-    return "librocblas.so lacks one of rocblas_create_handle / destroy_handle / set_stream / sgemm / status_to_string";
-  }
-  a.lib = h;
-  g_blas = a;
-  return nullptr;
-}
-}  // namespace
-static const char* blas_err(rocblas_status s) { return g_blas.status_to_string(s); }
-#define LB_BLAS(call)                                                                            \
-  do {                                                                                           \
-    rocblas_status _s = (call);                                                                  \
-    if (_s != rocblas_status_success) return lb_fail(LB_ERR_HIP, "%s: %s", #call, blas_err(_s)); \
-  } while (0)
+#define LB_PACK_MAX 1024
 
 // ---------------------------------------------------------------------------------------------- kernels
 // y[r][c] = relu?(y[r][c] + b[c])
@@ -307,6 +270,29 @@ __global__ void __launch_bounds__(1024) k_part_reduce(const float* __restrict__ 
     if (e < n0) dst0[e] += v; else dst1[e - n0] += v;
   }
 }
+// ---- tall-skinny products without the library (round 5): k_pack_w / k_lin32 / k_lin32f of lb_lin32.h
+
+// dW[K x M] += X^T dY for a NARROW dY (M <= 4: the decoder's output Linear), which k_dw_part's 128-column tiling does not
+// cover: thread c of a 128-thread workgroup owns column c of X over a contiguous chunk of rows; partials
+// part[g][K][4] are summed over g in ascending order by k_part_reduce.
+__global__ void __launch_bounds__(128) k_dw_narrow(const float* __restrict__ X, int ldx, int K, const float* __restrict__ dY,
+                                                    int ldy, int M, int64_t rows, int64_t chunk, float* __restrict__ part) {
+  const int c = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * chunk, r1 = r0 + chunk < rows ? r0 + chunk : rows;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < K)
+    for (int64_t r = r0; r < r1; ++r) {
+      const float x = X[r * ldx + c];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (m < M) acc[m] += x * dY[r * ldy + m];
+    }
+  if (c < K)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (m < M) part[((int64_t)blockIdx.x * K + c) * M + m] = acc[m];
+}
+
 // LayerNorm backward with the parameter gradients folded in (round 4; k_ln_bwd + two column-sum passes over a scratch copy
 // of dy * zhat before): a workgroup of 4 waves walks LNB_ROWS rows, every lane keeps the running sums of dy * zhat and dy of
 // its two columns, the four waves are combined through LDS in wave order -> part[block][2][128] (k_part_reduce sums the blocks
@@ -559,30 +545,89 @@ __global__ void k_adamw(float* __restrict__ w, const float* __restrict__ g, floa
 // ------------------------------------------------------------------------------------------- host helpers
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
 
-// row-major Y[rows x M] (ldy) = X[rows x K] (ldx) * W[K x M] (+ beta * Y)
+// the packed copy of Wop (NR x NO) = W (trans 0, row stride ldw) or W^T (trans 1): registered (and packed) at its first use
+static int pack_lookup(lb_gns_train* t, const float* W, int NR, int NO, int ldw, int trans, int nob, const float** out) {
+  const int64_t src = W - t->w;
+  if (src < 0 || src >= t->n_floats) return lb_fail(LB_ERR_STATE, "k_lin32 operand outside the weight blob");
+  for (const lb_pack_ent& e : t->pack_tab)
+    if (e.src == src && e.NR == NR && e.NO == NO && e.ldw == ldw && e.trans == trans) {
+      *out = t->wpack + e.dst;
+      return LB_OK;
+    }
+  if (!t->wpack) {
+    t->wpack_cap = 2 * t->n_floats + ((int64_t)1 << 21);
+    LB_TRY(lb_alloc(&t->wpack, (size_t)t->wpack_cap));
+    LB_TRY(lb_alloc(&t->pack_dev, (size_t)LB_PACK_MAX));
+  }
+  lb_pack_ent e{};
+  e.src = src; e.dst = t->wpack_floats; e.NR = NR; e.NO = NO; e.ldw = ldw; e.trans = trans;
+  e.NJ = (NR + 15) / 16; e.NOB = nob;
+  const int64_t n = (int64_t)e.NJ * e.NOB * 256;
+  if (t->wpack_floats + n > t->wpack_cap || t->pack_tab.size() >= LB_PACK_MAX)
+    return lb_fail(LB_ERR_STATE, "k_lin32: packed operand table is full");
+  const size_t idx = t->pack_tab.size();
+  t->pack_tab.push_back(e);
+  t->wpack_floats += n;
+  LB_HIP(hipMemcpyAsync(t->pack_dev + idx, &t->pack_tab[idx], sizeof(lb_pack_ent), hipMemcpyHostToDevice, t->eng->stream));
+  LB_HIP(hipStreamSynchronize(t->eng->stream));  // (the vector may move; first step only)
+  hipLaunchKernelGGL(k_pack_w, dim3(16, 1), dim3(256), 0, t->eng->stream, t->w, t->wpack, t->pack_dev + idx);
+  *out = t->wpack + e.dst;
+  return LB_OK;
+}
+// every registered operand, from the current weights (the optimiser / lb_gns_train_write changed them)
+static void pack_all(lb_gns_train* t) {
+  if (t->pack_tab.empty()) return;
+  hipLaunchKernelGGL(k_pack_w, dim3(16, (unsigned)t->pack_tab.size()), dim3(256), 0, t->eng->stream, t->w, t->wpack, t->pack_dev);
+}
+// Y[rows x NO] = X[rows x NR] * Wop (+ epilogue) on k_lin32 / k_lin32f; a.Wp is filled in here
+static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int trans) {
+  if (a.rows == 0) return LB_OK;
+  if (a.NR > 256 || a.NO > 128) return lb_fail(LB_ERR_UNSUPPORTED, "k_lin32: %d x %d operand", a.NR, a.NO);
+  const int nob = a.NO <= 16 ? 1 : 8;
+  a.NJ = (a.NR + 15) / 16;
+  const size_t lds = (size_t)a.NJ * nob * 64 * sizeof(f32x4);
+  LB_TRY(pack_lookup(t, W, a.NR, a.NO, ldw, trans, nob, &a.Wp));
+  const int64_t tiles = (a.rows + 15) / 16;
+  const int grid = (int)std::min<int64_t>(tiles, 256);  // one workgroup per CU; tile t -> workgroup t % grid first
+  hipStream_t s = t->eng->stream;
+  const bool fast = a.NO == 128 && (a.NR & 127) == 0 && (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && (!a.mask || (a.ldm & 3) == 0) &&
+                    !(a.mask && a.accum);
+#define LB_LIN_GO(KERNEL)                                                                                                    \
+  do {                                                                                                                       \
+    static bool raised = false;                                                                                              \
+    if (!raised) {                                                                                                           \
+      (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                \
+      raised = true;                                                                                                         \
+    }                                                                                                                        \
+    hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(512), lds, s, a);                                                            \
+  } while (0)
+  if (fast) {
+    if (a.mask) LB_LIN_GO(k_lin32f<1>);
+    else if (a.accum) LB_LIN_GO(k_lin32f<2>);
+    else LB_LIN_GO(k_lin32f<0>);
+  } else if (nob == 1) LB_LIN_GO(k_lin32<1>);
+  else LB_LIN_GO(k_lin32<8>);
+#undef LB_LIN_GO
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+// row-major Y[rows x M] (ldy) = X[rows x K] (ldx) * W[K x M] (+ beta * Y) [+ bias, ReLU]
 static int gemm_nn(lb_gns_train* t, int64_t rows, int M, int K, const float* X, int ldx, const float* W, float* Y,
-                   int ldy, float beta = 0.f) {
-  const float alpha = 1.f;
-  if (rows == 0) return LB_OK;
-  LB_BLAS(g_blas.sgemm(t->blas, rocblas_operation_none, rocblas_operation_none, M, (int)rows, K, &alpha, W, M, X, ldx,
-                        &beta, Y, ldy));
-  return LB_OK;
+                   int ldy, float beta = 0.f, const float* bias = nullptr, int relu = 0) {
+  lb_lin_args a{};
+  a.X = X; a.ldx = ldx; a.NR = K; a.Y = Y; a.ldy = ldy; a.NO = M; a.rows = rows;
+  a.bias = bias; a.relu = relu; a.accum = beta != 0.f;
+  return lin32(t, a, W, M, 0);
 }
-// dX[rows x K] (ldx) = dY[rows x M] (ldy) * W^T (+ beta * dX)
+// dX[rows x K] (ldx) = dY[rows x M] (ldy) * W^T (+ beta * dX) [* (mask > 0)]; K > 128: 128 output columns per launch
 static int gemm_nt(lb_gns_train* t, int64_t rows, int M, int K, const float* dY, const float* W, float* dX, int ldx,
-                   float beta = 0.f, int ldy = 0) {
-  const float alpha = 1.f;
-  if (rows == 0) return LB_OK;
-  LB_BLAS(g_blas.sgemm(t->blas, rocblas_operation_transpose, rocblas_operation_none, K, (int)rows, M, &alpha, W, M, dY,
-                        ldy ? ldy : M, &beta, dX, ldx));
-  return LB_OK;
-}
-// dW[K x M] += X^T[K x rows] * dY[rows x M]
-static int gemm_tn(lb_gns_train* t, int64_t rows, int M, int K, const float* X, int ldx, const float* dY, float* dW) {
-  const float alpha = 1.f, beta = 1.f;
-  if (rows == 0) return LB_OK;
-  LB_BLAS(g_blas.sgemm(t->blas, rocblas_operation_none, rocblas_operation_transpose, M, K, (int)rows, &alpha, dY, M, X, ldx,
-                        &beta, dW, M));
+                   float beta = 0.f, int ldy = 0, const float* mask = nullptr, int ldm = 0) {
+  for (int c0 = 0; c0 < K; c0 += 128) {
+    lb_lin_args a{};
+    a.X = dY; a.ldx = ldy ? ldy : M; a.NR = M; a.Y = dX + c0; a.ldy = ldx; a.NO = std::min(128, K - c0); a.rows = rows;
+    a.mask = mask ? mask + c0 : nullptr; a.ldm = ldm; a.accum = beta != 0.f;
+    LB_TRY(lin32(t, a, W + (size_t)c0 * M, M, 1));
+  }
   return LB_OK;
 }
 // dW[K x 128] += X^T dY, db[128] += column sums of dY (k_dw_part / k_part_reduce); false = shape not covered (caller falls
@@ -595,7 +640,7 @@ static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx
   chunk = (chunk + 3) / 4 * 4;
   const int G = (int)((rows + chunk - 1) / chunk);
   hipStream_t s = t->eng->stream;
-  if (K & 1) return false;
+  if ((K & 1) && ldx <= K) return false;  // (the pair load of an odd K reads the row's padding column: never stored)
 #define DW_GO(NA) hipLaunchKernelGGL((k_dw_part<NA>), dim3(G), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, t->dwpart)
   if (K <= 128) DW_GO(1);
   else if (K <= 256) DW_GO(2);
@@ -605,6 +650,19 @@ static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx
   hipLaunchKernelGGL(k_part_reduce, dim3((K * 128 + nb1 + 63) / 64), dim3(1024), 0, s, t->dwpart, G, (int64_t)(K + 1) * 128,
                      K * 128, nb1, K * 128, dW, db);
   return true;
+}
+// dW[K x M] += X^T dY for M <= 4 (k_dw_narrow + the ordered reduce)
+static int dw_narrow(lb_gns_train* t, int64_t rows, int M, int K, const float* X, int ldx, const float* dY, int ldy, float* dW) {
+  if (rows == 0) return LB_OK;
+  if (M > 4 || K > 128) return lb_fail(LB_ERR_UNSUPPORTED, "dw_narrow: %d x %d", K, M);
+  int64_t chunk = (rows + DW_MAX_G - 1) / DW_MAX_G;
+  if (chunk < 64) chunk = 64;
+  const int G = (int)((rows + chunk - 1) / chunk);
+  hipStream_t s = t->eng->stream;
+  hipLaunchKernelGGL(k_dw_narrow, dim3(G), dim3(128), 0, s, X, ldx, K, dY, ldy, M, rows, chunk, t->dwpart);
+  hipLaunchKernelGGL(k_part_reduce, dim3((K * M + 63) / 64), dim3(1024), 0, s, t->dwpart, G, (int64_t)K * M, K * M, 0, 0, dW,
+                     (float*)nullptr);
+  return LB_OK;
 }
 static int colsum_add(lb_gns_train* t, const float* x, int64_t rows, int cols, int ld, float* out) {
   if (rows == 0) return LB_OK;
@@ -620,8 +678,8 @@ static int mlp_fwd_tail(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, fl
 static int mlp_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* X, int ldx, float* a, float* z,
                    const float* resid, float* y) {
   hipStream_t s = t->eng->stream;
-  LB_TRY(gemm_nn(t, rows, TD, p.in, X, ldx, t->w + p.w0, a, TD));
-  if (rows) hipLaunchKernelGGL(k_bias_act, GRID1(rows * TD), 0, s, a, t->w + p.b0, rows, TD, 1);
+  (void)s;
+  LB_TRY(gemm_nn(t, rows, TD, p.in, X, ldx, t->w + p.w0, a, TD, 0.f, t->w + p.b0, 1));  // bias + ReLU in the epilogue
   return mlp_fwd_tail(t, p, rows, a, z, resid, y);
 }
 // forward of the edge block (gns.py:86-101) without the concatenated input: see k_edge_pre
@@ -640,8 +698,7 @@ static int mlp_fwd_tail(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, fl
                         float* y) {
   hipStream_t s = t->eng->stream;
   float* zz = p.ln ? z : y;
-  LB_TRY(gemm_nn(t, rows, p.out, TD, a, TD, t->w + p.w1, zz, p.out));
-  if (rows && !p.ln) hipLaunchKernelGGL(k_bias_act, GRID1(rows * p.out), 0, s, zz, t->w + p.b1, rows, p.out, 0);
+  LB_TRY(gemm_nn(t, rows, p.out, TD, a, TD, t->w + p.w1, zz, p.out, 0.f, p.ln ? nullptr : t->w + p.b1, 0));
   if (p.ln && rows)
     hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, z, t->w + p.b1, t->w + p.lns, t->w + p.lno, resid,
                        y, rows, t->lat);
@@ -662,21 +719,18 @@ static int mlp_bwd_head(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, co
     dzz = t->dz;
   }
   if (p.out != TD || !dw_acc(t, rows, TD, a, TD, dzz, t->g + p.w1, t->g + p.b1)) {
-    LB_TRY(gemm_tn(t, rows, p.out, TD, a, TD, dzz, t->g + p.w1));
+    LB_TRY(dw_narrow(t, rows, p.out, TD, a, TD, dzz, p.out, t->g + p.w1));
     LB_TRY(colsum_add(t, dzz, rows, p.out, p.out, t->g + p.b1));
   }
-  LB_TRY(gemm_nt(t, rows, p.out, TD, dzz, t->w + p.w1, t->da, TD));
-  hipLaunchKernelGGL(k_relu_bwd, GRID1(rows * TD), 0, s, t->da, a, rows * TD);
+  LB_TRY(gemm_nt(t, rows, p.out, TD, dzz, t->w + p.w1, t->da, TD, 0.f, 0, a, TD));  // ReLU mask in the epilogue
   return LB_OK;
 }
 static int mlp_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* X, int ldx, const float* a,
                    const float* z, const float* dy, float* dX) {
   if (rows == 0) return LB_OK;
   LB_TRY(mlp_bwd_head(t, p, rows, a, z, dy));
-  if (!dw_acc(t, rows, p.in, X, ldx, t->da, t->g + p.w0, t->g + p.b0)) {
-    LB_TRY(gemm_tn(t, rows, TD, p.in, X, ldx, t->da, t->g + p.w0));
-    LB_TRY(colsum_add(t, t->da, rows, TD, TD, t->g + p.b0));
-  }
+  if (!dw_acc(t, rows, p.in, X, ldx, t->da, t->g + p.w0, t->g + p.b0))
+    return lb_fail(LB_ERR_UNSUPPORTED, "training: first Linear with %d inputs (row stride %d) is not covered", p.in, ldx);
   if (dX) LB_TRY(gemm_nt(t, rows, TD, p.in, t->da, t->w + p.w0, dX, ldx));
   return LB_OK;
 }
@@ -842,11 +896,6 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
   if (!rc) rc = lb_alloc(&t->loss_dev, 1);
   if (!rc) rc = lb_alloc(&t->cnt_dev, (size_t)e->g.B);
   if (!rc) {
-    const char* why = lb_blas_load();
-    if (why) rc = lb_fail(LB_ERR_HIP, "%s", why);
-  }
-  if (!rc && g_blas.create_handle(&t->blas) != rocblas_status_success) rc = lb_fail(LB_ERR_HIP, "rocblas_create_handle failed");
-  if (!rc) {
     std::vector<float> padded;
     const float* src = w;
     if (!t->cmap.empty()) {
@@ -869,10 +918,10 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
 
 extern "C" void lb_gns_train_destroy(lb_gns_train* t) {
   if (!t) return;
-  if (t->blas) (void)g_blas.destroy_handle(t->blas);
   std::vector<void*> bufs = {t->w, t->g, t->m, t->v, t->xnode, t->a_en, t->z_en, t->a_ee, t->z_ee, t->a_d, t->pred,
                              t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->colsum, t->dwpart, t->proj, t->node_w,
-                             t->loss_dev, t->loss_part, t->cnt_dev, t->snd_key, t->snd_perm, t->iota, t->snd_ptr, t->sort_tmp};
+                             t->loss_dev, t->loss_part, t->cnt_dev, t->snd_key, t->snd_perm, t->iota, t->snd_ptr, t->sort_tmp,
+                             t->wpack, t->pack_dev};
   for (auto* v : {&t->nlat, &t->elat, &t->ae, &t->ze, &t->xn, &t->an, &t->zn})
     for (float* p : *v) bufs.push_back(p);
   for (void* b : bufs)
@@ -889,13 +938,13 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
   lb_engine* e = t->eng;
   if (e->e_cap <= 0) return lb_fail(LB_ERR_STATE, "lb_gns_train_loss_grad before lb_nl_allocate");
   hipStream_t s = e->stream;
-  LB_BLAS(g_blas.set_stream(t->blas, s));
   LB_HIP(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(lb_ctrl), hipMemcpyDeviceToHost, s));
   LB_HIP(hipStreamSynchronize(s));
   if (e->ctrl_host->overflow_step >= 0) return lb_fail(LB_ERR_STATE, "neighbor list overflowed: re-allocate first");
   const int64_t E = e->ctrl_host->n_edges_total, BN = e->BN;
   const int L = t->desc.num_mp_steps, dim = t->desc.out_dim;
   LB_TRY(train_ensure(t, BN, E));
+  pack_all(t);  // the Linear operands in fragment order, from the current weights
   const bool has_emb = t->desc.num_particle_types > 1;
   const int emb = has_emb ? t->desc.embedding_size : 0;
   // ---- features (engine kernels): node row [features | embedding | 0-pad], edge features from the neighbor build

@@ -9,7 +9,7 @@ exponentially decaying learning rate (:183-193) -> every ``eval_steps``: validat
 
 What runs where: neighbor list, feature assembly, integrator, every evaluation rollout AND the loss step are the
 HIP engine: ``lb_gns_train_loss_grad`` (csrc/lb_train.hip: forward with saved activations, masked MSE, hand-written
-backward kernels + rocBLAS sgemm for the dense contractions) accumulates the gradients of the whole batch,
+backward kernels, fp32-MFMA GEMMs of our own for the dense contractions) accumulates the gradients of the whole batch,
 ``lb_adamw_step`` applies optax.adamw on the device; weights, gradients and both moments stay in HBM (exact fp32).
 torch is used for the noise / sampling random streams and as the tensor container only.  Only GNS (latent 128, two
 Linears per MLP) is trainable; wandb logging is not wired (stdout, as the reference's default).

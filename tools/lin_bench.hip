@@ -1,0 +1,131 @@
+// tools/lin_bench.hip - micro-benchmark + self-check of the training step's tall-skinny fp32-MFMA GEMMs (lb_lin32.h):
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -Ilagrangebench_amd/csrc -Iinclude tools/lin_bench.hip -o tools/bin/lin_bench
+//   tools/bin/lin_bench [rows=62000] [node_rows=8000]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "lb_lin32.h"
+
+#define CK(x)                                                                  \
+  do {                                                                         \
+    hipError_t e_ = (x);                                                       \
+    if (e_ != hipSuccess) {                                                    \
+      printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__);    \
+      exit(1);                                                                 \
+    }                                                                          \
+  } while (0)
+
+int main(int argc, char** argv) {
+  const int64_t rows = argc > 1 ? atoll(argv[1]) : 62000;
+  const int64_t nrows = argc > 2 ? atoll(argv[2]) : 8000;
+  float *X, *W, *Y, *M, *Wp;
+  lb_pack_ent* tab;
+  CK(hipMalloc(&X, rows * 256 * 4));
+  CK(hipMalloc(&Y, rows * 256 * 4));
+  CK(hipMalloc(&M, rows * 256 * 4));
+  CK(hipMalloc(&W, 256 * 256 * 4));
+  CK(hipMalloc(&Wp, 4 * 256 * 256 * 4));
+  CK(hipMalloc(&tab, sizeof(lb_pack_ent)));
+  std::vector<float> hx((size_t)rows * 256), hw(256 * 256), hm((size_t)rows * 256);
+  srand(5);
+  for (auto& v : hx) v = (rand() % 2001 - 1000) * 1e-3f;
+  for (auto& v : hm) v = (rand() % 2001 - 1000) * 1e-3f;
+  for (auto& v : hw) v = (rand() % 2001 - 1000) * 1e-3f;
+  CK(hipMemcpy(X, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(M, hm.data(), hm.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+  CK(hipFuncSetAttribute((const void*)k_lin32<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_lin32<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_lin32f<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_lin32f<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_lin32f<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  int bad = 0;
+  // mode: 0 plain, 1 bias + relu, 2 mask, 3 accum;  fast: use k_lin32f
+  auto run = [&](const char* name, int NR, int NO, int trans, int mode, int64_t r, bool fast) {
+    const int nob = NO <= 16 ? 1 : 8, nj = (NR + 15) / 16;
+    lb_pack_ent pe{0, 0, NR, NO, trans ? NR : NO, trans, nj, nob};
+    CK(hipMemcpy(tab, &pe, sizeof(pe), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_pack_w, dim3(16, 1), dim3(256), 0, 0, W, Wp, tab);
+    lb_lin_args a{};
+    a.X = X; a.ldx = NR; a.NR = NR; a.Wp = Wp; a.NJ = nj; a.Y = Y; a.ldy = NO; a.NO = NO; a.rows = r;
+    if (mode == 1) { a.bias = W; a.relu = 1; }
+    if (mode == 2) { a.mask = M; a.ldm = NO; }
+    if (mode == 3) a.accum = 1;
+    const size_t lds = (size_t)nj * nob * 64 * 16;
+    const int64_t tiles = (r + 15) / 16;
+    const int grid = (int)std::min<int64_t>(tiles, 256);
+    auto go = [&] {
+      if (fast) {
+        if (mode == 2) hipLaunchKernelGGL((k_lin32f<1>), dim3(grid), dim3(512), lds, 0, a);
+        else if (mode == 3) hipLaunchKernelGGL((k_lin32f<2>), dim3(grid), dim3(512), lds, 0, a);
+        else hipLaunchKernelGGL((k_lin32f<0>), dim3(grid), dim3(512), lds, 0, a);
+      } else if (nob == 1) hipLaunchKernelGGL((k_lin32<1>), dim3(grid), dim3(512), lds, 0, a);
+      else hipLaunchKernelGGL((k_lin32<8>), dim3(grid), dim3(512), lds, 0, a);
+    };
+    // ---- check (sampled rows, fp64 reference)
+    std::vector<float> y0;
+    if (mode == 3) {
+      CK(hipMemcpy(Y, hm.data(), (size_t)r * NO * 4, hipMemcpyHostToDevice));
+    } else {
+      CK(hipMemset(Y, 0xff, (size_t)r * NO * 4));
+    }
+    go();
+    CK(hipDeviceSynchronize());
+    std::vector<float> hy((size_t)r * NO);
+    CK(hipMemcpy(hy.data(), Y, hy.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (int64_t s = 0; s < 400; ++s) {
+      const int64_t row = s < 40 ? s : (s < 80 ? r - 1 - (s - 40) : (int64_t)((double)rand() / RAND_MAX * (r - 1)));
+      for (int m = 0; m < NO; ++m) {
+        double acc = 0, mag = 0;
+        for (int k = 0; k < NR; ++k) {
+          const double w = trans ? hw[(size_t)m * NR + k] : hw[(size_t)k * NO + m];
+          acc += (double)hx[(size_t)row * NR + k] * w;
+          mag += std::fabs((double)hx[(size_t)row * NR + k] * w);
+        }
+        if (mode == 1) acc = std::max(acc + hw[m], 0.0);
+        if (mode == 2) acc = hm[(size_t)row * NO + m] > 0.f ? acc : 0.0;
+        if (mode == 3) acc += hm[(size_t)row * NO + m];
+        const double err = std::fabs(acc - hy[(size_t)row * NO + m]) / (mag + 1.0);
+        worst = std::max(worst, err);
+      }
+    }
+    if (!(worst < 2e-6)) ++bad;
+    for (int i = 0; i < 50; ++i) go();
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
+    const int it = 200;
+    for (int i = 0; i < it; ++i) go();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / it, tf = 2.0 * r * NR * NO / (us * 1e-6) / 1e12;
+    printf("%-8s %-40s rows %7lld  %8.2f us  %6.1f TFLOP/s (%.2f of 157)  err %.1e %s\n", fast ? "lin32f" : "lin32", name,
+           (long long)r, us, tf, tf / 157.3, worst, worst < 2e-6 ? "" : "WRONG");
+  };
+  for (int rep = 0; rep < 2; ++rep) {
+    for (int fast = 0; fast < 2; ++fast) {
+      run("Y = X W      128 x 128", 128, 128, 0, 0, rows, fast);
+      run("Y = X W      128 x 128 + bias + relu", 128, 128, 0, 1, rows, fast);
+      run("dX = dY W^T  128 x 128 * mask", 128, 128, 1, 2, rows, fast);
+      run("dX += dY W^T 128 x 128", 128, 128, 1, 3, rows, fast);
+      run("Y = X W      256 x 128 (node sized)", 256, 128, 0, 1, nrows, fast);
+      run("Y = X W      128 x 128 (node sized)", 128, 128, 0, 0, nrows, fast);
+      run("Y = X W      128 x 128 (odd rows)", 128, 128, 0, 3, nrows * 3 + 5, fast);
+    }
+    run("Y = X W      32 x 128", 32, 128, 0, 1, nrows, false);
+    run("Y = X W      3 x 128 (decoder back)", 3, 128, 1, 0, nrows, false);
+    run("Y = X W      128 x 3 (decoder)", 128, 3, 0, 1, nrows, false);
+  }
+  printf(bad ? "FAILED: %d wrong results\n" : "all results match the fp64 reference (%d wrong)\n", bad);
+  return bad ? 1 : 0;
+}
