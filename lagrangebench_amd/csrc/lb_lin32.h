@@ -39,6 +39,14 @@ struct lb_lin_args {
   const float* mask;    // [rows][ldm] or null: y *= (mask > 0)
   int ldm;
   int accum;            // y += Y
+  // LayerNorm epilogue (k_lin32f<3>): Y receives z = X Wop WITHOUT the bias (what the backward reads), then
+  // x = z + bias, y = scale * (x - mean) / sqrt(var + 1e-5) + offset over the first ln_d of the 128 columns, Yln = y (if not
+  // null), Y2 = resid + y (if not null).  Row stride 128 for Yln / Y2 / resid.  (ln_d < 128: latents narrower than the
+  // 128-wide rows - weights, biases and LayerNorm parameters are zero in the padded columns, so those columns of x are 0:
+  // mean = sum / d, variance = (sum_128 (x - mean)^2 - (128 - d) mean^2) / d, padded outputs = scale 0 x .. + offset 0 = 0.)
+  const float *ln_scale, *ln_offset, *resid;
+  float *Yln, *Y2;
+  int ln_d;
 };
 
 struct lb_pack_ent {    // one operand matrix of k_pack_w
@@ -149,11 +157,13 @@ __global__ void __launch_bounds__(512) k_lin32(lb_lin_args a) {
   }
 }
 
-// ---- the shapes that matter: NR % 128 == 0, NO == 128, ldx % 4 == 0, ldy % 4 == 0.  EPI: 0 none, 1 ReLU mask, 2 accumulate
+// ---- the shapes that matter: NR % 128 == 0, NO == 128, ldx % 4 == 0, ldy % 4 == 0.
+// EPI: 0 bias / ReLU, 1 ReLU mask, 2 accumulate, 3 LayerNorm (+ residual).
 // Software pipeline (the compiler neither double-buffers the LDS reads nor keeps the global loads where they are written: it
 // sinks all eight of a chunk behind the chunk's last MFMA, which exposes the latency of the first one): per k-group the LDS
 // reads of the NEXT group are issued first, then the 32 MFMAs of this group, then the ring slot is refilled; sched_barriers pin
-// the three parts.
+// the three parts.  Bias / LayerNorm scale / offset sit in LDS behind the operand (a global load in the epilogue would wait,
+// through the in-order vmcnt, for the stores in front of it).
 template <int EPI>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lin32f(lb_lin_args a) {
   constexpr int NOB = 8;
@@ -168,19 +178,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     r = r < a.rows ? r : a.rows - 1;
     return a.X + r * a.ldx + 4 * kq;
   };
-  // the first eight fragments (and the bias) are requested before the operand is staged
+  // the first eight fragments are requested before the operand is staged
   const float* xr = row_ptr(t);
   f32x4 ring[8];
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) ring[jj] = *reinterpret_cast<const f32x4*>(xr + 16 * jj);
-  const bool has_bias = a.bias != nullptr;
-  f32x4 bv[NOB];
-#pragma unroll
-  for (int mb = 0; mb < NOB; ++mb)
-    bv[mb] = has_bias ? *reinterpret_cast<const f32x4*>(a.bias + 16 * mb + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4* sV = sWl + NJ * NOB * 64;  // [32] bias, [32] scale, [32] offset
+  if (tid < 96) {
+    const float* src = tid < 32 ? a.bias : (tid < 64 ? a.ln_scale : a.ln_offset);
+    sV[tid] = (src && (EPI == 3 || tid < 32)) ? reinterpret_cast<const f32x4*>(src)[tid & 31] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   lb_lin_stage(sWl, a.Wp, NJ * NOB * 64, tid);
   __syncthreads();
+  const bool has_bias = a.bias != nullptr;
   const f32x4* sw0 = sWl + lane;
+  const f32x4* sv = sV + kq;  // + 4 mb: columns 16 mb + 4 kq ..
   f32x4 wv[2][NOB];
 #pragma unroll
   for (int mb = 0; mb < NOB; ++mb) wv[0][mb] = sw0[mb * 64];
@@ -198,6 +210,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       const float* yo = a.Y + rowc * a.ldy + 4 * kq;
 #pragma unroll
       for (int mb = 0; mb < NOB; ++mb) ep[mb] = *reinterpret_cast<const f32x4*>(yo + 16 * mb);
+    } else if (EPI == 3) {
+      if (a.resid) {
+        const float* rr = a.resid + rowc * 128 + 4 * kq;
+#pragma unroll
+        for (int mb = 0; mb < NOB; ++mb) ep[mb] = *reinterpret_cast<const f32x4*>(rr + 16 * mb);
+      }
     }
     f32x4 acc[NOB];
 #pragma unroll
@@ -226,21 +244,58 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     if (live) {
       float* yr = a.Y + row * a.ldy + 4 * kq;
+      if (EPI == 3) {
+        // z (without the bias) for the backward; LayerNorm of z + bias over the row: the lanes (n, 0 .. 3) hold it
+        float s = 0.f;
 #pragma unroll
-      for (int mb = 0; mb < NOB; ++mb) {
-        f32x4 y = acc[mb];
-        if (has_bias) y = y + bv[mb];
-        if (a.relu) {
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) y[jj] = fmaxf(y[jj], 0.f);
+        for (int mb = 0; mb < NOB; ++mb) {
+          *reinterpret_cast<f32x4*>(yr + 16 * mb) = acc[mb];
+          acc[mb] = acc[mb] + sv[4 * mb];
+          s += (acc[mb][0] + acc[mb][1]) + (acc[mb][2] + acc[mb][3]);
         }
-        if (EPI == 1) {
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const float inv_d = 1.f / (float)a.ln_d;
+        const float mean = s * inv_d;
+        float q = 0.f;
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) y[jj] = ep[mb][jj] > 0.f ? y[jj] : 0.f;
-        } else if (EPI == 2) {
-          y = ep[mb] + y;
+        for (int mb = 0; mb < NOB; ++mb) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[mb][jj] -= mean;
+          q += (acc[mb][0] * acc[mb][0] + acc[mb][1] * acc[mb][1]) + (acc[mb][2] * acc[mb][2] + acc[mb][3] * acc[mb][3]);
         }
-        *reinterpret_cast<f32x4*>(yr + 16 * mb) = y;
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        q -= (float)(128 - a.ln_d) * mean * mean;  // the padded columns hold 0 - mean
+        const float rs = 1.0f / sqrtf(q * inv_d + 1e-5f);
+        float* y1 = a.Yln ? a.Yln + row * 128 + 4 * kq : nullptr;
+        float* y2 = a.Y2 ? a.Y2 + row * 128 + 4 * kq : nullptr;
+#pragma unroll
+        for (int mb = 0; mb < NOB; ++mb) {
+          const f32x4 sc = sv[32 + 4 * mb], of = sv[64 + 4 * mb];
+          f32x4 y;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) y[jj] = sc[jj] * (acc[mb][jj] * rs) + of[jj];
+          if (y1) *reinterpret_cast<f32x4*>(y1 + 16 * mb) = y;
+          if (y2) *reinterpret_cast<f32x4*>(y2 + 16 * mb) = a.resid ? y + ep[mb] : y;
+        }
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < NOB; ++mb) {
+          f32x4 y = acc[mb];
+          if (has_bias) y = y + sv[4 * mb];
+          if (a.relu) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) y[jj] = fmaxf(y[jj], 0.f);
+          }
+          if (EPI == 1) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) y[jj] = ep[mb][jj] > 0.f ? y[jj] : 0.f;
+          } else if (EPI == 2) {
+            y = ep[mb] + y;
+          }
+          *reinterpret_cast<f32x4*>(yr + 16 * mb) = y;
+        }
       }
     }
     xr = xnext;

@@ -46,6 +46,15 @@ struct lb_train_mlp {
   bool ln;
 };
 
+// one gradient reduction of the step (k_part_reduce)
+struct lb_red_ent {
+  int64_t part;     // float offset of the slot in the partial buffer
+  int64_t stride;   // floats between the partials of consecutive g
+  int64_t dst0, dst1;  // float offsets into the gradient blob (dst1 unused when n1 == 0)
+  int G, n0, n1, off1;
+  int blk0, pad;    // first block of this reduction in the flat grid (64 outputs per block)
+};
+
 struct lb_gns_train {
   lb_gns_desc desc;
   lb_engine* eng;
@@ -67,8 +76,13 @@ struct lb_gns_train {
   float *a_d = nullptr, *pred = nullptr;
   float *dn = nullptr, *de = nullptr, *dy = nullptr, *dz = nullptr, *da = nullptr, *dx = nullptr, *dagg = nullptr;
   float* agg = nullptr;
-  float* colsum = nullptr;   // partial column sums [blocks][<=256]
-  float* dwpart = nullptr;   // k_dw_part partials [DW_MAX_G][385][128]
+  // partial sums of every gradient reduction of a step (k_dw_part / k_dw_narrow / k_ln_bwd2 / k_colsum_part): one slot per
+  // producer, summed in one k_part_reduce launch at the end of the backward pass
+  float* dwpart = nullptr;
+  int64_t red_cap = 0, red_off = 0;
+  std::vector<lb_red_ent> red_tab;
+  lb_red_ent *red_host = nullptr, *red_dev = nullptr;  // pinned staging copy / device table
+  int red_blocks = 0;
   float* proj = nullptr;     // edge block: [n W_s ; n W_r] (2 x cap_n x 128), reused for their gradients
   float* node_w = nullptr;   // per node loss weight (0 for kinematic particles)
   double* loss_dev = nullptr;
@@ -90,48 +104,6 @@ struct lb_gns_train {
 #define LB_PACK_MAX 1024
 
 // ---------------------------------------------------------------------------------------------- kernels
-// y[r][c] = relu?(y[r][c] + b[c])
-__global__ void k_bias_act(float* __restrict__ y, const float* __restrict__ b, int64_t rows, int cols, int relu) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * cols) return;
-  float x = y[i] + b[i % cols];
-  y[i] = relu ? fmaxf(x, 0.f) : x;
-}
-// LayerNorm forward over 128 columns: z (pre, bias already added) -> y = scale * zhat + offset [+ resid]; 64 lanes
-// own one row, 2 columns each
-// (d < 128: latents narrower than the 128-wide rows - weights, biases and LayerNorm parameters are zero in the padded
-// columns, so those columns of z are 0: mean = sum / d, variance = (sum_128 (x - mean)^2 - (128 - d) mean^2) / d, and the
-// padded outputs are scale 0 x .. + offset 0 = 0)
-__global__ void k_ln_fwd(const float* __restrict__ z, const float* __restrict__ b1, const float* __restrict__ sc,
-                         const float* __restrict__ of, const float* __restrict__ resid, float* __restrict__ y, int64_t rows,
-                         int d) {
-  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int l = threadIdx.x & 63;
-  if (r >= rows) return;
-  // z = a W1 as the GEMM left it: the second Linear's bias is added here (and in k_ln_bwd2), not in a pass of its own
-  const float x0 = z[r * TD + l] + b1[l], x1 = z[r * TD + 64 + l] + b1[64 + l];
-  float s = x0 + x1;
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float inv_d = 1.f / (float)d;
-  const float mean = s * inv_d;
-  const float d0 = x0 - mean, d1 = x1 - mean;
-  float q = d0 * d0 + d1 * d1;
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  q -= (float)(TD - d) * mean * mean;
-  const float rs = 1.0f / sqrtf(q * inv_d + 1e-5f);
-  float y0 = sc[l] * (d0 * rs) + of[l], y1 = sc[64 + l] * (d1 * rs) + of[64 + l];
-  if (resid) {
-    y0 += resid[r * TD + l];
-    y1 += resid[r * TD + 64 + l];
-  }
-  y[r * TD + l] = y0;
-  y[r * TD + 64 + l] = y1;
-}
-// da *= (a > 0)
-__global__ void k_relu_bwd(float* __restrict__ da, const float* __restrict__ a, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && !(a[i] > 0.f)) da[i] = 0.f;
-}
 // column sums of x (rows x cols, cols <= 128): deterministic two-level reduction (fixed row blocks of 128 rows)
 __global__ void k_colsum_part(const float* __restrict__ x, int64_t rows, int cols, int ld, float* __restrict__ part) {
   const int c = threadIdx.x;
@@ -140,13 +112,6 @@ __global__ void k_colsum_part(const float* __restrict__ x, int64_t rows, int col
   float s = 0.f;
   for (int64_t r = r0; r < r1; ++r) s += x[r * ld + c];
   part[(int64_t)blockIdx.x * 128 + c] = s;
-}
-__global__ void k_colsum_fin(const float* __restrict__ part, int nblocks, int cols, float* __restrict__ out) {
-  const int c = threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * 128 + c];
-  out[c] += s;
 }
 // ---- weight gradient (round 4): dW[K x 128] += X^T dY and db[128] += column sums of dY, without the library.
 // rocBLAS ran this contraction - reduction over ~1e5 rows into a 384 x 128 result - at 16 TFLOP/s (660 us per call, 29 %
@@ -243,13 +208,26 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 // Ordered sum of partials: out e < n0: dst0[e] += sum_g part[g * stride + e]; n0 <= e < n0 + n1: dst1[e - n0] += sum_g
 // part[g * stride + off1 + e - n0].  A 1024-thread block owns 64 outputs x 16 ranges of g (four loads in flight per thread,
 // added in ascending g), the 16 range sums are combined in range order through LDS: the result does not depend on timing.
-__global__ void __launch_bounds__(1024) k_part_reduce(const float* __restrict__ part, int G, int64_t stride, int n0, int n1,
-                                                      int off1, float* __restrict__ dst0, float* __restrict__ dst1) {
+// Round 5: ONE launch per training step for all reductions (88 of them: every weight / bias / LayerNorm gradient) - each
+// producer writes its partials into a slot of its own and leaves a descriptor; a flat grid, each block finds its descriptor by bisection.  (One
+// launch per producer before: 0.5 ms of a 7 ms TGV3D step, 0.4 ms of a 3.5 ms TGV2D step, mostly launch latency.)
+__global__ void __launch_bounds__(1024) k_part_reduce(const float* __restrict__ part_base, const lb_red_ent* __restrict__ tab,
+                                                      int n_ent, float* __restrict__ grad) {
   __shared__ float s_red[16][64];
+  int lo = 0, hi = n_ent - 1;  // the last descriptor with blk0 <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const lb_red_ent d = tab[lo];
+  const int bx = (int)blockIdx.x - d.blk0;
+  const float* part = part_base + d.part;
+  const int G = d.G, n0 = d.n0;
+  const int64_t stride = d.stride;
   const int c = threadIdx.x & 63, seg = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + c;
-  const bool ok = e < n0 + n1;
-  const int64_t src = e < n0 ? e : (int64_t)off1 + (e - n0);
+  const int e = bx * 64 + c;
+  const bool ok = e < n0 + d.n1;
+  const int64_t src = e < n0 ? e : (int64_t)d.off1 + (e - n0);
   const int per = (G + 15) / 16, g0 = seg * per, g1 = g0 + per < G ? g0 + per : G;
   float s = 0.f;
   if (ok) {
@@ -267,7 +245,7 @@ __global__ void __launch_bounds__(1024) k_part_reduce(const float* __restrict__ 
     float v = s_red[0][c];
 #pragma unroll
     for (int k = 1; k < 16; ++k) v += s_red[k][c];
-    if (e < n0) dst0[e] += v; else dst1[e - n0] += v;
+    if (e < n0) grad[d.dst0 + e] += v; else grad[d.dst1 + (e - n0)] += v;
   }
 }
 // ---- tall-skinny products without the library (round 5): k_pack_w / k_lin32 / k_lin32f of lb_lin32.h
@@ -308,11 +286,29 @@ __global__ void __launch_bounds__(256) k_ln_bwd2(const float* __restrict__ z, co
   const float inv_d = 1.f / (float)d;
   const bool real0 = l < d, real1 = 64 + l < d;
   const int64_t rb = (int64_t)blockIdx.x * LNB_ROWS;
-  for (int it = 0; it < LNB_ROWS / 4; ++it) {
+  // round 5: the loads of all 16 rows of this wave are issued before the first row is reduced (one row at a time, each
+  // behind three dependent shuffle trees, the kernel paid the memory latency 16 times: 20 us on 17 k rows)
+  constexpr int NIT = LNB_ROWS / 4;
+  float zx0[NIT], zx1[NIT], gg0[NIT], gg1[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
     const int64_t r = rb + 4 * it + wv;
-    if (r >= rows) break;
-    const float x0 = z[r * TD + l] + bb0, x1 = z[r * TD + 64 + l] + bb1;
-    const float g0 = dy[r * TD + l], g1 = dy[r * TD + 64 + l];
+    const bool ok = r < rows;
+    const int64_t rc = ok ? r : rows - 1;
+    zx0[it] = z[rc * TD + l];
+    zx1[it] = z[rc * TD + 64 + l];
+    gg0[it] = dy[rc * TD + l];
+    gg1[it] = dy[rc * TD + 64 + l];
+  }
+  // branch-free over the 16 rows (a row past the end recomputes row rows - 1 and stores the same values again; its sums are
+  // masked): the rows' shuffle trees - 18 dependent ds_bpermute round trips each - interleave instead of running in sequence
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int64_t r0 = rb + 4 * it + wv;
+    const bool ok = r0 < rows;
+    const int64_t r = ok ? r0 : rows - 1;
+    const float x0 = zx0[it] + bb0, x1 = zx1[it] + bb1;
+    const float g0 = gg0[it], g1 = gg1[it];
     float s = x0 + x1;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mean = s * inv_d;
@@ -332,10 +328,10 @@ __global__ void __launch_bounds__(256) k_ln_bwd2(const float* __restrict__ z, co
     b *= inv_d;
     dz[r * TD + l] = real0 ? rs * (u0 - a - h0 * b) : 0.f;   // (u is 0 in the padded columns: they add nothing to a, b)
     dz[r * TD + 64 + l] = real1 ? rs * (u1 - a - h1 * b) : 0.f;
-    ps0 += g0 * h0;
-    ps1 += g1 * h1;
-    po0 += g0;
-    po1 += g1;
+    ps0 += ok ? g0 * h0 : 0.f;
+    ps1 += ok ? g1 * h1 : 0.f;
+    po0 += ok ? g0 : 0.f;
+    po1 += ok ? g1 : 0.f;
   }
   s_red[wv][0][l] = ps0;
   s_red[wv][1][l] = ps1;
@@ -414,18 +410,6 @@ __global__ void k_concat_node_in(const float* __restrict__ n, const float* __res
   reinterpret_cast<f32x4*>(xn)[i] = q < 32 ? reinterpret_cast<const f32x4*>(n)[r * 32 + q]
                                            : reinterpret_cast<const f32x4*>(agg)[r * 32 + (q - 32)];
 }
-// dn += dxn[:, :128]; dagg = dxn[:, 128:]
-__global__ void k_split_node_in(const float* __restrict__ dxn, float* __restrict__ dn, float* __restrict__ dagg,
-                                int64_t N) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * 256) return;
-  const int64_t r = i / 256;
-  const int c = (int)(i % 256);
-  if (c < 128)
-    dn[r * TD + c] += dxn[i];
-  else
-    dagg[r * TD + (c - 128)] = dxn[i];
-}
 // jraph.segment_sum on the receiver-sorted CSR (rows are contiguous edge ranges): agg[r] = sum_e msg[e]
 __global__ void k_seg_sum(const int32_t* __restrict__ row_ptr, const float* __restrict__ msg, float* __restrict__ agg,
                           int64_t N, int64_t E) {
@@ -450,11 +434,6 @@ __global__ void k_seg_sum_bwd(const float* __restrict__ base, const float* __res
   f32x4 v = reinterpret_cast<const f32x4*>(dagg)[(int64_t)rcv[e] * 32 + q];
   if (base) v = v + reinterpret_cast<const f32x4*>(base)[i];
   reinterpret_cast<f32x4*>(out)[i] = v;
-}
-// out = a + b (n4 float4s)
-__global__ void k_add2(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, int64_t n4) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n4) reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
 }
 // non-kinematic particle count per trajectory (utils.py:28-35) and the per-node loss weight 1 / count
 __global__ void k_count_nonkin(const int32_t* __restrict__ ptype, int64_t BN, int N, int32_t* __restrict__ cnt) {
@@ -585,13 +564,16 @@ static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int tr
   if (a.NR > 256 || a.NO > 128) return lb_fail(LB_ERR_UNSUPPORTED, "k_lin32: %d x %d operand", a.NR, a.NO);
   const int nob = a.NO <= 16 ? 1 : 8;
   a.NJ = (a.NR + 15) / 16;
-  const size_t lds = (size_t)a.NJ * nob * 64 * sizeof(f32x4);
+  size_t lds = (size_t)a.NJ * nob * 64 * sizeof(f32x4);
   LB_TRY(pack_lookup(t, W, a.NR, a.NO, ldw, trans, nob, &a.Wp));
   const int64_t tiles = (a.rows + 15) / 16;
   const int grid = (int)std::min<int64_t>(tiles, 256);  // one workgroup per CU; tile t -> workgroup t % grid first
   hipStream_t s = t->eng->stream;
   const bool fast = a.NO == 128 && (a.NR & 127) == 0 && (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && (!a.mask || (a.ldm & 3) == 0) &&
-                    !(a.mask && a.accum);
+                    !(a.mask && a.accum) && (((uintptr_t)a.bias | (uintptr_t)a.ln_scale | (uintptr_t)a.ln_offset) & 15) == 0;
+  if (a.ln_scale && (!fast || a.mask || a.accum || a.relu))
+    return lb_fail(LB_ERR_UNSUPPORTED, "k_lin32: LayerNorm epilogue on a %d x %d operand", a.NR, a.NO);
+  if (fast) lds += 96 * sizeof(f32x4);  // bias | LayerNorm scale | offset
 #define LB_LIN_GO(KERNEL)                                                                                                    \
   do {                                                                                                                       \
     static bool raised = false;                                                                                              \
@@ -602,7 +584,8 @@ static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int tr
     hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(512), lds, s, a);                                                            \
   } while (0)
   if (fast) {
-    if (a.mask) LB_LIN_GO(k_lin32f<1>);
+    if (a.ln_scale) LB_LIN_GO(k_lin32f<3>);
+    else if (a.mask) LB_LIN_GO(k_lin32f<1>);
     else if (a.accum) LB_LIN_GO(k_lin32f<2>);
     else LB_LIN_GO(k_lin32f<0>);
   } else if (nob == 1) LB_LIN_GO(k_lin32<1>);
@@ -612,11 +595,19 @@ static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int tr
   return LB_OK;
 }
 // row-major Y[rows x M] (ldy) = X[rows x K] (ldx) * W[K x M] (+ beta * Y) [+ bias, ReLU]
+struct lb_ln_epi {  // LayerNorm epilogue of gemm_nn (k_lin32f<3>): see lb_lin_args
+  const float *scale, *offset, *resid;
+  float *yln, *y2;
+  int d;
+};
 static int gemm_nn(lb_gns_train* t, int64_t rows, int M, int K, const float* X, int ldx, const float* W, float* Y,
-                   int ldy, float beta = 0.f, const float* bias = nullptr, int relu = 0) {
+                   int ldy, float beta = 0.f, const float* bias = nullptr, int relu = 0, const lb_ln_epi* ln = nullptr) {
   lb_lin_args a{};
   a.X = X; a.ldx = ldx; a.NR = K; a.Y = Y; a.ldy = ldy; a.NO = M; a.rows = rows;
   a.bias = bias; a.relu = relu; a.accum = beta != 0.f;
+  if (ln) {
+    a.ln_scale = ln->scale; a.ln_offset = ln->offset; a.resid = ln->resid; a.Yln = ln->yln; a.Y2 = ln->y2; a.ln_d = ln->d;
+  }
   return lin32(t, a, W, M, 0);
 }
 // dX[rows x K] (ldx) = dY[rows x M] (ldy) * W^T (+ beta * dX) [* (mask > 0)]; K > 128: 128 output columns per launch
@@ -630,61 +621,120 @@ static int gemm_nt(lb_gns_train* t, int64_t rows, int M, int K, const float* dY,
   }
   return LB_OK;
 }
-// dW[K x 128] += X^T dY, db[128] += column sums of dY (k_dw_part / k_part_reduce); false = shape not covered (caller falls
-// back to the library call + column sums)
+// ---- the step's gradient reductions: producers take a slot for their partials and leave a descriptor, red_flush sums all
+// of them in one launch (lb_red_ent / k_part_reduce)
 #define DW_MAX_G 256
+#define LB_RED_MAX 512
+static int dw_groups(int64_t rows, int64_t* chunk_out) {
+  int64_t chunk = (rows + DW_MAX_G - 1) / DW_MAX_G;
+  if (chunk < 64) chunk = 64;  // (128 halves the partials of node-sized products but k_dw_part is a latency chain per
+                               //  workgroup: 10 -> 16 us per launch on TGV2D, measured)
+  chunk = (chunk + 3) / 4 * 4;
+  if (chunk_out) *chunk_out = chunk;
+  return (int)((rows + chunk - 1) / chunk);
+}
+static float* red_slot(lb_gns_train* t, int64_t floats, int64_t* off) {
+  floats = (floats + 63) / 64 * 64;
+  if (t->red_off + floats > t->red_cap || t->red_tab.size() >= LB_RED_MAX) {
+    lb_fail(LB_ERR_STATE, "training: the partial-sum buffer is full (%lld + %lld of %lld floats, %zu reductions)",
+            (long long)t->red_off, (long long)floats, (long long)t->red_cap, t->red_tab.size());
+    return nullptr;
+  }
+  *off = t->red_off;
+  t->red_off += floats;
+  return t->dwpart + *off;
+}
+static void red_push(lb_gns_train* t, int64_t part, int G, int64_t stride, int n0, int n1, int off1, const float* dst0,
+                     const float* dst1) {
+  lb_red_ent d{};
+  d.part = part; d.stride = stride; d.G = G; d.n0 = n0; d.n1 = n1; d.off1 = off1;
+  d.dst0 = dst0 - t->g;
+  d.dst1 = dst1 ? dst1 - t->g : 0;
+  d.blk0 = t->red_blocks;
+  t->red_tab.push_back(d);
+  t->red_blocks += (n0 + n1 + 63) / 64;
+}
+static int red_flush(lb_gns_train* t) {
+  const size_t n = t->red_tab.size();
+  if (n) {
+    hipStream_t s = t->eng->stream;
+    memcpy(t->red_host, t->red_tab.data(), n * sizeof(lb_red_ent));  // (pinned; the previous step's copy was synchronised)
+    LB_HIP(hipMemcpyAsync(t->red_dev, t->red_host, n * sizeof(lb_red_ent), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_part_reduce, dim3((unsigned)t->red_blocks), dim3(1024), 0, s, t->dwpart, t->red_dev, (int)n, t->g);
+  }
+  t->red_tab.clear();
+  t->red_off = 0;
+  t->red_blocks = 0;
+  return LB_OK;
+}
+// floats of partial-sum slots a step needs for BN <= cn nodes and E <= ce edges (mirrors the backward pass below)
+static int64_t red_capacity(const lb_gns_train* t, int64_t cn, int64_t ce) {
+  auto slot = [](int64_t rows, int K) { return ((int64_t)dw_groups(std::max<int64_t>(rows, 1), nullptr) * (K + 1) * 128 + 63) / 64 * 64; };
+  auto lnp = [](int64_t rows) { return ((rows + LNB_ROWS - 1) / LNB_ROWS * 256 + 63) / 64 * 64 + 64; };
+  const int L = t->desc.num_mp_steps;
+  int64_t tot = 0;
+  tot += (int64_t)L * (2 * slot(ce, 128) + 3 * slot(cn, 128) + slot(cn, 256) + lnp(ce) + lnp(cn));  // processor blocks
+  tot += slot(cn, 128) + slot(cn, std::max(128, t->kpad)) + lnp(cn);                             // node encoder
+  tot += 2 * slot(ce, 128) + lnp(ce);                                                            // edge encoder
+  tot += 2 * slot(cn, 128) + (cn + 127) / 128 * 128 + 64;                                        // decoder (narrow dW, column sums)
+  return tot + 4096;
+}
+// dW[K x 128] += X^T dY, db[128] += column sums of dY (k_dw_part + a descriptor for k_part_reduce); false = refused
 static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx, const float* dY, float* dW, float* db) {
   if (K > 384 || rows <= 0) return false;
-  int64_t chunk = (rows + DW_MAX_G - 1) / DW_MAX_G;
-  if (chunk < 64) chunk = 64;
-  chunk = (chunk + 3) / 4 * 4;
-  const int G = (int)((rows + chunk - 1) / chunk);
+  int64_t chunk = 0, off = 0;
+  const int G = dw_groups(rows, &chunk);
   hipStream_t s = t->eng->stream;
   if ((K & 1) && ldx <= K) return false;  // (the pair load of an odd K reads the row's padding column: never stored)
-#define DW_GO(NA) hipLaunchKernelGGL((k_dw_part<NA>), dim3(G), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, t->dwpart)
+  float* part = red_slot(t, (int64_t)G * (K + 1) * 128, &off);
+  if (!part) return false;
+#define DW_GO(NA) hipLaunchKernelGGL((k_dw_part<NA>), dim3(G), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part)
   if (K <= 128) DW_GO(1);
   else if (K <= 256) DW_GO(2);
   else DW_GO(3);
 #undef DW_GO
-  const int nb1 = db ? 128 : 0;
-  hipLaunchKernelGGL(k_part_reduce, dim3((K * 128 + nb1 + 63) / 64), dim3(1024), 0, s, t->dwpart, G, (int64_t)(K + 1) * 128,
-                     K * 128, nb1, K * 128, dW, db);
+  red_push(t, off, G, (int64_t)(K + 1) * 128, K * 128, db ? 128 : 0, K * 128, dW, db);
   return true;
 }
 // dW[K x M] += X^T dY for M <= 4 (k_dw_narrow + the ordered reduce)
 static int dw_narrow(lb_gns_train* t, int64_t rows, int M, int K, const float* X, int ldx, const float* dY, int ldy, float* dW) {
   if (rows == 0) return LB_OK;
   if (M > 4 || K > 128) return lb_fail(LB_ERR_UNSUPPORTED, "dw_narrow: %d x %d", K, M);
-  int64_t chunk = (rows + DW_MAX_G - 1) / DW_MAX_G;
+  int64_t chunk = (rows + DW_MAX_G - 1) / DW_MAX_G, off = 0;
   if (chunk < 64) chunk = 64;
   const int G = (int)((rows + chunk - 1) / chunk);
-  hipStream_t s = t->eng->stream;
-  hipLaunchKernelGGL(k_dw_narrow, dim3(G), dim3(128), 0, s, X, ldx, K, dY, ldy, M, rows, chunk, t->dwpart);
-  hipLaunchKernelGGL(k_part_reduce, dim3((K * M + 63) / 64), dim3(1024), 0, s, t->dwpart, G, (int64_t)K * M, K * M, 0, 0, dW,
-                     (float*)nullptr);
+  float* part = red_slot(t, (int64_t)G * K * M, &off);
+  if (!part) return LB_ERR_STATE;
+  hipLaunchKernelGGL(k_dw_narrow, dim3(G), dim3(128), 0, t->eng->stream, X, ldx, K, dY, ldy, M, rows, chunk, part);
+  red_push(t, off, G, (int64_t)K * M, K * M, 0, 0, dW, nullptr);
   return LB_OK;
 }
+// out[cols] += column sums of x (k_colsum_part: fixed blocks of 128 rows, summed in block order by k_part_reduce)
 static int colsum_add(lb_gns_train* t, const float* x, int64_t rows, int cols, int ld, float* out) {
   if (rows == 0) return LB_OK;
   const int nb = (int)((rows + 127) / 128);
-  hipStream_t s = t->eng->stream;
-  hipLaunchKernelGGL(k_colsum_part, dim3(nb), dim3(128), 0, s, x, rows, cols, ld, t->colsum);
-  hipLaunchKernelGGL(k_colsum_fin, dim3(1), dim3(128), 0, s, t->colsum, nb, cols, out);
+  int64_t off = 0;
+  float* part = red_slot(t, (int64_t)nb * 128, &off);
+  if (!part) return LB_ERR_STATE;
+  hipLaunchKernelGGL(k_colsum_part, dim3(nb), dim3(128), 0, t->eng->stream, x, rows, cols, ld, part);
+  red_push(t, off, nb, 128, cols, 0, 0, out, nullptr);
   return LB_OK;
 }
 
-static int mlp_fwd_tail(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, float* a, float* z, const float* resid, float* y);
+static int mlp_fwd_tail(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, float* a, float* z, const float* resid, float* y,
+                        float* y2);
 // forward of one MLP block: X (rows x in, ldx) -> a = relu(X W0 + b0) -> z = a W1 + b1 -> [LayerNorm (+ resid)] -> y
 static int mlp_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* X, int ldx, float* a, float* z,
                    const float* resid, float* y) {
   hipStream_t s = t->eng->stream;
   (void)s;
   LB_TRY(gemm_nn(t, rows, TD, p.in, X, ldx, t->w + p.w0, a, TD, 0.f, t->w + p.b0, 1));  // bias + ReLU in the epilogue
-  return mlp_fwd_tail(t, p, rows, a, z, resid, y);
+  return resid ? mlp_fwd_tail(t, p, rows, a, z, resid, nullptr, y) : mlp_fwd_tail(t, p, rows, a, z, nullptr, y, nullptr);
 }
 // forward of the edge block (gns.py:86-101) without the concatenated input: see k_edge_pre
+// y = e' = LN(MLP([n_s | n_r | e])) (the message), el_next = e + e' (the next edge latent)
 static int edge_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t E, int64_t BN, const float* n, const float* el, float* a,
-                    float* z, float* y) {
+                    float* z, float* y, float* el_next) {
   hipStream_t s = t->eng->stream;
   lb_engine* e = t->eng;
   float *Ps = t->proj, *Pr = t->proj + (size_t)BN * TD;
@@ -692,17 +742,18 @@ static int edge_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t E, int64_t B
   LB_TRY(gemm_nn(t, BN, TD, TD, n, TD, t->w + p.w0 + (size_t)TD * TD, Pr, TD));
   LB_TRY(gemm_nn(t, E, TD, TD, el, TD, t->w + p.w0 + (size_t)2 * TD * TD, a, TD));
   if (E) hipLaunchKernelGGL(k_edge_pre, GRID1(E * 32), 0, s, a, Ps, Pr, e->senders, e->receivers, t->w + p.b0, E);
-  return mlp_fwd_tail(t, p, E, a, z, nullptr, y);
+  return mlp_fwd_tail(t, p, E, a, z, el, y, el_next);
 }
+// y = LN(...) (may be null), y2 = resid + y (may be null); without LayerNorm (decoder): y = a W1 + b1
 static int mlp_fwd_tail(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, float* a, float* z, const float* resid,
-                        float* y) {
+                        float* y, float* y2) {
   hipStream_t s = t->eng->stream;
-  float* zz = p.ln ? z : y;
-  LB_TRY(gemm_nn(t, rows, p.out, TD, a, TD, t->w + p.w1, zz, p.out, 0.f, p.ln ? nullptr : t->w + p.b1, 0));
-  if (p.ln && rows)
-    hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, z, t->w + p.b1, t->w + p.lns, t->w + p.lno, resid,
-                       y, rows, t->lat);
-  return LB_OK;
+  (void)s;
+  if (!p.ln) return gemm_nn(t, rows, p.out, TD, a, TD, t->w + p.w1, y, p.out, 0.f, t->w + p.b1, 0);
+  // second Linear with the LayerNorm in its epilogue: z = a W1 (kept without the bias for the backward), y = LN(z + b1),
+  // y2 = resid + y (round 4: k_ln_fwd and, in the edge block, k_add2 were launches of their own over the same arrays)
+  lb_ln_epi ln{t->w + p.lns, t->w + p.lno, resid, y, y2, t->lat};
+  return gemm_nn(t, rows, TD, TD, a, TD, t->w + p.w1, z, TD, 0.f, t->w + p.b1, 0, &ln);
 }
 // backward of one MLP block.  dy: gradient w.r.t. the block's output BEFORE the residual add (rows x out);
 // produces parameter gradients (accumulated) and, if dX != null, dX (rows x in, ld = ldx).  Scratch: t->dz, t->da.
@@ -713,9 +764,11 @@ static int mlp_bwd_head(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, co
   const float* dzz = dy;
   if (p.ln) {
     const int nb = (int)((rows + LNB_ROWS - 1) / LNB_ROWS);
-    hipLaunchKernelGGL(k_ln_bwd2, dim3(nb), dim3(256), 0, s, z, t->w + p.b1, t->w + p.lns, dy, t->dz, rows, t->colsum, t->lat);
-    hipLaunchKernelGGL(k_part_reduce, dim3(4), dim3(1024), 0, s, t->colsum, nb, (int64_t)256, 128, 128, 128, t->g + p.lns,
-                       t->g + p.lno);
+    int64_t off = 0;
+    float* part = red_slot(t, (int64_t)nb * 256, &off);
+    if (!part) return LB_ERR_STATE;
+    hipLaunchKernelGGL(k_ln_bwd2, dim3(nb), dim3(256), 0, s, z, t->w + p.b1, t->w + p.lns, dy, t->dz, rows, part, t->lat);
+    red_push(t, off, nb, 256, 128, 128, 128, t->g + p.lns, t->g + p.lno);
     dzz = t->dz;
   }
   if (p.out != TD || !dw_acc(t, rows, TD, a, TD, dzz, t->g + p.w1, t->g + p.b1)) {
@@ -795,8 +848,12 @@ static int train_ensure(lb_gns_train* t, int64_t BN, int64_t E) {
   LB_TRY(tr_alloc(&t->dx, (size_t)cn * std::max(3 * TD, t->kpad)));
   LB_TRY(tr_alloc(&t->dagg, (size_t)cn * TD));
   LB_TRY(tr_alloc(&t->agg, (size_t)cn * TD));
-  LB_TRY(tr_alloc(&t->colsum, (size_t)(cm / LNB_ROWS + 2) * 256));
-  if (!t->dwpart) LB_TRY(lb_alloc(&t->dwpart, (size_t)256 * 385 * 128));
+  t->red_cap = red_capacity(t, cn, ce);
+  LB_TRY(tr_alloc(&t->dwpart, (size_t)t->red_cap));
+  if (!t->red_dev) {
+    LB_TRY(lb_alloc(&t->red_dev, (size_t)LB_RED_MAX));
+    LB_HIP(hipHostMalloc((void**)&t->red_host, sizeof(lb_red_ent) * LB_RED_MAX));
+  }
   LB_TRY(tr_alloc(&t->proj, (size_t)cn * 2 * TD));
   LB_TRY(tr_alloc(&t->node_w, (size_t)cn));
   LB_TRY(tr_alloc(&t->loss_part, (size_t)(cn / 64 + 8)));
@@ -919,13 +976,14 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
 extern "C" void lb_gns_train_destroy(lb_gns_train* t) {
   if (!t) return;
   std::vector<void*> bufs = {t->w, t->g, t->m, t->v, t->xnode, t->a_en, t->z_en, t->a_ee, t->z_ee, t->a_d, t->pred,
-                             t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->colsum, t->dwpart, t->proj, t->node_w,
+                             t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->dwpart, t->red_dev, t->proj, t->node_w,
                              t->loss_dev, t->loss_part, t->cnt_dev, t->snd_key, t->snd_perm, t->iota, t->snd_ptr, t->sort_tmp,
                              t->wpack, t->pack_dev};
   for (auto* v : {&t->nlat, &t->elat, &t->ae, &t->ze, &t->xn, &t->an, &t->zn})
     for (float* p : *v) bufs.push_back(p);
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  if (t->red_host) (void)hipHostFree(t->red_host);
   delete t;
 }
 
@@ -945,6 +1003,9 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
   const int L = t->desc.num_mp_steps, dim = t->desc.out_dim;
   LB_TRY(train_ensure(t, BN, E));
   pack_all(t);  // the Linear operands in fragment order, from the current weights
+  t->red_tab.clear();
+  t->red_off = 0;
+  t->red_blocks = 0;
   const bool has_emb = t->desc.num_particle_types > 1;
   const int emb = has_emb ? t->desc.embedding_size : 0;
   // ---- features (engine kernels): node row [features | embedding | 0-pad], edge features from the neighbor build
@@ -959,9 +1020,8 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
   LB_TRY(mlp_fwd(t, t->enc_edge, E, e->efeat, 8, t->a_ee, t->z_ee, nullptr, t->elat[0]));
   for (int k = 0; k < L; ++k) {
     // e' = LN(MLP([n_s | n_r | e])) is both the message and (plus e) the next edge latent: keep e' in dy, then residual
-    LB_TRY(edge_fwd(t, t->pe[k], E, BN, t->nlat[k], t->elat[k], t->ae[k], t->ze[k], t->dy));
+    LB_TRY(edge_fwd(t, t->pe[k], E, BN, t->nlat[k], t->elat[k], t->ae[k], t->ze[k], t->dy, t->elat[k + 1]));
     hipLaunchKernelGGL(k_seg_sum, GRID1(BN * 32), 0, s, e->row_ptr, t->dy, t->agg, BN, E);
-    if (E) hipLaunchKernelGGL(k_add2, GRID1(E * 32), 0, s, t->elat[k + 1], t->elat[k], t->dy, E * 32);
     hipLaunchKernelGGL(k_concat_node_in, GRID1(BN * 64), 0, s, t->nlat[k], t->agg, t->xn[k], BN);
     LB_TRY(mlp_fwd(t, t->pn[k], BN, t->xn[k], 2 * TD, t->an[k], t->zn[k], t->nlat[k], t->nlat[k + 1]));
   }
@@ -1003,8 +1063,11 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
   LB_HIP(hipMemsetAsync(t->de, 0, sizeof(float) * std::max<int64_t>(E, 1) * TD, s));  // e_L has no reader
   for (int k = L - 1; k >= 0; --k) {
     // node block: n_{k+1} = n_k + LN(MLP([n_k | agg_k])): dy = dn (also flows to n_k through the residual)
-    LB_TRY(mlp_bwd(t, t->pn[k], BN, t->xn[k], 2 * TD, t->an[k], t->zn[k], t->dn, t->dx));
-    hipLaunchKernelGGL(k_split_node_in, GRID1(BN * 256), 0, s, t->dx, t->dn, t->dagg, BN);
+    // d [n_k | agg_k] = da W0^T lands where it is used: the n_k half is added to dn, the agg_k half is dagg (round 4 wrote
+    // the 256-wide product and split it in a pass of its own).  dn was consumed (LayerNorm backward) before it is updated.
+    LB_TRY(mlp_bwd(t, t->pn[k], BN, t->xn[k], 2 * TD, t->an[k], t->zn[k], t->dn, nullptr));
+    LB_TRY(gemm_nt(t, BN, TD, TD, t->da, t->w + t->pn[k].w0, t->dn, TD, 1.f));
+    LB_TRY(gemm_nt(t, BN, TD, TD, t->da, t->w + t->pn[k].w0 + (size_t)TD * TD, t->dagg, TD));
     // edge block: e' feeds agg (gather of dagg over receivers) and e_{k+1} = e_k + e' (de)
     if (E) hipLaunchKernelGGL(k_seg_sum_bwd, GRID1(E * 32), 0, s, t->de, t->dagg, e->receivers, t->dy, E);
     LB_TRY(edge_bwd(t, t->pe[k], E, BN, t->nlat[k], t->elat[k], t->ae[k], t->ze[k], t->dy, t->de, t->dn));
@@ -1014,6 +1077,7 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
   if (has_emb)
     hipLaunchKernelGGL(k_embed_grad, dim3(t->desc.num_particle_types), dim3(1024), 0, s, t->dx, t->kpad, t->desc.node_in, emb,
                        e->ptype, t->desc.num_particle_types, BN, t->g + t->off_embed);
+  LB_TRY(red_flush(t));  // every weight / bias / LayerNorm gradient: partials -> gradient blob, one launch
   LB_HIP(hipGetLastError());
   if (loss_out) {
     LB_HIP(hipMemcpyAsync(loss_out, t->loss_dev, sizeof(double), hipMemcpyDeviceToHost, s));

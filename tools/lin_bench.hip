@@ -44,8 +44,11 @@ int main(int argc, char** argv) {
   CK(hipFuncSetAttribute((const void*)k_lin32f<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   CK(hipFuncSetAttribute((const void*)k_lin32f<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   CK(hipFuncSetAttribute((const void*)k_lin32f<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_lin32f<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  float* Y2;
+  CK(hipMalloc(&Y2, rows * 128 * 4 * 2));
   int bad = 0;
-  // mode: 0 plain, 1 bias + relu, 2 mask, 3 accum;  fast: use k_lin32f
+  // mode: 0 plain, 1 bias + relu, 2 mask, 3 accum, 4 LayerNorm + residual (fast only);  fast: use k_lin32f
   auto run = [&](const char* name, int NR, int NO, int trans, int mode, int64_t r, bool fast) {
     const int nob = NO <= 16 ? 1 : 8, nj = (NR + 15) / 16;
     lb_pack_ent pe{0, 0, NR, NO, trans ? NR : NO, trans, nj, nob};
@@ -56,12 +59,16 @@ int main(int argc, char** argv) {
     if (mode == 1) { a.bias = W; a.relu = 1; }
     if (mode == 2) { a.mask = M; a.ldm = NO; }
     if (mode == 3) a.accum = 1;
-    const size_t lds = (size_t)nj * nob * 64 * 16;
+    if (mode == 4) {
+      a.bias = W; a.ln_scale = W + 128; a.ln_offset = W + 256; a.resid = M; a.Yln = Y2; a.Y2 = Y2 + r * 128; a.ln_d = 128;
+    }
+    const size_t lds = (size_t)nj * nob * 64 * 16 + (fast ? 96 * 16 : 0);
     const int64_t tiles = (r + 15) / 16;
     const int grid = (int)std::min<int64_t>(tiles, 256);
     auto go = [&] {
       if (fast) {
-        if (mode == 2) hipLaunchKernelGGL((k_lin32f<1>), dim3(grid), dim3(512), lds, 0, a);
+        if (mode == 4) hipLaunchKernelGGL((k_lin32f<3>), dim3(grid), dim3(512), lds, 0, a);
+        else if (mode == 2) hipLaunchKernelGGL((k_lin32f<1>), dim3(grid), dim3(512), lds, 0, a);
         else if (mode == 3) hipLaunchKernelGGL((k_lin32f<2>), dim3(grid), dim3(512), lds, 0, a);
         else hipLaunchKernelGGL((k_lin32f<0>), dim3(grid), dim3(512), lds, 0, a);
       } else if (nob == 1) hipLaunchKernelGGL((k_lin32<1>), dim3(grid), dim3(512), lds, 0, a);
@@ -79,6 +86,12 @@ int main(int argc, char** argv) {
     std::vector<float> hy((size_t)r * NO);
     CK(hipMemcpy(hy.data(), Y, hy.size() * 4, hipMemcpyDeviceToHost));
     double worst = 0;
+    std::vector<float> hy1, hy2;
+    if (mode == 4) {
+      hy1.resize((size_t)r * 128); hy2.resize((size_t)r * 128);
+      CK(hipMemcpy(hy1.data(), Y2, hy1.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hy2.data(), Y2 + r * 128, hy2.size() * 4, hipMemcpyDeviceToHost));
+    }
     for (int64_t s = 0; s < 400; ++s) {
       const int64_t row = s < 40 ? s : (s < 80 ? r - 1 - (s - 40) : (int64_t)((double)rand() / RAND_MAX * (r - 1)));
       for (int m = 0; m < NO; ++m) {
@@ -93,6 +106,18 @@ int main(int argc, char** argv) {
         if (mode == 3) acc += hm[(size_t)row * NO + m];
         const double err = std::fabs(acc - hy[(size_t)row * NO + m]) / (mag + 1.0);
         worst = std::max(worst, err);
+      }
+      if (mode == 4) {  // LayerNorm of (z + bias) from the device's z, in fp64
+        double x[128], mean = 0, var = 0;
+        for (int m = 0; m < 128; ++m) { x[m] = (double)hy[(size_t)row * 128 + m] + hw[m]; mean += x[m]; }
+        mean /= 128;
+        for (int m = 0; m < 128; ++m) var += (x[m] - mean) * (x[m] - mean);
+        var /= 128;
+        for (int m = 0; m < 128; ++m) {
+          const double y = hw[128 + m] * ((x[m] - mean) / std::sqrt(var + 1e-5)) + hw[256 + m];
+          worst = std::max(worst, std::fabs(y - hy1[(size_t)row * 128 + m]) / 8.0);
+          worst = std::max(worst, std::fabs(y + hm[(size_t)row * 128 + m] - hy2[(size_t)row * 128 + m]) / 8.0);
+        }
       }
     }
     if (!(worst < 2e-6)) ++bad;
@@ -118,6 +143,8 @@ int main(int argc, char** argv) {
       run("Y = X W      128 x 128 + bias + relu", 128, 128, 0, 1, rows, fast);
       run("dX = dY W^T  128 x 128 * mask", 128, 128, 1, 2, rows, fast);
       run("dX += dY W^T 128 x 128", 128, 128, 1, 3, rows, fast);
+      if (fast) run("Y = LN(X W + b) + resid  128 x 128", 128, 128, 0, 4, rows, fast);
+      if (fast) run("Y = LN(X W + b) + resid  (odd rows)", 128, 128, 0, 4, nrows * 3 + 5, fast);
       run("Y = X W      256 x 128 (node sized)", 256, 128, 0, 1, nrows, fast);
       run("Y = X W      128 x 128 (node sized)", 128, 128, 0, 0, nrows, fast);
       run("Y = X W      128 x 128 (odd rows)", 128, 128, 0, 3, nrows * 3 + 5, fast);
