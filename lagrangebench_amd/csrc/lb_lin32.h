@@ -47,6 +47,10 @@ struct lb_lin_args {
   const float *ln_scale, *ln_offset, *resid;
   float *Yln, *Y2;
   int ln_d;
+  // gather epilogue (k_lin32f<4>): y = relu(((X Wop + gat1[gidx1[row]]) + gat2[gidx2[row]]) + bias), rows of 128 - the edge
+  // block's first Linear, [n_s | n_r | e] W0 + b0 with the two node-sized products gathered (k_edge_pre until round 5)
+  const float *gat1, *gat2;
+  const int32_t *gidx1, *gidx2;
 };
 
 struct lb_pack_ent {    // one operand matrix of k_pack_w
@@ -158,7 +162,7 @@ __global__ void __launch_bounds__(512) k_lin32(lb_lin_args a) {
 }
 
 // ---- the shapes that matter: NR % 128 == 0, NO == 128, ldx % 4 == 0, ldy % 4 == 0.
-// EPI: 0 bias / ReLU, 1 ReLU mask, 2 accumulate, 3 LayerNorm (+ residual).
+// EPI: 0 bias / ReLU, 1 ReLU mask, 2 accumulate, 3 LayerNorm (+ residual), 4 two gathered rows + bias + ReLU.
 // Software pipeline (the compiler neither double-buffers the LDS reads nor keeps the global loads where they are written: it
 // sinks all eight of a chunk behind the chunk's last MFMA, which exposes the latency of the first one): per k-group the LDS
 // reads of the NEXT group are issued first, then the 32 MFMAs of this group, then the ring slot is refilled; sched_barriers pin
@@ -191,6 +195,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   lb_lin_stage(sWl, a.Wp, NJ * NOB * 64, tid);
   __syncthreads();
   const bool has_bias = a.bias != nullptr;
+  int gi1 = 0, gi2 = 0;  // EPI 4: the gather indices of the wave's current tile (fetched one tile ahead)
+  if (EPI == 4) {
+    int64_t r = t * 16 + n;
+    r = r < a.rows ? r : a.rows - 1;
+    gi1 = a.gidx1[r];
+    gi2 = a.gidx2[r];
+  }
   const f32x4* sw0 = sWl + lane;
   const f32x4* sv = sV + kq;  // + 4 mb: columns 16 mb + 4 kq ..
   f32x4 wv[2][NOB];
@@ -201,7 +212,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const bool live = row < a.rows;
     const int64_t rowc = live ? row : a.rows - 1;
     const float* xnext = row_ptr(t + tstep);
-    f32x4 ep[NOB];
+    f32x4 ep[NOB], ep2[EPI == 4 ? NOB : 1];
     if (EPI == 1) {
       const float* mr = a.mask + rowc * a.ldm + 4 * kq;
 #pragma unroll
@@ -210,6 +221,17 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       const float* yo = a.Y + rowc * a.ldy + 4 * kq;
 #pragma unroll
       for (int mb = 0; mb < NOB; ++mb) ep[mb] = *reinterpret_cast<const f32x4*>(yo + 16 * mb);
+    } else if (EPI == 4) {
+      const float *p1 = a.gat1 + (int64_t)gi1 * 128 + 4 * kq, *p2 = a.gat2 + (int64_t)gi2 * 128 + 4 * kq;
+#pragma unroll
+      for (int mb = 0; mb < NOB; ++mb) {
+        ep[mb] = *reinterpret_cast<const f32x4*>(p1 + 16 * mb);
+        ep2[mb] = *reinterpret_cast<const f32x4*>(p2 + 16 * mb);
+      }
+      int64_t rn = (t + tstep) * 16 + n;
+      rn = rn < a.rows ? rn : a.rows - 1;
+      gi1 = a.gidx1[rn];
+      gi2 = a.gidx2[rn];
     } else if (EPI == 3) {
       if (a.resid) {
         const float* rr = a.resid + rowc * 128 + 4 * kq;
@@ -293,6 +315,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int jj = 0; jj < 4; ++jj) y[jj] = ep[mb][jj] > 0.f ? y[jj] : 0.f;
           } else if (EPI == 2) {
             y = ep[mb] + y;
+          }
+          if (EPI == 4) {
+            y = ((acc[mb] + ep[mb]) + ep2[mb]) + sv[4 * mb];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) y[jj] = fmaxf(y[jj], 0.f);
           }
           *reinterpret_cast<f32x4*>(yr + 16 * mb) = y;
         }

@@ -15,7 +15,7 @@
 // since round 4 (k_dw_part: fp32 MFMA, split over the rows, bias column sums folded in, partials combined in a fixed order -
 // 95 TFLOP/s on the 384 x 128 case; k_dw_narrow for the decoder's 128 x dim matrix).
 // The edge block never forms [n_s | n_r | e]: its first Linear is split by rows of W0 into two node-sized products and one
-// edge-sized one (k_edge_pre / k_edge_dP).  Hand-written HIP for everything that is not a GEMM: [n | agg], bias + ReLU,
+// edge-sized one (the gather epilogue of k_lin32f / k_edge_dP).  Hand-written HIP for everything that is not a GEMM: [n | agg], bias + ReLU,
 // LayerNorm forward and backward (the backward keeps the running sums of d scale / d offset in registers, no scratch copy),
 // ReLU masking, jraph.segment_sum and its transpose on the receiver-sorted CSR, the sender-side transpose of the gather
 // through a sender-sorted permutation (stable radix sort: ascending edge order per sender, no atomics), the embedding-table
@@ -276,9 +276,13 @@ __global__ void __launch_bounds__(128) k_dw_narrow(const float* __restrict__ X, 
 // its two columns, the four waves are combined through LDS in wave order -> part[block][2][128] (k_part_reduce sums the blocks
 // in ascending order).
 #define LNB_ROWS 64
+template <bool GATHER>
 __global__ void __launch_bounds__(256) k_ln_bwd2(const float* __restrict__ z, const float* __restrict__ b1,
                                                  const float* __restrict__ sc, const float* __restrict__ dy,
-                                                 float* __restrict__ dz, int64_t rows, float* __restrict__ part, int d) {
+                                                 float* __restrict__ dz, int64_t rows, float* __restrict__ part, int d,
+                                                 const float* __restrict__ gth, const int32_t* __restrict__ gidx) {
+  // gth != null: the incoming gradient is dy[r] + gth[gidx[r]] - the transpose of jraph.segment_sum (the aggregate's gradient
+  // gathered over the receivers) folded into this load (round 4: k_seg_sum_bwd, a pass of its own over E x 128)
   __shared__ float s_red[4][4][64];
   const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float sc0 = sc[l], sc1 = sc[64 + l], bb0 = b1[l], bb1 = b1[64 + l];
@@ -299,6 +303,19 @@ __global__ void __launch_bounds__(256) k_ln_bwd2(const float* __restrict__ z, co
     zx1[it] = z[rc * TD + 64 + l];
     gg0[it] = dy[rc * TD + l];
     gg1[it] = dy[rc * TD + 64 + l];
+  }
+  if (GATHER) {  // (a compile-time branch: a run-time one inside the loop above serialises its loads)
+    int gi[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int64_t r = rb + 4 * it + wv;
+      gi[it] = gidx[r < rows ? r : rows - 1];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      gg0[it] = gth[(int64_t)gi[it] * TD + l] + gg0[it];
+      gg1[it] = gth[(int64_t)gi[it] * TD + 64 + l] + gg1[it];
+    }
   }
   // branch-free over the 16 rows (a row past the end recomputes row rows - 1 and stores the same values again; its sums are
   // masked): the rows' shuffle trees - 18 dependent ds_bpermute round trips each - interleave instead of running in sequence
@@ -350,23 +367,9 @@ __global__ void __launch_bounds__(256) k_ln_bwd2(const float* __restrict__ z, co
 // rows, so  [n_s | n_r | e] W0 = (n W_s)[snd] + (n W_r)[rcv] + e W_e  - the two node-sized products are formed once per NODE
 // (N rows) instead of once per EDGE (E ~ 14 N rows): the edge block's first Linear costs a third of the flops, forward
 // and backward, and the E x 384 concatenated inputs are never stored.
-//   a[e] = relu(a[e] + Ps[snd[e]] + Pr[rcv[e]] + b0)        (a holds e W_e on entry, Ps = n W_s, Pr = n W_r)
-__global__ void k_edge_pre(float* __restrict__ a, const float* __restrict__ Ps, const float* __restrict__ Pr,
-                           const int32_t* __restrict__ snd, const int32_t* __restrict__ rcv, const float* __restrict__ b0,
-                           int64_t E) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= E * 32) return;
-  const int64_t e = i / 32;
-  const int q = (int)(i % 32);
-  f32x4 v = reinterpret_cast<const f32x4*>(a)[i];
-  v = v + reinterpret_cast<const f32x4*>(Ps)[(int64_t)snd[e] * 32 + q];
-  v = v + reinterpret_cast<const f32x4*>(Pr)[(int64_t)rcv[e] * 32 + q];
-  v = v + reinterpret_cast<const f32x4*>(b0)[q];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-  reinterpret_cast<f32x4*>(a)[i] = v;
-}
-// its transpose: dPs[i] = sum over the edges i SENDS of da[e] (sender-sorted permutation, ascending edge index),
+//   a[e] = relu(e W_e + Ps[snd[e]] + Pr[rcv[e]] + b0)        (Ps = n W_s, Pr = n W_r; the gathers, the bias and the ReLU are
+//   the epilogue of the edge-sized product: k_lin32f<4>)
+// the transpose of the two gathers: dPs[i] = sum over the edges i SENDS of da[e] (sender-sorted permutation, ascending edge index),
 // dPr[i] = sum over the edges i RECEIVES (its CSR row).  One 32-lane group per node, no atomics.
 __global__ void k_edge_dP(const float* __restrict__ da, const int32_t* __restrict__ snd_ptr, const int32_t* __restrict__ snd_perm,
                           const int32_t* __restrict__ row_ptr, float* __restrict__ dPs, float* __restrict__ dPr, int64_t N,
@@ -423,17 +426,6 @@ __global__ void k_seg_sum(const int32_t* __restrict__ row_ptr, const float* __re
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   for (int64_t k = k0; k < k1; ++k) s = s + reinterpret_cast<const f32x4*>(msg)[k * 32 + q];
   reinterpret_cast<f32x4*>(agg)[i] = s;
-}
-// its transpose: dmsg[e] = base[e] + dagg[rcv[e]]
-__global__ void k_seg_sum_bwd(const float* __restrict__ base, const float* __restrict__ dagg,
-                              const int32_t* __restrict__ rcv, float* __restrict__ out, int64_t E) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= E * 32) return;
-  const int64_t e = i / 32;
-  const int q = (int)(i % 32);
-  f32x4 v = reinterpret_cast<const f32x4*>(dagg)[(int64_t)rcv[e] * 32 + q];
-  if (base) v = v + reinterpret_cast<const f32x4*>(base)[i];
-  reinterpret_cast<f32x4*>(out)[i] = v;
 }
 // non-kinematic particle count per trajectory (utils.py:28-35) and the per-node loss weight 1 / count
 __global__ void k_count_nonkin(const int32_t* __restrict__ ptype, int64_t BN, int N, int32_t* __restrict__ cnt) {
@@ -571,6 +563,8 @@ static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int tr
   hipStream_t s = t->eng->stream;
   const bool fast = a.NO == 128 && (a.NR & 127) == 0 && (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && (!a.mask || (a.ldm & 3) == 0) &&
                     !(a.mask && a.accum) && (((uintptr_t)a.bias | (uintptr_t)a.ln_scale | (uintptr_t)a.ln_offset) & 15) == 0;
+  if (a.gat1 && (!fast || a.mask || a.accum || a.ln_scale || !a.bias))
+    return lb_fail(LB_ERR_UNSUPPORTED, "k_lin32: gather epilogue on a %d x %d operand", a.NR, a.NO);
   if (a.ln_scale && (!fast || a.mask || a.accum || a.relu))
     return lb_fail(LB_ERR_UNSUPPORTED, "k_lin32: LayerNorm epilogue on a %d x %d operand", a.NR, a.NO);
   if (fast) lds += 96 * sizeof(f32x4);  // bias | LayerNorm scale | offset
@@ -584,7 +578,8 @@ static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int tr
     hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(512), lds, s, a);                                                            \
   } while (0)
   if (fast) {
-    if (a.ln_scale) LB_LIN_GO(k_lin32f<3>);
+    if (a.gat1) LB_LIN_GO(k_lin32f<4>);
+    else if (a.ln_scale) LB_LIN_GO(k_lin32f<3>);
     else if (a.mask) LB_LIN_GO(k_lin32f<1>);
     else if (a.accum) LB_LIN_GO(k_lin32f<2>);
     else LB_LIN_GO(k_lin32f<0>);
@@ -731,7 +726,7 @@ static int mlp_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const f
   LB_TRY(gemm_nn(t, rows, TD, p.in, X, ldx, t->w + p.w0, a, TD, 0.f, t->w + p.b0, 1));  // bias + ReLU in the epilogue
   return resid ? mlp_fwd_tail(t, p, rows, a, z, resid, nullptr, y) : mlp_fwd_tail(t, p, rows, a, z, nullptr, y, nullptr);
 }
-// forward of the edge block (gns.py:86-101) without the concatenated input: see k_edge_pre
+// forward of the edge block (gns.py:86-101) without the concatenated input (see k_edge_dP's comment)
 // y = e' = LN(MLP([n_s | n_r | e])) (the message), el_next = e + e' (the next edge latent)
 static int edge_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t E, int64_t BN, const float* n, const float* el, float* a,
                     float* z, float* y, float* el_next) {
@@ -740,8 +735,12 @@ static int edge_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t E, int64_t B
   float *Ps = t->proj, *Pr = t->proj + (size_t)BN * TD;
   LB_TRY(gemm_nn(t, BN, TD, TD, n, TD, t->w + p.w0, Ps, TD));
   LB_TRY(gemm_nn(t, BN, TD, TD, n, TD, t->w + p.w0 + (size_t)TD * TD, Pr, TD));
-  LB_TRY(gemm_nn(t, E, TD, TD, el, TD, t->w + p.w0 + (size_t)2 * TD * TD, a, TD));
-  if (E) hipLaunchKernelGGL(k_edge_pre, GRID1(E * 32), 0, s, a, Ps, Pr, e->senders, e->receivers, t->w + p.b0, E);
+  {  // a = relu(e W_e + Ps[snd] + Pr[rcv] + b0): the gathers and the bias ride in the product's epilogue
+    lb_lin_args g{};
+    g.X = el; g.ldx = TD; g.NR = TD; g.Y = a; g.ldy = TD; g.NO = TD; g.rows = E;
+    g.bias = t->w + p.b0; g.gat1 = Ps; g.gidx1 = e->senders; g.gat2 = Pr; g.gidx2 = e->receivers;
+    LB_TRY(lin32(t, g, t->w + p.w0 + (size_t)2 * TD * TD, TD, 0));
+  }
   return mlp_fwd_tail(t, p, E, a, z, el, y, el_next);
 }
 // y = LN(...) (may be null), y2 = resid + y (may be null); without LayerNorm (decoder): y = a W1 + b1
@@ -758,7 +757,8 @@ static int mlp_fwd_tail(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, fl
 // backward of one MLP block.  dy: gradient w.r.t. the block's output BEFORE the residual add (rows x out);
 // produces parameter gradients (accumulated) and, if dX != null, dX (rows x in, ld = ldx).  Scratch: t->dz, t->da.
 // first part (shared with the edge block): LayerNorm and second Linear backward, ReLU mask -> t->da = d loss / d (X W0 + b0)
-static int mlp_bwd_head(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* a, const float* z, const float* dy) {
+static int mlp_bwd_head(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* a, const float* z, const float* dy,
+                        const float* gth = nullptr, const int32_t* gidx = nullptr) {
   hipStream_t s = t->eng->stream;
   if (rows == 0) return LB_OK;
   const float* dzz = dy;
@@ -767,7 +767,10 @@ static int mlp_bwd_head(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, co
     int64_t off = 0;
     float* part = red_slot(t, (int64_t)nb * 256, &off);
     if (!part) return LB_ERR_STATE;
-    hipLaunchKernelGGL(k_ln_bwd2, dim3(nb), dim3(256), 0, s, z, t->w + p.b1, t->w + p.lns, dy, t->dz, rows, part, t->lat);
+    if (gth)
+      hipLaunchKernelGGL(k_ln_bwd2<true>, dim3(nb), dim3(256), 0, s, z, t->w + p.b1, t->w + p.lns, dy, t->dz, rows, part, t->lat, gth, gidx);
+    else
+      hipLaunchKernelGGL(k_ln_bwd2<false>, dim3(nb), dim3(256), 0, s, z, t->w + p.b1, t->w + p.lns, dy, t->dz, rows, part, t->lat, gth, gidx);
     red_push(t, off, nb, 256, 128, 128, 128, t->g + p.lns, t->g + p.lno);
     dzz = t->dz;
   }
@@ -788,13 +791,14 @@ static int mlp_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const f
   return LB_OK;
 }
 
-// backward of the edge block: parameter gradients, de += d loss / d e_k, dn += the node-side terms (see k_edge_pre / k_edge_dP)
+// backward of the edge block: parameter gradients, de += d loss / d e_k, dn += the node-side terms (see k_edge_dP)
 static int edge_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t E, int64_t BN, const float* n, const float* el,
-                    const float* a, const float* z, const float* dy, float* de, float* dn) {
+                    const float* a, const float* z, const float* dagg, float* de, float* dn) {
   if (E == 0) return LB_OK;
   hipStream_t s = t->eng->stream;
   lb_engine* e = t->eng;
-  LB_TRY(mlp_bwd_head(t, p, E, a, z, dy));  // -> t->da (E x 128)
+  // e' feeds agg (gather of dagg over the receivers) and e_{k+1} = e_k + e' (de): d e' = de + dagg[rcv], formed in the load
+  LB_TRY(mlp_bwd_head(t, p, E, a, z, de, dagg, e->receivers));  // -> t->da (E x 128)
   const float *Ws = t->w + p.w0, *Wr = Ws + (size_t)TD * TD, *We = Wr + (size_t)TD * TD;
   float *gWs = t->g + p.w0, *gWr = gWs + (size_t)TD * TD, *gWe = gWr + (size_t)TD * TD;
   // edge rows: dW_e += e^T da, db0 += column sums of da, de += da W_e^T
@@ -1068,9 +1072,7 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
     LB_TRY(mlp_bwd(t, t->pn[k], BN, t->xn[k], 2 * TD, t->an[k], t->zn[k], t->dn, nullptr));
     LB_TRY(gemm_nt(t, BN, TD, TD, t->da, t->w + t->pn[k].w0, t->dn, TD, 1.f));
     LB_TRY(gemm_nt(t, BN, TD, TD, t->da, t->w + t->pn[k].w0 + (size_t)TD * TD, t->dagg, TD));
-    // edge block: e' feeds agg (gather of dagg over receivers) and e_{k+1} = e_k + e' (de)
-    if (E) hipLaunchKernelGGL(k_seg_sum_bwd, GRID1(E * 32), 0, s, t->de, t->dagg, e->receivers, t->dy, E);
-    LB_TRY(edge_bwd(t, t->pe[k], E, BN, t->nlat[k], t->elat[k], t->ae[k], t->ze[k], t->dy, t->de, t->dn));
+    LB_TRY(edge_bwd(t, t->pe[k], E, BN, t->nlat[k], t->elat[k], t->ae[k], t->ze[k], t->dagg, t->de, t->dn));
   }
   LB_TRY(mlp_bwd(t, t->enc_edge, E, e->efeat, 8, t->a_ee, t->z_ee, t->de, nullptr));
   LB_TRY(mlp_bwd(t, t->enc_node, BN, t->xnode, t->kpad, t->a_en, t->z_en, t->dn, has_emb ? t->dx : nullptr));
