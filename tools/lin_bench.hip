@@ -45,10 +45,20 @@ int main(int argc, char** argv) {
   CK(hipFuncSetAttribute((const void*)k_lin32f<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   CK(hipFuncSetAttribute((const void*)k_lin32f<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   CK(hipFuncSetAttribute((const void*)k_lin32f<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_lin32f<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  // gather indices (mode 5): two "node" rows per row, nodes = rows / 14
+  const int64_t nodes = std::max<int64_t>(rows / 14, 1);
+  std::vector<int32_t> hi1(rows), hi2(rows);
+  for (int64_t i = 0; i < rows; ++i) { hi1[i] = rand() % nodes; hi2[i] = (int32_t)(i * nodes / rows); }
+  int32_t *I1, *I2;
+  CK(hipMalloc(&I1, rows * 4));
+  CK(hipMalloc(&I2, rows * 4));
+  CK(hipMemcpy(I1, hi1.data(), rows * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(I2, hi2.data(), rows * 4, hipMemcpyHostToDevice));
   float* Y2;
   CK(hipMalloc(&Y2, rows * 128 * 4 * 2));
   int bad = 0;
-  // mode: 0 plain, 1 bias + relu, 2 mask, 3 accum, 4 LayerNorm + residual (fast only);  fast: use k_lin32f
+  // mode: 0 plain, 1 bias + relu, 2 mask, 3 accum, 4 LayerNorm + residual, 5 two gathers + bias + relu (4, 5: fast only);  fast: use k_lin32f
   auto run = [&](const char* name, int NR, int NO, int trans, int mode, int64_t r, bool fast) {
     const int nob = NO <= 16 ? 1 : 8, nj = (NR + 15) / 16;
     lb_pack_ent pe{0, 0, NR, NO, trans ? NR : NO, trans, nj, nob};
@@ -59,6 +69,7 @@ int main(int argc, char** argv) {
     if (mode == 1) { a.bias = W; a.relu = 1; }
     if (mode == 2) { a.mask = M; a.ldm = NO; }
     if (mode == 3) a.accum = 1;
+    if (mode == 5) { a.bias = W; a.gat1 = M; a.gidx1 = I1; a.gat2 = M + 128; a.gidx2 = I2; }
     if (mode == 4) {
       a.bias = W; a.ln_scale = W + 128; a.ln_offset = W + 256; a.resid = M; a.Yln = Y2; a.Y2 = Y2 + r * 128; a.ln_d = 128;
     }
@@ -67,7 +78,8 @@ int main(int argc, char** argv) {
     const int grid = (int)std::min<int64_t>(tiles, 256);
     auto go = [&] {
       if (fast) {
-        if (mode == 4) hipLaunchKernelGGL((k_lin32f<3>), dim3(grid), dim3(512), lds, 0, a);
+        if (mode == 5) hipLaunchKernelGGL((k_lin32f<4>), dim3(grid), dim3(512), lds, 0, a);
+        else if (mode == 4) hipLaunchKernelGGL((k_lin32f<3>), dim3(grid), dim3(512), lds, 0, a);
         else if (mode == 2) hipLaunchKernelGGL((k_lin32f<1>), dim3(grid), dim3(512), lds, 0, a);
         else if (mode == 3) hipLaunchKernelGGL((k_lin32f<2>), dim3(grid), dim3(512), lds, 0, a);
         else hipLaunchKernelGGL((k_lin32f<0>), dim3(grid), dim3(512), lds, 0, a);
@@ -104,6 +116,8 @@ int main(int argc, char** argv) {
         if (mode == 1) acc = std::max(acc + hw[m], 0.0);
         if (mode == 2) acc = hm[(size_t)row * NO + m] > 0.f ? acc : 0.0;
         if (mode == 3) acc += hm[(size_t)row * NO + m];
+        if (mode == 5)
+          acc = std::max(acc + hm[(size_t)hi1[row] * 128 + m] + hm[128 + (size_t)hi2[row] * 128 + m] + hw[m], 0.0);
         const double err = std::fabs(acc - hy[(size_t)row * NO + m]) / (mag + 1.0);
         worst = std::max(worst, err);
       }
@@ -145,6 +159,7 @@ int main(int argc, char** argv) {
       run("dX += dY W^T 128 x 128", 128, 128, 1, 3, rows, fast);
       if (fast) run("Y = LN(X W + b) + resid  128 x 128", 128, 128, 0, 4, rows, fast);
       if (fast) run("Y = LN(X W + b) + resid  (odd rows)", 128, 128, 0, 4, nrows * 3 + 5, fast);
+      if (fast) run("Y = relu(X W + G1[i1] + G2[i2] + b)", 128, 128, 0, 5, rows, fast);
       run("Y = X W      256 x 128 (node sized)", 256, 128, 0, 1, nrows, fast);
       run("Y = X W      128 x 128 (node sized)", 128, 128, 0, 0, nrows, fast);
       run("Y = X W      128 x 128 (odd rows)", 128, 128, 0, 3, nrows * 3 + 5, fast);

@@ -21,3 +21,13 @@ python tools/rocpd_summary.py $(find /tmp/p_sq2 -name "*.db" | head -1) >> $O/r0
 # the roofline of the bench line recomputed from these files alone + the MFMA-per-tile self-check
 python tools/roofline_check.py $O/kt.json $O/r05_kernel_trace_stats.txt $O/pmc_traffic.json $O/r05_pmc_sq.txt > $O/r05_roofline_check.txt 2>&1
 cat $O/r05_roofline_check.txt
+# the training step (section 8 row N4): kernel traces of both workloads + dispatch-gap summary, the GEMM micro-benchmark
+rm -rf /tmp/p_tr /tmp/p_tr2
+rocprofv3 --kernel-trace --stats -d /tmp/p_tr -- python tools/train_profile.py tgv3d 7 > $O/train3d.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/p_tr2 -- python tools/train_profile.py tgv2d 7 > $O/train2d.log 2>&1
+python tools/rocpd_summary.py $(find /tmp/p_tr -name "*.db" | head -1) > $O/r05_train_tgv3d_kernel_trace.txt 2>&1
+python tools/rocpd_gaps.py $(find /tmp/p_tr -name "*.db" | head -1) >> $O/r05_train_tgv3d_kernel_trace.txt 2>&1
+python tools/rocpd_summary.py $(find /tmp/p_tr2 -name "*.db" | head -1) > $O/r05_train_tgv2d_kernel_trace.txt 2>&1
+python tools/rocpd_gaps.py $(find /tmp/p_tr2 -name "*.db" | head -1) >> $O/r05_train_tgv2d_kernel_trace.txt 2>&1
+(python tools/train_profile.py tgv3d 20; python tools/train_profile.py tgv2d 20) > $O/r05_train_step_ms.txt 2>&1
+[ -x tools/bin/lin_bench ] && tools/bin/lin_bench 109000 8000 > $O/r05_lin_bench.txt 2>&1
