@@ -240,6 +240,16 @@ typedef struct lb_segnn_desc {
  *   (oracle/segnn_oracle.py:tp_inputs); the 1/sqrt(K) of e3nn's Linear is applied here. */
 int lb_segnn_create(lb_engine* eng, const lb_segnn_desc* desc, const float* weights_host,
                     int64_t n_floats, lb_segnn** out);
+
+/* The same training step for SEGNN (round 5; reference: train/trainer.py:35-89 is model-agnostic, models/segnn.py:44-362,
+ * 595-610 is the network).  The handle type is lb_gns_train (round 3's name for "a training handle"): lb_gns_train_zero_grad,
+ * lb_adamw_step, lb_gns_train_read / _write (flat blob in SEGNN.flatten order = lb_segnn_create's), lb_gns_train_step_count
+ * and lb_gns_train_destroy work on it unchanged; lb_gns_train_loss_grad dispatches to lb_segnn_train_loss_grad.
+ * hidden <= 32, lmax 1, norm None (the shipped configs); gradients bit-reproducible. */
+int lb_segnn_train_create(lb_engine* eng, const lb_segnn_desc* desc, const float* weights_host, int64_t n_floats,
+                          lb_gns_train** out);
+int lb_segnn_train_loss_grad(lb_gns_train* t, const float* target_dev, float loss_weight, double* loss_out,
+                             float* pred_out_dev);
 void lb_segnn_destroy(lb_segnn* segnn);
 
 /* SEGNN.__call__ -> {"acc": (B,N,dim) fp32} (segnn.py:595-610) on the current window + list. */

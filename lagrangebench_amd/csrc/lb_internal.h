@@ -393,6 +393,8 @@ int lb_rollout_generic(lb_engine* e, int (*forward)(lb_engine*, void*), void* mo
 // lb_segnn.hip
 struct lb_segnn;
 int lbk_segnn_forward(lb_engine* e, lb_segnn* m);
+int lbk_sg_prep(lb_engine* e, int homogeneous, int vel_avg, int ns4, int nv4, float* xnode, float* eattr, float* msgsv,
+                float* nodesv, float* nattr, int64_t ecap);
 
 // lb_segnn_msg.hip
 void lb_sg_msg_image(const float* ws0, const float* wv0, const float* b0, const float* ws1,

@@ -185,6 +185,20 @@ __global__ void k_sg_node_prep(lb_geom g, int64_t BN, const lb_ctrl* __restrict_
       f32x4{1.f, vm[0] * inv + acc[1] / cnt, vm[1] * inv + acc[2] / cnt, vm[2] * inv + acc[3] / cnt};
 }
 
+// SEGNN._transform for a caller outside this file (the training step, lb_train_segnn.h): engine features -> node SV rows,
+// node / edge attributes, message SV rows.  xnode [BN][32], eattr [ecap][4], msgsv [ecap][16], nodesv [BN][ns4 + 3 nv4].
+int lbk_sg_prep(lb_engine* e, int homogeneous, int vel_avg, int ns4, int nv4, float* xnode, float* eattr, float* msgsv,
+                float* nodesv, float* nattr, int64_t ecap) {
+  hipStream_t s = e->stream;
+  LB_TRY(lbk_node_features_raw(e, xnode, 32));
+  hipLaunchKernelGGL(k_sg_edge_prep, dim3((unsigned)((ecap + 255) / 256)), dim3(256), 0, s, e->ctrl, e->g.dim, e->efeat, eattr,
+                     msgsv, ecap);
+  hipLaunchKernelGGL(k_sg_node_prep, dim3((unsigned)((e->BN + 255) / 256)), dim3(256), 0, s, e->g, e->BN, e->ctrl, xnode, 32,
+                     e->ptype, e->row_ptr, eattr, homogeneous, vel_avg, ns4, nv4, nodesv, nattr);
+  LB_HIP(hipGetLastError());
+  return LB_OK;
+}
+
 // -------------------------------------------------------------------- tensor product + linear
 __device__ __forceinline__ float sg_silu(float x) { return x / (1.f + expf(-x)); }
 __device__ __forceinline__ float sg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }

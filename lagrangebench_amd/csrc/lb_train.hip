@@ -55,7 +55,10 @@ struct lb_red_ent {
   int blk0, pad;    // first block of this reduction in the flat grid (64 outputs per block)
 };
 
+struct lb_sgt;  // SEGNN-specific state of a training handle (lb_train_segnn.h)
+
 struct lb_gns_train {
+  lb_sgt* sg = nullptr;   // non-null: this handle trains a SEGNN (created by lb_segnn_train_create)
   lb_gns_desc desc;
   lb_engine* eng;
   int64_t n_floats = 0;   // floats of the DEVICE blobs (latent padded to 128)
@@ -628,6 +631,8 @@ static int dw_groups(int64_t rows, int64_t* chunk_out) {
   if (chunk_out) *chunk_out = chunk;
   return (int)((rows + chunk - 1) / chunk);
 }
+// upper bound of dw_groups over every row count <= rows_cap (dw_groups is not monotonic: the chunk is rounded up to 4 rows)
+static int64_t dw_groups_max(int64_t rows_cap) { return std::min<int64_t>(DW_MAX_G, (rows_cap + 63) / 64 + 1); }
 static float* red_slot(lb_gns_train* t, int64_t floats, int64_t* off) {
   floats = (floats + 63) / 64 * 64;
   if (t->red_off + floats > t->red_cap || t->red_tab.size() >= LB_RED_MAX) {
@@ -664,7 +669,7 @@ static int red_flush(lb_gns_train* t) {
 }
 // floats of partial-sum slots a step needs for BN <= cn nodes and E <= ce edges (mirrors the backward pass below)
 static int64_t red_capacity(const lb_gns_train* t, int64_t cn, int64_t ce) {
-  auto slot = [](int64_t rows, int K) { return ((int64_t)dw_groups(std::max<int64_t>(rows, 1), nullptr) * (K + 1) * 128 + 63) / 64 * 64; };
+  auto slot = [](int64_t rows, int K) { return (dw_groups_max(std::max<int64_t>(rows, 1)) * (K + 1) * 128 + 63) / 64 * 64; };
   auto lnp = [](int64_t rows) { return ((rows + LNB_ROWS - 1) / LNB_ROWS * 256 + 63) / 64 * 64 + 64; };
   const int L = t->desc.num_mp_steps;
   int64_t tot = 0;
@@ -866,6 +871,49 @@ static int train_ensure(lb_gns_train* t, int64_t BN, int64_t E) {
   return LB_OK;
 }
 
+// _mse of trainer.py:35-60 on the device: loss (into t->loss_dev) and d loss / d pred (BN x dim) for the whole batch
+static int train_loss(lb_gns_train* t, const float* pred, const float* target_dev, float loss_weight, float* dpred) {
+  lb_engine* e = t->eng;
+  hipStream_t s = e->stream;
+  const int64_t BN = e->BN;
+  LB_HIP(hipMemsetAsync(t->cnt_dev, 0, sizeof(int32_t) * e->g.B, s));
+  LB_HIP(hipMemsetAsync(t->loss_dev, 0, sizeof(double), s));
+  hipLaunchKernelGGL(k_count_nonkin, GRID1(BN), 0, s, e->ptype, BN, e->g.N, t->cnt_dev);
+  hipLaunchKernelGGL(k_node_weight, GRID1(BN), 0, s, e->ptype, t->cnt_dev, BN, e->g.N, t->node_w);
+  hipLaunchKernelGGL(k_mse_grad, GRID1(BN), 0, s, pred, target_dev, t->node_w, BN, e->g.dim, loss_weight, 1.0f / (float)e->g.B,
+                     dpred, t->loss_part);
+  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, s, t->loss_part, (int64_t)((BN + 255) / 256) * 4, t->loss_dev);
+  return LB_OK;
+}
+// sender-sorted view of the step's edge list (stable radix sort of (sender, edge index): ascending edges per sender) ->
+// t->snd_perm (E), t->snd_ptr (BN + 1)
+static int train_sender_sort(lb_gns_train* t, int64_t E, int64_t BN) {
+  lb_engine* e = t->eng;
+  hipStream_t s = e->stream;
+  if (!E) return LB_OK;
+  if (E > t->sort_cap || BN + 1 > t->sort_cap) {
+    LB_HIP(hipStreamSynchronize(s));
+    for (void* b : {(void*)t->snd_key, (void*)t->snd_perm, (void*)t->iota, (void*)t->snd_ptr, t->sort_tmp})
+      if (b) (void)hipFree(b);
+    t->snd_key = t->snd_perm = t->iota = t->snd_ptr = nullptr;
+    t->sort_tmp = nullptr;
+    t->sort_cap = std::max<int64_t>(E + E / 8 + 1024, BN + 2);
+    LB_HIP(hipMalloc((void**)&t->snd_key, sizeof(int32_t) * t->sort_cap));
+    LB_HIP(hipMalloc((void**)&t->snd_perm, sizeof(int32_t) * t->sort_cap));
+    LB_HIP(hipMalloc((void**)&t->iota, sizeof(int32_t) * t->sort_cap));
+    LB_HIP(hipMalloc((void**)&t->snd_ptr, sizeof(int32_t) * t->sort_cap));
+    hipLaunchKernelGGL(k_iota, GRID1(t->sort_cap), 0, s, t->iota, t->sort_cap);
+    t->sort_tmp_bytes = 0;
+    LB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, t->sort_tmp_bytes, e->senders, t->snd_key, t->iota, t->snd_perm,
+                                              (int)t->sort_cap, 0, 32, s));
+    LB_HIP(hipMalloc(&t->sort_tmp, t->sort_tmp_bytes));
+  }
+  size_t bytes = t->sort_tmp_bytes;
+  LB_HIP(hipcub::DeviceRadixSort::SortPairs(t->sort_tmp, bytes, e->senders, t->snd_key, t->iota, t->snd_perm, (int)E, 0, 32, s));
+  hipLaunchKernelGGL(k_lower_bounds, GRID1(BN + 1), 0, s, t->snd_key, E, BN, t->snd_ptr);
+  return LB_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const float* w, int64_t n_floats,
                                    lb_gns_train** out) {
@@ -977,8 +1025,10 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
   return LB_OK;
 }
 
+static void sgt_free(lb_gns_train* t);
 extern "C" void lb_gns_train_destroy(lb_gns_train* t) {
   if (!t) return;
+  sgt_free(t);
   std::vector<void*> bufs = {t->w, t->g, t->m, t->v, t->xnode, t->a_en, t->z_en, t->a_ee, t->z_ee, t->a_d, t->pred,
                              t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->dwpart, t->red_dev, t->proj, t->node_w,
                              t->loss_dev, t->loss_part, t->cnt_dev, t->snd_key, t->snd_perm, t->iota, t->snd_ptr, t->sort_tmp,
@@ -997,6 +1047,7 @@ extern "C" void lb_gns_train_destroy(lb_gns_train* t) {
 extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, float loss_weight, double* loss_out,
                                       float* pred_out_dev) {
   if (!t || !target_dev) return lb_fail(LB_ERR_ARG, "null argument");
+  if (t->sg) return lb_segnn_train_loss_grad(t, target_dev, loss_weight, loss_out, pred_out_dev);
   lb_engine* e = t->eng;
   if (e->e_cap <= 0) return lb_fail(LB_ERR_STATE, "lb_gns_train_loss_grad before lb_nl_allocate");
   hipStream_t s = e->stream;
@@ -1031,37 +1082,9 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
   }
   LB_TRY(mlp_fwd(t, t->dec, BN, t->nlat[L], TD, t->a_d, nullptr, nullptr, t->pred));
   if (pred_out_dev) LB_HIP(hipMemcpyAsync(pred_out_dev, t->pred, sizeof(float) * BN * dim, hipMemcpyDeviceToDevice, s));
-  // ---- loss and d loss / d pred
-  LB_HIP(hipMemsetAsync(t->cnt_dev, 0, sizeof(int32_t) * e->g.B, s));
-  LB_HIP(hipMemsetAsync(t->loss_dev, 0, sizeof(double), s));
-  hipLaunchKernelGGL(k_count_nonkin, GRID1(BN), 0, s, e->ptype, BN, e->g.N, t->cnt_dev);
-  hipLaunchKernelGGL(k_node_weight, GRID1(BN), 0, s, e->ptype, t->cnt_dev, BN, e->g.N, t->node_w);
-  hipLaunchKernelGGL(k_mse_grad, GRID1(BN), 0, s, t->pred, target_dev, t->node_w, BN, dim, loss_weight, 1.0f / (float)e->g.B,
-                     t->dy, t->loss_part);
-  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, s, t->loss_part, (int64_t)((BN + 255) / 256) * 4, t->loss_dev);
-  // ---- sender-sorted view of this step's edge list (stable radix sort of (sender, edge index): ascending edges per sender)
-  if (E) {
-    if (E > t->sort_cap || BN + 1 > t->sort_cap) {
-      LB_HIP(hipStreamSynchronize(s));
-      for (void* b : {(void*)t->snd_key, (void*)t->snd_perm, (void*)t->iota, (void*)t->snd_ptr, t->sort_tmp})
-        if (b) (void)hipFree(b);
-      t->snd_key = t->snd_perm = t->iota = t->snd_ptr = nullptr;
-      t->sort_tmp = nullptr;
-      t->sort_cap = std::max<int64_t>(E + E / 8 + 1024, BN + 2);
-      LB_HIP(hipMalloc((void**)&t->snd_key, sizeof(int32_t) * t->sort_cap));
-      LB_HIP(hipMalloc((void**)&t->snd_perm, sizeof(int32_t) * t->sort_cap));
-      LB_HIP(hipMalloc((void**)&t->iota, sizeof(int32_t) * t->sort_cap));
-      LB_HIP(hipMalloc((void**)&t->snd_ptr, sizeof(int32_t) * t->sort_cap));
-      hipLaunchKernelGGL(k_iota, GRID1(t->sort_cap), 0, s, t->iota, t->sort_cap);
-      t->sort_tmp_bytes = 0;
-      LB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, t->sort_tmp_bytes, e->senders, t->snd_key, t->iota, t->snd_perm,
-                                                (int)t->sort_cap, 0, 32, s));
-      LB_HIP(hipMalloc(&t->sort_tmp, t->sort_tmp_bytes));
-    }
-    size_t bytes = t->sort_tmp_bytes;
-    LB_HIP(hipcub::DeviceRadixSort::SortPairs(t->sort_tmp, bytes, e->senders, t->snd_key, t->iota, t->snd_perm, (int)E, 0, 32, s));
-    hipLaunchKernelGGL(k_lower_bounds, GRID1(BN + 1), 0, s, t->snd_key, E, BN, t->snd_ptr);
-  }
+  // ---- loss and d loss / d pred, the sender-sorted view of this step's edge list
+  LB_TRY(train_loss(t, t->pred, target_dev, loss_weight, t->dy));
+  LB_TRY(train_sender_sort(t, E, BN));
   // ---- backward
   LB_TRY(mlp_bwd(t, t->dec, BN, t->nlat[L], TD, t->a_d, nullptr, t->dy, t->dn));  // dn = d loss / d n_L
   LB_HIP(hipMemsetAsync(t->de, 0, sizeof(float) * std::max<int64_t>(E, 1) * TD, s));  // e_L has no reader
@@ -1136,3 +1159,6 @@ extern "C" int lb_gns_train_write(lb_gns_train* t, int32_t which, const float* i
   if (step >= 0) t->step = step;
   return LB_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ SEGNN
+#include "lb_train_segnn.h"

@@ -265,6 +265,15 @@ class RolloutEngine:
                                            C.c_int64(blob.size), C.byref(h)), "lb_gns_train_create")
         return GnsTrainHandle(self, h, desc, blob.size)
 
+    def segnn_train_create(self, desc: SegnnDesc, blob: np.ndarray) -> "GnsTrainHandle":
+        """Device-resident training state of one SEGNN (csrc/lb_train_segnn.h); the handle type and its zero_grad /
+        loss_grad / adamw_step / read / write are the GNS ones (lb_gns_train_loss_grad dispatches on the handle)."""
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        h = C.c_void_p()
+        check(self.lib.lb_segnn_train_create(self._h, C.byref(desc), blob.ctypes.data_as(C.POINTER(C.c_float)),
+                                             C.c_int64(blob.size), C.byref(h)), "lb_segnn_train_create")
+        return GnsTrainHandle(self, h, desc, blob.size)
+
     def gns_forward(self, gns: "GnsHandle", out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
             out = torch.empty((self.B, self.N, self.dim), dtype=torch.float32, device=self.device)

@@ -133,6 +133,33 @@ class SEGNN(BaseModel):
             out += [ws.ravel(), wv.ravel(), b.ravel()]
         return np.concatenate(out)
 
+    def unflatten(self, blob, like=None) -> Dict:
+        """Inverse of flatten: a flat blob (weights, gradients or AdamW moments of the training handle) -> parameter dict."""
+        blob = np.asarray(blob, np.float32)
+        out, o = {}, 0
+        for name, K, ms, mv in self.block_shapes():
+            blk = {}
+            for leaf, shape in (("ws", (K, ms)), ("wv", (K, mv)), ("b", (ms,))):
+                n = int(np.prod(shape))
+                blk[leaf] = blob[o:o + n].reshape(shape).copy()
+                o += n
+            out[name] = blk
+        if o != blob.size:
+            raise ValueError(f"SEGNN.unflatten: blob has {blob.size} floats, the model {o}")
+        return out
+
+    def _desc(self) -> SegnnDesc:
+        d = SegnnDesc()
+        d.hidden, d.blocks_per_step, d.num_mp_steps = self._hidden, self._blocks_per_step, self._num_mp_steps
+        d.homogeneous = int(bool(self._homogeneous_particles))
+        d.n_vels = self._n_vels
+        d.velocity_avg = int(self._velocity_aggregate == "avg")
+        return d
+
+    def train_handle(self, engine, params):
+        """Device-resident training state for `params` on `engine` (csrc/lb_train_segnn.h, round 5)."""
+        return engine.segnn_train_create(self._desc(), self.flatten(params))
+
     # ------------------------------------------------------------------ engine binding
     def handle(self, engine, params):
         key = (id(engine), id(params))
