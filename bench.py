@@ -476,6 +476,50 @@ def train_step_lines(device):
             del eng, feats
         except Exception as exc:
             res.append({"workload": workload, "error": repr(exc)[:200]})
+    # config 5's model (round 5: lb_segnn_train_loss_grad, csrc/lb_train_segnn.h): SEGNN-10-64 on DAM2D, B = 1
+    try:
+        from lagrangebench_amd.models import SEGNN, node_irreps
+        ds = make_case("dam2d", n_trajs=1, extra_seq_length=2)
+        ds.magnitude_features = True
+        dim, isl = len(ds.box), ds.input_seq_length
+        homog = bool((ds[0][1] == 0).all())
+        model = SEGNN(node_irreps(ds.metadata, isl, ds.external_force_fn is not None, True, homog), "1x1o+1x0e", 64, 1, 1, "1x1o",
+                      num_mp_steps=10, n_vels=isl - 1, homogeneous_particles=homog)
+        params = model.init_params(1234)
+        case = hip_case(ds)
+        pos, pt = ds[0]
+        feats, _ = case.allocate_eval((pos[None, :, :isl], pt[None]))
+        eng = feats.engine
+        E, N, K = eng.stats()["n_edges_total"], len(pt), 10
+        th = model.train_handle(eng, params)
+        target = torch.randn((1, N, dim), generator=torch.Generator().manual_seed(5)).to(device)
+        for _ in range(2):
+            th.zero_grad()
+            th.loss_grad(target, 1.0)
+            th.adamw_step(1e-4)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(K):
+            th.zero_grad()
+            loss = th.loss_grad(target, 1.0)
+            th.adamw_step(1e-4)
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / K
+        # flops EXECUTED: every tensor product is a (4 rows per row) x Kp x 128 product, forward + dW + dZ
+        fwd = sum(2 * 4 * (E if name.split("/")[-1].startswith("message") else N) * (128 if Kb <= 128 else 256) * 128
+                  for name, Kb, _, _ in model.block_shapes())
+        tf = 3 * fwd / dt / 1e12
+        res.append({"workload": "dam2d SEGNN-10-64 training step (B = 1)", "n_particles": int(N), "edges": int(E), "steps": K,
+                    "ms_per_step": 1e3 * dt, "value": N / dt, "unit": "particle-steps/s", "loss": float(loss), "dtype": "f32",
+                    "roofline": {"kernel": "k_lin32f + k_dw_part on the stacked tensor-product operands (lb_train_segnn.h)", "bound": "mfma",
+                                 "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                                 "flop_per_step": int(3 * fwd),
+                                 "note": "executed flops (2x the necessary ones: cross terms of the side-by-side operand, K padded to "
+                                         "128 / 256), whole step against the fp32 MFMA peak"}})
+        th.close()
+        del eng, feats
+    except Exception as exc:
+        res.append({"workload": "dam2d segnn", "error": repr(exc)[:200]})
     return res
 
 

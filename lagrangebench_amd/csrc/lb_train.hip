@@ -680,7 +680,9 @@ static int64_t red_capacity(const lb_gns_train* t, int64_t cn, int64_t ce) {
   return tot + 4096;
 }
 // dW[K x 128] += X^T dY, db[128] += column sums of dY (k_dw_part + a descriptor for k_part_reduce); false = refused
-static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx, const float* dY, float* dW, float* db) {
+// (nb: how many of dY's 128 column sums are added to db - the SEGNN blocks keep only their Ms scalar-output columns)
+static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx, const float* dY, float* dW, float* db,
+                   int nb = 128) {
   if (K > 384 || rows <= 0) return false;
   int64_t chunk = 0, off = 0;
   const int G = dw_groups(rows, &chunk);
@@ -693,7 +695,7 @@ static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx
   else if (K <= 256) DW_GO(2);
   else DW_GO(3);
 #undef DW_GO
-  red_push(t, off, G, (int64_t)(K + 1) * 128, K * 128, db ? 128 : 0, K * 128, dW, db);
+  red_push(t, off, G, (int64_t)(K + 1) * 128, K * 128, db ? nb : 0, K * 128, dW, db);
   return true;
 }
 // dW[K x M] += X^T dY for M <= 4 (k_dw_narrow + the ordered reduce)

@@ -328,8 +328,10 @@ static int sgt_bwd(lb_gns_train* t, lb_sgt_block& b, int64_t R, const float* dou
   oa.raw = b.raw; oa.bias = t->w + b.off_b; oa.dout = dout; oa.gidx = gidx; oa.draw = g->draw; oa.R = R; oa.Ms = b.Ms; oa.Mv = b.Mv;
   oa.mode = b.mode; oa.dim = t->eng->g.dim;
   hipLaunchKernelGGL(k_sgt_out_bwd, GRID1(R * 32), 0, s, oa);
-  if (!dw_acc(t, 4 * R, b.Kp, b.Z, b.Kp, g->draw, t->g + b.off_w, nullptr)) return LB_ERR_STATE;  // (red_slot said why)
-  if (b.Ms) LB_TRY(colsum_add(t, g->draw, 4 * R, b.Ms, 128, t->g + b.off_b));
+  // dW = Z^T d raw; db = the column sums of d raw's first Ms columns (the vector rows hold zeros there), which k_dw_part forms
+  // on the way: only those Ms of its 128 sums are added to the bias gradient, the padded entries stay exactly zero
+  if (!dw_acc(t, 4 * R, b.Kp, b.Z, b.Kp, g->draw, t->g + b.off_w, b.Ms ? t->g + b.off_b : nullptr, b.Ms))
+    return LB_ERR_STATE;  // (red_slot said why)
   bool need = false;
   for (int o = 0; o < b.n_op; ++o) need = need || ops[o].dx;
   if (!need) return LB_OK;

@@ -3,7 +3,7 @@
 ``train_or_infer(cfg)`` (runner.py:25-143), ``setup_data`` (:146-189) and ``setup_model`` (:192-292)
 keep their signatures.  ``cfg`` is a nested mapping with the reference's keys (a dict or anything
 dict-like such as an OmegaConf DictConfig); missing keys fall back to ``defaults``.  `mode: train | all`
-runs ``train.Trainer`` (GNS only).
+runs ``train.Trainer`` (GNS and SEGNN).
 """
 from __future__ import annotations
 

@@ -11,8 +11,9 @@ What runs where: neighbor list, feature assembly, integrator, every evaluation r
 HIP engine: ``lb_gns_train_loss_grad`` (csrc/lb_train.hip: forward with saved activations, masked MSE, hand-written
 backward kernels, fp32-MFMA GEMMs of our own for the dense contractions) accumulates the gradients of the whole batch,
 ``lb_adamw_step`` applies optax.adamw on the device; weights, gradients and both moments stay in HBM (exact fp32).
-torch is used for the noise / sampling random streams and as the tensor container only.  Only GNS (latent 128, two
-Linears per MLP) is trainable; wandb logging is not wired (stdout, as the reference's default).
+torch is used for the noise / sampling random streams and as the tensor container only.  Trainable: GNS (latent <= 128,
+two Linears per MLP) and, since round 5, SEGNN (lmax 1, hidden <= 32x0e+32x1o: ``lb_segnn_train_loss_grad``,
+csrc/lb_train_segnn.h - the loop below is the reference's model-agnostic one); wandb logging is not wired (stdout).
 """
 from __future__ import annotations
 
@@ -27,7 +28,7 @@ from ..evaluate import MetricsComputer, averaged_metrics, eval_rollout
 from ..evaluate.rollout import _Loader
 from ..models.gns import GNS
 from ..utils import (broadcast_from_batch, get_kinematic_mask, gns_params_from_haiku, gns_params_to_haiku,
-                     load_haiku, save_haiku)
+                     load_haiku, save_haiku, segnn_params_from_haiku, segnn_params_to_haiku)
 from .strats import push_forward_build, push_forward_sample_steps
 
 
@@ -62,8 +63,10 @@ class Trainer:
             raise NotImplementedError(
                 f"training is built for GNS with latent_size <= 128 and num_mlp_layers 2 (got latent_size "
                 f"{model._latent_size}, num_mlp_layers {model._blocks_per_step}); inference runs every size")
-        if not isinstance(model, GNS):
-            raise NotImplementedError("Trainer: only GNS has a device training step (csrc/lb_train.hip)")
+        if not hasattr(model, "train_handle"):
+            raise NotImplementedError("Trainer: the model has no device training step (GNS: csrc/lb_train.hip, SEGNN: "
+                                      "csrc/lb_train_segnn.h)")
+        self._is_gns = isinstance(model, GNS)
         self.model, self.case, self.input_seq_length = model, case, input_seq_length
         self.cfg_train = merge(defaults.train, cfg_train)
         self.cfg_eval = merge(defaults.eval, cfg_eval)
@@ -109,8 +112,10 @@ class Trainer:
             state = {} if state is None else state
         elif load_ckp:
             params, state, opt_state, step = load_haiku(load_ckp)
-            if "enc_node/linear_0" not in params:
+            if self._is_gns and "enc_node/linear_0" not in params:
                 params = gns_params_from_haiku(params, model._mp_steps, model._blocks_per_step)
+            elif not self._is_gns and "embedding_nodes" not in params:
+                params = segnn_params_from_haiku(params, model)
         else:
             params, state = model.init(torch.randint(0, 2**31 - 1, (1,), generator=key).numpy(), (features, raw_sample[1]))
         B = self.loader_train.batch_size
@@ -128,7 +133,7 @@ class Trainer:
         def opt_state_dict():
             # count: the device's AdamW step counter - NOT the loop index (it is step + 1 after an update, and differs
             # again after neighbor-list overflow `continue`s); a resumed run restores it, as optax does from opt_state
-            return {"kind": "lagrangebench_amd adamw (flat blobs in GNS.flatten order)", "m": th.read("m"),
+            return {"kind": "lagrangebench_amd adamw (flat blobs in the model's flatten order)", "m": th.read("m"),
                     "v": th.read("v"), "step": int(step), "count": th.step_count()}
         if store_ckp is not None:
             os.makedirs(os.path.join(store_ckp, "best"), exist_ok=True)
@@ -178,8 +183,9 @@ class Trainer:
                                                 rollout_dir=cfg_eval.rollout_dir, out_type=cfg_eval.train.out_type)
                     metrics = averaged_metrics(eval_metrics)
                     if store_ckp is not None:
-                        save_haiku(store_ckp, gns_params_to_haiku(params_np, model._mp_steps, model._blocks_per_step),
-                                   state, opt_state_dict(), {"step": step, "loss": metrics.get("val/loss", None)})
+                        hk = (gns_params_to_haiku(params_np, model._mp_steps, model._blocks_per_step) if self._is_gns
+                              else segnn_params_to_haiku(params_np, model))
+                        save_haiku(store_ckp, hk, state, opt_state_dict(), {"step": step, "loss": metrics.get("val/loss", None)})
                     print(metrics)
                     # the validation rollouts re-sized / re-used the engine: the training list is rebuilt
                     key, _, _, neighbors = case.allocate(key, raw_sample)

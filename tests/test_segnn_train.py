@@ -145,3 +145,53 @@ def test_hip_segnn_gradients_match_torch_autograd(name, scale, L, B, blocks):
                 assert np.abs(w_h[blk][leaf] - ref).max() <= 2e-6 * max(np.abs(ref).max(), 1.0) + 1e-7, (blk, leaf)
     assert th.step_count() == 1
     th.close()
+
+
+@pytest.mark.gpu
+def test_trainer_trains_segnn_and_runner_mode_all(tmp_path):
+    """The reference's trainer is model-agnostic (train/trainer.py:36-89; tests/runner_test.py:14-57 runs train_or_infer end
+    to end and expects 0): the Trainer lowers the loss of a SEGNN on the LJ dataset, writes a checkpoint in the reference's
+    on-disk format (e3nn leaf names and row order), resumes from it, and `mode: all` of the runner returns 0."""
+    import json
+    import os
+    import shutil
+    from lagrangebench_amd.case_setup import case_builder
+    from lagrangebench_amd.data import H5Dataset
+    from lagrangebench_amd.models import SEGNN, node_irreps
+    from lagrangebench_amd.runner import train_or_infer
+    from lagrangebench_amd.train import Trainer
+    from lagrangebench_amd.utils import load_haiku
+    root = os.path.dirname(os.path.abspath(__file__))
+    ds_dir = tmp_path / "3D_LJ_3_1214every1"
+    shutil.copytree(os.path.join(root, "golden", "3D_LJ_3_1214every1"), ds_dir)
+    md = json.load(open(ds_dir / "metadata.json"))
+    md.setdefault("write_every", 1)
+    json.dump(md, open(ds_dir / "metadata.json", "w"))
+    isl, L = 6, 2
+    data_train = H5Dataset("train", str(ds_dir), name="lj3d", input_seq_length=isl, extra_seq_length=1)
+    data_valid = H5Dataset("valid", str(ds_dir), name="lj3d", input_seq_length=isl, extra_seq_length=10)
+    bounds = np.array(md["bounds"])
+    case = case_builder(bounds[:, 1] - bounds[:, 0], md, isl, cfg_model={"magnitude_features": True}, noise_std=3e-4)
+    irr = node_irreps(md, isl, False, True, True)
+    model = SEGNN(irr, "1x1o+1x0e", 64, 1, 1, "1x1o", num_mp_steps=L, n_vels=isl - 1, homogeneous_particles=True)
+    cfg_train = {"batch_size": 2, "noise_std": 3e-4,
+                 "optimizer": {"lr_start": 1e-3, "lr_final": 1e-5, "lr_decay_rate": 0.1, "lr_decay_steps": 200},
+                 "pushforward": {"steps": [-1, 20], "unrolls": [0, 1], "probs": [1, 1]}}
+    trainer = Trainer(model, case, data_train, data_valid, cfg_train=cfg_train,
+                      cfg_eval={"n_rollout_steps": 10, "train": {"n_trajs": 2, "metrics": ["mse"]}},
+                      cfg_logging={"log_steps": 5, "eval_steps": 30}, input_seq_length=isl, seed=0)
+    ckp = str(tmp_path / "ckp")
+    params, state, opt_state = trainer.train(step_max=60, store_ckp=ckp)
+    losses = [l for _, l in trainer.loss_log]
+    assert np.isfinite(losses).all() and np.mean(losses[-4:]) < 0.8 * np.mean(losses[:3]), losses
+    loaded, _, opt_loaded, step = load_haiku(ckp)
+    assert step in (30, 60) and set(opt_loaded) >= {"m", "v", "step"} and np.abs(opt_loaded["v"]).max() > 0
+    p2, _, _ = trainer.train(step_max=step + 3, load_ckp=ckp)
+    assert set(p2) == set(params)
+    cfg = {"mode": "all", "dataset": {"src": str(ds_dir), "name": "lj3d"},
+           "model": {"name": "segnn", "num_mp_steps": 1, "input_seq_length": isl, "latent_dim": 64, "magnitude_features": True},
+           "train": {"step_max": 12, "batch_size": 1, "pushforward": {"steps": [-1], "unrolls": [0], "probs": [1]}},
+           "logging": {"log_steps": 5, "eval_steps": 5, "ckp_dir": str(tmp_path / "ckp2"), "run_name": "r"},
+           "eval": {"n_rollout_steps": 5, "train": {"n_trajs": 1, "metrics": ["mse"]},
+                    "infer": {"n_trajs": 1, "batch_size": 1, "metrics": ["mse"], "out_type": "none"}}}
+    assert train_or_infer(cfg) == 0
