@@ -17,7 +17,7 @@
 // is a 128-wide tall-skinny fp32 GEMM that k_lin32f / k_dw_part already run (dW = Z^T d raw gives [dWs | dWv] in one ordered
 // reduction because d raw is written with zeros in the cross-term columns; dZ = d raw W^T), and the SEGNN-specific work is four
 // small elementwise kernels: k_sgt_in (operands (+ gathers) x attribute -> Z), k_sgt_out (bias, gate / residual -> SV rows),
-// and their transposes.  Z and raw of every block are kept for the backward (0.33 GB per 10 k edges of a 10-layer network).
+// and their transposes.  Z and raw of every block are kept for the backward (~1 GB per 10 k edges of a 10-layer network).
 // Gathers (f[snd], f[rcv]) are transposed without atomics: per-edge gradient rows, then k_sgt_scatter adds, per node, the
 // rows of the edges it sends (sender-sorted permutation, ascending edge index) and receives (CSR row) in a fixed order -
 // a step is bit-reproducible.  jraph.segment_sum's transpose is a gather folded into k_sgt_out_bwd's load.
