@@ -85,8 +85,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if force or jobs or _stale(LIB, objs):
         # no library besides the HIP runtime (round 5: the training step has no library GEMM left)
         libdir = os.path.join(_rocm_root(), "lib")
-        run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs +
-            ["-ldl", "-Wl,-rpath," + libdir])
+        run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-Wl,-rpath," + libdir])
     return LIB
 
 

@@ -31,3 +31,9 @@ python tools/rocpd_summary.py $(find /tmp/p_tr2 -name "*.db" | head -1) > $O/r05
 python tools/rocpd_gaps.py $(find /tmp/p_tr2 -name "*.db" | head -1) >> $O/r05_train_tgv2d_kernel_trace.txt 2>&1
 (python tools/train_profile.py tgv3d 20; python tools/train_profile.py tgv2d 20) > $O/r05_train_step_ms.txt 2>&1
 [ -x tools/bin/lin_bench ] && tools/bin/lin_bench 109000 8000 > $O/r05_lin_bench.txt 2>&1
+# SEGNN training step (config 5's model, lb_train_segnn.h)
+rm -rf /tmp/p_sgt
+rocprofv3 --kernel-trace --stats -d /tmp/p_sgt -- python tools/train_profile.py dam2d 7 segnn > $O/train_segnn.log 2>&1
+python tools/rocpd_summary.py $(find /tmp/p_sgt -name "*.db" | head -1) > $O/r05_train_segnn_kernel_trace.txt 2>&1
+python tools/rocpd_gaps.py $(find /tmp/p_sgt -name "*.db" | head -1) >> $O/r05_train_segnn_kernel_trace.txt 2>&1
+python tools/train_profile.py dam2d 20 segnn >> $O/r05_train_step_ms.txt 2>&1
