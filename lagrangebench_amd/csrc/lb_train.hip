@@ -557,7 +557,7 @@ static void pack_all(lb_gns_train* t) {
 static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int trans) {
   if (a.rows == 0) return LB_OK;
   if (a.NR > 256 || a.NO > 128) return lb_fail(LB_ERR_UNSUPPORTED, "k_lin32: %d x %d operand", a.NR, a.NO);
-  const int nob = a.NO <= 16 ? 1 : 8;
+  const int nob = a.NO <= 16 ? 1 : (a.NO <= 64 ? 4 : 8);  // 16-column output blocks per wave (generic kernel)
   a.NJ = (a.NR + 15) / 16;
   size_t lds = (size_t)a.NJ * nob * 64 * sizeof(f32x4);
   LB_TRY(pack_lookup(t, W, a.NR, a.NO, ldw, trans, nob, &a.Wp));
@@ -587,6 +587,7 @@ static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int tr
     else if (a.accum) LB_LIN_GO(k_lin32f<2>);
     else LB_LIN_GO(k_lin32f<0>);
   } else if (nob == 1) LB_LIN_GO(k_lin32<1>);
+  else if (nob == 4) LB_LIN_GO(k_lin32<4>);
   else LB_LIN_GO(k_lin32<8>);
 #undef LB_LIN_GO
   LB_HIP(hipGetLastError());

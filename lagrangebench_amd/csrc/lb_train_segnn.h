@@ -9,7 +9,7 @@
 // Design.  For lmax 1 an O3TensorProduct with the attribute (a0, a) followed by e3nn's Linear is four dense products that
 // share two weight matrices (lb_segnn.hip):   out_s = [s a0 | (v.a)/sqrt3] Ws / sqrt K + b,   out_v[c] = [s a_c | v_c a0] Wv / sqrt K.
 // The training step makes that literal.  Per block and row r the modulated inputs are FOUR rows 4 r + p of a matrix Z
-// (p = 0: the scalar part, p = 1..3: the x / y / z part; K columns zero-padded to Kp = 128 or 256, pre-multiplied by
+// (p = 0: the scalar part, p = 1..3: the x / y / z part; K columns zero-padded to a multiple of 16, pre-multiplied by
 // 1 / sqrt K) and both weight matrices sit side by side in ONE 128-column operand W = [Ws (cols 0 .. Ms-1) | 0 | Wv (cols
 // 64 .. 64+Mv-1) | 0]:   raw = Z W  (4 R x 128) holds every output the block needs - row 4 r: the scalar outputs in columns
 // < Ms, rows 4 r + 1 + c: the vector outputs in columns 64 .. - plus cross terms nobody reads (Ws on vector rows and vice
@@ -387,7 +387,7 @@ extern "C" int lb_segnn_train_create(lb_engine* e, const lb_segnn_desc* d, const
       b.nv[q] = ops[q].second;
       b.K += ops[q].first + ops[q].second;
     }
-    b.Kp = b.K <= 128 ? 128 : 256;
+    b.Kp = (b.K + 15) / 16 * 16;   // (128 / 256 at first: the blocks with 64 and 130 channels did twice the work)
     b.Ms = Ms; b.Mv = Mv; b.mode = mode; b.edge = edge;
     b.off_w = o; o += (int64_t)b.Kp * 128;
     b.off_b = o; o += 128;
