@@ -128,7 +128,7 @@ __global__ void k_colsum_part(const float* __restrict__ x, int64_t rows, int col
 // 8 NA MFMAs (a first version with one dword per operand and MFMA ran at 61 TFLOP/s, load-issue bound).  The column sums
 // of dY are the running sums of the B values.  Partials go to part[g][K + 1][128] and are summed over g in ascending order
 // by k_part_reduce: bit-reproducible, no atomics.
-template <int NA>
+template <int NA, int DEPTH>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_dw_part(const float* __restrict__ X, int ldx, int K, const float* __restrict__ dY,
                                                   int64_t rows, int64_t chunk, float* __restrict__ part) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -151,7 +151,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   // software pipeline: the operands of DEPTH reduction steps are in flight (the compiler does not hoist the loads of an
   // unrolled loop above the MFMAs of the previous steps; gfx9 returns loads in order, so consuming the oldest slot waits
   // for exactly that slot)
-  constexpr int DEPTH = NA == 3 ? 4 : 6;
+  // DEPTH reduction steps in flight.  Round 5: 12 (NA 1) / 8 (NA 2) for long chunks - 8 MFMAs per step and wave do not cover the
+  // HBM latency with 6 (TGV3D step -1.5 %, SEGNN -2.5 %); short chunks (node-sized products) keep 6: a deeper prologue fetches
+  // past the chunk's end (TGV2D step +4 % with 12 everywhere)
   f32x4 bq[DEPTH];
   f32x2 aq[DEPTH][NA];
   auto fetch = [&](int64_t r0, f32x4& b, f32x2 (&av)[NA]) {
@@ -691,10 +693,11 @@ static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx
   if ((K & 1) && ldx <= K) return false;  // (the pair load of an odd K reads the row's padding column: never stored)
   float* part = red_slot(t, (int64_t)G * (K + 1) * 128, &off);
   if (!part) return false;
-#define DW_GO(NA) hipLaunchKernelGGL((k_dw_part<NA>), dim3(G), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part)
-  if (K <= 128) DW_GO(1);
-  else if (K <= 256) DW_GO(2);
-  else DW_GO(3);
+#define DW_GO(NA, DEPTH) hipLaunchKernelGGL((k_dw_part<NA, DEPTH>), dim3(G), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part)
+  const bool deep = chunk >= 192;
+  if (K <= 128) { if (deep) DW_GO(1, 12); else DW_GO(1, 6); }
+  else if (K <= 256) { if (deep) DW_GO(2, 8); else DW_GO(2, 6); }
+  else DW_GO(3, 4);
 #undef DW_GO
   red_push(t, off, G, (int64_t)(K + 1) * 128, K * 128, db ? nb : 0, K * 128, dW, db);
   return true;
