@@ -190,7 +190,7 @@ int lb_case_integrate(lb_engine* eng, int32_t mode, const float* pred_dev, const
 int lb_rollout(lb_engine* eng, lb_gns* gns, const double* traj_dev, int32_t T, int32_t n_steps,
                double* pred_out_dev, int32_t* n_realloc_out);
 
-/* ---- SEGNN (models/segnn.py:403-610), lmax_hidden = lmax_attributes = 1 --------------------- */
+/* ---- SEGNN (models/segnn.py:403-610) ---------------------------------------------------------- */
 
 /* ---- training step ----------------------------------------------------
  * trainer.py:35-89: loss = _mse (weighted squared error of the normalised accelerations, summed over dim, masked
@@ -224,20 +224,31 @@ typedef struct lb_segnn lb_segnn;
 /* SEGNN hyper-parameters (runner.py:217-237; configs: scalar_units 64 -> hidden irreps
  * 32x0e+32x1o through weight_balanced_irreps, segnn.py:365-400). */
 typedef struct lb_segnn_desc {
-  int32_t hidden;           /* multiplicity of 0e and of 1o in the hidden irreps; only 32 is built */
+  int32_t hidden;           /* multiplicity n of every irrep of the hidden irreps n x (0e + 1o + ..) (weight_balanced_irreps) */
   int32_t blocks_per_step;  /* num_mlp_layers (2) */
   int32_t num_mp_steps;
   int32_t homogeneous;      /* homogeneous_particles: 1 = no one-hot particle-type scalars */
   int32_t n_vels;           /* input_seq_length - 1 */
   int32_t velocity_avg;     /* velocity_aggregate: 1 "avg", 0 "last" */
+  int32_t lmax_hidden;      /* 0 .. 2 (segnn.py:482-484) */
+  int32_t lmax_attributes;  /* 0 .. 2: attributes = spherical harmonics up to this order (segnn.py:481) */
+  int32_t norm;             /* segnn_norm: 0 None, 1 "instance", 2 "batch" (segnn.py:303,346-351) */
+  float norm_eps;           /* eps of e3nn's BatchNorm; <= 0: 1e-5 */
 } lb_segnn_desc;
 
-/* SEGNN(...) + params.  weights_host: one (ws, wv, b) triple per O3TensorProduct in call order
+/* SEGNN(...) + params.  Two weight layouts.
+ * (1) hidden == 32, lmax_hidden == lmax_attributes == 1, norm == 0 (every shipped config; the fused kernels):
+ *   weights_host: one (ws, wv, b) triple per O3TensorProduct in call order
  * (embedding_nodes; per layer message tp_0.. then update tp_0..; readout_0..; output):
  *   ws (K, Ms) weights of the 0e outputs (gated blocks: Ms = 2*hidden, activated scalars first,
  *   then the gates), wv (K, Mv) weights of the 1o outputs, b (Ms).  K indexes the tensor-product
  *   channels operand by operand, scalar-derived channels first, then vector-derived
- *   (oracle/segnn_oracle.py:tp_inputs); the 1/sqrt(K) of e3nn's Linear is applied here. */
+ *   (oracle/segnn_oracle.py:tp_inputs); the 1/sqrt(K) of e3nn's Linear is applied here.
+ * (2) anything else with lmax <= 2 (csrc/lb_segnn_gen.hip): per O3TensorProduct in the same call order, per output irrep
+ *   l = 0, 1, 2: W_l (K_l, mul_l) with the rows in e3nn's regrouped order (x chunk major, attribute l minor), then b (the
+ *   scalar outputs) if the output has 0e; then, with norm, per layer [messages: weight, bias - "batch" only], nodes:
+ *   weight (one per channel of every hidden irrep), bias (one per hidden scalar) (e3nn BatchNorm, training-mode statistics
+ *   as the reference calls it). */
 int lb_segnn_create(lb_engine* eng, const lb_segnn_desc* desc, const float* weights_host,
                     int64_t n_floats, lb_segnn** out);
 
@@ -281,8 +292,10 @@ int32_t lb_math_fallbacks(lb_engine* eng);
 int lb_debug_inject_guard(lb_engine* eng, int32_t flags, int32_t step);
 
 /* Debug/parity tap: hidden node state after the embedding and after each layer,
- * ((num_mp_steps+1), B*N, 128) fp32 rows [s(32) | vx(32) | vy(32) | vz(32)], or NULL. */
+ * ((num_mp_steps+1), B*N, lb_segnn_row_floats) fp32 rows, or NULL.  Layout (1): 128 floats [s(32) | vx(32) | vy(32) | vz(32)];
+ * layout (2): e3nn's own layout (n scalars, n x 3, n x 5), padded to a multiple of 4 floats. */
 int lb_segnn_set_tap(lb_segnn* segnn, float* hidden_out_dev);
+int32_t lb_segnn_row_floats(lb_segnn* segnn);
 
 /* lb_rollout with SEGNN as the model. */
 int lb_segnn_rollout(lb_engine* eng, lb_segnn* segnn, const double* traj_dev, int32_t T,

@@ -45,7 +45,15 @@ class SegnnDesc(C.Structure):
     _fields_ = [
         ("hidden", C.c_int32), ("blocks_per_step", C.c_int32), ("num_mp_steps", C.c_int32),
         ("homogeneous", C.c_int32), ("n_vels", C.c_int32), ("velocity_avg", C.c_int32),
+        ("lmax_hidden", C.c_int32), ("lmax_attributes", C.c_int32), ("norm", C.c_int32), ("norm_eps", C.c_float),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        if "lmax_hidden" not in kw and len(args) < 7:
+            self.lmax_hidden = 1
+        if "lmax_attributes" not in kw and len(args) < 8:
+            self.lmax_attributes = 1
 
 
 # name -> (restype, argtypes).  Every symbol include/lbhip.h declares must be listed here;
@@ -107,6 +115,7 @@ _SIGS = {
     "lb_segnn_create": (C.c_int, [_P, C.POINTER(SegnnDesc), _P, C.c_int64, C.POINTER(_P)]),
     "lb_segnn_destroy": (None, [_P]),
     "lb_segnn_forward": (C.c_int, [_P, _P, _P]),
+    "lb_segnn_row_floats": (C.c_int32, [_P]),
     "lb_segnn_set_tap": (C.c_int, [_P, _P]),
     "lb_segnn_rollout": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_int32)]),
 }

@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liblbhip.so")
-SOURCES = ["lb_api.hip", "lb_neighbor.hip", "lb_state.hip", "lb_gns.hip", "lb_edge16.hip", "lb_segnn.hip", "lb_segnn_msg.hip", "lb_segnn_node.hip", "lb_sinkhorn.hip", "lb_edge16v.hip", "lb_edge16w.hip", "lb_node16s.hip", "lb_gns_generic.hip", "lb_msplit.hip", "lb_train.hip"]
+SOURCES = ["lb_api.hip", "lb_neighbor.hip", "lb_state.hip", "lb_gns.hip", "lb_edge16.hip", "lb_segnn.hip", "lb_segnn_gen.hip", "lb_segnn_msg.hip", "lb_segnn_node.hip", "lb_sinkhorn.hip", "lb_edge16v.hip", "lb_edge16w.hip", "lb_node16s.hip", "lb_gns_generic.hip", "lb_msplit.hip", "lb_train.hip"]
 HEADERS = ["lb_internal.h", "lb_device.h", "lb_f16x2.h", "lb_segnn_dev.h", "lb_features.h", "lb_msplit.h", "lb_msplit_dev.h", "lb_lin32.h", "lb_train_segnn.h", os.path.join("..", "..", "include", "lbhip.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]

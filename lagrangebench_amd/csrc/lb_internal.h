@@ -396,6 +396,14 @@ int lbk_segnn_forward(lb_engine* e, lb_segnn* m);
 int lbk_sg_prep(lb_engine* e, int homogeneous, int vel_avg, int ns4, int nv4, float* xnode, float* eattr, float* msgsv,
                 float* nodesv, float* nattr, int64_t ecap);
 
+// lb_segnn_gen.hip: general irreps (lmax <= 2) and the e3nn BatchNorm switches
+struct lb_sgg;
+int lb_sgg_create(lb_engine* e, const lb_segnn_desc* d, const float* w, int64_t n_floats, lb_sgg** out);
+void lb_sgg_destroy(lb_sgg* m);
+void lb_sgg_set_tap(lb_sgg* m, float* tap);
+int lb_sgg_row_floats(const lb_sgg* m);
+int lbk_sgg_forward(lb_engine* e, lb_sgg* m);
+
 // lb_segnn_msg.hip
 void lb_sg_msg_image(const float* ws0, const float* wv0, const float* b0, const float* ws1,
                      const float* wv1, const float* b1, float* out);

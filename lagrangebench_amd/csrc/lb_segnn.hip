@@ -73,6 +73,7 @@ struct lb_sg_block {       // one O3TensorProduct(+Gate) on the device
 struct lb_segnn {
   lb_segnn_desc desc;
   lb_engine* eng;
+  lb_sgg* gen = nullptr;   // non-null: general irreps / norm (lb_segnn_gen.hip); nothing else below is used then
   int node_ns, node_nv, node_ns4, node_nv4, node_stride;
   float* blob;
   lb_sg_block embedding, output;
@@ -374,6 +375,7 @@ static int sg_ensure_edges(lb_segnn* m) {
 
 extern "C" void lb_segnn_destroy(lb_segnn* m) {
   if (!m) return;
+  if (m->gen) lb_sgg_destroy(m->gen);
   for (void* b : {(void*)m->blob, (void*)m->xnode, (void*)m->nodesv, (void*)m->nattr, (void*)m->f,
                   (void*)m->agg, (void*)m->tn[0], (void*)m->tn[1], (void*)m->eattr, (void*)m->msgsv})
     if (b) (void)hipFree(b);
@@ -383,11 +385,24 @@ extern "C" void lb_segnn_destroy(lb_segnn* m) {
 extern "C" int lb_segnn_create(lb_engine* e, const lb_segnn_desc* d, const float* w, int64_t n_floats,
                                lb_segnn** out) {
   if (!e || !d || !w || !out) return lb_fail(LB_ERR_ARG, "null argument");
-  if (d->hidden != 32)
-    return lb_fail(LB_ERR_UNSUPPORTED, "segnn: hidden multiplicity %d not built (32 = scalar_units 64, lmax 1)", d->hidden);
   if (d->blocks_per_step < 1 || d->blocks_per_step > 8) return lb_fail(LB_ERR_ARG, "bad blocks_per_step");
   if (d->num_mp_steps < 0 || d->num_mp_steps > 64) return lb_fail(LB_ERR_ARG, "bad num_mp_steps");
   if (d->n_vels != e->g.isl - 1) return lb_fail(LB_ERR_ARG, "n_vels %d != input_seq_length-1", d->n_vels);
+  if (d->hidden != 32 || d->lmax_hidden != 1 || d->lmax_attributes != 1 || d->norm != 0) {
+    // not the configuration the fused kernels are built for: the general-irreps path
+    lb_segnn* m = new lb_segnn();
+    m->desc = *d;
+    m->eng = e;
+    m->blob = nullptr; m->xnode = m->nodesv = m->nattr = m->f = m->agg = m->part = nullptr;
+    m->tn[0] = m->tn[1] = nullptr; m->eattr = m->msgsv = nullptr; m->tap = nullptr; m->e_alloc = 0;
+    const int rc = lb_sgg_create(e, d, w, n_floats, &m->gen);
+    if (rc) {
+      delete m;
+      return rc;
+    }
+    *out = m;
+    return LB_OK;
+  }
   const int C = 32, B = d->blocks_per_step, L = d->num_mp_steps, K = e->g.isl - 1;
   lb_segnn* m = new lb_segnn();
   m->desc = *d;
@@ -554,10 +569,13 @@ extern "C" int lb_segnn_create(lb_engine* e, const lb_segnn_desc* d, const float
 extern "C" int lb_segnn_set_tap(lb_segnn* m, float* tap) {
   if (!m) return lb_fail(LB_ERR_ARG, "null model");
   m->tap = tap;
+  if (m->gen) lb_sgg_set_tap(m->gen, tap);
   return LB_OK;
 }
+extern "C" int32_t lb_segnn_row_floats(lb_segnn* m) { return !m ? 0 : m->gen ? lb_sgg_row_floats(m->gen) : 128; }
 
 int lbk_segnn_forward(lb_engine* e, lb_segnn* m) {
+  if (m->gen) return lbk_sgg_forward(e, m->gen);
   hipStream_t s = e->stream;
   const int64_t BN = e->BN;
   const int B = m->desc.blocks_per_step, L = m->desc.num_mp_steps;
@@ -707,7 +725,7 @@ extern "C" int lb_segnn_rollout(lb_engine* e, lb_segnn* m, const double* traj_de
                                 int32_t n_steps, double* pred_out_dev, int32_t* n_realloc_out) {
   if (!e || !m || !traj_dev || !pred_out_dev) return lb_fail(LB_ERR_ARG, "null argument");
   if (m->eng != e) return lb_fail(LB_ERR_ARG, "model was created for another engine");
-  e->feat_job = lb_feat_job{m->xnode, nullptr, 0, 1, 32, e->ptype, e->force};  // node-feature rows ride along with the search
+  if (!m->gen) e->feat_job = lb_feat_job{m->xnode, nullptr, 0, 1, 32, e->ptype, e->force};  // node-feature rows ride along with the search
   const int rc = lb_rollout_generic(e, sg_forward_thunk, m, traj_dev, T, n_steps, pred_out_dev, n_realloc_out);
   e->feat_job = lb_feat_job{};
   return rc;

@@ -360,6 +360,9 @@ extern "C" int lb_segnn_train_create(lb_engine* e, const lb_segnn_desc* d, const
   if (!e || !d || !w || !out) return lb_fail(LB_ERR_ARG, "null argument");
   if (d->hidden < 1 || d->hidden > 32)
     return lb_fail(LB_ERR_UNSUPPORTED, "segnn training: hidden multiplicity %d not built (<= 32: scalar_units <= 64, lmax 1)", d->hidden);
+  if (d->lmax_hidden != 1 || d->lmax_attributes != 1 || d->norm != 0)
+    return lb_fail(LB_ERR_UNSUPPORTED, "segnn training: lmax_hidden %d / lmax_attributes %d / norm %d not built (1 / 1 / none; inference has them)",
+                   d->lmax_hidden, d->lmax_attributes, d->norm);
   if (d->blocks_per_step < 1 || d->blocks_per_step > 8) return lb_fail(LB_ERR_ARG, "bad blocks_per_step");
   if (d->num_mp_steps < 0 || d->num_mp_steps > 64) return lb_fail(LB_ERR_ARG, "bad num_mp_steps");
   if (d->n_vels != e->g.isl - 1) return lb_fail(LB_ERR_ARG, "n_vels %d != input_seq_length-1", d->n_vels);

@@ -338,10 +338,82 @@ def _segnn_module_order(hk_params, num_mp_steps: int, blocks_per_step: int):
     return order
 
 
+# General irreps / norm (models.SEGNN.generic): the engine keeps e3nn's own row order, one matrix per output irrep
+# ("w{l}"), so the leaves map one to one.  e3nn.haiku.BatchNorm modules ([mem]: "batch_norm", "batch_norm_1" inside
+# layer_k in creation order - messages first for "batch" - with parameters "weight" / "bias"; the running statistics
+# live in Haiku STATE and are never read: the reference calls the module in training mode, segnn.py:303,347-351).
+_IR = {0: "0e", 1: "1o", 2: "2e"}
+
+
+def _segnn_bn_modules(hk_params, n: int):
+    mods = []
+    for k in hk_params:
+        m = _re.search(rf"(?:^|/)layer_{n}(?:/|$).*?batch_norm(?:_(\d+))?(?:/|$)", k)
+        if m:
+            mods.append((int(m.group(1) or 0), k))
+    return [k for _, k in sorted(mods)]
+
+
+def _segnn_generic_from_haiku(hk_params, model):
+    mods = _segnn_module_order(hk_params, model._num_mp_steps, model._blocks_per_step)
+    out = {}
+    for (name, _, _), mod in zip(model.gen_blocks(), mods):
+        blk = {}
+        for leaf, arr in hk_params[mod].items():
+            m = _W_RE.match(leaf)
+            if m:
+                if int(m.group(4)) != int(m.group(7)):
+                    raise ValueError(f"{mod}/{leaf}: path between different irreps")
+                blk[f"w{int(m.group(4))}"] = np.asarray(arr, np.float32)
+            elif _B_RE.match(leaf):
+                blk["b"] = np.asarray(arr, np.float32)
+        out[name] = blk
+    which = {0: [], 1: ["norm_nodes"], 2: ["norm_msg", "norm_nodes"]}[model._norm]
+    for n in range(model._num_mp_steps if which else 0):
+        bn = _segnn_bn_modules(hk_params, n)
+        if len(bn) != len(which):
+            raise ValueError(f"SEGNN checkpoint: layer_{n} holds {len(bn)} BatchNorm modules, expected {len(which)}")
+        for w, mod in zip(which, bn):
+            out[f"layer_{n}/{w}"] = {"weight": np.asarray(hk_params[mod]["weight"], np.float32).ravel(),
+                                    "bias": np.asarray(hk_params[mod]["bias"], np.float32).ravel()}
+    for blk, leaf, shape in model.gen_leaves():     # unreachable / absent leaves stay zero
+        out.setdefault(blk, {}).setdefault(leaf, np.zeros(shape, np.float32))
+        if out[blk][leaf].shape != shape:
+            raise ValueError(f"{blk}/{leaf}: got {out[blk][leaf].shape}, expected {shape}")
+    return out
+
+
+def _segnn_generic_to_haiku(params, model, module: str = "segnn"):
+    B = model._blocks_per_step
+    names = ["o3_embedding/embedding_nodes"]
+    for n in range(model._num_mp_steps):
+        names += [f"layer_{n}/tp_{i}" for i in range(B)] + [f"layer_{n}/tp_{i}_1" for i in range(B)]
+    names += [f"o3_decoder/readout_{i}" for i in range(B)] + ["o3_decoder/output"]
+    out = {}
+    for (name, _, outs), hk_name in zip(model.gen_blocks(), names):
+        leaves, blk = {}, params[name]
+        present = [(mul, l) for mul, l in outs if f"w{l}" in blk]
+        for i, (mul, l) in enumerate(present):
+            w = np.asarray(blk[f"w{l}"], np.float32)
+            leaves[f"w[{i},{i}] {w.shape[0]}x{_IR[l]},{mul}x{_IR[l]}"] = w
+        if "b" in blk and np.asarray(blk["b"]).size:
+            leaves[f"b[0] {np.asarray(blk['b']).size}x0e"] = np.asarray(blk["b"], np.float32)
+        out[f"{module}/{hk_name}/linear"] = leaves
+    which = {0: [], 1: ["norm_nodes"], 2: ["norm_msg", "norm_nodes"]}[model._norm]
+    for n in range(model._num_mp_steps if which else 0):
+        for j, w in enumerate(which):
+            out[f"{module}/layer_{n}/batch_norm" + (f"_{j}" if j else "")] = {
+                "weight": np.asarray(params[f"layer_{n}/{w}"]["weight"], np.float32),
+                "bias": np.asarray(params[f"layer_{n}/{w}"]["bias"], np.float32)}
+    return out
+
+
 def segnn_params_from_haiku(hk_params, model):
     """Haiku/e3nn SEGNN parameter dict -> this package's {block: {"ws", "wv", "b"}} layout
     (lagrangebench_amd.models.SEGNN.block_shapes).  `model`: the SEGNN instance (its irreps fix the
     row permutation)."""
+    if getattr(model, "generic", False):
+        return _segnn_generic_from_haiku(hk_params, model)
     shapes = model.block_shapes()
     mods = _segnn_module_order(hk_params, model._num_mp_steps, model._blocks_per_step)
     operands = _segnn_block_operands(model)
@@ -375,6 +447,8 @@ def segnn_params_from_haiku(hk_params, model):
 
 def segnn_params_to_haiku(params, model, module: str = "segnn"):
     """Inverse of segnn_params_from_haiku (e3nn leaf names, e3nn row order)."""
+    if getattr(model, "generic", False):
+        return _segnn_generic_to_haiku(params, model, module)
     shapes = model.block_shapes()
     operands = _segnn_block_operands(model)
     B = model._blocks_per_step

@@ -104,10 +104,12 @@ def test_model_shapes_match_oracle():
         assert p[name]["ws"].shape == (K, ms) and p[name]["wv"].shape == (K, mv), name
     assert m.flatten(p).size == sum(v["ws"].size + v["wv"].size + v["b"].size
                                     for v in p.values() if isinstance(v, dict))
+    # (round 5: lmax 2 and the norm switches are built - tests/test_segnn_irreps.py; they take the general-irreps kernels)
+    assert SEGNN(irr, "1x1o+1x0e", 64, 2, 1, "1x1o", 3, 5).generic
+    assert SEGNN(irr, "1x1o+1x0e", 64, 1, 1, "1x1o", 3, 5, norm="instance").generic
+    assert not m.generic
     with pytest.raises(NotImplementedError):
-        SEGNN(irr, "1x1o+1x0e", 64, 2, 1, "1x1o", 3, 5)
-    with pytest.raises(NotImplementedError):
-        SEGNN(irr, "1x1o+1x0e", 64, 1, 1, "1x1o", 3, 5, norm="instance")
+        SEGNN(irr, "1x1o+1x0e", 64, 3, 1, "1x1o", 3, 5)
 
 
 # ------------------------------------------------------------------------------- GPU
