@@ -224,13 +224,31 @@ def test_general_segnn_forward_parity(name, scale, L, lh, la, norm, blocks, unit
     assert tap.shape[2] == (hdim + 3) // 4 * 4
     for b in range(2):
         of, _ = ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))
-        ref, lat = G.segnn_apply(params, of, pt[b], isl - 1, homog, return_latents=True, norm_eps=model.norm_eps)
+        ref, lat = G.segnn_apply(params, dict(of), pt[b], isl - 1, homog, return_latents=True, norm_eps=model.norm_eps)
+        # Yardstick for the norm switches: the same restatement in float64.  e3nn's BatchNorm divides by the batch's (or, for
+        # "instance", the single node's) root-mean-square, which amplifies rounding: measured on these cases the float32
+        # restatement itself sits 1e-5 .. 3e-4 off its float64 twin and the device (exact-fp32 MFMA, ordered sums) 7e-6 .. 5e-5.
+        # Bar: 1e-5 against the float32 oracle without norm; with norm, no worse than 2x the float32 oracle's own distance
+        # from float64.
+        with S.precision(np.float64):
+            ref64, lat64 = G.segnn_apply(params, dict(of), pt[b], isl - 1, homog, return_latents=True, norm_eps=model.norm_eps)
+        assert ref64["acc"].dtype == np.float64
         for k, f in enumerate(lat):
             got = tap[k][b * N:(b + 1) * N]
-            assert rel_err(got[:, :hdim], f) < 1e-5, f"hidden state {k}"
             assert not got[:, hdim:].any()
+            if norm is None:
+                assert rel_err(got[:, :hdim], f) < 1e-5, f"hidden state {k}"
+            else:
+                e_dev, e_f32 = rel_err(got[:, :hdim], lat64[k]), rel_err(f, lat64[k])
+                assert e_dev <= max(1e-5, 2.0 * e_f32), (k, e_dev, e_f32)
         assert np.abs(ref["acc"]).max() > 1e-4
-        assert rel_err(acc[b], ref["acc"]) < 1e-5
+        if norm is None:
+            assert rel_err(acc[b], ref["acc"]) < 1e-5
+        else:
+            e_dev, e_f32 = rel_err(acc[b], ref64["acc"]), rel_err(ref["acc"], ref64["acc"])
+            print(f"[general segnn {name} norm={norm} b={b}] acc: device vs f64 {e_dev:.2e}, f32 oracle vs f64 {e_f32:.2e}")
+            assert e_dev <= max(1e-5, 2.0 * e_f32), (e_dev, e_f32)
+            assert e_dev < 1e-4
     # no atomics, fixed summation order: bit-reproducible
     again = _np(model.apply(params, {}, (feats, pt))[0]["acc"])
     assert np.array_equal(again, acc)
