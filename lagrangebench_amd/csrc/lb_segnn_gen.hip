@@ -9,9 +9,12 @@
 // One kernel per O3TensorProduct (k_sgg_tp), one 16-row tile per 256-thread workgroup:
 //   1. the operands' rows (gathered through senders / receivers for the message input), the attribute rows and the
 //      Clebsch-Gordan tables go to LDS;
-//   2. per output irrep l3: the tensor-product channels X[m3][row][k] (k in e3nn's regrouped order: x chunk major,
-//      attribute l2 minor) are formed in LDS from a path table - X = sum_{m1 m2} C[m1][m2][m3] x[m1] a[m2],
-//      C = sqrt(2 l3 + 1) * real 3j symbol;
+//   2. the attribute is contracted into the Clebsch-Gordan tables ONCE per row and (l1, l2, l3) combination,
+//      M[row][l1 l2 l3][m1][m3] = sum_m2 C[m1][m2][m3] a[row][l2][m2]  (C = sqrt(2 l3 + 1) * real 3j symbol; at most 11
+//      combinations, 115 floats per row) - the channels of a path share it, so forming a tensor-product channel costs
+//      (2 l1 + 1)(2 l3 + 1) multiply-adds instead of (2 l1 + 1)(2 l2 + 1)(2 l3 + 1);
+//      per output irrep l3 the channels X[m3][row][k] = sum_m1 M[..][m1][m3] x[m1] (k in e3nn's regrouped order: x chunk
+//      major, attribute l2 minor) are formed in LDS from a path table;
 //   3. e3nn's Linear for that irrep is (2 l3 + 1) x ceil(mul / 16) MFMA tiles (v_mfma_f32_16x16x4_f32: exact fp32 products):
 //      A = X[m3] (16 rows x K) from LDS, B = W_l3 (K x mul, zero-padded, pre-multiplied by 1 / sqrt K) from L2; the four waves
 //      take tiles round-robin and leave the result in an LDS row buffer in e3nn layout;
@@ -31,9 +34,11 @@
 
 namespace {
 
-constexpr int SGG_MAX_CH = 6;
 constexpr int SGG_MAX_PATH = 48;
 constexpr int SGG_PATH_INTS = 8;
+constexpr int SGG_MAX_M = 128;  // sum over the (l1, l2, l3) combinations of (2 l1 + 1)(2 l3 + 1): 115 for lmax 2
+// M element decode: bits 0-11 offset of C[m1][0][m3] in the table, 12-15 d3 (stride between m2), 16-19 d2, 20-23 l2^2
+__host__ __device__ constexpr int sgg_mdec(int cg0, int d3, int d2, int a0) { return cg0 | (d3 << 12) | (d2 << 16) | (a0 << 20); }
 constexpr float SGG_C_SILU = 1.6765620f;     // 1 / sqrt(E[silu(z)^2]), z ~ N(0, 1)  (oracle/segnn_oracle.py A5)
 constexpr float SGG_C_SIGMOID = 1.8462292f;
 enum { SGG_PLAIN = 0, SGG_GATE = 1, SGG_OUTVEC = 2 };
@@ -57,8 +62,10 @@ struct sgg_args {
   const float* attr;
   int32_t attr_stride, n_out;
   sgg_out out[3];
-  int32_t path[SGG_MAX_PATH][SGG_PATH_INTS];   // {x offset in the LDS row, cs, ms, l1, l2, koff, mul, cg offset}
+  int32_t path[SGG_MAX_PATH][SGG_PATH_INTS];   // {x offset in the LDS row, cs, ms, l1, l2, koff, mul, offset of M[combination]}
   int32_t n_path_total, cg_floats;
+  int32_t mdec[SGG_MAX_M];   // element e of a row's M block: cg offset of (m1, m2 = 0, m3) | d2 * d3 << 16 | d3... see sgg_mdec
+  int32_t ms;                // M floats per row
   const float* cg;
   const float* w;
   const float* bias;       // [scalars of the tensor product's output] or null
@@ -85,7 +92,8 @@ __global__ void __launch_bounds__(256) k_sgg_tp(sgg_args a) {
   int* spath = reinterpret_cast<int*>(cgt + ((a.cg_floats + 3) & ~3));   // [n_path_total][8]
   int* sidx = spath + SGG_MAX_PATH * SGG_PATH_INTS;  // [3][16]
   int* kmap = sidx + 48;                             // [kmax4]
-  float* X = reinterpret_cast<float*>(kmap + a.kmax4);  // [5][16][xs]
+  float* Mt = reinterpret_cast<float*>(kmap + a.kmax4);  // [16][ms (rounded to 4)]
+  float* X = Mt + 16 * ((a.ms + 3) & ~3);            // [2 l3max + 1][16][xs]
   float* Y = X + a.x_floats;                         // [16][ys]
 
   if (tid < 16 * a.n_op) {
@@ -107,6 +115,19 @@ __global__ void __launch_bounds__(256) k_sgg_tp(sgg_args a) {
     }
   }
   __syncthreads();
+  {   // the attribute contracted into the Clebsch-Gordan tables, per row and combination
+    const int ms = a.ms, ms4 = (a.ms + 3) & ~3;
+    for (int i = tid; i < 16 * ms; i += 256) {
+      const int r = i / ms, el = i - r * ms;
+      const int dec = a.mdec[el];
+      const int d3 = (dec >> 12) & 15, d2 = (dec >> 16) & 15;
+      const float* c = cgt + (dec & 0xfff);
+      const float* ar = att + r * 16 + (dec >> 20);
+      float t = 0.f;
+      for (int m2 = 0; m2 < d2; ++m2) t += c[m2 * d3] * ar[m2];
+      Mt[r * ms4 + el] = t;
+    }
+  }
   for (int o = 0; o < a.n_op; ++o) {
     const int s4 = a.op[o].stride >> 2;
     const f32x4* src = reinterpret_cast<const f32x4*>(a.op[o].x);
@@ -138,19 +159,14 @@ __global__ void __launch_bounds__(256) k_sgg_tp(sgg_args a) {
       if (km >= 0) {
         const int* P = spath + (km >> 16) * SGG_PATH_INTS;
         const int u = km & 0xffff;
-        const int d1 = 2 * P[3] + 1, l2 = P[4], d2 = 2 * l2 + 1;
+        const int d1 = 2 * P[3] + 1;
         const float* xr = xin + r * a.xin_stride + P[0] + u * P[1];
-        const float* ar = att + r * 16 + l2 * l2;
-        const float* C = cgt + P[7];
+        const float* Mr = Mt + r * ((a.ms + 3) & ~3) + P[7];   // [m1][m3]
         for (int m1 = 0; m1 < d1; ++m1) {
           const float x1 = xr[m1 * P[2]];
-          for (int m2 = 0; m2 < d2; ++m2) {
-            const float t = x1 * ar[m2];
-            const float* c3 = C + (m1 * d2 + m2) * d3;
 #pragma unroll
-            for (int m3 = 0; m3 < 5; ++m3)
-              if (m3 < d3) acc[m3] += c3[m3] * t;
-          }
+          for (int m3 = 0; m3 < 5; ++m3)
+            if (m3 < d3) acc[m3] += Mr[m1 * d3 + m3] * x1;
         }
       }
 #pragma unroll
@@ -166,9 +182,21 @@ __global__ void __launch_bounds__(256) k_sgg_tp(sgg_args a) {
       const float* xa = X + (m3 * 16 + (lane & 15)) * a.xs + (lane >> 4);
       const float* wb = W + (int64_t)(lane >> 4) * O.N16 + nt * 16 + (lane & 15);
       const int nj = O.K4 >> 2;
-#pragma unroll 4
-      for (int j = 0; j < nj; ++j)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[4 * j], wb[(int64_t)4 * j * O.N16], acc, 0, 0, 0);
+      // the weight operand comes from L2: 16 k-steps' worth of loads are in flight while the previous 16 are multiplied
+      float bq[16], bn[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) bq[q] = q < nj ? wb[(int64_t)4 * q * O.N16] : 0.f;
+      for (int j0 = 0; j0 < nj; j0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bn[q] = j0 + 16 + q < nj ? wb[(int64_t)4 * (j0 + 16 + q) * O.N16] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float av = j0 + q < nj ? xa[4 * (j0 + q)] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[q], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bq[q] = bn[q];
+      }
       const int n = nt * 16 + (lane & 15);
       if (n < O.mul) {
 #pragma unroll
@@ -694,6 +722,24 @@ int lb_sgg_create(lb_engine* e, const lb_segnn_desc* d, const float* w, int64_t 
       }
   m->cg_floats = (int)host.size();
   host.resize((host.size() + 63) & ~(size_t)63, 0.f);
+  // the rows' M blocks: one (2 l1 + 1) x (2 l3 + 1) matrix per combination that the attributes' lmax admits
+  int m_off[3][3][3], ms_total = 0;
+  std::vector<int32_t> mdec;
+  for (int l1 = 0; l1 <= 2; ++l1)
+    for (int l2 = 0; l2 <= m->La; ++l2)
+      for (int l3 = 0; l3 <= 2; ++l3) {
+        m_off[l1][l2][l3] = -1;
+        if (cg_off[l1][l2][l3] < 0) continue;
+        m_off[l1][l2][l3] = ms_total;
+        const int d1 = 2 * l1 + 1, d2 = 2 * l2 + 1, d3 = 2 * l3 + 1;
+        for (int m1 = 0; m1 < d1; ++m1)
+          for (int m3 = 0; m3 < d3; ++m3) mdec.push_back(sgg_mdec(cg_off[l1][l2][l3] + m1 * d2 * d3 + m3, d3, d2, l2 * l2));
+        ms_total += d1 * d3;
+      }
+  if (ms_total > SGG_MAX_M || m->cg_floats > 0xfff) {
+    delete m;
+    return lb_fail(LB_ERR_STATE, "segnn: Clebsch-Gordan tables larger than planned (%d, %d)", ms_total, m->cg_floats);
+  }
 
   const float* p = w;
   const float* pend = w + n_floats;
@@ -728,7 +774,7 @@ int lb_sgg_create(lb_engine* e, const lb_segnn_desc* d, const float* w, int64_t 
             if (np >= SGG_MAX_PATH) { bad = true; return; }
             int32_t* P = a.path[np++];
             P[0] = a.op[o].lds_off + c.off; P[1] = c.cs; P[2] = c.ms; P[3] = c.l; P[4] = l2; P[5] = K; P[6] = c.mul;
-            P[7] = cg_off[c.l][l2][O.l];
+            P[7] = m_off[c.l][l2][O.l];
             K += c.mul;
           }
       O.n_path = np - O.path0;
@@ -761,7 +807,10 @@ int lb_sgg_create(lb_engine* e, const lb_segnn_desc* d, const float* w, int64_t 
     a.ys = yoff + 1;
     a.kmax4 = kmax4;
     a.xs = ((kmax4 + 27) / 32) * 32 + 4;   // row stride of X: = 4 (mod 32), >= kmax4
-    a.x_floats = 5 * 16 * a.xs;
+    int d3max = 1;
+    for (int oi = 0; oi < a.n_out; ++oi)
+      if (a.out[oi].K > 0 && a.out[oi].mul > 0) d3max = std::max(d3max, 2 * a.out[oi].l + 1);
+    a.x_floats = d3max * 16 * a.xs;
     a.dst_stride = m->HS;
     a.dst_dim = m->hdim;
     if (mode == SGG_GATE) {
@@ -775,8 +824,10 @@ int lb_sgg_create(lb_engine* e, const lb_segnn_desc* d, const float* w, int64_t 
       a.n_gated = ng;
     }
     a.cg_floats = m->cg_floats;
+    a.ms = ms_total;
+    for (int i = 0; i < ms_total; ++i) a.mdec[i] = mdec[(size_t)i];
     b.lds_bytes = sizeof(float) * ((size_t)16 * a.xin_stride + 256 + ((a.cg_floats + 3) & ~3) + SGG_MAX_PATH * SGG_PATH_INTS + 48 +
-                                   a.kmax4 + a.x_floats + (size_t)16 * a.ys);
+                                   a.kmax4 + (size_t)16 * ((ms_total + 3) & ~3) + a.x_floats + (size_t)16 * a.ys);
     m->blocks.push_back(b);
   };
   std::vector<std::pair<int, int>> hid_out, gate_out;

@@ -432,8 +432,7 @@ class GnsHandle:
         if on:
             # the kernels work on 128-wide rows (narrower latents are zero-padded): the tap buffer is
             # 128 wide, the caller sees the first latent_size columns
-            width = int(e.lib.lb_segnn_row_floats(self._h))   # 128, or the e3nn row of the general-irreps path
-            self._tap = torch.zeros((self.desc.num_mp_steps + 1, e.B * e.N, width), dtype=torch.float32,
+            self._tap = torch.zeros((self.desc.num_mp_steps + 1, e.B * e.N, 128), dtype=torch.float32,
                                     device=e.device)
             check(e.lib.lb_gns_set_tap(self._h, ptr(self._tap)))
             return self._tap[:, :, :self.desc.latent_size]
