@@ -361,22 +361,45 @@ __device__ __forceinline__ void sgg_bn_range(const sgg_bn_args& a, int b, int64_
     *r1 = (int64_t)(b + 1) * a.N;
   }
 }
-// pass 0: column sums; pass 1: column sums of (x - mean)^2 (mean is zero on the non-scalar columns); grid (G, B)
+// pass 0: column sums; pass 1: column sums of (x - mean)^2 (mean is zero on the non-scalar columns); grid (G, B).
+// A workgroup is RL row lanes x S4 four-column groups (RL = 256 / S4): lane rl takes the rows q0 + rl, q0 + rl + RL, ..
+// of its group's chunk four at a time (four independent loads in flight), the RL partial sums are added in lane order
+// through LDS: a fixed order, no atomics.
 __global__ void __launch_bounds__(256) k_sgg_bn_part(sgg_bn_args a, int pass) {
   if (a.ctrl->overflow_step >= 0) return;
+  __shared__ f32x4 red[256];
   const int b = blockIdx.y, g = blockIdx.x;
   int64_t r0, r1;
   sgg_bn_range(a, b, &r0, &r1);
   const int64_t n = r1 - r0, chunk = (n + a.G - 1) / a.G;
   const int64_t q0 = r0 + g * chunk, q1 = q0 + chunk < r1 ? q0 + chunk : r1;
-  for (int c = threadIdx.x; c < a.stride; c += 256) {
-    const float mu = pass ? a.mean[b * a.stride + c] : 0.f;
-    float s = 0.f;
-    for (int64_t r = q0; r < q1; ++r) {
-      const float v = a.x[r * a.stride + c] - mu;
-      s += pass ? v * v : v;
+  const int S4 = a.stride >> 2;
+  const int RL = S4 >= 256 ? 1 : 256 / S4;
+  const int rl = threadIdx.x / S4, c4 = threadIdx.x - rl * S4;
+  const bool on = rl < RL && c4 < S4;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (on) {
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f};
+    if (pass) mu = reinterpret_cast<const f32x4*>(a.mean)[b * S4 + c4];
+    int64_t r = q0 + rl;
+    for (; r + 3 * RL < q1; r += 4 * RL) {
+      f32x4 v0 = x4[r * S4 + c4] - mu, v1 = x4[(r + RL) * S4 + c4] - mu, v2 = x4[(r + 2 * RL) * S4 + c4] - mu,
+            v3 = x4[(r + 3 * RL) * S4 + c4] - mu;
+      if (pass) { v0 = v0 * v0; v1 = v1 * v1; v2 = v2 * v2; v3 = v3 * v3; }
+      s = s + ((v0 + v1) + (v2 + v3));
     }
-    a.part[((int64_t)b * a.G + g) * a.stride + c] = s;
+    for (; r < q1; r += RL) {
+      f32x4 v = x4[r * S4 + c4] - mu;
+      if (pass) v = v * v;
+      s = s + v;
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && c4 < S4) {
+    for (int q = 1; q < RL; ++q) s = s + red[q * S4 + c4];
+    reinterpret_cast<f32x4*>(a.part)[((int64_t)b * a.G + g) * S4 + c4] = s;
   }
 }
 // pass 0: mean of the scalar columns; pass 1: per-column affine map  y = x * scale + shift;  grid (B)
@@ -559,7 +582,7 @@ struct lb_sgg {
   float *eattr4 = nullptr, *eattr = nullptr, *msgsv = nullptr;
   float* te[2] = {nullptr, nullptr};
   float *bn_part = nullptr, *bn_mean = nullptr, *bn_scale = nullptr, *bn_shift = nullptr;
-  int bn_G = 64;
+  int bn_G = 128;
   float* tap = nullptr;
 };
 
