@@ -6,7 +6,7 @@
 // fused kernels of lb_segnn_msg.hip / lb_segnn_node.hip); it exists so that every switch of the reference's SEGNN runs on
 // the device.
 //
-// One kernel per O3TensorProduct (k_sgg_tp), one 16-row tile per 256-thread workgroup:
+// One kernel per O3TensorProduct (k_sgg_tp), one 16-row tile per 256- or 512-thread workgroup:
 //   1. the operands' rows (gathered through senders / receivers for the message input), the attribute rows and the
 //      Clebsch-Gordan tables go to LDS;
 //   2. the attribute is contracted into the Clebsch-Gordan tables ONCE per row and (l1, l2, l3) combination,
@@ -14,9 +14,10 @@
 //      combinations, 115 floats per row) - the channels of a path share it, so forming a tensor-product channel costs
 //      (2 l1 + 1)(2 l3 + 1) multiply-adds instead of (2 l1 + 1)(2 l2 + 1)(2 l3 + 1);
 //      per output irrep l3 the channels X[m3][row][k] = sum_m1 M[..][m1][m3] x[m1] (k in e3nn's regrouped order: x chunk
-//      major, attribute l2 minor) are formed in LDS from a path table;
+//      major, attribute l2 minor) are formed in LDS from a per-channel table built at lb_segnn_create (where x[u] sits in
+//      the staged row, its component stride, 2 l1 + 1, which M block);
 //   3. e3nn's Linear for that irrep is (2 l3 + 1) x ceil(mul / 16) MFMA tiles (v_mfma_f32_16x16x4_f32: exact fp32 products):
-//      A = X[m3] (16 rows x K) from LDS, B = W_l3 (K x mul, zero-padded, pre-multiplied by 1 / sqrt K) from L2; the four waves
+//      A = X[m3] (16 rows x K) from LDS, B = W_l3 (K x mul, zero-padded, pre-multiplied by 1 / sqrt K) from L2; the four or eight waves
 //      take tiles round-robin and leave the result in an LDS row buffer in e3nn layout;
 //   4. epilogue: bias on the scalars, e3nn.gate (normalised silu / sigmoid) or the residual, coalesced row stores.
 // Hidden rows are stored in e3nn's own layout (chunk after chunk, (mul, 2 l + 1) row-major) with the row stride padded to 4
@@ -34,8 +35,6 @@
 
 namespace {
 
-constexpr int SGG_MAX_PATH = 48;
-constexpr int SGG_PATH_INTS = 8;
 constexpr int SGG_MAX_M = 128;  // sum over the (l1, l2, l3) combinations of (2 l1 + 1)(2 l3 + 1): 115 for lmax 2
 // M element decode: bits 0-11 offset of C[m1][0][m3] in the table, 12-15 d3 (stride between m2), 16-19 d2, 20-23 l2^2
 __host__ __device__ constexpr int sgg_mdec(int cg0, int d3, int d2, int a0) { return cg0 | (d3 << 12) | (d2 << 16) | (a0 << 20); }
@@ -50,8 +49,8 @@ struct sgg_opnd {
   int32_t stride, lds_off;
 };
 struct sgg_out {           // one output irrep of the block's Linear
-  int32_t l, mul, K, K4, N16, path0, n_path, yoff;
-  int64_t w_off;           // floats into the weight blob: K4 x N16, pre-scaled by 1 / sqrt K
+  int32_t l, mul, K, K4, N16, k_off, pad0, yoff;   // K4: K padded to a multiple of 32 (one chunk of 8 MFMA k-steps); k_off: int2 entries into ktab
+  int64_t w_off;           // floats into the weight blob: the matrix in MFMA fragment order (sgg_pack_w), pre-scaled by 1 / sqrt K
 };
 struct sgg_gated { int32_t out_off, y_off, mul, d, gate0; };
 struct sgg_args {
@@ -62,8 +61,9 @@ struct sgg_args {
   const float* attr;
   int32_t attr_stride, n_out;
   sgg_out out[3];
-  int32_t path[SGG_MAX_PATH][SGG_PATH_INTS];   // {x offset in the LDS row, cs, ms, l1, l2, koff, mul, offset of M[combination]}
-  int32_t n_path_total, cg_floats;
+  int32_t cg_floats;
+  const int32_t* ktab;       // per output irrep (sgg_out::k_off) and channel k < K4: {offset of x[u][0] in the staged row,
+                             //   component stride | 2 l1 + 1 << 12 | offset of M[combination] << 16}; 2 l1 + 1 = 0: padding
   int32_t mdec[SGG_MAX_M];   // element e of a row's M block: cg offset of (m1, m2 = 0, m3) | d2 * d3 << 16 | d3... see sgg_mdec
   int32_t ms;                // M floats per row
   const float* cg;
@@ -79,7 +79,11 @@ struct sgg_args {
 
 __device__ __forceinline__ float sgg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ void __launch_bounds__(256) k_sgg_tp(sgg_args a) {
+// SGG_NT threads share one 16-row tile: 256 (four waves) when the Linear of an irrep is a handful of MFMA tiles (lmax_hidden
+// <= 1: 4 + 6 tiles; measured 3.7 vs 4.9 ms per DAM2D forward against 512), 512 at lmax_hidden 2 (5 + 6 + 10 tiles, one workgroup
+// per CU by LDS anyway: 12.5 -> 9.9 ms)
+template <int SGG_NT>
+__global__ void __launch_bounds__(SGG_NT) k_sgg_tp(sgg_args a) {
   extern __shared__ float lds[];
   if (a.ctrl->overflow_step >= 0) return;
   const int64_t n_rows = a.rows_from_ctrl ? (int64_t)a.ctrl->n_edges_total : a.n_rows;
@@ -89,10 +93,11 @@ __global__ void __launch_bounds__(256) k_sgg_tp(sgg_args a) {
   float* xin = lds;                                  // [16][xin_stride]
   float* att = xin + 16 * a.xin_stride;              // [16][16]
   float* cgt = att + 256;                            // [cg_floats (rounded to 4)]
-  int* spath = reinterpret_cast<int*>(cgt + ((a.cg_floats + 3) & ~3));   // [n_path_total][8]
-  int* sidx = spath + SGG_MAX_PATH * SGG_PATH_INTS;  // [3][16]
-  int* kmap = sidx + 48;                             // [kmax4]
-  float* Mt = reinterpret_cast<float*>(kmap + a.kmax4);  // [16][ms (rounded to 4)]
+  int* sidx = reinterpret_cast<int*>(cgt + ((a.cg_floats + 3) & ~3));   // [3][16]
+  int* kmap = sidx + 48;                             // [kmax4][2]: this irrep's slice of ktab
+  float* Mt = reinterpret_cast<float*>(kmap + 2 * a.kmax4);  // [16][ms (rounded to 4)]
+  constexpr int TPR = SGG_NT / 16;                   // threads per row in the row-wise phases
+  const int rr = tid / TPR, rc = tid % TPR;
   float* X = Mt + 16 * ((a.ms + 3) & ~3);            // [2 l3max + 1][16][xs]
   float* Y = X + a.x_floats;                         // [16][ys]
 
@@ -102,23 +107,18 @@ __global__ void __launch_bounds__(256) k_sgg_tp(sgg_args a) {
     row = row < n_rows ? row : n_rows - 1;
     sidx[tid] = a.op[o].gather ? a.op[o].gather[row] : (int)row;
   }
-  for (int i = tid; i < a.n_path_total * SGG_PATH_INTS; i += 256) spath[i] = (&a.path[0][0])[i];
-  for (int i = tid; i < a.cg_floats; i += 256) cgt[i] = a.cg[i];
-  for (int i = tid; i < 16 * a.ys; i += 256) Y[i] = 0.f;
+  for (int i = tid; i < a.cg_floats; i += SGG_NT) cgt[i] = a.cg[i];
+  for (int i = tid; i < 16 * a.ys; i += SGG_NT) Y[i] = 0.f;
   {
-    const int as = a.attr_stride;
-    for (int i = tid; i < 16 * as; i += 256) {
-      const int r = i / as, c = i - r * as;
-      int64_t row = row0 + r;
-      row = row < n_rows ? row : n_rows - 1;
-      att[r * 16 + c] = a.attr[row * as + c];
-    }
+    int64_t row = row0 + rr;
+    row = row < n_rows ? row : n_rows - 1;
+    for (int c = rc; c < a.attr_stride; c += TPR) att[rr * 16 + c] = a.attr[row * a.attr_stride + c];
   }
   __syncthreads();
   {   // the attribute contracted into the Clebsch-Gordan tables, per row and combination
     const int ms = a.ms, ms4 = (a.ms + 3) & ~3;
-    for (int i = tid; i < 16 * ms; i += 256) {
-      const int r = i / ms, el = i - r * ms;
+    for (int el = rc; el < ms; el += TPR) {
+      const int r = rr;
       const int dec = a.mdec[el];
       const int d3 = (dec >> 12) & 15, d2 = (dec >> 16) & 15;
       const float* c = cgt + (dec & 0xfff);
@@ -131,71 +131,77 @@ __global__ void __launch_bounds__(256) k_sgg_tp(sgg_args a) {
   for (int o = 0; o < a.n_op; ++o) {
     const int s4 = a.op[o].stride >> 2;
     const f32x4* src = reinterpret_cast<const f32x4*>(a.op[o].x);
-    for (int i = tid; i < 16 * s4; i += 256) {
-      const int r = i / s4, c = i - r * s4;
-      const f32x4 v = src[(int64_t)sidx[o * 16 + r] * s4 + c];
-      *reinterpret_cast<f32x4*>(xin + r * a.xin_stride + a.op[o].lds_off + 4 * c) = v;
-    }
+    const f32x4* srow = src + (int64_t)sidx[o * 16 + rr] * s4;
+    float* drow = xin + rr * a.xin_stride + a.op[o].lds_off;
+    for (int c = rc; c < s4; c += TPR) *reinterpret_cast<f32x4*>(drow + 4 * c) = srow[c];
   }
 
   for (int oi = 0; oi < a.n_out; ++oi) {
     const sgg_out& O = a.out[oi];
     const int d3 = 2 * O.l + 1;
     if (O.K == 0 || O.mul == 0) continue;
-    __syncthreads();   // operands staged / the previous irrep's MFMA reads of X are done
-    for (int k = tid; k < O.K4; k += 256) {
-      int km = -1;
-      for (int p = O.path0; p < O.path0 + O.n_path; ++p) {
-        const int ko = spath[p * SGG_PATH_INTS + 5], mu = spath[p * SGG_PATH_INTS + 6];
-        if (k >= ko && k < ko + mu) km = (p << 16) | (k - ko);
-      }
-      kmap[k] = km;
+    const int ntile = O.N16 >> 4, T = d3 * ntile, nc = O.K4 >> 5, ps = O.K4 >> 2;
+    // W in fragment order (sgg_pack_w): f32x4 entry ((nt * (nc + 2) + c) * 2 + q) * 64 + lane holds, for i = 0 .. 3, the
+    // operand of k-step 8 c + 4 q + i - one 16-byte load per four MFMAs, and chunks nc, nc + 1 of every column tile are zeros so
+    // that the look-ahead loads need no branch.  The first two chunks of this wave's first tile are requested before the
+    // channels are formed (nothing of them depends on X), chunk c + 2 while chunk c multiplies.
+    const f32x4* W = reinterpret_cast<const f32x4*>(a.w + O.w_off);
+    f32x4 b0, b1, n0, n1;
+    {
+      const int nt = wave < T ? wave % ntile : 0;
+      const f32x4* wp = W + (int64_t)nt * (nc + 2) * 128 + lane;
+      b0 = wp[0];
+      b1 = wp[64];
+      n0 = wp[128];
+      n1 = wp[192];
     }
+    __syncthreads();   // operands staged / the previous irrep's MFMA reads of X are done
+    for (int k = tid; k < 2 * O.K4; k += SGG_NT) kmap[k] = a.ktab[2 * O.k_off + k];
     __syncthreads();
-    for (int i = tid; i < 16 * O.K4; i += 256) {
-      const int r = i / O.K4, k = i - r * O.K4;
-      const int km = kmap[k];
-      float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-      if (km >= 0) {
-        const int* P = spath + (km >> 16) * SGG_PATH_INTS;
-        const int u = km & 0xffff;
-        const int d1 = 2 * P[3] + 1;
-        const float* xr = xin + r * a.xin_stride + P[0] + u * P[1];
-        const float* Mr = Mt + r * ((a.ms + 3) & ~3) + P[7];   // [m1][m3]
+    {
+      const float* xrow = xin + rr * a.xin_stride;
+      const float* Mrow = Mt + rr * ((a.ms + 3) & ~3);
+      for (int k = rc; k < O.K4; k += TPR) {
+        const int kx = kmap[2 * k], ki = kmap[2 * k + 1];
+        const int d1 = (ki >> 12) & 15, cs = ki & 0xfff;
+        const float* xr = xrow + kx;
+        const float* Mr = Mrow + (ki >> 16);   // [m1][m3]
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         for (int m1 = 0; m1 < d1; ++m1) {
-          const float x1 = xr[m1 * P[2]];
+          const float x1 = xr[m1 * cs];
 #pragma unroll
           for (int m3 = 0; m3 < 5; ++m3)
             if (m3 < d3) acc[m3] += Mr[m1 * d3 + m3] * x1;
         }
-      }
 #pragma unroll
-      for (int m3 = 0; m3 < 5; ++m3)
-        if (m3 < d3) X[(m3 * 16 + r) * a.xs + k] = acc[m3];
+        for (int m3 = 0; m3 < 5; ++m3)
+          if (m3 < d3) X[(m3 * 16 + rr) * a.xs + (k & 3) * ps + (k >> 2)] = acc[m3];   // plane k mod 4, position k / 4
+      }
     }
     __syncthreads();
-    const int ntile = O.N16 >> 4, T = d3 * ntile;
-    const float* W = a.w + O.w_off;
-    for (int t = wave; t < T; t += 4) {
+    for (int t = wave; t < T; t += SGG_NT / 64) {
       const int m3 = t / ntile, nt = t - m3 * ntile;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float* xa = X + (m3 * 16 + (lane & 15)) * a.xs + (lane >> 4);
-      const float* wb = W + (int64_t)(lane >> 4) * O.N16 + nt * 16 + (lane & 15);
-      const int nj = O.K4 >> 2;
-      // the weight operand comes from L2: 16 k-steps' worth of loads are in flight while the previous 16 are multiplied
-      float bq[16], bn[16];
+      // lane (row, kq) multiplies k = 4 j + kq in k-step j: its operands of four consecutive k-steps are one 16-byte LDS read
+      const f32x4* xa = reinterpret_cast<const f32x4*>(X + (m3 * 16 + (lane & 15)) * a.xs + (lane >> 4) * ps);
+      const f32x4* wp = W + (int64_t)nt * (nc + 2) * 128 + lane;
+      if (t != wave) {
+        b0 = wp[0];
+        b1 = wp[64];
+        n0 = wp[128];
+        n1 = wp[192];
+      }
+      for (int c = 0; c < nc; ++c) {
+        const f32x4 m0 = wp[(c + 2) * 128], m1 = wp[(c + 2) * 128 + 64];   // two chunks (16 MFMAs) ahead
+        const f32x4 a0 = xa[2 * c], a1 = xa[2 * c + 1];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) bq[q] = q < nj ? wb[(int64_t)4 * q * O.N16] : 0.f;
-      for (int j0 = 0; j0 < nj; j0 += 16) {
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[i], acc, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) bn[q] = j0 + 16 + q < nj ? wb[(int64_t)4 * (j0 + 16 + q) * O.N16] : 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float av = j0 + q < nj ? xa[4 * (j0 + q)] : 0.f;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[q], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) bq[q] = bn[q];
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], b1[i], acc, 0, 0, 0);
+        b0 = n0;
+        b1 = n1;
+        n0 = m0;
+        n1 = m1;
       }
       const int n = nt * 16 + (lane & 15);
       if (n < O.mul) {
@@ -215,8 +221,8 @@ __global__ void __launch_bounds__(256) k_sgg_tp(sgg_args a) {
     return;
   }
   const int ds = a.dst_stride;
-  for (int i = tid; i < 16 * ds; i += 256) {
-    const int r = i / ds, c = i - r * ds;
+  for (int c = rc; c < ds; c += TPR) {
+    const int r = rr;
     if (row0 + r >= n_rows) continue;
     const float* y = Y + r * a.ys;
     float val = 0.f;
@@ -572,6 +578,7 @@ struct lb_sgg {
   sgg_chunk hch[3];
   int node_ns = 0, node_nv = 0, node_ns4 = 0, node_nv4 = 0, node_stride = 0;
   float* blob = nullptr;
+  int32_t* ktab = nullptr;
   const float* cg_dev = nullptr;
   int cg_floats = 0;
   std::vector<sgg_block> blocks;   // call order
@@ -628,7 +635,8 @@ int sgg_launch(lb_sgg* m, const sgg_block& b, int64_t rows, bool rows_from_ctrl,
   a.dst = dst;
   if (rows <= 0) return LB_OK;
   const unsigned nb = (unsigned)((rows + 15) / 16);
-  hipLaunchKernelGGL(k_sgg_tp, dim3(nb), dim3(256), b.lds_bytes, e->stream, a);
+  if (m->Lh >= 2) hipLaunchKernelGGL(k_sgg_tp<512>, dim3(nb), dim3(512), b.lds_bytes, e->stream, a);
+  else hipLaunchKernelGGL(k_sgg_tp<256>, dim3(nb), dim3(256), b.lds_bytes, e->stream, a);
   LB_HIP(hipGetLastError());
   return LB_OK;
 }
@@ -676,7 +684,7 @@ int sgg_batch_norm(lb_sgg* m, int64_t off_w, int64_t off_b, float* x, bool edges
 
 void lb_sgg_destroy(lb_sgg* m) {
   if (!m) return;
-  for (void* b : {(void*)m->blob, (void*)m->xnode, (void*)m->nodesv, (void*)m->nattr4, (void*)m->nattr, (void*)m->f, (void*)m->agg,
+  for (void* b : {(void*)m->blob, (void*)m->ktab, (void*)m->xnode, (void*)m->nodesv, (void*)m->nattr4, (void*)m->nattr, (void*)m->f, (void*)m->agg,
                   (void*)m->tn[0], (void*)m->tn[1], (void*)m->eattr4, (void*)m->eattr, (void*)m->msgsv, (void*)m->te[0],
                   (void*)m->te[1], (void*)m->bn_part, (void*)m->bn_mean, (void*)m->bn_scale, (void*)m->bn_shift})
     if (b) (void)hipFree(b);
@@ -767,6 +775,7 @@ int lb_sgg_create(lb_engine* e, const lb_segnn_desc* d, const float* w, int64_t 
   const float* p = w;
   const float* pend = w + n_floats;
   bool short_blob = false, bad = false;
+  std::vector<int32_t> ktab_host;   // every block's channel tables, uploaded behind the float blob
   struct Op { std::vector<sgg_chunk> ch; int stride; };
   auto add_block = [&](const std::vector<Op>& ops, const std::vector<std::pair<int, int>>& outs /* (mul, l) ascending l */, int mode) {
     sgg_block b;
@@ -781,41 +790,53 @@ int lb_sgg_create(lb_engine* e, const lb_segnn_desc* d, const float* w, int64_t 
     a.xin_stride = lo + 4;
     a.attr_stride = m->La >= 2 ? 12 : 4;
     a.n_out = (int)outs.size();
-    int np = 0, yoff = 0, kmax4 = 4;
+    int yoff = 0, kmax4 = 32;
     for (int oi = 0; oi < a.n_out; ++oi) {
       sgg_out& O = a.out[oi];
       O.mul = outs[oi].first;
       O.l = outs[oi].second;
-      O.path0 = np;
       O.yoff = yoff;
       yoff += O.mul * (2 * O.l + 1);
+      // the channels of this irrep in e3nn's regrouped order (x chunk major, attribute l2 minor): one ktab entry each
       int K = 0;
+      std::vector<int32_t> kt;
       for (int o = 0; o < b.n_op; ++o)
         for (const sgg_chunk& c : ops[o].ch)
           for (int l2 = 0; l2 <= m->La; ++l2) {
             if (!sgg_path_ok(c.l, l2, O.l)) continue;
-            if (np >= SGG_MAX_PATH) { bad = true; return; }
-            int32_t* P = a.path[np++];
-            P[0] = a.op[o].lds_off + c.off; P[1] = c.cs; P[2] = c.ms; P[3] = c.l; P[4] = l2; P[5] = K; P[6] = c.mul;
-            P[7] = m_off[c.l][l2][O.l];
+            for (int u = 0; u < c.mul; ++u) {
+              kt.push_back(a.op[o].lds_off + c.off + u * c.cs);
+              kt.push_back(c.ms | ((2 * c.l + 1) << 12) | (m_off[c.l][l2][O.l] << 16));
+            }
             K += c.mul;
           }
-      O.n_path = np - O.path0;
       O.K = K;
-      O.K4 = (K + 3) & ~3;
+      O.K4 = (K + 31) & ~31;
       O.N16 = (O.mul + 15) & ~15;
       kmax4 = std::max(kmax4, O.K4);
+      kt.resize((size_t)2 * O.K4, 0);                      // padding channels: 2 l1 + 1 = 0 -> zeros
+      O.k_off = (int32_t)(ktab_host.size() / 2);
+      ktab_host.insert(ktab_host.end(), kt.begin(), kt.end());
       if (K == 0 || O.mul == 0) { O.w_off = 0; continue; }
       if (p + (size_t)K * O.mul > pend) { short_blob = true; return; }
+      // MFMA fragment order: [column tile nt][chunk c < nc + 2][q < 2][lane][i < 4] = W[32 c + 16 q + 4 i + (lane >> 4)][16 nt + (lane & 15)]
+      // (k-step j = 8 c + 4 q + i multiplies k = 4 j + kq); chunks nc, nc + 1 are zeros (look-ahead loads of the kernel)
+      const int nc = O.K4 / 32, ntl = O.N16 / 16;
       const size_t woff = (host.size() + 63) & ~(size_t)63;
-      host.resize(woff + (size_t)O.K4 * O.N16, 0.f);
+      host.resize(woff + (size_t)ntl * (nc + 2) * 512, 0.f);
       const float sc = 1.0f / sqrtf((float)K);   // e3nn Linear, "element" normalisation (A4)
-      for (int k = 0; k < K; ++k)
-        for (int c = 0; c < O.mul; ++c) host[woff + (size_t)k * O.N16 + c] = p[(size_t)k * O.mul + c] * sc;
+      for (int nt = 0; nt < ntl; ++nt)
+        for (int c = 0; c < nc; ++c)
+          for (int q = 0; q < 2; ++q)
+            for (int ln = 0; ln < 64; ++ln)
+              for (int i = 0; i < 4; ++i) {
+                const int k = 32 * c + 16 * q + 4 * i + (ln >> 4), n = 16 * nt + (ln & 15);
+                if (k < K && n < O.mul)
+                  host[woff + ((((size_t)nt * (nc + 2) + c) * 2 + q) * 64 + ln) * 4 + i] = p[(size_t)k * O.mul + n] * sc;
+              }
       O.w_off = (int64_t)woff;
       p += (size_t)K * O.mul;
     }
-    a.n_path_total = np;
     a.m0 = (a.n_out > 0 && a.out[0].l == 0) ? a.out[0].mul : 0;
     // bias (stored as an offset in `bias` until the blob is uploaded)
     size_t boff = (host.size() + 63) & ~(size_t)63;
@@ -829,7 +850,7 @@ int lb_sgg_create(lb_engine* e, const lb_segnn_desc* d, const float* w, int64_t 
     a.mode = mode;
     a.ys = yoff + 1;
     a.kmax4 = kmax4;
-    a.xs = ((kmax4 + 27) / 32) * 32 + 4;   // row stride of X: = 4 (mod 32), >= kmax4
+    a.xs = ((kmax4 + 63) / 64) * 64 + 4;   // row stride of X: = 4 (mod 64) - the 16 rows' 16-byte reads of an MFMA operand hit 64 distinct banks
     int d3max = 1;
     for (int oi = 0; oi < a.n_out; ++oi)
       if (a.out[oi].K > 0 && a.out[oi].mul > 0) d3max = std::max(d3max, 2 * a.out[oi].l + 1);
@@ -849,8 +870,8 @@ int lb_sgg_create(lb_engine* e, const lb_segnn_desc* d, const float* w, int64_t 
     a.cg_floats = m->cg_floats;
     a.ms = ms_total;
     for (int i = 0; i < ms_total; ++i) a.mdec[i] = mdec[(size_t)i];
-    b.lds_bytes = sizeof(float) * ((size_t)16 * a.xin_stride + 256 + ((a.cg_floats + 3) & ~3) + SGG_MAX_PATH * SGG_PATH_INTS + 48 +
-                                   a.kmax4 + (size_t)16 * ((ms_total + 3) & ~3) + a.x_floats + (size_t)16 * a.ys);
+    b.lds_bytes = sizeof(float) * ((size_t)16 * a.xin_stride + 256 + ((a.cg_floats + 3) & ~3) + 48 +
+                                   2 * a.kmax4 + (size_t)16 * ((ms_total + 3) & ~3) + a.x_floats + (size_t)16 * a.ys);
     m->blocks.push_back(b);
   };
   std::vector<std::pair<int, int>> hid_out, gate_out;
@@ -868,10 +889,6 @@ int lb_sgg_create(lb_engine* e, const lb_segnn_desc* d, const float* w, int64_t 
   }
   for (int i = 0; i < B && !bad && !short_blob; ++i) add_block({hop}, gate_out, SGG_GATE);
   if (!bad && !short_blob) add_block({hop}, {{1, 1}}, SGG_OUTVEC);
-  if (bad) {
-    lb_sgg_destroy(m);
-    return lb_fail(LB_ERR_UNSUPPORTED, "segnn: a tensor product with more than %d paths", SGG_MAX_PATH);
-  }
   // norm parameters
   if (!short_blob && m->norm) {
     const int nw = m->n * (m->Lh + 1), nb0 = m->n;
@@ -903,14 +920,19 @@ int lb_sgg_create(lb_engine* e, const lb_segnn_desc* d, const float* w, int64_t 
     lb_sgg_destroy(m);
     return lb_fail(LB_ERR_UNSUPPORTED, "segnn: a tensor product needs %zu bytes of LDS (<= 160 KiB)", max_lds);
   }
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sgg_tp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds) != hipSuccess) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(m->Lh >= 2 ? k_sgg_tp<512> : k_sgg_tp<256>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds) != hipSuccess) {
     lb_sgg_destroy(m);
     return lb_fail(LB_ERR_HIP, "hipFuncSetAttribute(k_sgg_tp, %zu bytes of LDS) failed", max_lds);
   }
   int rc = sgg_alloc(&m->blob, host.size());
   if (!rc && hipMemcpy(m->blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
     rc = lb_fail(LB_ERR_HIP, "weight upload failed");
+  if (!rc) rc = sgg_alloc(&m->ktab, ktab_host.size());
+  if (!rc && hipMemcpy(m->ktab, ktab_host.data(), ktab_host.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+    rc = lb_fail(LB_ERR_HIP, "table upload failed");
   for (sgg_block& b : m->blocks) {
+    b.a.ktab = m->ktab;
     b.a.w = m->blob;
     b.a.cg = m->blob;
     b.a.bias = m->blob + reinterpret_cast<size_t>(b.a.bias);

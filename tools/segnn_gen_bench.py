@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--case", default="dam2d")
     ap.add_argument("--layers", type=int, default=10)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", type=int, default=-1, help="index of the one configuration to run (for rocprofv3)")
     a = ap.parse_args()
     ds = make_case(a.case, n_trajs=1, extra_seq_length=2)
     ds.magnitude_features = True
@@ -33,7 +34,8 @@ def main():
     eng = feats.engine
     st = eng.stats()
     print(f"case {a.case}: N = {pos.shape[0]}, E = {st.get('n_edges', st)}, layers {a.layers}")
-    for lh, la, norm in [(1, 1, None), (1, 1, "instance"), (1, 1, "batch"), (2, 1, None), (1, 2, None), (2, 2, None), (2, 2, "batch")]:
+    cfgs = [(1, 1, None), (1, 1, "instance"), (1, 1, "batch"), (2, 1, None), (1, 2, None), (2, 2, None), (2, 2, "batch")]
+    for lh, la, norm in (cfgs if a.only < 0 else [cfgs[a.only]]):
         model = SEGNN(irr, "1x1o+1x0e", 64, lh, la, "1x1o", num_mp_steps=a.layers, n_vels=isl - 1, homogeneous_particles=homog, norm=norm)
         params = model.init_params(3)
         h = model.handle(eng, params)
