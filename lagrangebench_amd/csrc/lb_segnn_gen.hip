@@ -920,11 +920,16 @@ int lb_sgg_create(lb_engine* e, const lb_segnn_desc* d, const float* w, int64_t 
     lb_sgg_destroy(m);
     return lb_fail(LB_ERR_UNSUPPORTED, "segnn: a tensor product needs %zu bytes of LDS (<= 160 KiB)", max_lds);
   }
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(m->Lh >= 2 ? k_sgg_tp<512> : k_sgg_tp<256>),
+  // the attribute belongs to the kernel, not to this model: only ever raise it (several models may be alive)
+  static size_t lds_set[2] = {0, 0};
+  const int which = m->Lh >= 2 ? 1 : 0;
+  if (max_lds > lds_set[which] &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(which ? k_sgg_tp<512> : k_sgg_tp<256>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds) != hipSuccess) {
     lb_sgg_destroy(m);
     return lb_fail(LB_ERR_HIP, "hipFuncSetAttribute(k_sgg_tp, %zu bytes of LDS) failed", max_lds);
   }
+  lds_set[which] = std::max(lds_set[which], max_lds);
   int rc = sgg_alloc(&m->blob, host.size());
   if (!rc && hipMemcpy(m->blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
     rc = lb_fail(LB_ERR_HIP, "weight upload failed");

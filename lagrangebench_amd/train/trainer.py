@@ -63,6 +63,10 @@ class Trainer:
             raise NotImplementedError(
                 f"training is built for GNS with latent_size <= 128 and num_mlp_layers 2 (got latent_size "
                 f"{model._latent_size}, num_mlp_layers {model._blocks_per_step}); inference runs every size")
+        if getattr(model, "generic", False):
+            raise NotImplementedError("training is built for SEGNN in the shipped configuration (scalar_units 64, lmax_hidden = "
+                                      "lmax_attributes = 1, norm None); the other switches are inference-only "
+                                      "(csrc/lb_segnn_gen.hip)")
         if not hasattr(model, "train_handle"):
             raise NotImplementedError("Trainer: the model has no device training step (GNS: csrc/lb_train.hip, SEGNN: "
                                       "csrc/lb_train_segnn.h)")

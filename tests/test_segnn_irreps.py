@@ -178,7 +178,7 @@ def test_model_leaves_match_oracle_and_roundtrip():
 
 
 # ------------------------------------------------------------------------------- GPU
-def _gpu_setup(name, scale, L, lh, la, norm, blocks=2, units=64, seed=7):
+def _gpu_setup(name, scale, L, lh, la, norm, blocks=2, units=64, seed=7, velocity_aggregate="avg"):
     from lagrangebench_amd.data import make_case
     from lagrangebench_amd.models import SEGNN, node_irreps
     ds = make_case(name, n_trajs=2, extra_seq_length=6, scale=scale)
@@ -188,7 +188,7 @@ def _gpu_setup(name, scale, L, lh, la, norm, blocks=2, units=64, seed=7):
     has_force = ds.external_force_fn is not None
     irr = node_irreps(ds.metadata, isl, has_force, True, homog)
     model = SEGNN(irr, "1x1o+1x0e", units, lh, la, "1x1o", num_mp_steps=L, n_vels=isl - 1, homogeneous_particles=homog, norm=norm,
-                  blocks_per_step=blocks)
+                  blocks_per_step=blocks, velocity_aggregate=velocity_aggregate)
     xn = G.node_chunks(isl - 1, not any(ds.metadata["periodic_boundary_conditions"]), has_force, True, homog)
     assert xn == model._node_chunks
     params = G.segnn_init(np.random.default_rng(seed), xn, num_mp_steps=L, scalar_units=units, lmax_hidden=lh, lmax_attr=la,
@@ -253,6 +253,30 @@ def test_general_segnn_forward_parity(name, scale, L, lh, la, norm, blocks, unit
     again = _np(model.apply(params, {}, (feats, pt))[0]["acc"])
     assert np.array_equal(again, acc)
     handle.set_tap(False)
+
+
+@pytest.mark.gpu
+def test_general_segnn_velocity_last_and_two_models_on_one_engine():
+    """velocity_aggregate="last" (segnn.py:530-536) feeds the l <= 2 node attributes; and two general models of different LDS
+    footprints alive on one engine (the kernel's dynamic-LDS attribute is per kernel, not per model)."""
+    _need_gpu()
+    ds, model, params, homog = _gpu_setup("small3d", 1.0, 2, 2, 2, None, velocity_aggregate="last")
+    _, small, sparams, _ = _gpu_setup("small3d", 1.0, 1, 2, 1, None, units=16)
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    isl = ds.input_seq_length
+    pos, pt = ds[0]
+    feats, _ = hcase.allocate_eval((pos[None, :, :isl], pt[None]))
+    h_big = model.handle(feats.engine, params)
+    h_small = small.handle(feats.engine, sparams)       # created second, needs less LDS
+    of, _ = ocase.allocate_eval((pos[:, :isl].astype(np.float64), pt))
+    for m, p, agg in ((model, params, "last"), (small, sparams, "avg"), (model, params, "last")):
+        acc = _np(m.apply(p, {}, (feats, pt[None]))[0]["acc"])[0]
+        ref = G.segnn_apply(p, dict(of), pt, isl - 1, homog, velocity_aggregate=agg)["acc"]
+        assert rel_err(acc, ref) < 1e-5
+    with S.precision(np.float64):
+        avg = G.segnn_apply(params, dict(of), pt, isl - 1, homog, velocity_aggregate="avg")["acc"]
+    assert rel_err(avg, ref) > 1e-3      # the switch matters on this input
+    del h_big, h_small
 
 
 @pytest.mark.gpu
