@@ -117,7 +117,7 @@ def main():
         sample = (jnp.asarray(pos[:, :isl]), jnp.asarray(ptype))
         features, nbrs = case.allocate_eval(sample)
 
-        def dump(model_name, model_fn, fname):
+        def dump(model_name, model_fn, fname, extra=None):
             model = hk.without_apply_rng(hk.transform_with_state(model_fn))
             policy = jmp.get_policy("params=float32,compute=float32,output=float32")  # runner.py:71-72
             hk.mixed_precision.set_policy(getattr(models, model_name), policy)
@@ -134,6 +134,7 @@ def main():
             out = {"position": pos, "particle_type": ptype, "metadata_json": np.array(json.dumps(md)),
                    "idx": np.asarray(nbrs.idx), "acc": np.asarray(pred["acc"]), "next_position": np.asarray(nxt),
                    "rollout": np.asarray(roll)[0], "num_mp_steps": np.array(L)}
+            out.update(extra or {})
             for k, v in features.items():
                 out[f"feat//{k}"] = np.asarray(v)
             for k, v in _flatten(hk.data_structures.to_mutable_dict(params)).items():
@@ -147,11 +148,17 @@ def main():
         try:
             from e3nn_jax import Irreps
             irr = node_irreps(md, isl, False, False, False)
-            dump("SEGNN", lambda x: models.SEGNN(node_features_irreps=irr, edge_features_irreps=Irreps("1x1o + 1x0e"),
-                                                scalar_units=64, lmax_hidden=1, lmax_attributes=1,
-                                                output_irreps=Irreps("1x1o"), num_mp_steps=L, n_vels=isl - 1,
-                                                velocity_aggregate="avg", homogeneous_particles=False,
-                                                blocks_per_step=2, norm="none")(x), f"jax_segnn_{tag}.npz")
+            # the shipped switches, then the ones csrc/lb_segnn_gen.hip runs (round 5): lmax 2 (pins the SIGNS of the real 3j
+            # symbols and the l = 2 harmonics: oracle/segnn_irreps_oracle.py A7 - A9) and e3nn's BatchNorm as the reference
+            # calls it (A10: training-mode statistics, eps, instance = statistics over an axis of length one)
+            for suffix, lh, la, norm in (("", 1, 1, "none"), ("_l22", 2, 2, "none"), ("_l21", 2, 1, "none"),
+                                         ("_bn", 1, 1, "batch"), ("_in", 1, 1, "instance"), ("_l22bn", 2, 2, "batch")):
+                dump("SEGNN", lambda x, lh=lh, la=la, norm=norm: models.SEGNN(
+                    node_features_irreps=irr, edge_features_irreps=Irreps("1x1o + 1x0e"), scalar_units=64, lmax_hidden=lh,
+                    lmax_attributes=la, output_irreps=Irreps("1x1o"), num_mp_steps=L, n_vels=isl - 1,
+                    velocity_aggregate="avg", homogeneous_particles=False, blocks_per_step=2, norm=norm)(x),
+                     f"jax_segnn{suffix}_{tag}.npz", extra={"lmax_hidden": np.array(lh), "lmax_attributes": np.array(la),
+                                                           "norm": np.array(norm)})
         except ImportError as exc:
             print("e3nn_jax missing, SEGNN fixture skipped:", exc)
     extras(a, jax, jnp, hk, jmp, lagrangebench, models, NodeType)

@@ -122,23 +122,67 @@ def test_engine_matches_jax_reference_gns(path):
     assert torch.isfinite(pred).all()
 
 
+def _segnn_from_fixture(z, md, hk, isl=6):
+    """The fixture's SEGNN as this package's model + parameters, and the oracle evaluation of its forward pass: the lmax-1
+    oracle for the shipped switches, the general-irreps oracle (A7 - A10) for lmax 2 / norm (fixtures *_l22_*, *_bn_*, ..)."""
+    from lagrangebench_amd.models import SEGNN, node_irreps
+    from lagrangebench_amd.utils import segnn_params_from_haiku
+    L = int(z["num_mp_steps"])
+    lh = int(z["lmax_hidden"]) if "lmax_hidden" in z else 1
+    la = int(z["lmax_attributes"]) if "lmax_attributes" in z else 1
+    norm = str(z["norm"]) if "norm" in z else "none"
+    irr = node_irreps(md, isl, False, False, False)
+    model = SEGNN(irr, "1x1o+1x0e", 64, lh, la, "1x1o", num_mp_steps=L, n_vels=isl - 1, homogeneous_particles=False,
+                  norm=norm, blocks_per_step=2)
+    return model, segnn_params_from_haiku(hk, model)
+
+
+def _segnn_oracle_acc(model, params, feats, pt, isl=6):
+    if not model.generic:
+        from oracle import segnn_oracle as S
+        return S.segnn_apply(params, feats, pt, isl - 1, False)["acc"]
+    from oracle import segnn_irreps_oracle as G
+    p = dict(params)
+    p.update({"hidden": model.hidden_chunks(), "blocks": model._blocks_per_step, "layers": model._num_mp_steps,
+              "lmax_attr": model._lmax_attributes, "norm": {0: None, 1: "instance", 2: "batch"}[model._norm],
+              "x_node": model._node_chunks})
+    return G.segnn_apply(p, feats, pt, isl - 1, False, norm_eps=model.norm_eps)["acc"]
+
+
 @pytest.mark.parametrize("path", SEGNN_FILES or [None])
 def test_oracle_matches_jax_reference_segnn(path):
     if path is None:
         pytest.skip(NO_FIXTURE)
-    from lagrangebench_amd.utils import segnn_params_from_haiku
-    from oracle import segnn_oracle as S
     z, md, hk = _load(path)
-    L = int(z["num_mp_steps"])
     pos, pt = z["position"], z["particle_type"]
     isl = 6
     box = np.array([b[1] - b[0] for b in md["bounds"]])
     case = O.case_builder(box, md, isl, cfg_neighbors={"multiplier": 1.25},
                           cfg_model={"isotropic_norm": False, "magnitude_features": False}, noise_std=3e-4)
     feats, _ = case.allocate_eval((pos[:, :isl].astype(np.float64), pt))
-    params = segnn_params_from_haiku(hk, L)
-    acc = S.segnn_apply(params, feats, pt, isl - 1, False)["acc"]
-    assert rel_err(acc[:, :md["dim"]], z["acc"]) < 1e-5
+    model, params = _segnn_from_fixture(z, md, hk, isl)
+    acc = _segnn_oracle_acc(model, params, feats, pt, isl)
+    # (norm fixtures: the float32 evaluation itself is only ~1e-4-reproducible, tests/test_segnn_irreps.py)
+    assert rel_err(acc[:, :md["dim"]], z["acc"]) < (1e-5 if model._norm == 0 else 3e-4)
+
+
+def test_segnn_fixture_reader_on_a_synthetic_fixture():
+    """No JAX here, so the SEGNN consumer above has never seen a fixture: build one in the generator's format from this
+    package's own model (Haiku leaf names through segnn_params_to_haiku, the generator's "param//<module>//<leaf>" keys,
+    lmax / norm scalars) and check that the reader reconstructs model and parameters - for the shipped switches and for a
+    general one."""
+    from lagrangebench_amd.models import SEGNN, node_irreps
+    from lagrangebench_amd.utils import segnn_params_to_haiku
+    md = {"periodic_boundary_conditions": [True, True, True], "dim": 3}
+    irr = node_irreps(md, 6, False, False, False)
+    for lh, la, norm in ((1, 1, "none"), (2, 2, "batch")):
+        src = SEGNN(irr, "1x1o+1x0e", 64, lh, la, "1x1o", num_mp_steps=2, n_vels=5, homogeneous_particles=False, norm=norm)
+        params = src.init_params(1)
+        z = {"num_mp_steps": np.array(2), "lmax_hidden": np.array(lh), "lmax_attributes": np.array(la), "norm": np.array(norm)}
+        hk = segnn_params_to_haiku(params, src)
+        model, back = _segnn_from_fixture(z, md, hk)
+        assert model.generic == src.generic
+        assert np.array_equal(model.flatten(back), src.flatten(params))
 
 
 # ---------------------------------------------------------------------------------------------------- jax_extras.npz
