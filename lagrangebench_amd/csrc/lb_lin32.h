@@ -25,6 +25,7 @@
 // Every sum has a fixed order: bit-reproducible, and independent of which kernel (k_lin32 / k_lin32f) or grid ran it.
 #pragma once
 #include "lb_device.h"
+#include "lb_f16x2.h"
 
 struct lb_lin_args {
   const float* X;
@@ -51,6 +52,8 @@ struct lb_lin_args {
   // block's first Linear, [n_s | n_r | e] W0 + b0 with the two node-sized products gathered (k_edge_pre until round 5)
   const float *gat1, *gat2;
   const int32_t *gidx1, *gidx2;
+  // k_lin32h: 1 / (power-of-two scale the operand matrix was packed with), written by k_pack_wh
+  const float* wsc;
 };
 
 struct lb_pack_ent {    // one operand matrix of k_pack_w
@@ -289,6 +292,237 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         q += __shfl_xor(q, 16);
         q += __shfl_xor(q, 32);
         q -= (float)(128 - a.ln_d) * mean * mean;  // the padded columns hold 0 - mean
+        const float rs = 1.0f / sqrtf(q * inv_d + 1e-5f);
+        float* y1 = a.Yln ? a.Yln + row * 128 + 4 * kq : nullptr;
+        float* y2 = a.Y2 ? a.Y2 + row * 128 + 4 * kq : nullptr;
+#pragma unroll
+        for (int mb = 0; mb < NOB; ++mb) {
+          const f32x4 sc = sv[32 + 4 * mb], of = sv[64 + 4 * mb];
+          f32x4 y;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) y[jj] = sc[jj] * (acc[mb][jj] * rs) + of[jj];
+          if (y1) *reinterpret_cast<f32x4*>(y1 + 16 * mb) = y;
+          if (y2) *reinterpret_cast<f32x4*>(y2 + 16 * mb) = a.resid ? y + ep[mb] : y;
+        }
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < NOB; ++mb) {
+          f32x4 y = acc[mb];
+          if (has_bias) y = y + sv[4 * mb];
+          if (a.relu) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) y[jj] = fmaxf(y[jj], 0.f);
+          }
+          if (EPI == 1) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) y[jj] = ep[mb][jj] > 0.f ? y[jj] : 0.f;
+          } else if (EPI == 2) {
+            y = ep[mb] + y;
+          }
+          if (EPI == 4) {
+            y = ((acc[mb] + ep[mb]) + ep2[mb]) + sv[4 * mb];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) y[jj] = fmaxf(y[jj], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(yr + 16 * mb) = y;
+        }
+      }
+    }
+    xr = xnext;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_lin32h: the same product in f16x2 arithmetic - every fp32 operand is carried as an fp16 hi + lo pair on
+// v_mfma_f32_16x16x32_f16 (hi hi + hi lo + lo hi, fp32 accumulate: 96 MFMAs of 16 cycles per 16 x 128 x 128 tile instead of 256
+// of 32), which is what the inference kernels do (lb_edge16v.hip).  Inference protects the fp16 range with a guard and an fp32
+// redo; a training step cannot redo half a backward pass, and its operands (gradients of 1e-6, post-ReLU rows of any size) are
+// not O(1) - so the range is MADE safe instead: every 128-wide chunk of every row is multiplied by the power of two that puts
+// its largest entry into [1, 2) before it is split (exact), the chunk's product is accumulated on its own and joins the row's
+// fp32 total times the inverse power (exact); the operand matrix is packed times the power of two that puts ITS largest entry
+// into [1, 2) (k_pack_wh).  The error of a product term is then <= 2^-22 of (row-chunk maximum x matrix maximum), with no
+// dependence on the magnitudes themselves.  Layout, ring, epilogues: k_lin32f's.  LDS entry ((p * 8 + mb) * 2 + part) * 64 + lane
+// holds the eight halves W[32 p + {4 g .. 4 g + 3, 16 + 4 g .. 16 + 4 g + 3}][16 mb + (lane & 15)], g = lane >> 4, part 0 = hi,
+// 1 = lo (the k order inside a 32-block is free as long as both operands use it: this one makes the B operand of k-step p the
+// ring fragments 2 p and 2 p + 1 as they are).
+struct lb_pack_ent_h {  // one operand matrix of k_pack_wh
+  int64_t src, dst;     // float offsets into the weight blob / the packed blob (NP * NOB * 512 floats)
+  int NR, NO, ldw, trans;
+  int NP, NOB;
+  int64_t sc;           // float offset of this matrix' inverse scale in the scale array
+};
+__global__ void __launch_bounds__(256) k_pack_wh(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wsc,
+                                                 const lb_pack_ent_h* __restrict__ tab) {
+  __shared__ float s_m[256];
+  const lb_pack_ent_h e = tab[blockIdx.y];
+  const float* src = w + e.src;
+  // the matrix' largest magnitude (every block of the entry computes it for itself: <= 49 k elements)
+  float m = 0.f;
+  for (int idx = threadIdx.x; idx < e.NR * e.NO; idx += 256) {
+    const int k = idx / e.NO, c = idx - k * e.NO;
+    m = fmaxf(m, fabsf(e.trans ? src[(int64_t)c * e.ldw + k] : src[(int64_t)k * e.ldw + c]));
+  }
+  s_m[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s_m[threadIdx.x] = fmaxf(s_m[threadIdx.x], s_m[threadIdx.x + o]);
+    __syncthreads();
+  }
+  m = s_m[0];
+  unsigned ex = (__float_as_uint(m) >> 23) & 0xffu;
+  ex = m == 0.f ? 127u : (ex < 1u ? 1u : (ex > 253u ? 253u : ex));
+  const float s = __uint_as_float((254u - ex) << 23);
+  if (blockIdx.x == 0 && threadIdx.x == 0) wsc[e.sc] = __uint_as_float(ex << 23);
+  _Float16* dst = reinterpret_cast<_Float16*>(wp + e.dst);
+  const int total = e.NP * e.NOB * 512;   // (p, mb, lane, i)
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int i = idx & 7, ln = (idx >> 3) & 63, q = idx >> 9;
+    const int mb = q % e.NOB, p = q / e.NOB, g = ln >> 4;
+    const int k = 32 * p + (i < 4 ? 4 * g + i : 16 + 4 * g + (i - 4)), c = 16 * mb + (ln & 15);
+    float v = 0.f;
+    if (k < e.NR && c < e.NO) v = (e.trans ? src[(int64_t)c * e.ldw + k] : src[(int64_t)k * e.ldw + c]) * s;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const size_t base = ((size_t)(p * e.NOB + mb) * 2) * 64;
+    dst[(base + ln) * 8 + i] = hi;
+    dst[(base + 64 + ln) * 8 + i] = lo;
+  }
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lin32h(lb_lin_args a) {
+  constexpr int NOB = 8;
+  extern __shared__ f32x4 sWl[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const int NJ = a.NJ, nch = NJ >> 3;
+  const int64_t ntiles = (a.rows + 15) >> 4, tstep = (int64_t)gridDim.x * 8;
+  int64_t t = (int64_t)wave * gridDim.x + blockIdx.x;
+  auto row_ptr = [&](int64_t tt) -> const float* {
+    int64_t r = tt * 16 + n;
+    r = r < a.rows ? r : a.rows - 1;
+    return a.X + r * a.ldx + 4 * kq;
+  };
+  const float* xr = row_ptr(t);
+  f32x4 ring[8];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) ring[jj] = *reinterpret_cast<const f32x4*>(xr + 16 * jj);
+  f32x4* sV = sWl + NJ * NOB * 64;  // [32] bias, [32] scale, [32] offset
+  if (tid < 96) {
+    const float* src = tid < 32 ? a.bias : (tid < 64 ? a.ln_scale : a.ln_offset);
+    sV[tid] = (src && (EPI == 3 || tid < 32)) ? reinterpret_cast<const f32x4*>(src)[tid & 31] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  lb_lin_stage(sWl, a.Wp, NJ * NOB * 64, tid);
+  const float winv = *a.wsc;
+  __syncthreads();
+  const bool has_bias = a.bias != nullptr;
+  int gi1 = 0, gi2 = 0;
+  if (EPI == 4) {
+    int64_t r = t * 16 + n;
+    r = r < a.rows ? r : a.rows - 1;
+    gi1 = a.gidx1[r];
+    gi2 = a.gidx2[r];
+  }
+  const h8* sw0 = reinterpret_cast<const h8*>(sWl) + lane;
+  const f32x4* sv = sV + kq;
+  for (; t < ntiles; t += tstep) {
+    const int64_t row = t * 16 + n;
+    const bool live = row < a.rows;
+    const int64_t rowc = live ? row : a.rows - 1;
+    const float* xnext = row_ptr(t + tstep);
+    f32x4 ep[NOB], ep2[EPI == 4 ? NOB : 1];
+    if (EPI == 1) {
+      const float* mr = a.mask + rowc * a.ldm + 4 * kq;
+#pragma unroll
+      for (int mb = 0; mb < NOB; ++mb) ep[mb] = *reinterpret_cast<const f32x4*>(mr + 16 * mb);
+    } else if (EPI == 2) {
+      const float* yo = a.Y + rowc * a.ldy + 4 * kq;
+#pragma unroll
+      for (int mb = 0; mb < NOB; ++mb) ep[mb] = *reinterpret_cast<const f32x4*>(yo + 16 * mb);
+    } else if (EPI == 4) {
+      const float *p1 = a.gat1 + (int64_t)gi1 * 128 + 4 * kq, *p2 = a.gat2 + (int64_t)gi2 * 128 + 4 * kq;
+#pragma unroll
+      for (int mb = 0; mb < NOB; ++mb) {
+        ep[mb] = *reinterpret_cast<const f32x4*>(p1 + 16 * mb);
+        ep2[mb] = *reinterpret_cast<const f32x4*>(p2 + 16 * mb);
+      }
+      int64_t rn = (t + tstep) * 16 + n;
+      rn = rn < a.rows ? rn : a.rows - 1;
+      gi1 = a.gidx1[rn];
+      gi2 = a.gidx2[rn];
+    } else if (EPI == 3) {
+      if (a.resid) {
+        const float* rr = a.resid + rowc * 128 + 4 * kq;
+#pragma unroll
+        for (int mb = 0; mb < NOB; ++mb) ep[mb] = *reinterpret_cast<const f32x4*>(rr + 16 * mb);
+      }
+    }
+    f32x4 acc[NOB];   // the row's total over its chunks, in true units
+#pragma unroll
+    for (int mb = 0; mb < NOB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int jc = 0; jc < nch; ++jc) {
+      // the chunk's largest magnitude over the row (this lane's 32 values, then the four lanes of the row)
+      float m = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m = fmaxf(m, fabsf(ring[jj][i]));
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      unsigned ex = (__float_as_uint(m) >> 23) & 0xffu;
+      ex = m == 0.f ? 127u : (ex < 1u ? 1u : (ex > 253u ? 253u : ex));
+      const float s = __uint_as_float((254u - ex) << 23), inv = __uint_as_float(ex << 23) * winv;
+      h8 hi[4], lo[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) lb_split8v(ring[2 * p] * s, ring[2 * p + 1] * s, hi[p], lo[p]);
+      // the ring is free: the next chunk (or the next tile's first) is requested before the first MFMA of this one
+      const float* nx = jc + 1 < nch ? xr + 128 * (jc + 1) : xnext;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) ring[jj] = *reinterpret_cast<const f32x4*>(nx + 16 * jj);
+      f32x4 part[NOB];
+#pragma unroll
+      for (int mb = 0; mb < NOB; ++mb) part[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const h8* sw = sw0 + (size_t)(jc * 4) * NOB * 2 * 64;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int mb = 0; mb < NOB; ++mb) {
+          const h8 wh = sw[((p * NOB + mb) * 2) * 64], wl = sw[((p * NOB + mb) * 2 + 1) * 64];
+          part[mb] = MFMA16H(wh, hi[p], part[mb]);
+          part[mb] = MFMA16H(wh, lo[p], part[mb]);
+          part[mb] = MFMA16H(wl, hi[p], part[mb]);
+        }
+      }
+#pragma unroll
+      for (int mb = 0; mb < NOB; ++mb)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[mb][jj] += part[mb][jj] * inv;
+    }
+    if (live) {
+      float* yr = a.Y + row * a.ldy + 4 * kq;
+      if (EPI == 3) {
+        float s = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < NOB; ++mb) {
+          *reinterpret_cast<f32x4*>(yr + 16 * mb) = acc[mb];
+          acc[mb] = acc[mb] + sv[4 * mb];
+          s += (acc[mb][0] + acc[mb][1]) + (acc[mb][2] + acc[mb][3]);
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const float inv_d = 1.f / (float)a.ln_d;
+        const float mean = s * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < NOB; ++mb) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[mb][jj] -= mean;
+          q += (acc[mb][0] * acc[mb][0] + acc[mb][1] * acc[mb][1]) + (acc[mb][2] * acc[mb][2] + acc[mb][3] * acc[mb][3]);
+        }
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        q -= (float)(128 - a.ln_d) * mean * mean;
         const float rs = 1.0f / sqrtf(q * inv_d + 1e-5f);
         float* y1 = a.Yln ? a.Yln + row * 128 + 4 * kq : nullptr;
         float* y2 = a.Y2 ? a.Y2 + row * 128 + 4 * kq : nullptr;

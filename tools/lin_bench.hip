@@ -60,6 +60,15 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&Y2, rows * 128 * 4 * 2));
   int bad = 0;
   CK(hipFuncSetAttribute((const void*)k_lin32g, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_lin32h<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_lin32h<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_lin32h<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_lin32h<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_lin32h<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  lb_pack_ent_h* tabh;
+  float* wsc;
+  CK(hipMalloc(&tabh, sizeof(lb_pack_ent_h)));
+  CK(hipMalloc(&wsc, 64));
   // mode: 0 plain, 1 bias + relu, 2 mask, 3 accum, 4 LayerNorm + residual, 5 two gathers + bias + relu (4, 5: fast only);  fast: use k_lin32f
   auto run = [&](const char* name, int NR, int NO, int trans, int mode, int64_t r, int fast) {
     const int nob = NO <= 16 ? 1 : 8, nj = (NR + 15) / 16;
@@ -76,12 +85,24 @@ int main(int argc, char** argv) {
       a.bias = W; a.ln_scale = W + 128; a.ln_offset = W + 256; a.resid = M; a.Yln = Y2; a.Y2 = Y2 + r * 128; a.ln_d = 128;
     }
     if (fast == 2) hipLaunchKernelGGL(k_pack_w32, dim3(16), dim3(256), 0, 0, W, Wp, NR, NO, trans ? NR : NO, trans);
+    if (fast == 3) {   // f16x2: the operand as fp16 hi / lo fragments times a power of two
+      lb_pack_ent_h ph{0, 0, NR, NO, trans ? NR : NO, trans, NR / 32, nob, 0};
+      CK(hipMemcpy(tabh, &ph, sizeof(ph), hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(k_pack_wh, dim3(16, 1), dim3(256), 0, 0, W, Wp, wsc, tabh);
+      a.wsc = wsc;
+    }
     const size_t lds = fast == 2 ? (size_t)(NR / 8) * 4 * 64 * 16 : (size_t)nj * nob * 64 * 16 + (fast ? 96 * 16 : 0);
     const int64_t tiles = (r + 15) / 16;
     const int grid = (int)std::min<int64_t>(fast == 2 ? (r + 31) / 32 : tiles, 256);
     auto go = [&] {
       if (fast == 2) hipLaunchKernelGGL(k_lin32g, dim3(grid), dim3(512), lds, 0, a);
-      else if (fast) {
+      else if (fast == 3) {
+        if (mode == 5) hipLaunchKernelGGL((k_lin32h<4>), dim3(grid), dim3(512), lds, 0, a);
+        else if (mode == 4) hipLaunchKernelGGL((k_lin32h<3>), dim3(grid), dim3(512), lds, 0, a);
+        else if (mode == 2) hipLaunchKernelGGL((k_lin32h<1>), dim3(grid), dim3(512), lds, 0, a);
+        else if (mode == 3) hipLaunchKernelGGL((k_lin32h<2>), dim3(grid), dim3(512), lds, 0, a);
+        else hipLaunchKernelGGL((k_lin32h<0>), dim3(grid), dim3(512), lds, 0, a);
+      } else if (fast) {
         if (mode == 5) hipLaunchKernelGGL((k_lin32f<4>), dim3(grid), dim3(512), lds, 0, a);
         else if (mode == 4) hipLaunchKernelGGL((k_lin32f<3>), dim3(grid), dim3(512), lds, 0, a);
         else if (mode == 2) hipLaunchKernelGGL((k_lin32f<1>), dim3(grid), dim3(512), lds, 0, a);
@@ -152,7 +173,7 @@ int main(int argc, char** argv) {
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = 1e3 * ms / it, tf = 2.0 * r * NR * NO / (us * 1e-6) / 1e12;
-    printf("%-8s %-40s rows %7lld  %8.2f us  %6.1f TFLOP/s (%.2f of 157)  err %.1e %s\n", fast == 2 ? "lin32g" : (fast ? "lin32f" : "lin32"), name,
+    printf("%-8s %-40s rows %7lld  %8.2f us  %6.1f TFLOP/s (%.2f of 157)  err %.1e %s\n", fast == 3 ? "lin32h" : fast == 2 ? "lin32g" : (fast ? "lin32f" : "lin32"), name,
            (long long)r, us, tf, tf / 157.3, worst, worst < 2e-6 ? "" : "WRONG");
   };
   for (int rep = 0; rep < 2; ++rep) {
@@ -168,6 +189,17 @@ int main(int argc, char** argv) {
       run("Y = X W      128 x 128 (node sized)", 128, 128, 0, 0, nrows, fast);
       run("Y = X W      128 x 128 (odd rows)", 128, 128, 0, 3, nrows * 3 + 5, fast);
     }
+    // f16x2 (k_lin32h): same shapes, same fp64 check
+    run("Y = X W      128 x 128", 128, 128, 0, 0, rows, 3);
+    run("Y = X W      128 x 128 + bias + relu", 128, 128, 0, 1, rows, 3);
+    run("dX = dY W^T  128 x 128 * mask", 128, 128, 1, 2, rows, 3);
+    run("dX += dY W^T 128 x 128", 128, 128, 1, 3, rows, 3);
+    run("Y = LN(X W + b) + resid  128 x 128", 128, 128, 0, 4, rows, 3);
+    run("Y = LN(X W + b) + resid  (odd rows)", 128, 128, 0, 4, nrows * 3 + 5, 3);
+    run("Y = relu(X W + G1[i1] + G2[i2] + b)", 128, 128, 0, 5, rows, 3);
+    run("Y = X W      256 x 128 (node sized)", 256, 128, 0, 1, nrows, 3);
+    run("Y = X W      128 x 128 (node sized)", 128, 128, 0, 0, nrows, 3);
+    run("Y = X W      128 x 128 (odd rows)", 128, 128, 0, 3, nrows * 3 + 5, 3);
     run("Y = X W      128 x 128 [32x32x2 experiment]", 128, 128, 0, 0, rows, 2);
     run("Y = X W + b, relu [32x32x2 experiment]", 128, 128, 0, 1, rows, 2);
     run("Y = X W      256 x 128 [32x32x2 experiment]", 256, 128, 0, 1, nrows * 3 + 5, 2);
