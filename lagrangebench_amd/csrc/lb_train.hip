@@ -55,6 +55,12 @@ struct lb_red_ent {
   int blk0, pad;    // first block of this reduction in the flat grid (64 outputs per block)
 };
 
+// LB_TRAIN_MATH=f32: the exact-fp32 product kernels (k_lin32f); default: f16x2 (k_lin32h)
+static bool lb_train_f16x2_default() {
+  const char* m = getenv("LB_TRAIN_MATH");
+  return !(m && (m[0] == 'f' && m[1] == '3'));
+}
+
 struct lb_sgt;  // SEGNN-specific state of a training handle (lb_train_segnn.h)
 
 struct lb_gns_train {
@@ -103,6 +109,12 @@ struct lb_gns_train {
   lb_pack_ent* pack_dev = nullptr;
   float* wpack = nullptr;
   int64_t wpack_floats = 0, wpack_cap = 0;
+  // f16x2 arithmetic of the tall-skinny products (k_lin32h, round 5): fp16 hi / lo fragments of the operand matrices in the
+  // same packed blob + one inverse power-of-two scale per matrix.  LB_TRAIN_MATH=f32 keeps the exact-fp32 kernels.
+  bool f16x2 = lb_train_f16x2_default();
+  std::vector<lb_pack_ent_h> pack_tab_h;
+  lb_pack_ent_h* pack_dev_h = nullptr;
+  float* wsc = nullptr;
 };
 #define LB_PACK_MAX 1024
 
@@ -550,10 +562,48 @@ static int pack_lookup(lb_gns_train* t, const float* W, int NR, int NO, int ldw,
   *out = t->wpack + e.dst;
   return LB_OK;
 }
+// the same for k_lin32h: fp16 hi / lo fragments times the matrix' power-of-two scale (k_pack_wh)
+static int pack_lookup_h(lb_gns_train* t, const float* W, int NR, int NO, int ldw, int trans, const float** out, const float** wsc) {
+  const int64_t src = W - t->w;
+  if (src < 0 || src >= t->n_floats) return lb_fail(LB_ERR_STATE, "k_lin32h operand outside the weight blob");
+  for (const lb_pack_ent_h& e : t->pack_tab_h)
+    if (e.src == src && e.NR == NR && e.NO == NO && e.ldw == ldw && e.trans == trans) {
+      *out = t->wpack + e.dst;
+      *wsc = t->wsc + e.sc;
+      return LB_OK;
+    }
+  if (!t->wpack) {
+    t->wpack_cap = 2 * t->n_floats + ((int64_t)1 << 21);
+    LB_TRY(lb_alloc(&t->wpack, (size_t)t->wpack_cap));
+    LB_TRY(lb_alloc(&t->pack_dev, (size_t)LB_PACK_MAX));
+  }
+  if (!t->pack_dev_h) {
+    LB_TRY(lb_alloc(&t->pack_dev_h, (size_t)LB_PACK_MAX));
+    LB_TRY(lb_alloc(&t->wsc, (size_t)LB_PACK_MAX));
+  }
+  lb_pack_ent_h e{};
+  e.src = src; e.dst = t->wpack_floats; e.NR = NR; e.NO = NO; e.ldw = ldw; e.trans = trans;
+  e.NP = NR / 32; e.NOB = 8; e.sc = (int64_t)t->pack_tab_h.size();
+  const int64_t n = (int64_t)e.NP * e.NOB * 512;
+  if (t->wpack_floats + n > t->wpack_cap || t->pack_tab_h.size() >= LB_PACK_MAX)
+    return lb_fail(LB_ERR_STATE, "k_lin32h: packed operand table is full");
+  const size_t idx = t->pack_tab_h.size();
+  t->pack_tab_h.push_back(e);
+  t->wpack_floats += n;
+  LB_HIP(hipMemcpyAsync(t->pack_dev_h + idx, &t->pack_tab_h[idx], sizeof(lb_pack_ent_h), hipMemcpyHostToDevice, t->eng->stream));
+  LB_HIP(hipStreamSynchronize(t->eng->stream));  // (the vector may move; first step only)
+  hipLaunchKernelGGL(k_pack_wh, dim3(16, 1), dim3(256), 0, t->eng->stream, t->w, t->wpack, t->wsc, t->pack_dev_h + idx);
+  *out = t->wpack + e.dst;
+  *wsc = t->wsc + e.sc;
+  return LB_OK;
+}
 // every registered operand, from the current weights (the optimiser / lb_gns_train_write changed them)
 static void pack_all(lb_gns_train* t) {
-  if (t->pack_tab.empty()) return;
-  hipLaunchKernelGGL(k_pack_w, dim3(16, (unsigned)t->pack_tab.size()), dim3(256), 0, t->eng->stream, t->w, t->wpack, t->pack_dev);
+  if (!t->pack_tab.empty())
+    hipLaunchKernelGGL(k_pack_w, dim3(16, (unsigned)t->pack_tab.size()), dim3(256), 0, t->eng->stream, t->w, t->wpack, t->pack_dev);
+  if (!t->pack_tab_h.empty())
+    hipLaunchKernelGGL(k_pack_wh, dim3(16, (unsigned)t->pack_tab_h.size()), dim3(256), 0, t->eng->stream, t->w, t->wpack, t->wsc,
+                       t->pack_dev_h);
 }
 // Y[rows x NO] = X[rows x NR] * Wop (+ epilogue) on k_lin32 / k_lin32f; a.Wp is filled in here
 static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int trans) {
@@ -562,12 +612,14 @@ static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int tr
   const int nob = a.NO <= 16 ? 1 : (a.NO <= 64 ? 4 : 8);  // 16-column output blocks per wave (generic kernel)
   a.NJ = (a.NR + 15) / 16;
   size_t lds = (size_t)a.NJ * nob * 64 * sizeof(f32x4);
-  LB_TRY(pack_lookup(t, W, a.NR, a.NO, ldw, trans, nob, &a.Wp));
   const int64_t tiles = (a.rows + 15) / 16;
   const int grid = (int)std::min<int64_t>(tiles, 256);  // one workgroup per CU; tile t -> workgroup t % grid first
   hipStream_t s = t->eng->stream;
   const bool fast = a.NO == 128 && (a.NR & 127) == 0 && (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && (!a.mask || (a.ldm & 3) == 0) &&
                     !(a.mask && a.accum) && (((uintptr_t)a.bias | (uintptr_t)a.ln_scale | (uintptr_t)a.ln_offset) & 15) == 0;
+  const bool half = fast && t->f16x2;
+  if (half) LB_TRY(pack_lookup_h(t, W, a.NR, a.NO, ldw, trans, &a.Wp, &a.wsc));
+  else LB_TRY(pack_lookup(t, W, a.NR, a.NO, ldw, trans, nob, &a.Wp));
   if (a.gat1 && (!fast || a.mask || a.accum || a.ln_scale || !a.bias))
     return lb_fail(LB_ERR_UNSUPPORTED, "k_lin32: gather epilogue on a %d x %d operand", a.NR, a.NO);
   if (a.ln_scale && (!fast || a.mask || a.accum || a.relu))
@@ -582,7 +634,13 @@ static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int tr
     }                                                                                                                        \
     hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(512), lds, s, a);                                                            \
   } while (0)
-  if (fast) {
+  if (half) {
+    if (a.gat1) LB_LIN_GO(k_lin32h<4>);
+    else if (a.ln_scale) LB_LIN_GO(k_lin32h<3>);
+    else if (a.mask) LB_LIN_GO(k_lin32h<1>);
+    else if (a.accum) LB_LIN_GO(k_lin32h<2>);
+    else LB_LIN_GO(k_lin32h<0>);
+  } else if (fast) {
     if (a.gat1) LB_LIN_GO(k_lin32f<4>);
     else if (a.ln_scale) LB_LIN_GO(k_lin32f<3>);
     else if (a.mask) LB_LIN_GO(k_lin32f<1>);
@@ -1038,7 +1096,7 @@ extern "C" void lb_gns_train_destroy(lb_gns_train* t) {
   std::vector<void*> bufs = {t->w, t->g, t->m, t->v, t->xnode, t->a_en, t->z_en, t->a_ee, t->z_ee, t->a_d, t->pred,
                              t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->dwpart, t->red_dev, t->proj, t->node_w,
                              t->loss_dev, t->loss_part, t->cnt_dev, t->snd_key, t->snd_perm, t->iota, t->snd_ptr, t->sort_tmp,
-                             t->wpack, t->pack_dev};
+                             t->wpack, t->pack_dev, t->pack_dev_h, t->wsc};
   for (auto* v : {&t->nlat, &t->elat, &t->ae, &t->ze, &t->xn, &t->an, &t->zn})
     for (float* p : *v) bufs.push_back(p);
   for (void* b : bufs)
