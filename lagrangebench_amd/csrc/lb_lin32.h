@@ -359,9 +359,12 @@ __global__ void __launch_bounds__(256) k_pack_wh(const float* __restrict__ w, fl
   const float* src = w + e.src;
   // the matrix' largest magnitude (every block of the entry computes it for itself: <= 49 k elements)
   float m = 0.f;
-  for (int idx = threadIdx.x; idx < e.NR * e.NO; idx += 256) {
-    const int k = idx / e.NO, c = idx - k * e.NO;
-    m = fmaxf(m, fabsf(e.trans ? src[(int64_t)c * e.ldw + k] : src[(int64_t)k * e.ldw + c]));
+  {   // in memory order (the maximum does not care which way the matrix is read): rows of ldw floats, `cols` used
+    const int rows_m = e.trans ? e.NO : e.NR, cols = e.trans ? e.NR : e.NO;
+    const int tpr = cols >= 256 ? 256 : (cols >= 128 ? 128 : (cols >= 64 ? 64 : 32)), rpi = 256 / tpr;
+    const int c0 = threadIdx.x % tpr, r0 = threadIdx.x / tpr;
+    for (int r = r0; r < rows_m; r += rpi)
+      for (int c = c0; c < cols; c += tpr) m = fmaxf(m, fabsf(src[(int64_t)r * e.ldw + c]));
   }
   s_m[threadIdx.x] = m;
   __syncthreads();

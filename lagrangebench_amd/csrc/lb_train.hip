@@ -222,6 +222,118 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (kk == 0) *reinterpret_cast<f32x4*>(out + K * 128 + 64 * mh + 4 * i) = bs;
   }
 }
+// ---- the same contraction in f16x2 arithmetic (round 5, second half; K a multiple of 128: every processor / decoder Linear).
+// dW = X^T dY reduces over the ROWS, so the fp16 operands of v_mfma_f32_16x16x32_f16 hold eight consecutive rows of ONE column:
+// a transpose of the row-major operands.  It goes through LDS, fused with the hi / lo split: thread (g, c) of the workgroup
+// loads the eight rows 8 g .. 8 g + 7 of column c of X and of dY of a 32-row step (each load instruction of a wave is 256
+// contiguous bytes of one row), splits them once - no wave repeats another's conversion - and stores them as two 16-byte
+// fragments per matrix, exactly the registers the MFMA wants: entry (tile * 2 + part) * 64 + (c & 15) + 16 g.  Wave (ah, bq)
+// multiplies the four tiles of X-column half ah with the two tiles of dY-column quarter bq: 24 MFMAs per step and wave,
+// 12 16-byte LDS reads; LDS double-buffered, one barrier per step; the next step's global loads are in flight meanwhile.
+// Range: X (activations) is split as it is; dY (gradients of any size) is multiplied by the power of two that puts the
+// largest |dY| of THIS workgroup's row chunk into [1, 2) - found in a first pass over the chunk (it is read again from L2 /
+// Infinity Cache) - and the partial result by its inverse: error <= 2^-22 of (|x| x chunk maximum of |dY|) per term, the
+// bound a global scale gives; rows far below their chunk's maximum contribute with less relative precision and
+// correspondingly little weight.  grid (G, K / 128); block (g, a) forms rows 128 a .. 128 a + 127 of part[g] and, for a = 0,
+// the column sums of dY (exact fp32 sums of the unscaled values).
+__global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, int ldx, int K, const float* __restrict__ dY,
+                                                   int64_t rows, int64_t chunk, float* __restrict__ part) {
+  __shared__ h8 sAB[2][2][1024];   // [buffer][A | B][(tile * 2 + part) * 64 + lane]: 64 KiB
+  float* red = reinterpret_cast<float*>(&sAB[0][0][0]);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = tid & 127, g = tid >> 7;
+  const int ablk = blockIdx.y;
+  X += 128 * ablk;
+  const int64_t r_begin = (int64_t)blockIdx.x * chunk, r_end = r_begin + chunk < rows ? r_begin + chunk : rows;
+  // pass 0: the chunk's largest |dY|
+  float m = 0.f;
+  {
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(dY + r_begin * 128);
+    const int64_t n4 = (r_end - r_begin) * 32;
+    for (int64_t i = tid; i < n4; i += 512) {
+      const f32x4 v = y4[i];
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+  }
+  red[tid] = m;
+  __syncthreads();
+  for (int o = 256; o > 0; o >>= 1) {
+    if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+    __syncthreads();
+  }
+  m = red[0];
+  __syncthreads();
+  unsigned ex = (__float_as_uint(m) >> 23) & 0xffu;
+  ex = m == 0.f ? 127u : (ex < 1u ? 1u : (ex > 253u ? 253u : ex));
+  const float sc = __uint_as_float((254u - ex) << 23), inv = __uint_as_float(ex << 23);
+
+  float xn[8], yn[8];
+  auto fetch = [&](int64_t r0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int64_t r = r0 + 8 * g + t;
+      const bool ok = r < r_end;
+      xn[t] = ok ? X[r * ldx + c] : 0.f;
+      yn[t] = ok ? dY[r * 128 + c] : 0.f;
+    }
+  };
+  fetch(r_begin);
+  const int ah = wave & 1, bq = wave >> 1;
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) acc[ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const int wslot = ((c >> 4) * 2) * 64 + (c & 15) + 16 * g;
+  int buf = 0;
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 32, buf ^= 1) {
+    f32x4 x0 = {xn[0], xn[1], xn[2], xn[3]}, x1 = {xn[4], xn[5], xn[6], xn[7]};
+    f32x4 y0 = {yn[0], yn[1], yn[2], yn[3]}, y1 = {yn[4], yn[5], yn[6], yn[7]};
+    fetch(r0 + 32);
+    bsum += (((y0[0] + y0[1]) + (y0[2] + y0[3])) + ((y1[0] + y1[1]) + (y1[2] + y1[3])));
+    h8 xh, xl, yh, yl;
+    lb_split8v(x0, x1, xh, xl);
+    lb_split8v(y0 * sc, y1 * sc, yh, yl);
+    sAB[buf][0][wslot] = xh;
+    sAB[buf][0][wslot + 64] = xl;
+    sAB[buf][1][wslot] = yh;
+    sAB[buf][1][wslot + 64] = yl;
+    __syncthreads();
+    h8 bh[2], bl[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+      bh[tb] = sAB[buf][1][((2 * bq + tb) * 2) * 64 + lane];
+      bl[tb] = sAB[buf][1][((2 * bq + tb) * 2 + 1) * 64 + lane];
+    }
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta) {
+      const h8 ahh = sAB[buf][0][((4 * ah + ta) * 2) * 64 + lane], all_ = sAB[buf][0][((4 * ah + ta) * 2 + 1) * 64 + lane];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+        acc[ta][tb] = MFMA16H(ahh, bh[tb], acc[ta][tb]);
+        acc[ta][tb] = MFMA16H(ahh, bl[tb], acc[ta][tb]);
+        acc[ta][tb] = MFMA16H(all_, bh[tb], acc[ta][tb]);
+      }
+    }
+  }
+  // D[i][j] of tile (ta, tb): lane (j = lane & 15, 4 (lane >> 4) + v = i): X column 16 (4 ah + ta) + i, dY column 16 (2 bq + tb) + j
+  float* out = part + (int64_t)blockIdx.x * (K + 1) * 128 + (int64_t)128 * ablk * 128;
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        out[(16 * (4 * ah + ta) + 4 * (lane >> 4) + v) * 128 + 16 * (2 * bq + tb) + (lane & 15)] = acc[ta][tb][v] * inv;
+  if (ablk == 0) {
+    __syncthreads();   // (the last step's fragments have been read)
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < 128)
+      part[(int64_t)blockIdx.x * (K + 1) * 128 + (int64_t)K * 128 + tid] = ((red[tid] + red[128 + tid]) + red[256 + tid]) + red[384 + tid];
+  }
+}
 // Ordered sum of partials: out e < n0: dst0[e] += sum_g part[g * stride + e]; n0 <= e < n0 + n1: dst1[e - n0] += sum_g
 // part[g * stride + off1 + e - n0].  A 1024-thread block owns 64 outputs x 16 ranges of g (four loads in flight per thread,
 // added in ascending g), the 16 range sums are combined in range order through LDS: the result does not depend on timing.
@@ -753,7 +865,9 @@ static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx
   if (!part) return false;
 #define DW_GO(NA, DEPTH) hipLaunchKernelGGL((k_dw_part<NA, DEPTH>), dim3(G), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part)
   const bool deep = chunk >= 192;
-  if (K <= 128) { if (deep) DW_GO(1, 12); else DW_GO(1, 6); }
+  if (t->f16x2 && (K & 127) == 0)
+    hipLaunchKernelGGL(k_dw_part_h, dim3((unsigned)G, (unsigned)(K / 128)), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part);
+  else if (K <= 128) { if (deep) DW_GO(1, 12); else DW_GO(1, 6); }
   else if (K <= 256) { if (deep) DW_GO(2, 8); else DW_GO(2, 6); }
   else DW_GO(3, 4);
 #undef DW_GO
