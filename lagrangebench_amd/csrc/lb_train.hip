@@ -250,7 +250,15 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
   {
     const f32x4* y4 = reinterpret_cast<const f32x4*>(dY + r_begin * 128);
     const int64_t n4 = (r_end - r_begin) * 32;
-    for (int64_t i = tid; i < n4; i += 512) {
+    int64_t i = tid;
+    for (; i + 7 * 512 < n4; i += 8 * 512) {   // eight loads in flight per thread
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = y4[i + u * 512];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u][0]), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3]))));
+    }
+    for (; i < n4; i += 512) {
       const f32x4 v = y4[i];
       m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     }
@@ -267,17 +275,33 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
   ex = m == 0.f ? 127u : (ex < 1u ? 1u : (ex > 253u ? 253u : ex));
   const float sc = __uint_as_float((254u - ex) << 23), inv = __uint_as_float(ex << 23);
 
-  float xn[8], yn[8];
-  auto fetch = [&](int64_t r0) {
+  // three steps' operands in flight (16 dwords per step and thread): one step of compute does not cover the HBM latency.
+  // Addressing costs no VALU: a load is (uniform base of the step) + (this thread's row offset, computed once); the main loop
+  // runs over the FULL 32-row steps only - no clamp, no mask, no branch inside its body (a select behind a load waits for
+  // the load, a branch inside the unrolled body makes the compiler wait for every outstanding load: both were measured) -
+  // look-ahead fetches past the last full step re-read that step (unused); the chunk's last n % 32 rows are one masked step
+  // after the loop.
+  const int64_t n = r_end - r_begin;
+  const int full = (int)(n >> 5);
+  const float* Xc = X + r_begin * ldx + c;
+  const float* Yc = dY + r_begin * 128 + c;
+  int xo[8], yo[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    xo[t] = (8 * g + t) * ldx;
+    yo[t] = (8 * g + t) * 128;
+  }
+  float xq[3][8], yq[3][8];
+  auto fetch = [&](int step, float (&xv)[8], float (&yv)[8]) {
+    const int st = step < full ? step : (full > 0 ? full - 1 : 0);   // (uniform)
+    const float* xb = Xc + (int64_t)st * 32 * ldx;
+    const float* yb = Yc + (int64_t)st * 32 * 128;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const int64_t r = r0 + 8 * g + t;
-      const bool ok = r < r_end;
-      xn[t] = ok ? X[r * ldx + c] : 0.f;
-      yn[t] = ok ? dY[r * 128 + c] : 0.f;
+      xv[t] = xb[xo[t]];
+      yv[t] = yb[yo[t]];
     }
   };
-  fetch(r_begin);
   const int ah = wave & 1, bq = wave >> 1;
   f32x4 acc[4][2];
 #pragma unroll
@@ -287,10 +311,7 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
   float bsum = 0.f;
   const int wslot = ((c >> 4) * 2) * 64 + (c & 15) + 16 * g;
   int buf = 0;
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += 32, buf ^= 1) {
-    f32x4 x0 = {xn[0], xn[1], xn[2], xn[3]}, x1 = {xn[4], xn[5], xn[6], xn[7]};
-    f32x4 y0 = {yn[0], yn[1], yn[2], yn[3]}, y1 = {yn[4], yn[5], yn[6], yn[7]};
-    fetch(r0 + 32);
+  auto mma_step = [&](const f32x4& x0, const f32x4& x1, const f32x4& y0, const f32x4& y1) {
     bsum += (((y0[0] + y0[1]) + (y0[2] + y0[3])) + ((y1[0] + y1[1]) + (y1[2] + y1[3])));
     h8 xh, xl, yh, yl;
     lb_split8v(x0, x1, xh, xl);
@@ -316,6 +337,48 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
         acc[ta][tb] = MFMA16H(all_, bh[tb], acc[ta][tb]);
       }
     }
+    buf ^= 1;
+  };
+  if (full > 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) fetch(d, xq[d], yq[d]);
+    int st = 0;
+    for (; st + 3 <= full; st += 3) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const f32x4 x0 = {xq[d][0], xq[d][1], xq[d][2], xq[d][3]}, x1 = {xq[d][4], xq[d][5], xq[d][6], xq[d][7]};
+        const f32x4 y0 = {yq[d][0], yq[d][1], yq[d][2], yq[d][3]}, y1 = {yq[d][4], yq[d][5], yq[d][6], yq[d][7]};
+        __builtin_amdgcn_sched_barrier(0);   // (the compiler otherwise sinks these loads to their use, three steps later)
+        fetch(st + d + 3, xq[d], yq[d]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(x0, x1, y0, y1);
+      }
+    }
+    // the one or two full steps left over: their operands are in stages 0 (and 1)
+    if (st < full) {
+      const f32x4 x0 = {xq[0][0], xq[0][1], xq[0][2], xq[0][3]}, x1 = {xq[0][4], xq[0][5], xq[0][6], xq[0][7]};
+      const f32x4 y0 = {yq[0][0], yq[0][1], yq[0][2], yq[0][3]}, y1 = {yq[0][4], yq[0][5], yq[0][6], yq[0][7]};
+      mma_step(x0, x1, y0, y1);
+    }
+    if (st + 1 < full) {
+      const f32x4 x0 = {xq[1][0], xq[1][1], xq[1][2], xq[1][3]}, x1 = {xq[1][4], xq[1][5], xq[1][6], xq[1][7]};
+      const f32x4 y0 = {yq[1][0], yq[1][1], yq[1][2], yq[1][3]}, y1 = {yq[1][4], yq[1][5], yq[1][6], yq[1][7]};
+      mma_step(x0, x1, y0, y1);
+    }
+  }
+  if (n & 31) {   // the chunk's last rows: clamped loads, zeros past the end
+    const int64_t rb = r_begin + (int64_t)full * 32 + 8 * g;
+    f32x4 x0, x1, y0, y1;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int64_t r = rb + t;
+      const bool ok = r < r_end;
+      const int64_t rc = ok ? r : r_end - 1;
+      const float xv = ok ? X[rc * ldx + c] : 0.f, yv = ok ? dY[rc * 128 + c] : 0.f;
+      if (t < 4) x0[t] = xv, y0[t] = yv;
+      else x1[t - 4] = xv, y1[t - 4] = yv;
+    }
+    mma_step(x0, x1, y0, y1);
   }
   // D[i][j] of tile (ta, tb): lane (j = lane & 15, 4 (lane >> 4) + v = i): X column 16 (4 ah + ta) + i, dY column 16 (2 bq + tb) + j
   float* out = part + (int64_t)blockIdx.x * (K + 1) * 128 + (int64_t)128 * ablk * 128;
