@@ -363,8 +363,17 @@ __global__ void __launch_bounds__(256) k_pack_wh(const float* __restrict__ w, fl
     const int rows_m = e.trans ? e.NO : e.NR, cols = e.trans ? e.NR : e.NO;
     const int tpr = cols >= 256 ? 256 : (cols >= 128 ? 128 : (cols >= 64 ? 64 : 32)), rpi = 256 / tpr;
     const int c0 = threadIdx.x % tpr, r0 = threadIdx.x / tpr;
-    for (int r = r0; r < rows_m; r += rpi)
-      for (int c = c0; c < cols; c += tpr) m = fmaxf(m, fabsf(src[(int64_t)r * e.ldw + c]));
+    for (int c = c0; c < cols; c += tpr) {
+      int r = r0;
+      for (; r + 7 * rpi < rows_m; r += 8 * rpi) {   // eight loads in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(r + u * rpi) * e.ldw + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(m, fabsf(v[u]));
+      }
+      for (; r < rows_m; r += rpi) m = fmaxf(m, fabsf(src[(int64_t)r * e.ldw + c]));
+    }
   }
   s_m[threadIdx.x] = m;
   __syncthreads();
