@@ -423,6 +423,18 @@ def measure_traffic(args, timeout_s=240):
         return None
 
 
+def _train_dtype():
+    """LB_TRAIN_MATH=f32: exact-fp32 MFMA products; default: fp16 hi/lo split products with power-of-two row / matrix scaling."""
+    return "f32" if os.environ.get("LB_TRAIN_MATH", "").startswith("f3") else \
+        "f32 (products as fp16 hi/lo splits under power-of-two row / matrix scaling, fp32 accumulate)"
+
+
+def _train_kernels():
+    if os.environ.get("LB_TRAIN_MATH", "").startswith("f3"):
+        return "k_lin32f (Y = XW, dX = dY W^T) + k_dw_part (dW += X^T dY): v_mfma_f32_16x16x4_f32, no library GEMM"
+    return "k_lin32h (Y = XW, dX = dY W^T) + k_dw_part_h (dW += X^T dY): v_mfma_f32_16x16x32_f16 x 3 split products, no library GEMM"
+
+
 def train_step_lines(device):
     """SURVEY section 8 row N4, the training step (trainer.py:35-89: value_and_grad of the masked MSE over the batch +
     optax.adamw), timed like the reference runs it: batch 1 (defaults.py train.batch_size), loss fetched every step.
@@ -467,11 +479,11 @@ def train_step_lines(device):
             tf = 3 * fwd / dt / 1e12
             res.append({"workload": f"{workload} GNS-10-128 training step (B = 1)", "n_particles": int(N), "edges": int(E),
                         "steps": K, "ms_per_step": 1e3 * dt, "value": N / dt, "unit": "particle-steps/s",
-                        "loss": float(loss), "dtype": "f32",
-                        "roofline": {"kernel": "k_lin32 (Y = XW, dX = dY W^T) + k_dw_part (dW += X^T dY): v_mfma_f32_16x16x4_f32, no library GEMM", "bound": "mfma",
+                        "loss": float(loss), "dtype": _train_dtype(),
+                        "roofline": {"kernel": _train_kernels(), "bound": "mfma",
                                      "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
                                      "flop_per_step": int(3 * fwd),
-                                     "note": "whole-step rate (GEMMs + everything else) against the fp32 MFMA peak"}})
+                                     "note": "whole-step rate (GEMMs + everything else) of fp32-equivalent flops against the fp32 MFMA peak"}})
             th.close()
             del eng, feats
         except Exception as exc:
@@ -510,8 +522,8 @@ def train_step_lines(device):
                   for name, Kb, _, _ in model.block_shapes())
         tf = 3 * fwd / dt / 1e12
         res.append({"workload": "dam2d SEGNN-10-64 training step (B = 1)", "n_particles": int(N), "edges": int(E), "steps": K,
-                    "ms_per_step": 1e3 * dt, "value": N / dt, "unit": "particle-steps/s", "loss": float(loss), "dtype": "f32",
-                    "roofline": {"kernel": "k_lin32f + k_dw_part on the stacked tensor-product operands (lb_train_segnn.h)", "bound": "mfma",
+                    "ms_per_step": 1e3 * dt, "value": N / dt, "unit": "particle-steps/s", "loss": float(loss), "dtype": _train_dtype(),
+                    "roofline": {"kernel": "k_lin32 / k_lin32h + k_dw_part / k_dw_part_h on the stacked tensor-product operands (lb_train_segnn.h)", "bound": "mfma",
                                  "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
                                  "flop_per_step": int(3 * fwd),
                                  "note": "executed flops (2x the necessary ones: cross terms of the side-by-side operand), whole step against the fp32 MFMA peak"}})
