@@ -1,3 +1,5 @@
+"""Average duration of the k_dw_part* / k_lin32h launches of a rocprofv3 rocpd database, grouped by (kernel, grid): separates the
+edge-sized from the node-sized calls of one kernel (python tools/rocpd_by_grid.py <results.db>)."""
 import sqlite3, glob, collections, sys
 db = sys.argv[1]
 c = sqlite3.connect(db)
