@@ -235,6 +235,39 @@ def test_hip_gradients_match_torch_autograd(name, scale, L, B, latent):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("math", ["f16x2", "f32"])
+def test_hip_gradients_are_equivariant_under_power_of_two_loss_weights(math, monkeypatch):
+    """The training step's products run in f16x2 arithmetic (csrc/lb_lin32.h: k_lin32h, csrc/lb_train.hip: k_dw_part_h) whose
+    fp16 range is MADE safe by power-of-two scaling of every row chunk / matrix / row block - not by a guard.  A loss weight of
+    2^-30 scales every gradient of the backward pass by 2^-30 (values around 1e-12 .. 1e-15, far below fp16's range): all
+    scale factors are exponent arithmetic, so every gradient must come out as EXACTLY 2^-30 times the unweighted one -
+    any dependence of the split arithmetic on magnitude would show as a different bit pattern.  LB_TRAIN_MATH=f32 (the exact
+    kernels) has the property trivially and runs as the control."""
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    from tests._common import hip_case
+    monkeypatch.setenv("LB_TRAIN_MATH", math)
+    ds = make_case("small3d", n_trajs=1, extra_seq_length=3)
+    hcase = hip_case(ds)
+    isl, dim = ds.input_seq_length, len(ds.box)
+    pos, pt = ds[0]
+    params = make_params(ds, num_mp_steps=2, decoder_scale=1.0)
+    model = GNS(dim, 128, 2, 2, 16)
+    feats, _ = hcase.allocate_eval((pos[None, :, :isl], pt[None]))
+    target = torch.randn((1, pos.shape[0], dim), generator=torch.Generator().manual_seed(5))
+    th = model.train_handle(feats.engine, params)
+    grads = {}
+    for w in (1.0, 2.0 ** -30, 2.0 ** 20):
+        th.zero_grad()
+        th.loss_grad(target, w)
+        grads[w] = th.read("grads").astype(np.float64)
+    assert np.abs(grads[1.0]).max() > 1e-6
+    for w in (2.0 ** -30, 2.0 ** 20):
+        assert np.array_equal(grads[w], grads[1.0] * w), (math, w, np.abs(grads[w] / w - grads[1.0]).max())
+    th.close()
+
+
+@pytest.mark.gpu
 def test_trainer_lowers_the_loss_and_runner_mode_all(tmp_path):
     """tests/runner_test.py:14-57 runs train_or_infer end to end on the LJ dataset and expects 0."""
     from lagrangebench_amd.case_setup import case_builder
