@@ -222,7 +222,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (kk == 0) *reinterpret_cast<f32x4*>(out + K * 128 + 64 * mh + 4 * i) = bs;
   }
 }
-// ---- the same contraction in f16x2 arithmetic (round 5, second half; K a multiple of 128: every processor / decoder Linear).
+// ---- the same contraction in f16x2 arithmetic (round 5, second half; K >= 32 in slices of 128 X columns: every processor /
+// decoder Linear of GNS, SEGNN's stacked operands).
 // dW = X^T dY reduces over the ROWS, so the fp16 operands of v_mfma_f32_16x16x32_f16 hold eight consecutive rows of ONE column:
 // a transpose of the row-major operands.  It goes through LDS, fused with the hi / lo split: thread (g, c) of the workgroup
 // loads the eight rows 8 g .. 8 g + 7 of column c of X and of dY of a 32-row step (each load instruction of a wave is 256
@@ -243,6 +244,10 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = tid & 127, g = tid >> 7;
   const int ablk = blockIdx.y;
+  // K need not be a multiple of 128 (SEGNN's stacked operands: 64, 144 ..): a thread whose X column lies past K reads the
+  // row's last column instead and multiplies by zero when the value is used
+  const int cx = 128 * ablk + c < K ? c : K - 1 - 128 * ablk;
+  const float xkeep = 128 * ablk + c < K ? 1.f : 0.f;
   X += 128 * ablk;
   const int64_t r_begin = (int64_t)blockIdx.x * chunk, r_end = r_begin + chunk < rows ? r_begin + chunk : rows;
   // pass 0: the chunk's largest |dY|
@@ -283,7 +288,7 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
   // after the loop.
   const int64_t n = r_end - r_begin;
   const int full = (int)(n >> 5);
-  const float* Xc = X + r_begin * ldx + c;
+  const float* Xc = X + r_begin * ldx + cx;
   const float* Yc = dY + r_begin * 128 + c;
   int xo[8], yo[8];
 #pragma unroll
@@ -314,7 +319,7 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
   auto mma_step = [&](const f32x4& x0, const f32x4& x1, const f32x4& y0, const f32x4& y1) {
     bsum += (((y0[0] + y0[1]) + (y0[2] + y0[3])) + ((y1[0] + y1[1]) + (y1[2] + y1[3])));
     h8 xh, xl, yh, yl;
-    lb_split8v(x0, x1, xh, xl);
+    lb_split8v(x0 * xkeep, x1 * xkeep, xh, xl);
     lb_split8v(y0 * sc, y1 * sc, yh, yl);
     sAB[buf][0][wslot] = xh;
     sAB[buf][0][wslot + 64] = xl;
@@ -374,7 +379,7 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
       const int64_t r = rb + t;
       const bool ok = r < r_end;
       const int64_t rc = ok ? r : r_end - 1;
-      const float xv = ok ? X[rc * ldx + c] : 0.f, yv = ok ? dY[rc * 128 + c] : 0.f;
+      const float xv = ok ? X[rc * ldx + cx] : 0.f, yv = ok ? dY[rc * 128 + c] : 0.f;
       if (t < 4) x0[t] = xv, y0[t] = yv;
       else x1[t - 4] = xv, y1[t - 4] = yv;
     }
@@ -387,8 +392,10 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        out[(16 * (4 * ah + ta) + 4 * (lane >> 4) + v) * 128 + 16 * (2 * bq + tb) + (lane & 15)] = acc[ta][tb][v] * inv;
+      for (int v = 0; v < 4; ++v) {
+        const int xr = 16 * (4 * ah + ta) + 4 * (lane >> 4) + v;
+        if (128 * ablk + xr < K) out[xr * 128 + 16 * (2 * bq + tb) + (lane & 15)] = acc[ta][tb][v] * inv;
+      }
   if (ablk == 0) {
     __syncthreads();   // (the last step's fragments have been read)
     red[tid] = bsum;
@@ -928,8 +935,8 @@ static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx
   if (!part) return false;
 #define DW_GO(NA, DEPTH) hipLaunchKernelGGL((k_dw_part<NA, DEPTH>), dim3(G), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part)
   const bool deep = chunk >= 192;
-  if (t->f16x2 && (K & 127) == 0)
-    hipLaunchKernelGGL(k_dw_part_h, dim3((unsigned)G, (unsigned)(K / 128)), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part);
+  if (t->f16x2 && K >= 32)   // (narrower operands - the encoders' raw features - stay on the fp32 kernel)
+    hipLaunchKernelGGL(k_dw_part_h, dim3((unsigned)G, (unsigned)((K + 127) / 128)), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part);
   else if (K <= 128) { if (deep) DW_GO(1, 12); else DW_GO(1, 6); }
   else if (K <= 256) { if (deep) DW_GO(2, 8); else DW_GO(2, 6); }
   else DW_GO(3, 4);
