@@ -54,6 +54,9 @@ struct lb_lin_args {
   const int32_t *gidx1, *gidx2;
   // k_lin32h: 1 / (power-of-two scale the operand matrix was packed with), written by k_pack_wh
   const float* wsc;
+  // k_lin32h: if not null, receives the largest |X| of every 16-row tile (the kernel finds the rows' maxima anyway): the
+  // weight-gradient kernel that contracts the same X as its dY operand scales by it instead of scanning X again
+  float* tmax;
 };
 
 struct lb_pack_ent {    // one operand matrix of k_pack_w
@@ -473,6 +476,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     f32x4 acc[NOB];   // the row's total over its chunks, in true units
 #pragma unroll
     for (int mb = 0; mb < NOB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrow = 0.f;
     for (int jc = 0; jc < nch; ++jc) {
       // the chunk's largest magnitude over the row (this lane's 32 values, then the four lanes of the row)
       float m = 0.f;
@@ -482,6 +486,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int i = 0; i < 4; ++i) m = fmaxf(m, fabsf(ring[jj][i]));
       m = fmaxf(m, __shfl_xor(m, 16));
       m = fmaxf(m, __shfl_xor(m, 32));
+      mrow = fmaxf(mrow, m);
       unsigned ex = (__float_as_uint(m) >> 23) & 0xffu;
       ex = m == 0.f ? 127u : (ex < 1u ? 1u : (ex > 253u ? 253u : ex));
       const float s = __uint_as_float((254u - ex) << 23), inv = __uint_as_float(ex << 23) * winv;
@@ -510,6 +515,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       for (int mb = 0; mb < NOB; ++mb)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[mb][jj] += part[mb][jj] * inv;
+    }
+    if (a.tmax) {   // the tile's largest |X| (rows past the end repeat the last row)
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) mrow = fmaxf(mrow, __shfl_xor(mrow, off));
+      if (lane == 0) a.tmax[t] = mrow;
     }
     if (live) {
       float* yr = a.Y + row * a.ldy + 4 * kq;

@@ -112,6 +112,8 @@ struct lb_gns_train {
   // f16x2 arithmetic of the tall-skinny products (k_lin32h, round 5): fp16 hi / lo fragments of the operand matrices in the
   // same packed blob + one inverse power-of-two scale per matrix.  LB_TRAIN_MATH=f32 keeps the exact-fp32 kernels.
   bool f16x2 = lb_train_f16x2_default();
+  float* tmax = nullptr;       // [rows / 16] largest |X| per row tile of the last k_lin32h call that was asked for it
+  bool tmax_ok = false;        // ... and whether that call ran on k_lin32h
   std::vector<lb_pack_ent_h> pack_tab_h;
   lb_pack_ent_h* pack_dev_h = nullptr;
   float* wsc = nullptr;
@@ -238,7 +240,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 // correspondingly little weight.  grid (G, K / 128); block (g, a) forms rows 128 a .. 128 a + 127 of part[g] and, for a = 0,
 // the column sums of dY (exact fp32 sums of the unscaled values).
 __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, int ldx, int K, const float* __restrict__ dY,
-                                                   int64_t rows, int64_t chunk, float* __restrict__ part) {
+                                                   int64_t rows, int64_t chunk, float* __restrict__ part,
+                                                   const float* __restrict__ tmax) {
   __shared__ h8 sAB[2][2][1024];   // [buffer][A | B][(tile * 2 + part) * 64 + lane]: 64 KiB
   float* red = reinterpret_cast<float*>(&sAB[0][0][0]);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -252,7 +255,9 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
   const int64_t r_begin = (int64_t)blockIdx.x * chunk, r_end = r_begin + chunk < rows ? r_begin + chunk : rows;
   // pass 0: the chunk's largest |dY|
   float m = 0.f;
-  {
+  if (tmax) {   // the producer's row-tile maxima (k_lin32h read dY as its X operand just before): the tiles this chunk touches
+    for (int64_t i = (r_begin >> 4) + tid; i < ((r_end + 15) >> 4); i += 512) m = fmaxf(m, tmax[i]);
+  } else {
     const f32x4* y4 = reinterpret_cast<const f32x4*>(dY + r_begin * 128);
     const int64_t n4 = (r_end - r_begin) * 32;
     int64_t i = tid;
@@ -800,6 +805,8 @@ static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int tr
   const bool fast = a.NO == 128 && (a.NR & 127) == 0 && (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && (!a.mask || (a.ldm & 3) == 0) &&
                     !(a.mask && a.accum) && (((uintptr_t)a.bias | (uintptr_t)a.ln_scale | (uintptr_t)a.ln_offset) & 15) == 0;
   const bool half = fast && t->f16x2;
+  t->tmax_ok = half && a.tmax;
+  if (!half) a.tmax = nullptr;
   if (half) LB_TRY(pack_lookup_h(t, W, a.NR, a.NO, ldw, trans, &a.Wp, &a.wsc));
   else LB_TRY(pack_lookup(t, W, a.NR, a.NO, ldw, trans, nob, &a.Wp));
   if (a.gat1 && (!fast || a.mask || a.accum || a.ln_scale || !a.bias))
@@ -853,9 +860,10 @@ static int gemm_nn(lb_gns_train* t, int64_t rows, int M, int K, const float* X, 
 }
 // dX[rows x K] (ldx) = dY[rows x M] (ldy) * W^T (+ beta * dX) [* (mask > 0)]; K > 128: 128 output columns per launch
 static int gemm_nt(lb_gns_train* t, int64_t rows, int M, int K, const float* dY, const float* W, float* dX, int ldx,
-                   float beta = 0.f, int ldy = 0, const float* mask = nullptr, int ldm = 0) {
+                   float beta = 0.f, int ldy = 0, const float* mask = nullptr, int ldm = 0, float* tmax = nullptr) {
   for (int c0 = 0; c0 < K; c0 += 128) {
     lb_lin_args a{};
+    a.tmax = tmax;
     a.X = dY; a.ldx = ldy ? ldy : M; a.NR = M; a.Y = dX + c0; a.ldy = ldx; a.NO = std::min(128, K - c0); a.rows = rows;
     a.mask = mask ? mask + c0 : nullptr; a.ldm = ldm; a.accum = beta != 0.f;
     LB_TRY(lin32(t, a, W + (size_t)c0 * M, M, 1));
@@ -925,7 +933,7 @@ static int64_t red_capacity(const lb_gns_train* t, int64_t cn, int64_t ce) {
 // dW[K x 128] += X^T dY, db[128] += column sums of dY (k_dw_part + a descriptor for k_part_reduce); false = refused
 // (nb: how many of dY's 128 column sums are added to db - the SEGNN blocks keep only their Ms scalar-output columns)
 static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx, const float* dY, float* dW, float* db,
-                   int nb = 128) {
+                   int nb = 128, const float* tmax = nullptr) {
   if (K > 384 || rows <= 0) return false;
   int64_t chunk = 0, off = 0;
   const int G = dw_groups(rows, &chunk);
@@ -936,7 +944,7 @@ static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx
 #define DW_GO(NA, DEPTH) hipLaunchKernelGGL((k_dw_part<NA, DEPTH>), dim3(G), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part)
   const bool deep = chunk >= 192;
   if (t->f16x2 && K >= 32)   // (narrower operands - the encoders' raw features - stay on the fp32 kernel)
-    hipLaunchKernelGGL(k_dw_part_h, dim3((unsigned)G, (unsigned)((K + 127) / 128)), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part);
+    hipLaunchKernelGGL(k_dw_part_h, dim3((unsigned)G, (unsigned)((K + 127) / 128)), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part, tmax);
   else if (K <= 128) { if (deep) DW_GO(1, 12); else DW_GO(1, 6); }
   else if (K <= 256) { if (deep) DW_GO(2, 8); else DW_GO(2, 6); }
   else DW_GO(3, 4);
@@ -1027,20 +1035,22 @@ static int mlp_bwd_head(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, co
     red_push(t, off, nb, 256, 128, 128, 128, t->g + p.lns, t->g + p.lno);
     dzz = t->dz;
   }
-  if (p.out != TD || !dw_acc(t, rows, TD, a, TD, dzz, t->g + p.w1, t->g + p.b1)) {
+  // dX first: k_lin32h leaves the row-tile maxima of dzz behind, which the weight-gradient kernel scales by
+  LB_TRY(gemm_nt(t, rows, p.out, TD, dzz, t->w + p.w1, t->da, TD, 0.f, 0, a, TD, t->tmax));  // ReLU mask in the epilogue
+  if (p.out != TD || !dw_acc(t, rows, TD, a, TD, dzz, t->g + p.w1, t->g + p.b1, 128, t->tmax_ok ? t->tmax : nullptr)) {
     LB_TRY(dw_narrow(t, rows, p.out, TD, a, TD, dzz, p.out, t->g + p.w1));
     LB_TRY(colsum_add(t, dzz, rows, p.out, p.out, t->g + p.b1));
   }
-  LB_TRY(gemm_nt(t, rows, p.out, TD, dzz, t->w + p.w1, t->da, TD, 0.f, 0, a, TD));  // ReLU mask in the epilogue
   return LB_OK;
 }
 static int mlp_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* X, int ldx, const float* a,
                    const float* z, const float* dy, float* dX) {
   if (rows == 0) return LB_OK;
   LB_TRY(mlp_bwd_head(t, p, rows, a, z, dy));
-  if (!dw_acc(t, rows, p.in, X, ldx, t->da, t->g + p.w0, t->g + p.b0))
+  t->tmax_ok = false;
+  if (dX) LB_TRY(gemm_nt(t, rows, TD, p.in, t->da, t->w + p.w0, dX, ldx, 0.f, 0, nullptr, 0, t->tmax));
+  if (!dw_acc(t, rows, p.in, X, ldx, t->da, t->g + p.w0, t->g + p.b0, 128, t->tmax_ok ? t->tmax : nullptr))
     return lb_fail(LB_ERR_UNSUPPORTED, "training: first Linear with %d inputs (row stride %d) is not covered", p.in, ldx);
-  if (dX) LB_TRY(gemm_nt(t, rows, TD, p.in, t->da, t->w + p.w0, dX, ldx));
   return LB_OK;
 }
 
@@ -1055,8 +1065,9 @@ static int edge_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t E, int64_t B
   const float *Ws = t->w + p.w0, *Wr = Ws + (size_t)TD * TD, *We = Wr + (size_t)TD * TD;
   float *gWs = t->g + p.w0, *gWr = gWs + (size_t)TD * TD, *gWe = gWr + (size_t)TD * TD;
   // edge rows: dW_e += e^T da, db0 += column sums of da, de += da W_e^T
-  if (!dw_acc(t, E, TD, el, TD, t->da, gWe, t->g + p.b0)) return lb_fail(LB_ERR_STATE, "dw_acc refused the edge block");
-  LB_TRY(gemm_nt(t, E, TD, TD, t->da, We, de, TD, 1.f));
+  LB_TRY(gemm_nt(t, E, TD, TD, t->da, We, de, TD, 1.f, 0, nullptr, 0, t->tmax));
+  if (!dw_acc(t, E, TD, el, TD, t->da, gWe, t->g + p.b0, 128, t->tmax_ok ? t->tmax : nullptr))
+    return lb_fail(LB_ERR_STATE, "dw_acc refused the edge block");
   // node rows: dP = transpose of the two gathers, then dW_s += n^T dPs, dW_r += n^T dPr, dn += dPs W_s^T + dPr W_r^T
   float *dPs = t->proj, *dPr = t->proj + (size_t)BN * TD;
   hipLaunchKernelGGL(k_edge_dP, GRID1(BN * 32), 0, s, t->da, t->snd_ptr, t->snd_perm, e->row_ptr, dPs, dPr, BN, E);
@@ -1105,6 +1116,7 @@ static int train_ensure(lb_gns_train* t, int64_t BN, int64_t E) {
   LB_TRY(tr_alloc(&t->dx, (size_t)cn * std::max(3 * TD, t->kpad)));
   LB_TRY(tr_alloc(&t->dagg, (size_t)cn * TD));
   LB_TRY(tr_alloc(&t->agg, (size_t)cn * TD));
+  LB_TRY(tr_alloc(&t->tmax, (size_t)(cm / 16 + 64)));
   t->red_cap = red_capacity(t, cn, ce);
   LB_TRY(tr_alloc(&t->dwpart, (size_t)t->red_cap));
   if (!t->red_dev) {
@@ -1280,7 +1292,7 @@ extern "C" void lb_gns_train_destroy(lb_gns_train* t) {
   std::vector<void*> bufs = {t->w, t->g, t->m, t->v, t->xnode, t->a_en, t->z_en, t->a_ee, t->z_ee, t->a_d, t->pred,
                              t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->dwpart, t->red_dev, t->proj, t->node_w,
                              t->loss_dev, t->loss_part, t->cnt_dev, t->snd_key, t->snd_perm, t->iota, t->snd_ptr, t->sort_tmp,
-                             t->wpack, t->pack_dev, t->pack_dev_h, t->wsc};
+                             t->wpack, t->pack_dev, t->pack_dev_h, t->wsc, t->tmax};
   for (auto* v : {&t->nlat, &t->elat, &t->ae, &t->ze, &t->xn, &t->an, &t->zn})
     for (float* p : *v) bufs.push_back(p);
   for (void* b : bufs)
