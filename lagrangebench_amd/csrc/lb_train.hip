@@ -480,6 +480,18 @@ __global__ void __launch_bounds__(128) k_dw_narrow(const float* __restrict__ X, 
 // its two columns, the four waves are combined through LDS in wave order -> part[block][2][128] (k_part_reduce sums the blocks
 // in ascending order).
 #define LNB_ROWS 64
+// Round 5, second half: a row is held by SIXTEEN lanes (eight consecutive columns each: two 16-byte loads per array instead of
+// two dwords), four rows per wave and step, and the row sums are four DPP steps inside the 16-lane row (quad_perm x 2,
+// row_half_mirror, row_mirror: no LDS crossbar) instead of six dependent ds_bpermute round trips over 64 lanes - the first
+// version spent 48 us on 170 MB per edge-sized call.  The per-column sums of dy * zhat and dy stay in the lane that owns the
+// column across its rows and are combined over the four row slots and four waves in a fixed order.
+__device__ __forceinline__ float lb_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  return v;
+}
 template <bool GATHER>
 __global__ void __launch_bounds__(256) k_ln_bwd2(const float* __restrict__ z, const float* __restrict__ b1,
                                                  const float* __restrict__ sc, const float* __restrict__ dy,
@@ -487,84 +499,93 @@ __global__ void __launch_bounds__(256) k_ln_bwd2(const float* __restrict__ z, co
                                                  const float* __restrict__ gth, const int32_t* __restrict__ gidx) {
   // gth != null: the incoming gradient is dy[r] + gth[gidx[r]] - the transpose of jraph.segment_sum (the aggregate's gradient
   // gathered over the receivers) folded into this load (round 4: k_seg_sum_bwd, a pass of its own over E x 128)
-  __shared__ float s_red[4][4][64];
-  const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const float sc0 = sc[l], sc1 = sc[64 + l], bb0 = b1[l], bb1 = b1[64 + l];
-  float ps0 = 0.f, ps1 = 0.f, po0 = 0.f, po1 = 0.f;
+  __shared__ float s_red[4][4][2][128];   // [wave][row slot][dy * zhat | dy][column]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int cl = lane & 15, rq = lane >> 4;     // columns 8 cl .. 8 cl + 7 of row slot rq
+  const f32x4 scA = reinterpret_cast<const f32x4*>(sc)[2 * cl], scB = reinterpret_cast<const f32x4*>(sc)[2 * cl + 1];
+  const f32x4 bA = reinterpret_cast<const f32x4*>(b1)[2 * cl], bB = reinterpret_cast<const f32x4*>(b1)[2 * cl + 1];
+  f32x4 psA = {0.f, 0.f, 0.f, 0.f}, psB = psA, poA = psA, poB = psA;
   const float inv_d = 1.f / (float)d;
-  const bool real0 = l < d, real1 = 64 + l < d;
-  const int64_t rb = (int64_t)blockIdx.x * LNB_ROWS;
-  // round 5: the loads of all 16 rows of this wave are issued before the first row is reduced (one row at a time, each
-  // behind three dependent shuffle trees, the kernel paid the memory latency 16 times: 20 us on 17 k rows)
-  constexpr int NIT = LNB_ROWS / 4;
-  float zx0[NIT], zx1[NIT], gg0[NIT], gg1[NIT];
+  f32x4 keepA, keepB;   // 1 in the real columns, 0 in the padding of a latent narrower than 128
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int64_t r = rb + 4 * it + wv;
-    const bool ok = r < rows;
-    const int64_t rc = ok ? r : rows - 1;
-    zx0[it] = z[rc * TD + l];
-    zx1[it] = z[rc * TD + 64 + l];
-    gg0[it] = dy[rc * TD + l];
-    gg1[it] = dy[rc * TD + 64 + l];
+  for (int j = 0; j < 4; ++j) {
+    keepA[j] = 8 * cl + j < d ? 1.f : 0.f;
+    keepB[j] = 8 * cl + 4 + j < d ? 1.f : 0.f;
+  }
+  const int64_t rb = (int64_t)blockIdx.x * LNB_ROWS + 16 * wv;   // this wave's 16 rows: four steps of four
+  constexpr int NIT = 4;
+  f32x4 zA[NIT], zB[NIT], gA[NIT], gB[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {   // every load of the wave's rows before the first reduction
+    const int64_t r = rb + 4 * it + rq;
+    const int64_t rc = r < rows ? r : rows - 1;
+    const f32x4* zr = reinterpret_cast<const f32x4*>(z + rc * TD) + 2 * cl;
+    const f32x4* gr = reinterpret_cast<const f32x4*>(dy + rc * TD) + 2 * cl;
+    zA[it] = zr[0]; zB[it] = zr[1];
+    gA[it] = gr[0]; gB[it] = gr[1];
   }
   if (GATHER) {  // (a compile-time branch: a run-time one inside the loop above serialises its loads)
     int gi[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int64_t r = rb + 4 * it + wv;
+      const int64_t r = rb + 4 * it + rq;
       gi[it] = gidx[r < rows ? r : rows - 1];
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      gg0[it] = gth[(int64_t)gi[it] * TD + l] + gg0[it];
-      gg1[it] = gth[(int64_t)gi[it] * TD + 64 + l] + gg1[it];
+      const f32x4* tr = reinterpret_cast<const f32x4*>(gth + (int64_t)gi[it] * TD) + 2 * cl;
+      gA[it] = tr[0] + gA[it];
+      gB[it] = tr[1] + gB[it];
     }
   }
-  // branch-free over the 16 rows (a row past the end recomputes row rows - 1 and stores the same values again; its sums are
-  // masked): the rows' shuffle trees - 18 dependent ds_bpermute round trips each - interleave instead of running in sequence
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int64_t r0 = rb + 4 * it + wv;
+    const int64_t r0 = rb + 4 * it + rq;
     const bool ok = r0 < rows;
-    const int64_t r = ok ? r0 : rows - 1;
-    const float x0 = zx0[it] + bb0, x1 = zx1[it] + bb1;
-    const float g0 = gg0[it], g1 = gg1[it];
-    float s = x0 + x1;
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s * inv_d;
-    const float d0 = x0 - mean, d1 = x1 - mean;
-    float q = d0 * d0 + d1 * d1;
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    q -= (float)(TD - d) * mean * mean;
-    const float rs = 1.0f / sqrtf(q * inv_d + 1e-5f);
-    const float h0 = d0 * rs, h1 = d1 * rs;
-    const float u0 = g0 * sc0, u1 = g1 * sc1;
-    float a = u0 + u1, b = u0 * h0 + u1 * h1;
-    for (int o = 32; o > 0; o >>= 1) {
-      a += __shfl_xor(a, o);
-      b += __shfl_xor(b, o);
+    const int64_t r = ok ? r0 : rows - 1;   // (a row past the end recomputes the last row and stores the same values again)
+    const f32x4 xA = zA[it] + bA, xB = zB[it] + bB;
+    const float mean = lb_row16_sum(((xA[0] + xA[1]) + (xA[2] + xA[3])) + ((xB[0] + xB[1]) + (xB[2] + xB[3]))) * inv_d;
+    f32x4 dA, dB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dA[j] = xA[j] - mean;
+      dB[j] = xB[j] - mean;
     }
-    a *= inv_d;
-    b *= inv_d;
-    dz[r * TD + l] = real0 ? rs * (u0 - a - h0 * b) : 0.f;   // (u is 0 in the padded columns: they add nothing to a, b)
-    dz[r * TD + 64 + l] = real1 ? rs * (u1 - a - h1 * b) : 0.f;
-    ps0 += ok ? g0 * h0 : 0.f;
-    ps1 += ok ? g1 * h1 : 0.f;
-    po0 += ok ? g0 : 0.f;
-    po1 += ok ? g1 : 0.f;
+    float q = lb_row16_sum(((dA[0] * dA[0] + dA[1] * dA[1]) + (dA[2] * dA[2] + dA[3] * dA[3])) +
+                           ((dB[0] * dB[0] + dB[1] * dB[1]) + (dB[2] * dB[2] + dB[3] * dB[3])));
+    q -= (float)(TD - d) * mean * mean;   // the padded columns hold 0 - mean
+    const float rs = 1.0f / sqrtf(q * inv_d + 1e-5f);
+    const f32x4 hA = dA * rs, hB = dB * rs;
+    const f32x4 uA = gA[it] * scA, uB = gB[it] * scB;
+    float a = ((uA[0] + uA[1]) + (uA[2] + uA[3])) + ((uB[0] + uB[1]) + (uB[2] + uB[3]));
+    float b = ((uA[0] * hA[0] + uA[1] * hA[1]) + (uA[2] * hA[2] + uA[3] * hA[3])) +
+              ((uB[0] * hB[0] + uB[1] * hB[1]) + (uB[2] * hB[2] + uB[3] * hB[3]));
+    a = lb_row16_sum(a) * inv_d;
+    b = lb_row16_sum(b) * inv_d;
+    f32x4 oA, oB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // (u is 0 in the padded columns: they add nothing to a, b)
+      oA[j] = keepA[j] * (rs * (uA[j] - a - hA[j] * b));
+      oB[j] = keepB[j] * (rs * (uB[j] - a - hB[j] * b));
+    }
+    f32x4* dr = reinterpret_cast<f32x4*>(dz + r * TD) + 2 * cl;
+    dr[0] = oA;
+    dr[1] = oB;
+    const float w = ok ? 1.f : 0.f;
+    psA = psA + gA[it] * hA * w; psB = psB + gB[it] * hB * w;
+    poA = poA + gA[it] * w;      poB = poB + gB[it] * w;
   }
-  s_red[wv][0][l] = ps0;
-  s_red[wv][1][l] = ps1;
-  s_red[wv][2][l] = po0;
-  s_red[wv][3][l] = po1;
+  f32x4* sr = reinterpret_cast<f32x4*>(&s_red[wv][rq][0][0]) + 2 * cl;
+  sr[0] = psA; sr[1] = psB;
+  sr[32] = poA; sr[33] = poB;
   __syncthreads();
   const int c = threadIdx.x;  // 0..127 scale columns, 128..255 offset columns
-  const int which = (c >> 6) & 3, ll = c & 63;  // (0: ps0, 1: ps1, 2: po0, 3: po1) x lane = column (c & 127) of its group
-  float v = s_red[0][which][ll];
-  v += s_red[1][which][ll];
-  v += s_red[2][which][ll];
-  v += s_red[3][which][ll];
+  const int which = c >> 7, col = c & 127;
+  float v = 0.f;
+#pragma unroll
+  for (int w2 = 0; w2 < 4; ++w2)
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) v += s_red[w2][q2][which][col];
   part[(int64_t)blockIdx.x * 256 + c] = v;
 }
 // Edge block, first Linear, without the concatenation (round 4, as the inference kernels do it): W0 = [W_s ; W_r ; W_e] by
