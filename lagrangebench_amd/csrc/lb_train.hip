@@ -709,12 +709,31 @@ __global__ void __launch_bounds__(1024) k_embed_grad(const float* __restrict__ d
   __shared__ float s_part[1024];
   const int type = blockIdx.x, c = threadIdx.x % emb, slice = threadIdx.x / emb, S = 1024 / emb;
   float acc = 0.f;
-  if (slice < S)
-    for (int64_t r = slice; r < BN; r += S) {
-      int pt = ptype[r];
-      if (pt < 0) pt += ntypes;  // hk.Embed wraps negative ids (padding type -1 -> row 8)
-      if (pt == type) acc += dx[r * ld + col0 + c];
+  if (slice < S) {
+    // branch-free and eight rows at a time: a load behind `if (pt == type)` waits for the type, and the loop was a chain of
+    // 125 dependent round trips (73 us on 8 k nodes); adding +0.f for the other types leaves the sum's bits unchanged
+    int64_t r = slice;
+    for (; r + 7 * S < BN; r += 8 * S) {
+      int pt[8];
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        pt[u] = ptype[r + u * S];
+        v[u] = dx[(r + u * S) * ld + col0 + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = pt[u] < 0 ? pt[u] + ntypes : pt[u];  // hk.Embed wraps negative ids (padding type -1 -> row 8)
+        acc += q == type ? v[u] : 0.f;
+      }
     }
+    for (; r < BN; r += S) {
+      int pt = ptype[r];
+      if (pt < 0) pt += ntypes;
+      const float v = dx[r * ld + col0 + c];
+      acc += pt == type ? v : 0.f;
+    }
+  }
   s_part[threadIdx.x] = acc;
   __syncthreads();
   if ((int)threadIdx.x < emb) {
