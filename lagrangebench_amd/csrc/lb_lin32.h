@@ -1,4 +1,5 @@
-// lb_lin32.h - the training step's tall-skinny fp32 products without the library (round 5; device code, included by
+// lb_lin32.h - the training step's tall-skinny products without the library: exact fp32 (k_lin32, k_lin32f) and, at the end of
+// the file, the scaled f16x2 form the step uses by default (k_lin32h, k_pack_wh) (round 5; device code, included by
 // lb_train.hip and by tools/lin_bench.hip):  Y[rows x NO] = X[rows x NR] * Wop[NR x NO]  with the elementwise neighbours of
 // the product in the epilogue.  Wop = W (Y = X W: forward) or W^T (dX = dY W^T: backward); rows ~1e4 .. 1e5, NR, NO <= 256.
 // Reference: the Linear layers of hk.nets.MLP inside GNS (models/gns.py:65-171) under value_and_grad (train/trainer.py:63-89).

@@ -14,6 +14,9 @@
 // product, dW += X^T dY, is a reduction over ~1e5 rows into a tiny result, which the library ran at 16 TFLOP/s: hand-written
 // since round 4 (k_dw_part: fp32 MFMA, split over the rows, bias column sums folded in, partials combined in a fixed order -
 // 95 TFLOP/s on the 384 x 128 case; k_dw_narrow for the decoder's 128 x dim matrix).
+// Round 5, second half: by default all three products run in f16x2 arithmetic - fp16 hi / lo pairs on v_mfma_f32_16x16x32_f16,
+// the operands put into fp16's range by exact power-of-two scales per row chunk / matrix / row block instead of a guard
+// (k_lin32h in lb_lin32.h, k_dw_part_h below; LB_TRAIN_MATH=f32 keeps the exact kernels): 6.05 -> 4.5 ms per TGV3D-8k step.
 // The edge block never forms [n_s | n_r | e]: its first Linear is split by rows of W0 into two node-sized products and one
 // edge-sized one (the gather epilogue of k_lin32f / k_edge_dP).  Hand-written HIP for everything that is not a GEMM: [n | agg], bias + ReLU,
 // LayerNorm forward and backward (the backward keeps the running sums of d scale / d offset in registers, no scratch copy),
