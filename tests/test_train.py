@@ -268,6 +268,38 @@ def test_hip_gradients_are_equivariant_under_power_of_two_loss_weights(math, mon
 
 
 @pytest.mark.gpu
+def test_hip_gradients_agree_between_the_two_arithmetics(monkeypatch):
+    """LB_TRAIN_MATH=f32 (exact-fp32 MFMA products: k_lin32f, k_dw_part) against the default scaled f16x2 products (k_lin32h,
+    k_dw_part_h) on the same step: loss equal to 1e-6, every gradient leaf within 2e-5 of the leaf's largest entry (the
+    autograd test above holds the default arithmetic to 1e-4 against float64; this keeps the exact kernels exercised)."""
+    from lagrangebench_amd.data import make_case
+    from lagrangebench_amd.models import GNS
+    from tests._common import hip_case
+    ds = make_case("small3d", n_trajs=2, extra_seq_length=3)
+    hcase = hip_case(ds)
+    isl, dim = ds.input_seq_length, len(ds.box)
+    pos = np.stack([ds[b][0] for b in range(2)])
+    pt = np.stack([ds[b][1] for b in range(2)])
+    params = make_params(ds, num_mp_steps=3, decoder_scale=1.0)
+    model = GNS(dim, 128, 2, 3, 16)
+    feats, _ = hcase.allocate_eval((pos[:, :, :isl], pt))
+    target = torch.randn((2, pos.shape[1], dim), generator=torch.Generator().manual_seed(5))
+    out = {}
+    for math in ("f32", "f16x2"):
+        monkeypatch.setenv("LB_TRAIN_MATH", math)
+        th = model.train_handle(feats.engine, params)
+        th.zero_grad()
+        loss = th.loss_grad(target, 1.0)
+        out[math] = (loss, model.unflatten(th.read("grads"), params))
+        th.close()
+    assert abs(out["f32"][0] - out["f16x2"][0]) <= 1e-6 * abs(out["f32"][0])
+    for mod, leaves in out["f32"][1].items():
+        for leaf, ref in leaves.items():
+            got = out["f16x2"][1][mod][leaf]
+            assert np.abs(got - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-30), (mod, leaf)
+
+
+@pytest.mark.gpu
 def test_trainer_lowers_the_loss_and_runner_mode_all(tmp_path):
     """tests/runner_test.py:14-57 runs train_or_infer end to end on the LJ dataset and expects 0."""
     from lagrangebench_amd.case_setup import case_builder
