@@ -280,6 +280,32 @@ def test_general_segnn_velocity_last_and_two_models_on_one_engine():
 
 
 @pytest.mark.gpu
+def test_general_segnn_float32_geometry_and_batch_consistency():
+    """dtype=float32 geometry (case.py:169) feeding the general path - DAM2D's walls, external force and particle types at
+    lmax 2 - against the oracle run in float32; and a batch of two trajectories gives each trajectory exactly what it gets
+    alone (the BatchNorm statistics are per trajectory)."""
+    _need_gpu()
+    ds, model, params, homog = _gpu_setup("dam2d", 0.3, 2, 2, 2, "batch")
+    isl = ds.input_seq_length
+    ocase, hcase = oracle_case(ds, dtype=np.float32), hip_case(ds, dtype="float32")
+    pos = np.stack([ds[0][0], ds[1][0]])
+    pt = np.stack([ds[0][1], ds[1][1]])
+    feats, _ = hcase.allocate_eval((pos[:, :, :isl], pt))
+    both = _np(model.apply(params, {}, (feats, pt))[0]["acc"])
+    for b in range(2):
+        of, _ = ocase.allocate_eval((pos[b][:, :isl].astype(np.float32), pt[b]))
+        with S.precision(np.float64):
+            ref64 = G.segnn_apply(params, dict(of), pt[b], isl - 1, homog, norm_eps=model.norm_eps)["acc"]
+        ref32 = G.segnn_apply(params, dict(of), pt[b], isl - 1, homog, norm_eps=model.norm_eps)["acc"]
+        e_dev, e_f32 = rel_err(both[b], ref64), rel_err(ref32, ref64)
+        assert e_dev <= max(1e-5, 2.0 * e_f32) and e_dev < 2e-4, (b, e_dev, e_f32)
+    hcase1 = hip_case(ds, dtype="float32")
+    f1, _ = hcase1.allocate_eval((pos[1:2, :, :isl], pt[1:2]))
+    alone = _np(model.apply(params, {}, (f1, pt[1:2]))[0]["acc"])[0]
+    assert np.array_equal(alone, both[1])
+
+
+@pytest.mark.gpu
 def test_general_segnn_rollout_matches_oracle():
     """lb_segnn_rollout with the general path as the model (device step loop) against the oracle's eval loop, 5 steps."""
     _need_gpu()
