@@ -502,15 +502,29 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
       for (int mb = 0; mb < NOB; ++mb) part[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
       const h8* sw = sw0 + (size_t)(jc * 4) * NOB * 2 * 64;
+      // groups of (k-step p, GM column blocks): the 2 GM 16-byte LDS reads of group g + 1 are issued before the 3 GM MFMAs of
+      // group g (left to itself the compiler reads a fragment pair right before its three MFMAs and waits for it).  GM = 4
+      // where the registers allow it (two waves per SIMD: 256), 2 for the gather epilogue, which holds two more rows.
+      constexpr int GM = EPI == 4 ? 2 : 4, NG = 4 * NOB / GM;
+      h8 wq[2][2 * GM];
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int u = 0; u < 2 * GM; ++u) wq[0][u] = sw[u * 64];
 #pragma unroll
-        for (int mb = 0; mb < NOB; ++mb) {
-          const h8 wh = sw[((p * NOB + mb) * 2) * 64], wl = sw[((p * NOB + mb) * 2 + 1) * 64];
-          part[mb] = MFMA16H(wh, hi[p], part[mb]);
-          part[mb] = MFMA16H(wh, lo[p], part[mb]);
-          part[mb] = MFMA16H(wl, hi[p], part[mb]);
+      for (int gq = 0; gq < NG; ++gq) {
+        const int p = gq / (NOB / GM), m0 = (gq % (NOB / GM)) * GM;
+        if (gq + 1 < NG) {
+#pragma unroll
+          for (int u = 0; u < 2 * GM; ++u) wq[(gq + 1) & 1][u] = sw[(((gq + 1) * GM) * 2 + u) * 64];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < GM; ++q) {
+          const h8 wh = wq[gq & 1][2 * q], wl = wq[gq & 1][2 * q + 1];
+          part[m0 + q] = MFMA16H(wh, hi[p], part[m0 + q]);
+          part[m0 + q] = MFMA16H(wh, lo[p], part[m0 + q]);
+          part[m0 + q] = MFMA16H(wl, hi[p], part[m0 + q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int mb = 0; mb < NOB; ++mb)
