@@ -631,19 +631,11 @@ __global__ void k_lower_bounds(const int32_t* __restrict__ keys, int64_t E, int6
   }
   ptr[s] = (int32_t)lo;
 }
-// xn[i] = [n[i] | agg[i]]
-__global__ void k_concat_node_in(const float* __restrict__ n, const float* __restrict__ agg, float* __restrict__ xn,
-                                 int64_t N) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * 64) return;
-  const int64_t r = i / 64;
-  const int q = (int)(i % 64);
-  reinterpret_cast<f32x4*>(xn)[i] = q < 32 ? reinterpret_cast<const f32x4*>(n)[r * 32 + q]
-                                           : reinterpret_cast<const f32x4*>(agg)[r * 32 + (q - 32)];
-}
 // jraph.segment_sum on the receiver-sorted CSR (rows are contiguous edge ranges): agg[r] = sum_e msg[e]
+// xn != null (the GNS node block): the sum goes straight into the right half of the node MLP's input row [n | agg] and the
+// node latent n into the left half - the concatenation (k_concat_node_in until round 5: a launch per layer) rides along
 __global__ void k_seg_sum(const int32_t* __restrict__ row_ptr, const float* __restrict__ msg, float* __restrict__ agg,
-                          int64_t N, int64_t E) {
+                          int64_t N, int64_t E, const float* __restrict__ n = nullptr, float* __restrict__ xn = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * 32) return;
   const int64_t r = i / 32;
@@ -653,7 +645,12 @@ __global__ void k_seg_sum(const int32_t* __restrict__ row_ptr, const float* __re
   k1 = k1 < E ? k1 : E;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   for (int64_t k = k0; k < k1; ++k) s = s + reinterpret_cast<const f32x4*>(msg)[k * 32 + q];
-  reinterpret_cast<f32x4*>(agg)[i] = s;
+  if (xn) {
+    reinterpret_cast<f32x4*>(xn)[r * 64 + q] = reinterpret_cast<const f32x4*>(n)[i];
+    reinterpret_cast<f32x4*>(xn)[r * 64 + 32 + q] = s;
+  } else {
+    reinterpret_cast<f32x4*>(agg)[i] = s;
+  }
 }
 // non-kinematic particle count per trajectory (utils.py:28-35) and the per-node loss weight 1 / count
 __global__ void k_count_nonkin(const int32_t* __restrict__ ptype, int64_t BN, int N, int32_t* __restrict__ cnt) {
@@ -1379,8 +1376,7 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
   for (int k = 0; k < L; ++k) {
     // e' = LN(MLP([n_s | n_r | e])) is both the message and (plus e) the next edge latent: keep e' in dy, then residual
     LB_TRY(edge_fwd(t, t->pe[k], E, BN, t->nlat[k], t->elat[k], t->ae[k], t->ze[k], t->dy, t->elat[k + 1]));
-    hipLaunchKernelGGL(k_seg_sum, GRID1(BN * 32), 0, s, e->row_ptr, t->dy, t->agg, BN, E);
-    hipLaunchKernelGGL(k_concat_node_in, GRID1(BN * 64), 0, s, t->nlat[k], t->agg, t->xn[k], BN);
+    hipLaunchKernelGGL(k_seg_sum, GRID1(BN * 32), 0, s, e->row_ptr, t->dy, t->agg, BN, E, t->nlat[k], t->xn[k]);
     LB_TRY(mlp_fwd(t, t->pn[k], BN, t->xn[k], 2 * TD, t->an[k], t->zn[k], t->nlat[k], t->nlat[k + 1]));
   }
   LB_TRY(mlp_fwd(t, t->dec, BN, t->nlat[L], TD, t->a_d, nullptr, nullptr, t->pred));

@@ -489,7 +489,8 @@ extern "C" int lb_segnn_train_loss_grad(lb_gns_train* t, const float* target_dev
       }
       cur = dst;
     }
-    hipLaunchKernelGGL(k_seg_sum, GRID1(BN * 32), 0, s, e->row_ptr, cur ? cur : g->te[0], g->agg, BN, E);
+    hipLaunchKernelGGL(k_seg_sum, GRID1(BN * 32), 0, s, e->row_ptr, cur ? cur : g->te[0], g->agg, BN, E, (const float*)nullptr,
+                       (float*)nullptr);
     const float* ncur = nullptr;
     for (int i = 0; i < B; ++i) {
       const bool last = i == B - 1;
