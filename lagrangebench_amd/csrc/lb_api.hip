@@ -1,5 +1,6 @@
 // lb_api.hip - the C ABI of liblbhip.so (include/lbhip.h): engine object, buffers, weight
 // packing, the device-resident rollout driver and the HIP-event timers used by bench.py.
+#include <cstddef>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -488,7 +489,13 @@ extern "C" int lb_edge_accounting(lb_engine* e, int64_t* sum_edges, int64_t* n_b
   if (first_edges) *first_edges = e->ctrl_host->acct_first;
   if (last_edges) *last_edges = e->ctrl_host->n_edges_unclamped;
   if (reset) {
-    LB_HIP(hipMemsetAsync(&e->ctrl->acct_builds, 0, sizeof(int32_t) * 2 + sizeof(int64_t), e->stream));
+    // acct_builds, acct_first, (padding,) acct_sum: everything from acct_builds to the end of acct_sum (the
+    // 8-aligned acct_sum sits behind 4 bytes of padding, a 16-byte memset left its high half alive)
+    static_assert(offsetof(lb_ctrl, acct_first) == offsetof(lb_ctrl, acct_builds) + sizeof(int32_t) &&
+                      offsetof(lb_ctrl, acct_sum) > offsetof(lb_ctrl, acct_first),
+                  "lb_ctrl accounting fields must be contiguous: acct_builds, acct_first, acct_sum");
+    LB_HIP(hipMemsetAsync(&e->ctrl->acct_builds, 0,
+                          offsetof(lb_ctrl, acct_sum) + sizeof(int64_t) - offsetof(lb_ctrl, acct_builds), e->stream));
     LB_HIP(hipStreamSynchronize(e->stream));
   }
   return LB_OK;
@@ -981,6 +988,10 @@ extern "C" int lb_debug_inject_guard(lb_engine* e, int32_t flags, int32_t step) 
   if (!e) return lb_fail(LB_ERR_ARG, "null engine");
   if (step >= 0 && !(flags & (LB_MATH_LARGE | LB_MATH_TINY | LB_MATH_NONFINITE)))
     return lb_fail(LB_ERR_ARG, "flags must carry at least one LB_MATH_* bit");
+  //  only the guarded f16x2 mode consumes the hook: arming it in any other mode is refused instead of
+  // leaving it armed for some later rollout
+  if (step >= 0 && !(e->f16x2 && e->math_auto))
+    return lb_fail(LB_ERR_STATE, "lb_debug_inject_guard needs the guarded f16x2 mode (lb_math_mode auto)");
   e->debug_guard_flags = flags;
   e->debug_guard_step = step < 0 ? -1 : step;
   return LB_OK;
@@ -1044,6 +1055,9 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
   } feat_guard{e};
   LB_TRY(lb_gns_bind(e, g));
   e->feat_job = lb_feat_job{e->xnode, g->embed, g->desc.embedding_size, g->desc.num_particle_types, e->g.kpad, e->ptype, e->force};
+  // the injection hook is one-shot per lb_rollout whatever the mode (a mode switch after arming must not leave it armed)
+  const int inj_step = e->debug_guard_step, inj_flags = e->debug_guard_flags;
+  e->debug_guard_step = -1;
   LB_TRY(lb_rollout_generic(e, gns_forward_thunk, g, traj_dev, T, n_steps, pred_out_dev, n_realloc_out));
   if (e->f16x2 && e->math_auto) {
     // The guard records the FIRST step at which a flag was raised (lb_ctrl::math_step).  Round 4: that ONE step is redone
@@ -1053,15 +1067,17 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
     // again.  Steps before the flagged one are valid f16x2 work only if every tile was tested: with LB_GUARD=sampled
     // (first tile of every wave, rounds 2-3) the rollout is repeated from step 0 instead.
     static const int max_fb = getenv("LB_GUARD_MAX_FALLBACKS") ? atoi(getenv("LB_GUARD_MAX_FALLBACKS")) : 3;
-    if (e->debug_guard_step >= 0) {
-      // lb_debug_inject_guard (tests): behave as if the guard had fired at that step of THIS rollout; one-shot
-      if (e->debug_guard_step < n_steps) {
-        const int32_t inj[2] = {e->debug_guard_flags, e->debug_guard_step};
-        LB_HIP(hipMemcpyAsync(&e->ctrl->math_flags, &inj[0], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-        LB_HIP(hipMemcpyAsync(&e->ctrl->math_step, &inj[1], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-        LB_HIP(hipStreamSynchronize(e->stream));
-      }
-      e->debug_guard_step = -1;
+    if (inj_step >= 0 && inj_step < n_steps) {
+      // lb_debug_inject_guard (tests): behave as if the guard had ALSO fired at that step of THIS rollout - flags the
+      // rollout raised itself stay (OR), the earlier step wins (min)
+      int32_t cur[2] = {0, 0};
+      LB_HIP(hipMemcpyAsync(&cur[0], &e->ctrl->math_flags, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+      LB_HIP(hipMemcpyAsync(&cur[1], &e->ctrl->math_step, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+      LB_HIP(hipStreamSynchronize(e->stream));
+      const int32_t inj[2] = {cur[0] | inj_flags, cur[0] ? std::min(cur[1], (int32_t)inj_step) : (int32_t)inj_step};
+      LB_HIP(hipMemcpyAsync(&e->ctrl->math_flags, &inj[0], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+      LB_HIP(hipMemcpyAsync(&e->ctrl->math_step, &inj[1], sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+      LB_HIP(hipStreamSynchronize(e->stream));
     }
     int rc = LB_OK;
     for (int fallbacks = 0;;) {

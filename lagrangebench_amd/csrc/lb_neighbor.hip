@@ -790,6 +790,292 @@ __global__ void __launch_bounds__(64 * NLW_WAVES)
   }
 }
 
+// One WAVE per CELL (round 6).  k_nlw pays the stencil walk, the candidate addressing, a rank pass
+// and one fp64 emission pass (three divisions and a square root, a dozen lanes busy) for EVERY receiver: ~740 VALU + ~390
+// SALU instructions per receiver, and its launch keeps the VALU pipes ~95 % busy (profiles/r06_nl_sq.txt).  Here the wave
+// of a cell builds the stencil table once, keeps the <= 128 stencil candidates (cell-sorted slot, particle id, fp64
+// position: 2 per lane) in registers for all the cell's receivers, appends every receiver's hits to ONE LDS list (ballot +
+// popcount prefix as before; the rank of a hit inside its row - ascending particle id - is taken right away with lane
+// broadcasts) and emits the list 64 edges at a time, so the fp64 feature arithmetic runs on full waves whatever rows the
+// edges belong to.  Predicate, features and operand order are k_nlw's: the edge list is bit-identical.  Stencils with more
+// than 128 candidates sweep in 128-candidate chunks per receiver (registers reloaded: dense cells, rare); the list holds
+// NLC_LIST hits and is flushed whenever the next row (<= LB_MAX_ROW hits) might not fit.
+#define NLC_WAVES 4
+#define NLC_LIST 448
+#define NLC_BATCH 128
+#define NLC_S 4   // candidate slots per lane held in registers (stencils of up to 256 particles in one chunk)
+template <int MODE, bool F32, int DIM>
+__global__ void __launch_bounds__(64 * NLC_WAVES, 5)
+    k_nlc(lb_geom g, int64_t BN, lb_ctrl* __restrict__ ctrl, lb_nl_args a) {
+  __shared__ int s_cstart_[NLC_WAVES][28], s_coff_[NLC_WAVES][29];
+  __shared__ int s_src_[NLC_WAVES][NLC_LIST], s_id_[NLC_WAVES][NLC_LIST];
+  __shared__ unsigned short s_kr_[NLC_WAVES][NLC_LIST];  // row of the batch << 8 | rank inside the row
+  if (ctrl->overflow_step >= 0) return;
+  if (MODE == NL_ROWS && a.nb_search > 0 && (int)blockIdx.x >= a.nb_search) {
+    // rollout step: the workgroups behind the search's write the node-feature rows (as in k_nlw)
+    const int64_t first = ((int64_t)(blockIdx.x - a.nb_search) * NLC_WAVES + (threadIdx.x >> 6)) * NL_FEAT_ROWS;
+    const int cnt = (int)min((int64_t)NL_FEAT_ROWS, BN - first);
+    if (cnt > 0)
+      lb_node_features_wave_multi(g, BN, a.win, ctrl->step, a.feat, [&](int p) -> int64_t { return first + p; }, cnt);
+    return;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int gc = __builtin_amdgcn_readfirstlane((int)blockIdx.x * NLC_WAVES + wave);
+  if (gc >= g.B * g.ncells) return;
+  const int own_start = a.cell_start[gc];
+  const int own_cnt = a.cell_start[gc + 1] - own_start;
+  if (own_cnt <= 0) return;
+  int* const s_cstart = s_cstart_[wave];
+  int* const s_coff = s_coff_[wave];
+  int* const s_src = s_src_[wave];
+  int* const s_id = s_id_[wave];
+  unsigned short* const s_kr = s_kr_[wave];
+  const int b = gc / g.ncells, h = gc % g.ncells;
+  {
+    int cnt = 0;
+    if (lane < g.nstencil) {
+      int nh = h;
+      if (g.use_cell_list) {
+        int c[3] = {h % g.ncell[0], (h / g.ncell[0]) % g.ncell[1], h / (g.ncell[0] * g.ncell[1])};
+        int o[3] = {lane % 3 - 1, (lane / 3) % 3 - 1, lane / 9 - 1};
+        nh = 0;
+        int mult = 1;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+          int cc = c[d] + o[d];  // jax-md rolls the cell buffer: the stencil always wraps
+          cc = cc < 0 ? cc + g.ncell[d] : (cc >= g.ncell[d] ? cc - g.ncell[d] : cc);
+          nh += cc * mult;
+          mult *= g.ncell[d];
+        }
+      }
+      const int ngc = b * g.ncells + nh;
+      const int st = a.cell_start[ngc];
+      s_cstart[lane] = st;
+      cnt = a.cell_start[ngc + 1] - st;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const int v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    if (lane < g.nstencil) s_coff[lane] = incl - cnt;
+    if (lane == g.nstencil - 1) s_coff[g.nstencil] = incl;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  const int M = __builtin_amdgcn_readfirstlane(s_coff[g.nstencil]);
+  const bool single = M <= 64 * NLC_S;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // candidates of one chunk of NLC_S * 64: cell-sorted slot + particle id (loads from clamped addresses, never selects);
+  // slots whose 64 candidates lie past M are skipped (wave-uniform)
+  int cj[NLC_S], cid[NLC_S];
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int s = 0; s < NLC_S; ++s) {
+      if (c0 + 64 * s >= M) continue;
+      const int j = min(c0 + 64 * s + lane, M - 1);
+      int lo = 0, hi = g.nstencil;  // largest k with s_coff[k] <= j
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_coff[mid] <= j) lo = mid; else hi = mid;
+      }
+      cj[s] = s_cstart[lo] + (j - s_coff[lo]);
+      cid[s] = a.cell_part[cj[s]];
+    }
+  };
+  const int cap = (MODE == NL_ROWS) ? min(a.maxd, LB_MAX_ROW) : LB_MAX_ROW;
+  int list_len = 0, kfirst = 0;
+  // emission of the list: 64 edges per pass, whatever rows they belong to
+  auto flush = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (int t0 = 0; t0 < list_len; t0 += 64) {
+      const int t = t0 + lane;
+      const bool act = t < list_len;
+      const int tc = act ? t : 0;
+      const int src = s_src[tc], my = s_id[tc], kr = s_kr[tc];
+      const int rslot = own_start + kfirst + (kr >> 8), rank = kr & 0xff;
+      const int gr = a.cell_part[rslot];
+      double pr[DIM], sp[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) {
+        pr[d] = a.cpos[(int64_t)d * BN + rslot];
+        sp[d] = a.cpos[(int64_t)d * BN + src];
+      }
+      if (!act) continue;
+      const int64_t base = (MODE == NL_ROWS) ? (int64_t)gr * a.maxd : (int64_t)a.row_ptr[gr];
+      const int64_t slot = base + rank;
+      if (MODE == NL_ROWS || slot < a.e_alloc) {
+        a.senders[slot] = my;
+        // features.py:115-124: disp(pos[receiver], pos[sender]) / r_c and its norm
+        double rd[3] = {0, 0, 0};
+        double s2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+          rd[d] = lb_r(lb_disp1(pr[d], sp[d], g.box[d], g.half_box[d], g.periodic, F32) / g.rc, F32);
+          s2 = (d == 0) ? lb_r(rd[d] * rd[d], F32) : lb_r(s2 + lb_r(rd[d] * rd[d], F32), F32);
+        }
+        const double dist = s2 > 0.0 ? lb_r(sqrt(s2), F32) : 0.0;
+        const f32x4 lo4 = (DIM == 2) ? f32x4{(float)rd[0], (float)rd[1], (float)dist, 0.f}
+                                     : f32x4{(float)rd[0], (float)rd[1], (float)rd[2], (float)dist};
+        if (MODE == NL_ROWS) {
+          reinterpret_cast<f32x4*>(a.efeat)[slot] = lo4;
+        } else {
+          a.receivers[slot] = gr;
+          f32x4* ef = reinterpret_cast<f32x4*>(a.efeat + slot * 8);
+          ef[0] = lo4;
+          ef[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (a.efeat64) {
+          double* e64 = a.efeat64 + slot * 4;
+          e64[0] = rd[0];
+          e64[1] = rd[1];
+          e64[2] = rd[2];
+          e64[3] = dist;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  };
+#pragma unroll
+  for (int s = 0; s < NLC_S; ++s) cj[s] = cid[s] = 0;
+  if (single) load_chunk(0);
+  // float pre-filter (single chunk, fp64 geometry).  q = (float) minimal image of (candidate - origin), origin = the cell's
+  // first particle, taken in fp64 ONCE per cell; a pair's squared distance in float, |q_s - q_r|^2, differs from the
+  // reference's fp64 value by < 4e-6 r_c^2 as long as every |q_d| <= 8 r_c (rounding of q: 2 * 2^-24 * 8 r_c per component,
+  // the float arithmetic: a few 2^-24), and it IS the minimal image's as long as 2 max|q_d| <= L_d - 1.001 r_c (then a
+  // component beyond L_d / 2 still leaves the image outside the cutoff).  Pairs whose float value is within 1e-4 r_c^2 of
+  // the threshold - ~1 cell in 50 has one - send the receiver to the exact fp64 predicate below (positions re-read from
+  // L1 / L2), which also serves float32 geometry and chunked stencils; everything else is decided in float: same edge
+  // list, bit for bit.  The candidates' fp64 positions never stay in registers.
+  float q[NLC_S][DIM];
+#pragma unroll
+  for (int s = 0; s < NLC_S; ++s)
+    _Pragma("unroll") for (int d = 0; d < DIM; ++d) q[s][d] = 0.f;
+  bool filt = false;
+  const float lo2 = (float)(g.rc2 * (1.0 - 1e-4)), hi2 = (float)(g.rc2 * (1.0 + 1e-4));
+  if (!F32 && single) {
+    bool bad = false;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      const double org = a.cpos[(int64_t)d * BN + own_start];
+      float lim = 8.f * (float)g.rc;
+      if (g.periodic) lim = fminf(lim, 0.5f * (float)(g.box[d] - 1.001 * g.rc));
+      _Pragma("unroll") for (int s = 0; s < NLC_S; ++s) {
+        if (64 * s >= M) continue;
+        q[s][d] = (float)lb_disp1(a.cpos[(int64_t)d * BN + cj[s]], org, g.box[d], g.half_box[d], g.periodic, 0);
+        bad = bad || !(fabsf(q[s][d]) <= lim);
+      }
+    }
+    filt = __ballot(bad) == 0ull;
+  }
+  const int own_off = __builtin_amdgcn_readfirstlane(s_coff[g.use_cell_list ? (DIM == 2 ? 4 : 13) : 0]);
+  for (int k = 0; k <= own_cnt; ++k) {  // (iteration own_cnt only flushes: ONE inlined copy of the emission)
+    if (MODE != NL_COUNT &&
+        (k == own_cnt ? list_len > 0 : (list_len > NLC_LIST - LB_MAX_ROW || k - kfirst >= NLC_BATCH))) {
+      flush();
+      list_len = 0;
+      kfirst = k;
+    }
+    if (k == own_cnt) break;
+    const int gr = a.cell_part[own_start + k];
+    const int kb = k - kfirst;
+    int count = 0;
+    for (int c0 = 0; c0 < M; c0 += 64 * NLC_S) {
+      if (!single) load_chunk(c0);
+      bool ok[NLC_S];
+#pragma unroll
+      for (int s = 0; s < NLC_S; ++s) ok[s] = false;
+      bool exact = !filt;
+      if (filt) {
+        const int idx = own_off + k, sel = idx >> 6, l = idx & 63;  // the receiver is candidate own_off + k
+        float pq[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+          float v = q[0][d];
+          _Pragma("unroll") for (int s = 1; s < NLC_S; ++s) v = sel == s ? q[s][d] : v;
+          pq[d] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+        }
+        bool unc = false;
+#pragma unroll
+        for (int s = 0; s < NLC_S; ++s) {
+          if (64 * s >= M) continue;
+          float dd = q[s][0] - pq[0];
+          float d2 = dd * dd;
+          _Pragma("unroll") for (int d = 1; d < DIM; ++d) {
+            dd = q[s][d] - pq[d];
+            d2 = __builtin_fmaf(dd, dd, d2);
+          }
+          const bool valid = 64 * s + lane < M;
+          ok[s] = valid && d2 < lo2;
+          unc = unc || (valid && !(d2 < lo2) && !(d2 > hi2));
+        }
+        exact = __ballot(unc) != 0ull;
+      }
+      if (exact) {
+        double pr[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) pr[d] = a.cpos[(int64_t)d * BN + own_start + k];
+#pragma unroll
+        for (int s = 0; s < NLC_S; ++s) {
+          if (c0 + 64 * s >= M) continue;
+          // metric_sq(position[sender], position[receiver]): sum of squares in x,y,z order, no FMA
+          double dd = lb_disp1(a.cpos[cj[s]], pr[0], g.box[0], g.half_box[0], g.periodic, F32);
+          double d2 = lb_r(dd * dd, F32);
+          _Pragma("unroll") for (int d = 1; d < DIM; ++d) {
+            dd = lb_disp1(a.cpos[(int64_t)d * BN + cj[s]], pr[d], g.box[d], g.half_box[d], g.periodic, F32);
+            d2 = lb_r(d2 + lb_r(dd * dd, F32), F32);
+          }
+          ok[s] = (c0 + 64 * s + lane < M) && (d2 < g.rc2);  // strict <
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < NLC_S; ++s) {
+        if (c0 + 64 * s >= M) continue;
+        const unsigned long long m = __ballot(ok[s]);
+        if (MODE != NL_COUNT) {
+          const int p = count + __popcll(m & lt_mask);
+          if (ok[s] && p < cap) {
+            s_src[list_len + p] = cj[s];
+            s_id[list_len + p] = cid[s];
+          }
+        }
+        count += __popcll(m);
+      }
+    }
+    if (MODE != NL_FILL && lane == 0) a.deg[gr] = count;  // (ctrl->max_deg is reduced by the degree scan, see k_nl)
+    if (MODE == NL_COUNT) continue;
+    if (count > LB_MAX_ROW) {
+      if (lane == 0) {
+        if (MODE == NL_ROWS)
+          atomicExch(&ctrl->row_overflow, 1);  // re-allocate (the allocation switches to the dense fall-back)
+        else
+          atomicExch(&ctrl->density_error, 2);
+      }
+      count = LB_MAX_ROW;
+    }
+    if (MODE == NL_ROWS && count > a.maxd) {
+      if (lane == 0) atomicExch(&ctrl->row_overflow, 1);  // per-node slots too small: re-allocate
+      count = a.maxd;
+    }
+    // rank of every hit inside its row (ids are unique): lane broadcasts for rows <= 64, the LDS row otherwise
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (count <= 64) {
+      const int my = s_id[list_len + min(lane, max(count - 1, 0))];
+      int rank = 0;
+      for (int u = 0; u < count; ++u) rank += (__builtin_amdgcn_readlane(my, u) < my) ? 1 : 0;
+      if (lane < count) s_kr[list_len + lane] = (unsigned short)((kb << 8) | rank);
+    } else {
+      for (int t = lane; t < count; t += 64) {
+        const int my = s_id[list_len + t];
+        int rank = 0;
+        for (int u = 0; u < count; ++u) rank += (s_id[list_len + u] < my) ? 1 : 0;
+        s_kr[list_len + t] = (unsigned short)((kb << 8) | rank);
+      }
+    }
+    list_len += count;
+  }
+}
+
 // NL_ROWS -> CSR: one 16-lane group per node copies its sorted row into place.
 __global__ void __launch_bounds__(256)
     k_nl_compact(int64_t BN, const lb_ctrl* __restrict__ ctrl, const int32_t* __restrict__ deg,
@@ -1583,6 +1869,30 @@ static void lb_launch_nl(lb_engine* e, int small, const lb_nl_args& a) {
   // NL_ROWS in a rollout step: every search wave also writes the node-feature row of its receiver
   const bool ride = MODE == NL_ROWS && e->feat_job.xnode && !a.efeat64;
   if (ride) e->feat_done = true;
+  // round 6: one wave per CELL (k_nlc) wherever the wave-per-receiver kernel ran on a cell list that is not dense;
+  // LB_NL_KERNEL=wave keeps k_nlw, =nlc sends the 3^2-cell stencils to k_nlc as well
+  const bool cell_wave = e->g.use_cell_list && !e->nl_dense && (e->g.dim == 2 || e->g.dim == 3) && (force ? force[0] == 'n' : per_wave);
+  if (cell_wave) {
+    const int ncell_all = e->g.B * e->g.ncells;
+    const int nb_s = (ncell_all + NLC_WAVES - 1) / NLC_WAVES;
+    int nb = nb_s;
+    lb_nl_args aw = a;
+    if (ride) {
+      aw.feat = e->feat_job;
+      aw.win = e->win;
+      aw.nb_search = nb_s;
+      nb = nb_s + (int)((e->BN + NLC_WAVES * NL_FEAT_ROWS - 1) / (NLC_WAVES * NL_FEAT_ROWS));
+    }
+#define LB_NLC_LAUNCH(F, D) \
+  hipLaunchKernelGGL((k_nlc<MODE, F, D>), dim3(nb), dim3(64 * NLC_WAVES), 0, e->stream, e->g, e->BN, e->ctrl, aw)
+    if (e->g.f32) {
+      if (e->g.dim == 3) LB_NLC_LAUNCH(true, 3); else LB_NLC_LAUNCH(true, 2);
+    } else {
+      if (e->g.dim == 3) LB_NLC_LAUNCH(false, 3); else LB_NLC_LAUNCH(false, 2);
+    }
+#undef LB_NLC_LAUNCH
+    return;
+  }
   if (per_wave) {
     const int nb_s = (int)((e->BN + NLW_WAVES - 1) / NLW_WAVES);
     int nb = nb_s;
