@@ -47,7 +47,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def pmc_traffic(kernel_substr: str, workload: str, batch: int):
+def pmc_traffic(kernel_substr: str, workload: str, batch: int, stationary: bool = False):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
     produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this command;
     FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  None if not measured."""
@@ -55,7 +55,10 @@ def pmc_traffic(kernel_substr: str, workload: str, batch: int):
     try:
         with open(path) as f:
             tab = json.load(f)
-        for key in (f"{workload}_b{batch}", f"{workload}_b{batch}_r01"):   # _r01: kernels only profiled in round 1
+        keys = (f"{workload}_b{batch}", f"{workload}_b{batch}_r01")   # _r01: kernels only profiled in round 1
+        if stationary:   # round 6: the headline's stationary trajectories have their own passes
+            keys = (f"{workload}_b{batch}_st",) + keys
+        for key in keys:
             for k, v in sorted(tab.get(key, {}).items()):
                 if kernel_substr in k:
                     return v["hbm_bytes_per_launch"]
@@ -103,8 +106,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short sub-runs of the other BASELINE.json configs appended as `other_configs`")
-    ap.add_argument("--no-pmc", action="store_true",
-                    help="do not re-measure roofline.traffic with two nested rocprofv3 PMC passes (use profiles/pmc_traffic.json)")
+    ap.add_argument("--pmc", action="store_true",
+                    help="re-measure roofline.traffic with two nested rocprofv3 PMC passes of this command (FETCH_SIZE, WRITE_SIZE; "
+                         "~10 s); default (round 6): the committed profiles/pmc_traffic.json value, `traffic_source` names it")
+    ap.add_argument("--no-pmc", action="store_true", help="(accepted for older scripts; the nested passes are opt-in now: --pmc)")
     ap.add_argument("--shuffle", action="store_true",
                     help="randomly permute the particle ids (memory-locality ablation; default: lattice order)")
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -119,7 +124,7 @@ def main():
                          "workload rounds 1-5 quoted `value` on (13.6 -> 18.5 -> 17.1, mean 16.2)")
     args = ap.parse_args()
     if args.cpu_baseline_only:   # legs one after the other in this process: they must not compete for the cores
-        print(json.dumps({w: cpu_baseline_leg(w, args.mp_steps) for w in args.cpu_baseline_only.split(",")}), flush=True)
+        print(json.dumps({w: cpu_baseline_leg(w, args.mp_steps, args.vel_amp) for w in args.cpu_baseline_only.split(",")}), flush=True)
         return
 
     t_start = time.perf_counter()
@@ -214,6 +219,29 @@ def main():
 
     if rank != 0:
         return
+    # power pass (round 6): the same rollout repeated for ~1.5 s while a thread samples the card's hwmon
+    # node (shader clock, package power) at 100 Hz: mean clock / power of the headline workload, joules per rollout step
+    power = None
+    if world == 1:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import power_probe as PP
+            with PP.PowerProbe(hz=100.0, pci=PP.hip_pci_address()) as probe:
+                eng.rollout(handle, traj, K)   # clocks settle
+                torch.cuda.synchronize(device)
+                tp0 = time.perf_counter()
+                n_pw = 0
+                while time.perf_counter() - tp0 < 1.5:
+                    eng.rollout(handle, traj, K)
+                    n_pw += K
+                torch.cuda.synchronize(device)
+                tp1 = time.perf_counter()
+            power = probe.summary(units=n_pw, t0=tp0, t1=tp1)
+            if power:
+                power["joules_per_step"] = power.pop("joules_per_unit", None)
+                power["steps_in_window"] = n_pw
+        except Exception as exc:
+            power = {"error": repr(exc)[:200]}
     value = world * B * N * K / dt
     ms_edge, n_edge = tm["edge_mlp"]
     ms_last, n_last = tm.get("edge_mlp_last", (0.0, 0))   # last layer: no edge-latent store (its own timer class)
@@ -263,8 +291,8 @@ def main():
     if math_mode == "f16x2":
         roof = {"kernel": kern, "bound": "hbm", "achieved": gbs_edge, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs_edge / HBM_PEAK_GBS, "last_layer_variant": last_variant,
-                "traffic": pmc_traffic(pmc_key, args.workload, B),
-                "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured by this run)",
+                "traffic": pmc_traffic(pmc_key, args.workload, B, args.vel_amp != 1.0),
+                "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured by this run - `--pmc` does)",
                 "us_per_launch": us_edge, "launches": int(n_edge), "bytes_per_launch": edge_bytes,
                 "edges_per_launch_mean": round(E_tot, 1), "tiles_per_launch_mean": round(E_tot / 16, 1),
                 "bytes_formula": "E_mean * (2*128*4 + 8) + B*N * 2*128*4  (SURVEY 8d; E_mean = mean real E of the timed steps)",
@@ -302,9 +330,11 @@ def main():
             "n_particles": int(N), "batch_per_gpu": B, "edges_per_traj": int(round(E_tot / B)),
             "edges_per_traj_first": int(acct_tm["first"] // B), "edges_per_traj_mean": round(E_tot / B, 1),
             "edges_per_traj_last": int(E_last // B), "edges_per_traj_mean_timed_repeats": round(acct["mean"] / B, 1),
+            "vel_amp": args.vel_amp,
             "edges_note": ("per-launch bytes / flops of every roofline object use the MEAN real E of the K steps the HIP-event "
-                           "timers cover (device-side sum over the neighbor-list builds, lb_edge_accounting); the synthetic "
-                           "rollout is not stationary - see `stationary` for the same engine at SURVEY 8d's neighbour count"),
+                           "timers cover (device-side sum over the neighbor-list builds, lb_edge_accounting); round 6: `value` "
+                           "is quoted on trajectories whose neighbour count is stationary (vel_amp 0.03, ~14.4 per particle; "
+                           "SURVEY 8d: 13.1) - the drifting workload of rounds 1 - 5 is other_configs[tag = tgv3d_drifting]"),
             "math_fallbacks": int(fallbacks_timed),
             "input_seq_length": ds.input_seq_length, "geometry_dtype": "f64", "network_math": math_mode,
             "weights": "haiku-default init (seed 1234), decoder x0.01", "n_realloc": int(n_realloc),
@@ -324,7 +354,16 @@ def main():
                      "fuses the aggregation into the edge-MLP epilogue (no message round trip)") if fused else "",
         },
         "breakdown_ms_per_step": breakdown,
+        "power": power,
     }
+    if power and power.get("power_w_mean") and power.get("power_cap_w"):
+        at_cap = power["power_w_mean"] >= 0.93 * power["power_cap_w"]
+        roof["sclk_mhz"] = power["sclk_mhz_mean"]
+        roof["power_w"] = power["power_w_mean"]
+        roof["joules_per_launch"] = power["power_w_mean"] * us_edge * 1e-6
+        roof["limiter"] = ("power: the package sits at its cap while this workload runs (hwmon, 100 Hz) and the shader clock "
+                           f"falls from 2400 to {power['sclk_mhz_mean']:.0f} MHz - only removing work moves the launch, overlap does not"
+                           ) if at_cap else "not at the power cap while this workload runs"
 
     if world == 1 and math_mode == "f16x2" and not args.no_f32:
         # the same K steps in exact-fp32 MFMA arithmetic (what LB_MATH=f32 selects and what the range guard falls
@@ -349,15 +388,17 @@ def main():
         out["other_configs"] = other_configs(device)
         log(f"[bench] other_configs done at {time.perf_counter() - t_start:.1f} s")
         out["stationary"] = {"lines": other_configs(device, STATIONARY_PLAN, repeats=3),
-                             "note": ("same engine, same weights, trajectories whose neighbour count does not drift over the "
-                                      "rollout (vel_amp 0.03: TGV3D holds ~14.4 neighbours per particle, SURVEY 8d quotes 13.1 "
-                                      "for the dataset); `value` of the headline line stays on the drifting workload of rounds "
-                                      "1-4 (13.6 -> 18.5 -> 17.1 per particle, mean 16.2) for comparability")}
+                             "note": ("more lines on trajectories whose neighbour count does not drift over the rollout "
+                                      "(vel_amp 0.03, as the headline since round 6: TGV3D holds ~14.4 neighbours per particle, "
+                                      "SURVEY 8d quotes 13.1 for the dataset)")}
         log(f"[bench] stationary lines done at {time.perf_counter() - t_start:.1f} s")
         out["train_step"] = train_step_lines(device)
         log(f"[bench] train_step done at {time.perf_counter() - t_start:.1f} s")
     # Everything TIMED on the GPU is done.  The CPU-baseline legs run NOW, one after the other, with nothing else on the
     # host (run beside the nested rocprofv3 passes their step times spread 3x); the PMC passes follow.
+    # Everything TIMED on the GPU is done.  The CPU-baseline legs run NOW, one after the other, with nothing else on the
+    # host (beside the GPU sub-runs - tried in round 6 with disjoint core sets - the sub-runs' host side stalls: a
+    # launch-bound B = 1 line read 12x slow); the opt-in PMC passes follow.
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_jobs = cpu_baseline_start(args)
         out["cpu_baseline"] = cpu_baseline_collect(cpu_jobs)
@@ -366,7 +407,7 @@ def main():
     # roofline.traffic measured by THIS run: two nested rocprofv3 passes of the same command (FETCH_SIZE, WRITE_SIZE:
     # the counters do not fit one pass; --kernel-trace + --pmc only), after the timed region; any failure or a
     # missing rocprofv3 falls back to the committed table above
-    if world == 1 and not args.no_pmc and os.environ.get("LB_BENCH_PMC", "1") != "0":
+    if world == 1 and args.pmc and not args.no_pmc:
         live = measure_traffic(args)
         if live:
             for key, dst in ((pmc_key, out["roofline"]), ("k_segment_sum", out["roofline_aggregate"])):
@@ -406,7 +447,7 @@ def measure_traffic(args, timeout_s=240):
                    "--no-cpu-baseline", "--no-other-configs", "--no-pmc", "--no-f32", "--repeats", "1",
                    "--steps", str(args.steps), "--warmup", str(args.warmup),   # the SAME steps as the timed region: same mean E
                    "--workload", args.workload, "--batch", str(args.batch), "--mp-steps", str(args.mp_steps),
-                   "--model", args.model]
+                   "--model", args.model, "--vel-amp", str(args.vel_amp)]
             p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                                  stderr=subprocess.DEVNULL, start_new_session=True)
             try:
@@ -539,13 +580,18 @@ def train_step_lines(device):
     return res
 
 
-OTHER_PLAN = [("tgv2d", "gns", 1, 20, 1.0), ("tgv2d", "gns", 8, 20, 1.0), ("rpf2d", "gns", 1, 400, 1.0),
+OTHER_PLAN = [("tgv3d", "gns", 8, 20, 1.0, "tgv3d_drifting"),
+              ("tgv2d", "gns", 1, 20, 1.0), ("tgv2d", "gns", 8, 20, 1.0), ("rpf2d", "gns", 1, 400, 1.0),
               ("tgv3d", "gns", 1, 20, 1.0), ("ldc3d", "gns", 1, 20, 1.0), ("ldc3d", "gns", 8, 20, 1.0),
               ("dam2d", "segnn", 1, 20, 1.0), ("dam2d", "segnn", 8, 20, 1.0)]
+# `value` of rounds 1 - 5 was quoted on the DRIFTING TGV3D x 8 workload (vel_amp 1.0: 13.6 -> 18.5 -> 17.1 neighbours per
+# particle over the rollout, mean 16.2); round 6 moves `value` to the stationary trajectories and keeps
+# the drifting run as other_configs[tag == "tgv3d_drifting"], the driver's round-5 figure beside it
+ROUND5_DRIFTING = {"value": 19249472.69, "ms_per_step": 3.3248, "source": "BENCH_r05.json (driver run, round 5)"}
 # the headline workload (and config 5) on trajectories whose neighbour count does NOT drift over the rollout: velocities
 # scaled down so that the ballistic rollout of untrained weights stays within half a spacing of the lattice
 # (lagrangebench_amd/data/synthetic.py: vel_amp); TGV3D then holds 14.4 neighbours per particle over all steps
-STATIONARY_PLAN = [("tgv3d", "gns", 8, 20, 0.03), ("tgv3d", "gns", 1, 20, 0.03), ("dam2d", "segnn", 8, 20, 0.03)]
+STATIONARY_PLAN = [("tgv3d", "gns", 1, 20, 0.03), ("dam2d", "segnn", 8, 20, 0.03)]
 
 
 def other_configs(device, plan=None, repeats=1):
@@ -556,7 +602,9 @@ def other_configs(device, plan=None, repeats=1):
     from lagrangebench_amd.data import make_case
     from lagrangebench_amd.models import GNS, SEGNN, node_irreps
     res = []
-    for workload, kind, B, K, vel_amp in (plan or OTHER_PLAN):
+    for item in (plan or OTHER_PLAN):
+        workload, kind, B, K, vel_amp = item[:5]
+        tag = item[5] if len(item) > 5 else None
         try:
             ds = make_case(workload, n_trajs=B, extra_seq_length=K, vel_amp=vel_amp)
             dim, isl = len(ds.box), ds.input_seq_length
@@ -595,6 +643,12 @@ def other_configs(device, plan=None, repeats=1):
                      "math_fallbacks": int(eng.math_fallbacks())}
             if vel_amp != 1.0:
                 entry["vel_amp"] = vel_amp
+            if tag:
+                entry["tag"] = tag
+            if tag == "tgv3d_drifting":
+                entry["round5"] = ROUND5_DRIFTING
+                entry["note"] = ("the workload `value` was quoted on in rounds 1 - 5: untrained weights at the datasets' velocity "
+                                 "scale compress the lattice, the neighbour count drifts")
             if repeats > 1:
                 entry["ms_per_step_all"] = [round(1e3 * x / K, 4) for x in dts]
             # this entry's own roofline: the processor edge (GNS) / message (SEGNN) kernel on the engine's HIP-event
@@ -736,8 +790,9 @@ CPU_PLAN = {
     # config 1 (TGV2D-2.5k, 20 steps) is mandatory; TGV3D-8k (the config the >= 5x target is quoted on)
     # costs ~1.8 s per step on this host: a bounded sample.  One rollout of warm + steps steps, every step timed
     # (the reference's step loop is host driven, rollout.py:125-169); the reported figure is the MEDIAN step.
-    "tgv2d": {"steps": 20, "warm": 2},
-    "tgv3d": {"steps": 5, "warm": 2},
+    # (round 6: 10 + 4 timed steps instead of 20 + 5, one warm-up step for TGV3D: ~12 s of CPU work, bench wall <= 20 s)
+    "tgv2d": {"steps": 10, "warm": 2},
+    "tgv3d": {"steps": 4, "warm": 1},
 }
 
 
@@ -752,7 +807,7 @@ def cpu_model_string():
     return "unknown"
 
 
-def cpu_baseline_leg(workload, L):
+def cpu_baseline_leg(workload, L, vel_amp=1.0):
     """One CPU-baseline leg (own process, `--cpu-baseline-only`): the CPU restatement in the reference's algorithmic
     shape (dense candidate matrix -> mask -> compaction; MLPs over all E_cap padded rows; unfused
     gather / GEMM / LayerNorm / scatter-add; fp64 geometry, fp32 network; batch 1): torch-CPU for the network
@@ -769,7 +824,7 @@ def cpu_baseline_leg(workload, L):
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     n_warm, n_steps = plan["warm"], plan["steps"]
-    ds = make_case(workload, n_trajs=1, extra_seq_length=n_warm + n_steps)
+    ds = make_case(workload, n_trajs=1, extra_seq_length=n_warm + n_steps, vel_amp=vel_amp)
     node_in, edge_in = gns_widths(ds)
     params = GNS(len(ds.box), D, 2, L, 16).init_params(1234, node_in, edge_in, decoder_scale=0.01)
     ocase = oracle_case(ds)
@@ -809,7 +864,8 @@ def cpu_baseline_start(args):
     byte counters, nothing timed - re-run the GPU workload)."""
     import subprocess
     legs = ["tgv2d"] + ([args.workload] if args.workload in CPU_PLAN and args.workload != "tgv2d" else ["tgv3d"])
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", ",".join(legs), "--mp-steps", str(args.mp_steps)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", ",".join(legs), "--mp-steps", str(args.mp_steps),
+           "--vel-amp", str(args.vel_amp)]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     return legs, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True,
                                   start_new_session=True)
@@ -833,7 +889,7 @@ def cpu_baseline_collect(job, timeout_s=240):
     res["configs"] = legs
     res["note"] = ("JAX is not installable here: this is the reference-shaped CPU restatement, not JAX-CPU; the legs "
                    "run one after the other in their own process with nothing else on the host (the GPU work of this "
-                   "command is finished, the PMC passes have not started); spread in ms_per_step_min / _max")
+                   "command is finished, the opt-in PMC passes have not started); spread in ms_per_step_min / _max")
     return res
 
 
