@@ -484,11 +484,11 @@ def _train_kernels():
 def train_step_lines(device):
     """SURVEY section 8 row N4, the training step (trainer.py:35-89: value_and_grad of the masked MSE over the batch +
     optax.adamw), timed like the reference runs it: batch 1 (defaults.py train.batch_size), loss fetched every step.
-    One line per workload: ms per step, particle-steps/s, and the dense-contraction rate against the fp32 MFMA peak (the
-    training path is exact fp32: forward 1x + backward 2x the forward's GEMM flops; Y = XW and dX = dY W^T on the
-    hand-written k_lin32f (fp32 MFMA, epilogues fused; rocBLAS sgemm until round 4), dW += X^T dY on the hand-written
-    fp32-MFMA k_dw_part; everything else - LayerNorm, gathers and their
-    deterministic transposes, AdamW - is hand-written HIP)."""
+    One line per workload: ms per step, particle-steps/s, and the rate of fp32-EQUIVALENT flops against the fp32 MFMA peak
+    (forward 1x + backward 2x the forward's GEMM flops).  Default arithmetic: Y = XW and dX = dY W^T on k_lin32h, dW += X^T dY
+    on k_dw_part_h - fp16 hi / lo split products under power-of-two scaling, fp32 accumulate, a range guard on dW's
+    activation operand (include/lbhip.h); LB_TRAIN_MATH=f32 selects the exact-fp32 MFMA kernels k_lin32f / k_dw_part.
+    Everything else - LayerNorm, gathers and their deterministic transposes, AdamW - is hand-written HIP; no library GEMM."""
     from lagrangebench_amd.data import make_case
     from lagrangebench_amd.models import GNS
     res = []

@@ -109,6 +109,7 @@ _SIGS = {
     "lb_gns_train_read": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.c_int64]),
     "lb_gns_train_write": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.c_int64, C.c_int64]),
     "lb_gns_train_step_count": (C.c_int64, [_P]),
+    "lb_gns_train_math_fallbacks": (C.c_int32, [_P]),
     "lb_segnn_train_create": (C.c_int, [_P, C.POINTER(SegnnDesc), C.POINTER(C.c_float), C.c_int64, C.POINTER(_P)]),
     "lb_segnn_train_loss_grad": (C.c_int, [_P, _P, C.c_float, C.POINTER(C.c_double), _P]),
     "lb_segment_sum": (C.c_int, [_P, _P, _P, C.c_int32]),

@@ -963,6 +963,13 @@ int lb_sgg_create(lb_engine* e, const lb_segnn_desc* d, const float* w, int64_t 
 }
 
 // SEGNN.__call__ (segnn.py:595-610) on the engine's current window + neighbor list -> e->acc
+// lb_toc on every way out of a timed region (lbk_sgg_forward returns from between lb_tic and lb_toc on launch errors)
+struct lb_toc_guard {
+  lb_engine* e;
+  bool armed = true;
+  ~lb_toc_guard() { if (armed) lb_toc(e); }
+  void done() { lb_toc(e); armed = false; }
+};
 int lbk_sgg_forward(lb_engine* e, lb_sgg* m) {
   hipStream_t s = e->stream;
   const int64_t BN = e->BN;
@@ -970,6 +977,7 @@ int lbk_sgg_forward(lb_engine* e, lb_sgg* m) {
   LB_TRY(sgg_ensure_edges(m));
   const int64_t ecap = (int64_t)e->e_cap * e->g.B;
   lb_tic(e, LB_T_NODEFEAT);
+  lb_toc_guard tg0{e};  // (an early return must not leave the timer open: ADVICE r05)
   LB_TRY(lbk_sg_prep(e, m->desc.homogeneous, m->desc.velocity_avg, m->node_ns4, m->node_nv4, m->xnode, m->eattr4, m->msgsv, m->nodesv,
                      m->nattr4, ecap));
   const float *eattr = m->eattr4, *nattr = m->nattr4;
@@ -980,7 +988,7 @@ int lbk_sgg_forward(lb_engine* e, lb_sgg* m) {
     eattr = m->eattr;
     nattr = m->nattr;
   }
-  lb_toc(e);
+  tg0.done();
   LB_HIP(hipGetLastError());
   auto tap = [&](int slot) -> int {
     if (m->tap)
@@ -991,14 +999,16 @@ int lbk_sgg_forward(lb_engine* e, lb_sgg* m) {
   {
     const float* xs[1] = {m->nodesv};
     lb_tic(e, LB_T_ENC_NODE);
+    lb_toc_guard tg1{e};  // (an early return must not leave the timer open: ADVICE r05)
     int rc = sgg_launch(m, m->blocks[bi++], BN, false, xs, nullptr, nattr, nullptr, m->f);
-    lb_toc(e);
+    tg1.done();
     if (rc) return rc;
   }
   LB_TRY(tap(0));
   const unsigned nb_seg = (unsigned)((BN * (m->HS / 4) + 255) / 256);
   for (int k = 0; k < L; ++k) {
     lb_tic(e, LB_T_EDGE_MLP);
+    lb_toc_guard tg2{e};  // (an early return must not leave the timer open: ADVICE r05)
     float* cur = nullptr;
     for (int i = 0; i < B; ++i) {
       float* dst = m->te[i & 1];
@@ -1015,11 +1025,13 @@ int lbk_sgg_forward(lb_engine* e, lb_sgg* m) {
       cur = dst;
     }
     if (m->norm == 2) LB_TRY(sgg_batch_norm(m, m->norm_off[(size_t)k * 4 + 0], m->norm_off[(size_t)k * 4 + 1], cur, true));
-    lb_toc(e);
+    tg2.done();
     lb_tic(e, LB_T_AGGREGATE);
+    lb_toc_guard tg3{e};  // (an early return must not leave the timer open: ADVICE r05)
     hipLaunchKernelGGL(k_sgg_segsum, dim3(nb_seg), dim3(256), 0, s, e->ctrl, e->row_ptr, cur, m->agg, BN, m->HS / 4);
-    lb_toc(e);
+    tg3.done();
     lb_tic(e, LB_T_NODE_MLP);
+    lb_toc_guard tg4{e};  // (an early return must not leave the timer open: ADVICE r05)
     const float* ncur = nullptr;
     for (int i = 0; i < B; ++i) {
       const bool last = i == B - 1;
@@ -1041,10 +1053,11 @@ int lbk_sgg_forward(lb_engine* e, lb_sgg* m) {
       sgg_bn_args a = sgg_bn_base(m, m->norm_off[(size_t)k * 2 + 0], m->norm_off[(size_t)k * 2 + 1], m->f, false);
       hipLaunchKernelGGL(k_sgg_inorm, dim3((unsigned)BN), dim3((unsigned)m->HS), 0, s, a, BN);
     }
-    lb_toc(e);
+    tg4.done();
     LB_TRY(tap(k + 1));
   }
   lb_tic(e, LB_T_DECODER);
+  lb_toc_guard tg5{e};  // (an early return must not leave the timer open: ADVICE r05)
   const float* ncur = m->f;
   for (int i = 0; i < B; ++i) {
     const float* xs[1] = {ncur};
@@ -1055,7 +1068,7 @@ int lbk_sgg_forward(lb_engine* e, lb_sgg* m) {
     const float* xs[1] = {ncur};
     LB_TRY(sgg_launch(m, m->blocks[bi++], BN, false, xs, nullptr, nattr, nullptr, e->acc));
   }
-  lb_toc(e);
+  tg5.done();
   LB_HIP(hipGetLastError());
   return LB_OK;
 }

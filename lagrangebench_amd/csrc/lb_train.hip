@@ -115,6 +115,11 @@ struct lb_gns_train {
   // f16x2 arithmetic of the tall-skinny products (k_lin32h, round 5): fp16 hi / lo fragments of the operand matrices in the
   // same packed blob + one inverse power-of-two scale per matrix.  LB_TRAIN_MATH=f32 keeps the exact-fp32 kernels.
   bool f16x2 = lb_train_f16x2_default();
+  // range guard of k_dw_part_h's X operand (round 6): activations are split "as they are"; a row chunk whose
+  // largest |X| leaves [2^-8, 2^15) raises *dw_flag, the step's gradient reductions then add NOTHING and
+  // lb_gns_train_loss_grad repeats the step on the exact-fp32 kernels (three such steps: the handle stays on them)
+  int32_t* dw_flag = nullptr;
+  int32_t dw_fallbacks = 0;
   float* tmax = nullptr;       // [rows / 16] largest |X| per row tile of the last k_lin32h call that was asked for it
   bool tmax_ok = false;        // ... and whether that call ran on k_lin32h
   std::vector<lb_pack_ent_h> pack_tab_h;
@@ -244,7 +249,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 // the column sums of dY (exact fp32 sums of the unscaled values).
 __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, int ldx, int K, const float* __restrict__ dY,
                                                    int64_t rows, int64_t chunk, float* __restrict__ part,
-                                                   const float* __restrict__ tmax) {
+                                                   const float* __restrict__ tmax, int32_t* __restrict__ xflag) {
   __shared__ h8 sAB[2][2][1024];   // [buffer][A | B][(tile * 2 + part) * 64 + lane]: 64 KiB
   float* red = reinterpret_cast<float*>(&sAB[0][0][0]);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -322,10 +327,15 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb) acc[ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
+  float xmax = 0.f;   // largest |X| this thread split (v_max3_f32 with |abs| modifiers: four instructions per step)
   const int wslot = ((c >> 4) * 2) * 64 + (c & 15) + 16 * g;
   int buf = 0;
   auto mma_step = [&](const f32x4& x0, const f32x4& x1, const f32x4& y0, const f32x4& y1) {
     bsum += (((y0[0] + y0[1]) + (y0[2] + y0[3])) + ((y1[0] + y1[1]) + (y1[2] + y1[3])));
+    xmax = fmaxf(fmaxf(fabsf(x0[0]), fabsf(x0[1])), xmax);
+    xmax = fmaxf(fmaxf(fabsf(x0[2]), fabsf(x0[3])), xmax);
+    xmax = fmaxf(fmaxf(fabsf(x1[0]), fabsf(x1[1])), xmax);
+    xmax = fmaxf(fmaxf(fabsf(x1[2]), fabsf(x1[3])), xmax);
     h8 xh, xl, yh, yl;
     lb_split8v(x0 * xkeep, x1 * xkeep, xh, xl);
     lb_split8v(y0 * sc, y1 * sc, yh, yl);
@@ -404,8 +414,24 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
         const int xr = 16 * (4 * ah + ta) + 4 * (lane >> 4) + v;
         if (128 * ablk + xr < K) out[xr * 128 + 16 * (2 * bq + tb) + (lane & 15)] = acc[ta][tb][v] * inv;
       }
-  if (ablk == 0) {
+  // X range guard: the chunk's largest |X| (this block's 128-column slice).  >= 2^15: the hi half is about to leave fp16
+  // (65504; infinities land here too); < 2^-8 and not all zero: every lo half of the slice is a fp16 subnormal, the terms
+  // keep 2^-25 absolute instead of 2^-22 relative precision.  Either way the whole step is redone in exact fp32.
+  {
+    float m = xmax * xkeep;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     __syncthreads();   // (the last step's fragments have been read)
+    if (lane == 0) red[512 + wave] = m;
+    __syncthreads();
+    if (tid == 0) {
+      float mm = red[512];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) mm = fmaxf(mm, red[512 + w]);
+      if (xflag && (!(mm < 32768.f) || (mm > 0.f && mm < 0.00390625f))) atomicOr(xflag, mm < 1.f ? 2 : 1);
+    }
+  }
+  if (ablk == 0) {
     red[tid] = bsum;
     __syncthreads();
     if (tid < 128)
@@ -419,8 +445,9 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
 // producer writes its partials into a slot of its own and leaves a descriptor; a flat grid, each block finds its descriptor by bisection.  (One
 // launch per producer before: 0.5 ms of a 7 ms TGV3D step, 0.4 ms of a 3.5 ms TGV2D step, mostly launch latency.)
 __global__ void __launch_bounds__(1024) k_part_reduce(const float* __restrict__ part_base, const lb_red_ent* __restrict__ tab,
-                                                      int n_ent, float* __restrict__ grad) {
+                                                      int n_ent, float* __restrict__ grad, const int32_t* __restrict__ skip) {
   __shared__ float s_red[16][64];
+  if (skip && *skip) return;   // k_dw_part_h's range guard fired: this step adds nothing, the host repeats it in fp32
   int lo = 0, hi = n_ent - 1;  // the last descriptor with blk0 <= blockIdx.x
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -705,8 +732,9 @@ __global__ void k_loss_finish(const double* __restrict__ part, int64_t n, double
 // type in index order, the S = 1024 / emb slice sums are added in slice order.
 __global__ void __launch_bounds__(1024) k_embed_grad(const float* __restrict__ dx, int ld, int col0, int emb,
                                                      const int32_t* __restrict__ ptype, int ntypes, int64_t BN,
-                                                     float* __restrict__ gembed) {
+                                                     float* __restrict__ gembed, const int32_t* __restrict__ skip) {
   __shared__ float s_part[1024];
+  if (skip && *skip) return;   // (see k_part_reduce)
   const int type = blockIdx.x, c = threadIdx.x % emb, slice = threadIdx.x / emb, S = 1024 / emb;
   float acc = 0.f;
   if (slice < S) {
@@ -951,7 +979,8 @@ static int red_flush(lb_gns_train* t) {
     hipStream_t s = t->eng->stream;
     memcpy(t->red_host, t->red_tab.data(), n * sizeof(lb_red_ent));  // (pinned; the previous step's copy was synchronised)
     LB_HIP(hipMemcpyAsync(t->red_dev, t->red_host, n * sizeof(lb_red_ent), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_part_reduce, dim3((unsigned)t->red_blocks), dim3(1024), 0, s, t->dwpart, t->red_dev, (int)n, t->g);
+    hipLaunchKernelGGL(k_part_reduce, dim3((unsigned)t->red_blocks), dim3(1024), 0, s, t->dwpart, t->red_dev, (int)n, t->g,
+                       t->f16x2 ? t->dw_flag : (const int32_t*)nullptr);
   }
   t->red_tab.clear();
   t->red_off = 0;
@@ -974,17 +1003,24 @@ static int64_t red_capacity(const lb_gns_train* t, int64_t cn, int64_t ce) {
 // (nb: how many of dY's 128 column sums are added to db - the SEGNN blocks keep only their Ms scalar-output columns)
 static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx, const float* dY, float* dW, float* db,
                    int nb = 128, const float* tmax = nullptr) {
-  if (K > 384 || rows <= 0) return false;
+  // (every refusal leaves its reason in lb_last_error - ADVICE r05: callers return a bare LB_ERR_STATE)
+  if (K > 384 || rows <= 0) {
+    (void)lb_fail(LB_ERR_STATE, "dw_acc: K = %d (<= 384) / rows = %lld (> 0) out of range", K, (long long)rows);
+    return false;
+  }
   int64_t chunk = 0, off = 0;
   const int G = dw_groups(rows, &chunk);
   hipStream_t s = t->eng->stream;
-  if ((K & 1) && ldx <= K) return false;  // (the pair load of an odd K reads the row's padding column: never stored)
+  if ((K & 1) && ldx <= K) {  // (the pair load of an odd K reads the row's padding column: never stored)
+    (void)lb_fail(LB_ERR_STATE, "dw_acc: odd K = %d needs a padded row (ldx = %d)", K, ldx);
+    return false;
+  }
   float* part = red_slot(t, (int64_t)G * (K + 1) * 128, &off);
-  if (!part) return false;
+  if (!part) return false;  // (red_slot said why)
 #define DW_GO(NA, DEPTH) hipLaunchKernelGGL((k_dw_part<NA, DEPTH>), dim3(G), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part)
   const bool deep = chunk >= 192;
   if (t->f16x2 && K >= 32)   // (narrower operands - the encoders' raw features - stay on the fp32 kernel)
-    hipLaunchKernelGGL(k_dw_part_h, dim3((unsigned)G, (unsigned)((K + 127) / 128)), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part, tmax);
+    hipLaunchKernelGGL(k_dw_part_h, dim3((unsigned)G, (unsigned)((K + 127) / 128)), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part, tmax, t->dw_flag);
   else if (K <= 128) { if (deep) DW_GO(1, 12); else DW_GO(1, 6); }
   else if (K <= 256) { if (deep) DW_GO(2, 8); else DW_GO(2, 6); }
   else DW_GO(3, 4);
@@ -1303,6 +1339,8 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
   for (float** p : {&t->w, &t->g, &t->m, &t->v})
     if (!rc) rc = lb_alloc(p, (size_t)o);
   if (!rc) rc = lb_alloc(&t->loss_dev, 1);
+  if (!rc) rc = lb_alloc(&t->dw_flag, 1);
+  if (!rc && hipMemset(t->dw_flag, 0, sizeof(int32_t)) != hipSuccess) rc = lb_fail(LB_ERR_HIP, "hipMemset");
   if (!rc) rc = lb_alloc(&t->cnt_dev, (size_t)e->g.B);
   if (!rc) {
     std::vector<float> padded;
@@ -1331,7 +1369,7 @@ extern "C" void lb_gns_train_destroy(lb_gns_train* t) {
   sgt_free(t);
   std::vector<void*> bufs = {t->w, t->g, t->m, t->v, t->xnode, t->a_en, t->z_en, t->a_ee, t->z_ee, t->a_d, t->pred,
                              t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->dwpart, t->red_dev, t->proj, t->node_w,
-                             t->loss_dev, t->loss_part, t->cnt_dev, t->snd_key, t->snd_perm, t->iota, t->snd_ptr, t->sort_tmp,
+                             t->loss_dev, t->dw_flag, t->loss_part, t->cnt_dev, t->snd_key, t->snd_perm, t->iota, t->snd_ptr, t->sort_tmp,
                              t->wpack, t->pack_dev, t->pack_dev_h, t->wsc, t->tmax};
   for (auto* v : {&t->nlat, &t->elat, &t->ae, &t->ze, &t->xn, &t->an, &t->zn})
     for (float* p : *v) bufs.push_back(p);
@@ -1344,10 +1382,41 @@ extern "C" void lb_gns_train_destroy(lb_gns_train* t) {
 // value_and_grad of _mse, summed over the batch (trainer.py:63-89), on the engine's CURRENT window / neighbor list.
 // target_dev: (B*N, dim) fp32 normalised accelerations.  Gradients ACCUMULATE into the gradient blob (zero it with
 // lb_gns_train_zero_grad); *loss_out = mean over the batch of the per-trajectory losses (host-synchronous).
+static int gns_train_loss_grad_once(lb_gns_train* t, const float* target_dev, float loss_weight, double* loss_out,
+                                    float* pred_out_dev);
+static int segnn_train_loss_grad_once(lb_gns_train* t, const float* target_dev, float loss_weight, double* loss_out,
+                                      float* pred_out_dev);
+// One training step's loss + gradients with the X range guard of the f16x2 weight-gradient kernel around it: the step runs
+// on the default arithmetic; if a k_dw_part_h block saw activations outside [2^-8, 2^15) the reductions have added nothing
+// (k_part_reduce / k_embed_grad read the flag) and the step runs again on the exact-fp32 kernels (LB_TRAIN_MATH=f32's).
+static int train_loss_grad_guarded(lb_gns_train* t, const float* target_dev, float loss_weight, double* loss_out,
+                                   float* pred_out_dev) {
+  auto once = [&]() {
+    return t->sg ? segnn_train_loss_grad_once(t, target_dev, loss_weight, loss_out, pred_out_dev)
+                 : gns_train_loss_grad_once(t, target_dev, loss_weight, loss_out, pred_out_dev);
+  };
+  if (!t->f16x2) return once();
+  hipStream_t s = t->eng->stream;
+  LB_HIP(hipMemsetAsync(t->dw_flag, 0, sizeof(int32_t), s));
+  LB_TRY(once());
+  int32_t flag = 0;
+  LB_HIP(hipMemcpyAsync(&flag, t->dw_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  LB_HIP(hipStreamSynchronize(s));
+  if (!flag) return LB_OK;
+  t->f16x2 = false;
+  const int rc = once();
+  t->f16x2 = ++t->dw_fallbacks < 3;   // three guarded steps: this model's activations do not suit the split, stay exact
+  return rc;
+}
+extern "C" int32_t lb_gns_train_math_fallbacks(lb_gns_train* t) { return t ? t->dw_fallbacks : -1; }
+
 extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, float loss_weight, double* loss_out,
                                       float* pred_out_dev) {
   if (!t || !target_dev) return lb_fail(LB_ERR_ARG, "null argument");
-  if (t->sg) return lb_segnn_train_loss_grad(t, target_dev, loss_weight, loss_out, pred_out_dev);
+  return train_loss_grad_guarded(t, target_dev, loss_weight, loss_out, pred_out_dev);
+}
+static int gns_train_loss_grad_once(lb_gns_train* t, const float* target_dev, float loss_weight, double* loss_out,
+                                    float* pred_out_dev) {
   lb_engine* e = t->eng;
   if (e->e_cap <= 0) return lb_fail(LB_ERR_STATE, "lb_gns_train_loss_grad before lb_nl_allocate");
   hipStream_t s = e->stream;
@@ -1400,7 +1469,8 @@ extern "C" int lb_gns_train_loss_grad(lb_gns_train* t, const float* target_dev, 
   LB_TRY(mlp_bwd(t, t->enc_node, BN, t->xnode, t->kpad, t->a_en, t->z_en, t->dn, has_emb ? t->dx : nullptr));
   if (has_emb)
     hipLaunchKernelGGL(k_embed_grad, dim3(t->desc.num_particle_types), dim3(1024), 0, s, t->dx, t->kpad, t->desc.node_in, emb,
-                       e->ptype, t->desc.num_particle_types, BN, t->g + t->off_embed);
+                       e->ptype, t->desc.num_particle_types, BN, t->g + t->off_embed,
+                       t->f16x2 ? t->dw_flag : (const int32_t*)nullptr);
   LB_TRY(red_flush(t));  // every weight / bias / LayerNorm gradient: partials -> gradient blob, one launch
   LB_HIP(hipGetLastError());
   if (loss_out) {

@@ -432,6 +432,8 @@ extern "C" int lb_segnn_train_create(lb_engine* e, const lb_segnn_desc* d, const
   for (float** p : {&t->w, &t->g, &t->m, &t->v})
     if (!rc) rc = lb_alloc(p, (size_t)o);
   if (!rc) rc = lb_alloc(&t->loss_dev, 1);
+  if (!rc) rc = lb_alloc(&t->dw_flag, 1);
+  if (!rc && hipMemset(t->dw_flag, 0, sizeof(int32_t)) != hipSuccess) rc = lb_fail(LB_ERR_HIP, "hipMemset");
   if (!rc) rc = lb_alloc(&t->cnt_dev, (size_t)e->g.B);
   if (!rc) {
     std::vector<float> padded((size_t)o, 0.f);
@@ -453,6 +455,10 @@ extern "C" int lb_segnn_train_create(lb_engine* e, const lb_segnn_desc* d, const
 extern "C" int lb_segnn_train_loss_grad(lb_gns_train* t, const float* target_dev, float loss_weight, double* loss_out,
                                         float* pred_out_dev) {
   if (!t || !t->sg || !target_dev) return lb_fail(LB_ERR_ARG, "null argument / not a SEGNN training handle");
+  return train_loss_grad_guarded(t, target_dev, loss_weight, loss_out, pred_out_dev);   // (X range guard: lb_train.hip)
+}
+static int segnn_train_loss_grad_once(lb_gns_train* t, const float* target_dev, float loss_weight, double* loss_out,
+                                      float* pred_out_dev) {
   lb_engine* e = t->eng;
   lb_sgt* g = t->sg;
   if (e->e_cap <= 0) return lb_fail(LB_ERR_STATE, "lb_segnn_train_loss_grad before lb_nl_allocate");

@@ -488,6 +488,10 @@ class GnsTrainHandle:
         """AdamW steps taken on the device (optax's `count`)."""
         return int(self.engine.lib.lb_gns_train_step_count(self._h))
 
+    def math_fallbacks(self) -> int:
+        """Training steps the X range guard of the f16x2 weight-gradient kernel sent to the exact-fp32 kernels (include/lbhip.h)."""
+        return int(self.engine.lib.lb_gns_train_math_fallbacks(self._h))
+
     def write(self, which: str, blob: np.ndarray, step: int = -1) -> None:
         idx = {"weights": 0, "grads": 1, "m": 2, "v": 3}[which]
         blob = np.ascontiguousarray(blob, dtype=np.float32)

@@ -9,8 +9,13 @@ exponentially decaying learning rate (:183-193) -> every ``eval_steps``: validat
 
 What runs where: neighbor list, feature assembly, integrator, every evaluation rollout AND the loss step are the
 HIP engine: ``lb_gns_train_loss_grad`` (csrc/lb_train.hip: forward with saved activations, masked MSE, hand-written
-backward kernels, fp32-MFMA GEMMs of our own for the dense contractions) accumulates the gradients of the whole batch,
-``lb_adamw_step`` applies optax.adamw on the device; weights, gradients and both moments stay in HBM (exact fp32).
+backward kernels, MFMA products of our own for the dense contractions) accumulates the gradients of the whole batch,
+``lb_adamw_step`` applies optax.adamw on the device; weights, gradients and both moments stay in HBM as fp32.
+Arithmetic of the products (include/lbhip.h, ``lb_gns_train_math_fallbacks``): by default three fp16 MFMA passes over hi / lo
+splits of the fp32 operands under exact power-of-two scaling, fp32 accumulate (error per term <= 2^-22 of the operand
+block's scale; gradients within 1e-4 per leaf of float64 autograd), with a range guard on the weight-gradient kernel's
+activation operand that repeats a step on the exact-fp32 MFMA kernels; ``LB_TRAIN_MATH=f32`` in the environment when the
+handle is created selects the exact kernels throughout (1.7x slower).
 torch is used for the noise / sampling random streams and as the tensor container only.  Trainable: GNS (latent <= 128,
 two Linears per MLP) and, since round 5, SEGNN (lmax 1, hidden <= 32x0e+32x1o: ``lb_segnn_train_loss_grad``,
 csrc/lb_train_segnn.h - the loop below is the reference's model-agnostic one); wandb logging is not wired (stdout).

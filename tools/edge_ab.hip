@@ -256,6 +256,8 @@ int main(int argc, char** argv) {
   report("k_edge16w<deep prefetch, defer nothing>", KW(false, 1, 0, 0, 2, 2));
   report("k_edge16w<deep prefetch, defer nothing, GEMM priority>", KW(false, 1, 0, 2, 2, 2));
   report("k_edge16w<loads at top, defer nothing>", KW(false, 1, 0, 0, 2, 0));
+  report("k_edge16w<loads at top, defer scan> storing", KW(false, 1, 1, 0, 2, 0));
+  report("k_edge16w<loads at top, defer all> storing", KW(false, 1, 2, 0, 2, 0));
   {
     int flip = 0;
     report("k_edge16w<deep prefetch, defer nothing>, alternating walk direction", [&] {
