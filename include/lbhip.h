@@ -220,12 +220,13 @@ int lb_gns_train_write(lb_gns_train* t, int32_t which, const float* in_host, int
 int64_t lb_gns_train_step_count(lb_gns_train* t);
 /* Arithmetic of the training step (round 5 / 6).  Default: every tall-skinny product (Y = XW, dX = dY W^T, dW += X^T dY) runs
  * as three fp16 MFMA passes over hi / lo splits of fp32 operands, fp32 accumulate; the operands of the first two are put into
- * fp16's range by exact power-of-two scales per row block / matrix, dY of the third per row chunk, and its X operand (saved
- * activations) is range-GUARDED: a chunk whose largest |X| leaves [2^-8, 2^15) makes lb_gns_train_loss_grad repeat the step on
- * the exact-fp32 MFMA kernels (the gradients of the first attempt are never added).  Error per product term <= 2^-22 of the
- * chunk's scale; gradients vs float64 autograd <= 1e-4 per leaf (tests/test_train.py).  LB_TRAIN_MATH=f32 in the environment
- * at handle creation selects the exact-fp32 kernels throughout (1.7x slower).  This returns how many steps were repeated; after
- * three the handle stays on the exact kernels. */
+ * fp16's range by exact power-of-two scales per row block / matrix, dY of the third per row chunk.  Its X operand (saved
+ * activations) carries ONE power-of-two scale per call site (initially 1) under a range GUARD: when a chunk's largest scaled
+ * |X| leaves [2^-8, 2^15) the step's gradients are NOT added, lb_gns_train_loss_grad re-centres the scales of the call sites
+ * that fired and repeats the step (a call site that fires again switches to per-chunk scales: one more pass over its X).
+ * Error per product term <= 2^-22 of the operand chunks' scales; gradients vs float64 autograd <= 1e-4 per leaf
+ * (tests/test_train.py).  LB_TRAIN_MATH=f32 in the environment at handle creation selects the exact-fp32 MFMA kernels
+ * throughout (1.7x slower).  This returns how many steps were repeated so far. */
 int32_t lb_gns_train_math_fallbacks(lb_gns_train* t);
 
 typedef struct lb_segnn lb_segnn;

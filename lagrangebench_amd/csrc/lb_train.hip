@@ -59,6 +59,7 @@ struct lb_red_ent {
 };
 
 // LB_TRAIN_MATH=f32: the exact-fp32 product kernels (k_lin32f); default: f16x2 (k_lin32h)
+#define LB_DW_CALLS 512   // k_dw_part_h launches per step the X range bookkeeping covers (GNS-10: 62, SEGNN-10-64: ~90)
 static bool lb_train_f16x2_default() {
   const char* m = getenv("LB_TRAIN_MATH");
   return !(m && (m[0] == 'f' && m[1] == '3'));
@@ -115,11 +116,19 @@ struct lb_gns_train {
   // f16x2 arithmetic of the tall-skinny products (k_lin32h, round 5): fp16 hi / lo fragments of the operand matrices in the
   // same packed blob + one inverse power-of-two scale per matrix.  LB_TRAIN_MATH=f32 keeps the exact-fp32 kernels.
   bool f16x2 = lb_train_f16x2_default();
-  // range guard of k_dw_part_h's X operand (round 6): activations are split "as they are"; a row chunk whose
-  // largest |X| leaves [2^-8, 2^15) raises *dw_flag, the step's gradient reductions then add NOTHING and
-  // lb_gns_train_loss_grad repeats the step on the exact-fp32 kernels (three such steps: the handle stays on them)
-  int32_t* dw_flag = nullptr;
-  int32_t dw_fallbacks = 0;
+  // Range of k_dw_part_h's X operand (saved activations; round 6).  dY is scaled per row chunk inside the
+  // kernel; X is multiplied by ONE power of two per call site (operand of the step: the c-th k_dw_part_h launch of every
+  // step has the same producer), 2^dw_xexp[c], initially 1, under a range guard: a block whose largest scaled |X| leaves
+  // [2^-8, 2^15) raises dw_flag[0] and leaves the largest raw |X| of the call in dw_flag[1 + c].  The step's gradient
+  // reductions then add NOTHING, lb_gns_train_loss_grad re-centres the exponents of the calls that fired and repeats the
+  // step.  A call whose chunks do not fit one window (it fires again right after a re-centring) switches to per-chunk
+  // scaling inside the kernel (dw_xdyn[c]: one more pass over its X slice).
+  int32_t* dw_flag = nullptr;   // [1 + LB_DW_CALLS] (bit 4 of [0]: k_sender_transpose met an edge without its transpose)
+  int32_t dw_fallbacks = 0;     // steps repeated because of the guard
+  int dw_call = 0;              // k_dw_part_h launches of the current step so far
+  std::vector<int8_t> dw_xexp;  // per call site
+  std::vector<uint8_t> dw_xdyn;
+  bool cub_sort = false;        // this step's sender-sorted view comes from the radix sort
   float* tmax = nullptr;       // [rows / 16] largest |X| per row tile of the last k_lin32h call that was asked for it
   bool tmax_ok = false;        // ... and whether that call ran on k_lin32h
   std::vector<lb_pack_ent_h> pack_tab_h;
@@ -249,7 +258,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 // the column sums of dY (exact fp32 sums of the unscaled values).
 __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, int ldx, int K, const float* __restrict__ dY,
                                                    int64_t rows, int64_t chunk, float* __restrict__ part,
-                                                   const float* __restrict__ tmax, int32_t* __restrict__ xflag) {
+                                                   const float* __restrict__ tmax, int32_t* __restrict__ xflag,
+                                                   int32_t* __restrict__ xslot, int xexp, int xscale) {
   __shared__ h8 sAB[2][2][1024];   // [buffer][A | B][(tile * 2 + part) * 64 + lane]: 64 KiB
   float* red = reinterpret_cast<float*>(&sAB[0][0][0]);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -292,6 +302,37 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
   unsigned ex = (__float_as_uint(m) >> 23) & 0xffu;
   ex = m == 0.f ? 127u : (ex < 1u ? 1u : (ex > 253u ? 253u : ex));
   const float sc = __uint_as_float((254u - ex) << 23), inv = __uint_as_float(ex << 23);
+  // X (activations): multiplied by the call site's power of two 2^xexp (host side, lb_gns_train::dw_xexp) under the range
+  // guard at the end of the kernel; xscale (a call site whose chunks do not fit one window): dY's treatment - a first pass over
+  // this block's 128-column slice of the chunk finds the largest |X| (the slice is read again right after), the operand is
+  // multiplied by the power of two that puts it into [1, 2) and the partial result by its inverse.
+  float scx = __uint_as_float((unsigned)(127 + xexp) << 23), invx = __uint_as_float((unsigned)(127 - xexp) << 23);
+  if (xscale) {
+    float mx = 0.f;
+    const float* xc = X + cx;
+    int64_t r = r_begin + g;
+    for (; r + 28 < r_end; r += 32) {   // eight rows in flight per thread (each load of a wave: 256 contiguous bytes of a row)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = xc[(r + 4 * u) * ldx];
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) mx = fmaxf(fmaxf(fabsf(v[u]), fabsf(v[u + 1])), mx);
+    }
+    for (; r < r_end; r += 4) mx = fmaxf(mx, fabsf(xc[r * ldx]));
+    mx *= xkeep;
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 256; o > 0; o >>= 1) {
+      if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+      __syncthreads();
+    }
+    mx = red[0];
+    __syncthreads();
+    unsigned exx = (__float_as_uint(mx) >> 23) & 0xffu;
+    exx = mx == 0.f ? 127u : (exx < 1u ? 1u : (exx > 253u ? 253u : exx));
+    scx = __uint_as_float((254u - exx) << 23);
+    invx = __uint_as_float(exx << 23);
+  }
 
   // three steps' operands in flight (16 dwords per step and thread): one step of compute does not cover the HBM latency.
   // Addressing costs no VALU: a load is (uniform base of the step) + (this thread's row offset, computed once); the main loop
@@ -328,6 +369,7 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
     for (int tb = 0; tb < 2; ++tb) acc[ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
   float xmax = 0.f;   // largest |X| this thread split (v_max3_f32 with |abs| modifiers: four instructions per step)
+  const float xk = xkeep * scx;
   const int wslot = ((c >> 4) * 2) * 64 + (c & 15) + 16 * g;
   int buf = 0;
   auto mma_step = [&](const f32x4& x0, const f32x4& x1, const f32x4& y0, const f32x4& y1) {
@@ -337,7 +379,7 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
     xmax = fmaxf(fmaxf(fabsf(x1[0]), fabsf(x1[1])), xmax);
     xmax = fmaxf(fmaxf(fabsf(x1[2]), fabsf(x1[3])), xmax);
     h8 xh, xl, yh, yl;
-    lb_split8v(x0 * xkeep, x1 * xkeep, xh, xl);
+    lb_split8v(x0 * xk, x1 * xk, xh, xl);
     lb_split8v(y0 * sc, y1 * sc, yh, yl);
     sAB[buf][0][wslot] = xh;
     sAB[buf][0][wslot + 64] = xl;
@@ -412,7 +454,7 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int xr = 16 * (4 * ah + ta) + 4 * (lane >> 4) + v;
-        if (128 * ablk + xr < K) out[xr * 128 + 16 * (2 * bq + tb) + (lane & 15)] = acc[ta][tb][v] * inv;
+        if (128 * ablk + xr < K) out[xr * 128 + 16 * (2 * bq + tb) + (lane & 15)] = (acc[ta][tb][v] * inv) * invx;
       }
   // X range guard: the chunk's largest |X| (this block's 128-column slice).  >= 2^15: the hi half is about to leave fp16
   // (65504; infinities land here too); < 2^-8 and not all zero: every lo half of the slice is a fp16 subnormal, the terms
@@ -428,7 +470,11 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
       float mm = red[512];
 #pragma unroll
       for (int w = 1; w < 8; ++w) mm = fmaxf(mm, red[512 + w]);
-      if (xflag && (!(mm < 32768.f) || (mm > 0.f && mm < 0.00390625f))) atomicOr(xflag, mm < 1.f ? 2 : 1);
+      const float ms = mm * scx;   // (mm: raw values)
+      if (xflag && !xscale && (!(ms < 32768.f) || (ms > 0.f && ms < 0.00390625f))) {
+        atomicOr(xflag, ms < 1.f ? 2 : 1);
+        atomicMax(reinterpret_cast<unsigned*>(xslot), __float_as_uint(mm));   // (non-negative floats order like their bits)
+      }
     }
   }
   if (ablk == 0) {
@@ -980,7 +1026,7 @@ static int red_flush(lb_gns_train* t) {
     memcpy(t->red_host, t->red_tab.data(), n * sizeof(lb_red_ent));  // (pinned; the previous step's copy was synchronised)
     LB_HIP(hipMemcpyAsync(t->red_dev, t->red_host, n * sizeof(lb_red_ent), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_part_reduce, dim3((unsigned)t->red_blocks), dim3(1024), 0, s, t->dwpart, t->red_dev, (int)n, t->g,
-                       t->f16x2 ? t->dw_flag : (const int32_t*)nullptr);
+                       t->dw_flag);
   }
   t->red_tab.clear();
   t->red_off = 0;
@@ -1019,8 +1065,12 @@ static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx
   if (!part) return false;  // (red_slot said why)
 #define DW_GO(NA, DEPTH) hipLaunchKernelGGL((k_dw_part<NA, DEPTH>), dim3(G), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part)
   const bool deep = chunk >= 192;
-  if (t->f16x2 && K >= 32)   // (narrower operands - the encoders' raw features - stay on the fp32 kernel)
-    hipLaunchKernelGGL(k_dw_part_h, dim3((unsigned)G, (unsigned)((K + 127) / 128)), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part, tmax, t->dw_flag);
+  if (t->f16x2 && K >= 32) {   // (narrower operands - the encoders' raw features - stay on the fp32 kernel)
+    const int c = std::min(t->dw_call++, LB_DW_CALLS - 1);
+    if ((int)t->dw_xexp.size() <= c) { t->dw_xexp.resize(c + 1, 0); t->dw_xdyn.resize(c + 1, 0); }
+    hipLaunchKernelGGL(k_dw_part_h, dim3((unsigned)G, (unsigned)((K + 127) / 128)), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part,
+                       tmax, t->dw_flag, t->dw_flag + 1 + c, (int)t->dw_xexp[c], (int)t->dw_xdyn[c]);
+  }
   else if (K <= 128) { if (deep) DW_GO(1, 12); else DW_GO(1, 6); }
   else if (K <= 256) { if (deep) DW_GO(2, 8); else DW_GO(2, 6); }
   else DW_GO(3, 4);
@@ -1221,13 +1271,57 @@ static int train_loss(lb_gns_train* t, const float* pred, const float* target_de
   hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, s, t->loss_part, (int64_t)((BN + 255) / 256) * 4, t->loss_dev);
   return LB_OK;
 }
-// sender-sorted view of the step's edge list (stable radix sort of (sender, edge index): ascending edges per sender) ->
-// t->snd_perm (E), t->snd_ptr (BN + 1)
+// Sender-sorted view of the step's edge list WITHOUT a sort (round 6; hipcub::DeviceRadixSort until then: three rocprim
+// kernels + a lower-bound pass per step).  The neighbor relation is symmetric - (r, s) is an edge iff (s, r) is - and the list
+// is sorted by (receiver, sender): the edges SENT by node s are the transposes of row s, so s sends as many edges as it
+// receives (snd_ptr == row_ptr) and, among the edges sent by s in ascending edge order (= ascending receiver), edge (r, s)
+// has the rank that r has among the senders of row s.  One thread per edge: a bisection of row s (a dozen L2-resident
+// integers) for r, then snd_perm[row_ptr[s] + rank] = edge.  The periodic displacement is antisymmetric only up to one
+// rounding of (x + L/2), so a pair within ~1e-16 of the cutoff CAN be an edge in one direction only: a thread that does
+// not find its transpose raises bit 4 of the step's guard flag - the reductions then add nothing and the step is repeated
+// with the radix sort below (train_loss_grad_guarded).
+__global__ void k_sender_transpose(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ senders,
+                                   const int32_t* __restrict__ receivers, int64_t E, int64_t BN, int32_t* __restrict__ snd_perm,
+                                   int32_t* __restrict__ snd_ptr, int32_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= BN) snd_ptr[i] = row_ptr[i];
+  if (i >= E) return;
+  const int r = receivers[i], s = senders[i];
+  int lo = row_ptr[s], hi = row_ptr[s + 1];   // first position of row s whose sender is >= r
+  const int end = hi;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (senders[mid] < r) lo = mid + 1; else hi = mid;
+  }
+  if (lo < end && senders[lo] == r)
+    snd_perm[lo] = (int32_t)i;
+  else
+    atomicOr(flag, 4);
+}
+// the same view by a stable radix sort of (sender, edge index) - the fall-back for a step whose list is not symmetric
+// -> t->snd_perm (E), t->snd_ptr (BN + 1)
 static int train_sender_sort(lb_gns_train* t, int64_t E, int64_t BN) {
   lb_engine* e = t->eng;
   hipStream_t s = e->stream;
   if (!E) return LB_OK;
-  if (E > t->sort_cap || BN + 1 > t->sort_cap) {
+  static const bool force_cub = getenv("LB_TRAIN_SORT") && getenv("LB_TRAIN_SORT")[0] == 'c';  // LB_TRAIN_SORT=cub: always the fall-back (test)
+  if (!t->cub_sort && !force_cub) {
+    if (E > t->sort_cap || BN + 1 > t->sort_cap) {
+      LB_HIP(hipStreamSynchronize(s));
+      for (void* b : {(void*)t->snd_key, (void*)t->snd_perm, (void*)t->iota, (void*)t->snd_ptr, t->sort_tmp})
+        if (b) (void)hipFree(b);
+      t->snd_key = t->iota = nullptr;
+      t->sort_tmp = nullptr;
+      t->sort_tmp_bytes = 0;
+      t->sort_cap = std::max<int64_t>(E + E / 8 + 1024, BN + 2);
+      LB_HIP(hipMalloc((void**)&t->snd_perm, sizeof(int32_t) * t->sort_cap));
+      LB_HIP(hipMalloc((void**)&t->snd_ptr, sizeof(int32_t) * t->sort_cap));
+    }
+    hipLaunchKernelGGL(k_sender_transpose, GRID1(std::max(E, BN + 1)), 0, s, e->row_ptr, e->senders, e->receivers, E, BN,
+                       t->snd_perm, t->snd_ptr, t->dw_flag);
+    return LB_OK;
+  }
+  if (E > t->sort_cap || BN + 1 > t->sort_cap || !t->sort_tmp) {
     LB_HIP(hipStreamSynchronize(s));
     for (void* b : {(void*)t->snd_key, (void*)t->snd_perm, (void*)t->iota, (void*)t->snd_ptr, t->sort_tmp})
       if (b) (void)hipFree(b);
@@ -1339,8 +1433,8 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
   for (float** p : {&t->w, &t->g, &t->m, &t->v})
     if (!rc) rc = lb_alloc(p, (size_t)o);
   if (!rc) rc = lb_alloc(&t->loss_dev, 1);
-  if (!rc) rc = lb_alloc(&t->dw_flag, 1);
-  if (!rc && hipMemset(t->dw_flag, 0, sizeof(int32_t)) != hipSuccess) rc = lb_fail(LB_ERR_HIP, "hipMemset");
+  if (!rc) rc = lb_alloc(&t->dw_flag, (size_t)(1 + LB_DW_CALLS));
+  if (!rc && hipMemset(t->dw_flag, 0, sizeof(int32_t) * (1 + LB_DW_CALLS)) != hipSuccess) rc = lb_fail(LB_ERR_HIP, "hipMemset");
   if (!rc) rc = lb_alloc(&t->cnt_dev, (size_t)e->g.B);
   if (!rc) {
     std::vector<float> padded;
@@ -1386,26 +1480,50 @@ static int gns_train_loss_grad_once(lb_gns_train* t, const float* target_dev, fl
                                     float* pred_out_dev);
 static int segnn_train_loss_grad_once(lb_gns_train* t, const float* target_dev, float loss_weight, double* loss_out,
                                       float* pred_out_dev);
-// One training step's loss + gradients with the X range guard of the f16x2 weight-gradient kernel around it: the step runs
-// on the default arithmetic; if a k_dw_part_h block saw activations outside [2^-8, 2^15) the reductions have added nothing
-// (k_part_reduce / k_embed_grad read the flag) and the step runs again on the exact-fp32 kernels (LB_TRAIN_MATH=f32's).
+// One training step's loss + gradients with the step's guard flag around it: if a k_dw_part_h block saw activations outside
+// [2^-8, 2^15) (bits 1 | 2), or k_sender_transpose an edge without its transpose (bit 4), the reductions have added nothing
+// (k_part_reduce / k_embed_grad read the flag) and the step runs again - with X scaled per chunk from now on, or with
+// the radix sort for this step.
 static int train_loss_grad_guarded(lb_gns_train* t, const float* target_dev, float loss_weight, double* loss_out,
                                    float* pred_out_dev) {
   auto once = [&]() {
     return t->sg ? segnn_train_loss_grad_once(t, target_dev, loss_weight, loss_out, pred_out_dev)
                  : gns_train_loss_grad_once(t, target_dev, loss_weight, loss_out, pred_out_dev);
   };
-  if (!t->f16x2) return once();
   hipStream_t s = t->eng->stream;
-  LB_HIP(hipMemsetAsync(t->dw_flag, 0, sizeof(int32_t), s));
-  LB_TRY(once());
-  int32_t flag = 0;
-  LB_HIP(hipMemcpyAsync(&flag, t->dw_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  LB_HIP(hipStreamSynchronize(s));
-  if (!flag) return LB_OK;
-  t->f16x2 = false;
-  const int rc = once();
-  t->f16x2 = ++t->dw_fallbacks < 3;   // three guarded steps: this model's activations do not suit the split, stay exact
+  int rc = LB_OK;
+  std::vector<int32_t> slots;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    LB_HIP(hipMemsetAsync(t->dw_flag, 0, sizeof(int32_t) * (1 + LB_DW_CALLS), s));
+    t->dw_call = 0;
+    rc = once();
+    if (rc) break;
+    int32_t flag = 0;
+    LB_HIP(hipMemcpyAsync(&flag, t->dw_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    LB_HIP(hipStreamSynchronize(s));
+    if (!flag) break;
+    // the reductions of this attempt added nothing (k_part_reduce / k_embed_grad saw the flag): repeat with what it asks for
+    if (attempt == 3) { rc = lb_fail(LB_ERR_STATE, "training: the step's guard flag (%d) does not clear", flag); break; }
+    if (flag & 4) {
+      if (t->cub_sort) { rc = lb_fail(LB_ERR_STATE, "training: sender view failed with the radix sort"); break; }
+      t->cub_sort = true;
+    }
+    if (flag & 3) {   // re-centre the X exponent of every call site that fired: largest |X| -> [2^3, 2^4)
+      const int n = std::min(t->dw_call, LB_DW_CALLS);
+      slots.assign((size_t)n, 0);
+      LB_HIP(hipMemcpy(slots.data(), t->dw_flag + 1, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+      for (int c = 0; c < n; ++c) {
+        if (!slots[c]) continue;
+        const int ex = (int)(((uint32_t)slots[c] >> 23) & 0xffu);   // biased exponent of the call's largest raw |X|
+        const int want = std::max(-100, std::min(100, 130 - ex));
+        if (ex >= 255 || t->dw_xdyn[c]) continue;                    // (non-finite activations: non-finite gradients in any arithmetic)
+        if (attempt > 0 || t->dw_xexp[c] == want) t->dw_xdyn[c] = 1;   // fired again after a re-centring: its chunks need their own scales
+        t->dw_xexp[c] = (int8_t)want;
+      }
+      ++t->dw_fallbacks;
+    }
+  }
+  t->cub_sort = false;
   return rc;
 }
 extern "C" int32_t lb_gns_train_math_fallbacks(lb_gns_train* t) { return t ? t->dw_fallbacks : -1; }
@@ -1469,8 +1587,7 @@ static int gns_train_loss_grad_once(lb_gns_train* t, const float* target_dev, fl
   LB_TRY(mlp_bwd(t, t->enc_node, BN, t->xnode, t->kpad, t->a_en, t->z_en, t->dn, has_emb ? t->dx : nullptr));
   if (has_emb)
     hipLaunchKernelGGL(k_embed_grad, dim3(t->desc.num_particle_types), dim3(1024), 0, s, t->dx, t->kpad, t->desc.node_in, emb,
-                       e->ptype, t->desc.num_particle_types, BN, t->g + t->off_embed,
-                       t->f16x2 ? t->dw_flag : (const int32_t*)nullptr);
+                       e->ptype, t->desc.num_particle_types, BN, t->g + t->off_embed, t->dw_flag);
   LB_TRY(red_flush(t));  // every weight / bias / LayerNorm gradient: partials -> gradient blob, one launch
   LB_HIP(hipGetLastError());
   if (loss_out) {

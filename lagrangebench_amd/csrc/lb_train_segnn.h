@@ -432,8 +432,8 @@ extern "C" int lb_segnn_train_create(lb_engine* e, const lb_segnn_desc* d, const
   for (float** p : {&t->w, &t->g, &t->m, &t->v})
     if (!rc) rc = lb_alloc(p, (size_t)o);
   if (!rc) rc = lb_alloc(&t->loss_dev, 1);
-  if (!rc) rc = lb_alloc(&t->dw_flag, 1);
-  if (!rc && hipMemset(t->dw_flag, 0, sizeof(int32_t)) != hipSuccess) rc = lb_fail(LB_ERR_HIP, "hipMemset");
+  if (!rc) rc = lb_alloc(&t->dw_flag, (size_t)(1 + LB_DW_CALLS));
+  if (!rc && hipMemset(t->dw_flag, 0, sizeof(int32_t) * (1 + LB_DW_CALLS)) != hipSuccess) rc = lb_fail(LB_ERR_HIP, "hipMemset");
   if (!rc) rc = lb_alloc(&t->cnt_dev, (size_t)e->g.B);
   if (!rc) {
     std::vector<float> padded((size_t)o, 0.f);

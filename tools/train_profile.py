@@ -45,5 +45,5 @@ for rep in range(3 if K >= 10 else 1):
         th.zero_grad(); loss = th.loss_grad(target, 1.0); th.adamw_step(1e-4)
     torch.cuda.synchronize(device)
     times.append(1e3 * (time.perf_counter() - t0) / K)
-print(workload, "E", eng.stats()["n_edges_total"], "ms/step", times[-1], "loss", float(loss),
+print(workload, "E", eng.stats()["n_edges_total"], "ms/step", times[-1], "loss", float(loss), "repeated steps", th.math_fallbacks(),
       "groups", [round(x, 3) for x in times])
