@@ -1118,10 +1118,10 @@ extern "C" int lb_rollout(lb_engine* e, lb_gns* g, const double* traj_dev, int32
 // One rollout step (neighbor list -> model -> integrator) enqueued on e->stream.
 static int lb_enqueue_step(lb_engine* e, int (*forward)(lb_engine*, void*), void* model,
                            const double* traj_dev, int32_t T, double* pred_out_dev, int32_t n_steps) {
-  // two launches ride along with others in a rollout step (LB_STEP_FUSE=0 switches that off): the node-feature rows
+  // two launches ride along with others in a rollout step (LB_SMALL_FUSED=0 switches that off): the node-feature rows
   // are written by extra workgroups of the neighbor search (lb_engine::feat_job, set by the model's rollout entry),
   // the integrator runs in the decoder's epilogue (lb_engine::integ_job)
-  static const bool fuse = !(getenv("LB_STEP_FUSE") && getenv("LB_STEP_FUSE")[0] == '0');
+  const bool fuse = lb_fused_launches();
   const lb_feat_job fj = e->feat_job;
   if (!fuse) e->feat_job.xnode = nullptr;
   e->feat_done = false;

@@ -316,11 +316,11 @@ int lbk_edge_enc16v(lb_engine* e, const lb_edge16_args& a) {
 // trajectory, where a wave has 3 - 4 tiles and fewer rounds might have paid: TGV3D-8k B = 1 42.4 us per launch against 36.4,
 // 0.668 vs 0.615 ms per step; not kept.)
 int lbk_edge16v(lb_engine* e, const lb_edge16_args& a) {
-  // LDS tile tickets (round 4): default on ONE trajectory (a few tiles per wave: the faster - older - wave of a SIMD takes
-  // more of them; LDC3D-8k B = 1 0.619 -> 0.604, TGV3D-8k 0.673 -> 0.663 ms/step), off on batches (neutral: 2.606 vs 2.617 ms
-  // of edge kernels per step on TGV3D x 8 - profiles/r04_ab_edge_ticket.txt).  LB_EDGE_TICKET=0|1 pins it.
-  static const int ticket_env = getenv("LB_EDGE_TICKET") ? atoi(getenv("LB_EDGE_TICKET")) : -1;
-  const bool ticket = ticket_env >= 0 ? ticket_env != 0 : ((int64_t)e->e_cap * e->g.B + 15) / 16 < 12288;
+  // LDS tile tickets (round 4) on ONE trajectory (a few tiles per wave: the faster - older - wave of a SIMD takes more of
+  // them; LDC3D-8k B = 1 0.619 -> 0.604, TGV3D-8k 0.673 -> 0.663 ms/step), the static strided walk on batches (tickets
+  // neutral there: profiles/r04_ab_edge_ticket.txt).  The same size (12288 capacity tiles = 96 MiB of latents) decides
+  // between plain accesses (cache-resident between layers) and nontemporal streams, so two of the four combinations exist.
+  const bool small = ((int64_t)e->e_cap * e->g.B + 15) / 16 < 12288;
 #define LB_E16V__(NT, G, GU, TK)                                                                        \
   do {                                                                                                  \
     if (a.skip_elat_store)                                                                              \
@@ -328,21 +328,14 @@ int lbk_edge16v(lb_engine* e, const lb_edge16_args& a) {
     else                                                                                                \
       LB_LAUNCH_TIMED(e, (k_edge16v<2, false, false, 0, true, NT, GU, TK>), dim3(G), dim3(512), a);     \
   } while (0)
-#define LB_E16V_(NT, G, GU)       \
-  do {                            \
-    if (ticket)                   \
-      LB_E16V__(NT, G, GU, true); \
-    else                          \
-      LB_E16V__(NT, G, GU, false);\
-  } while (0)
-#define LB_E16V(NT, G)                           \
+#define LB_E16V(NT, G, TK)                       \
   do {                                           \
     if (e->guard_full)                           \
-      LB_E16V_(NT, G, 2);                        \
+      LB_E16V__(NT, G, 2, TK);                   \
     else if (e->math_auto && !e->guard_sampled)  \
-      LB_E16V_(NT, G, 1);                        \
+      LB_E16V__(NT, G, 1, TK);                   \
     else                                         \
-      LB_E16V_(NT, G, 0);                        \
+      LB_E16V__(NT, G, 0, TK);                   \
   } while (0)
   // Small graphs (one 2.5 k-particle trajectory = ~1000 tiles): a launch is the latency chain
   // "stage 133 KiB of weights -> one tile per wave", so launch no more workgroups than there are tiles for.
@@ -350,17 +343,12 @@ int lbk_edge16v(lb_engine* e, const lb_edge16_args& a) {
   const int64_t tiles_cap = ((int64_t)e->e_cap * e->g.B + 15) / 16;
   int64_t g = (tiles_cap + 7) / 8;
   g = (g + 7) / 8 * 8;  // the XCD-aware walk wants a multiple of 8
-  // LB_EDGE_GRID (measurement): cap on the workgroups (= CUs) the persistent kernel occupies
-  static const int grid_cap = getenv("LB_EDGE_GRID") ? atoi(getenv("LB_EDGE_GRID")) : 256;
-  const int grid = (int)(g < 8 ? 8 : (g > grid_cap ? grid_cap : g));
-  // latents of the whole graph <= 96 MiB (LB_EDGE_NT_MIN_TILES tiles): cache-resident between layers, plain accesses
-  static const int64_t nt_min_tiles = getenv("LB_EDGE_NT_MIN_TILES") ? atoll(getenv("LB_EDGE_NT_MIN_TILES")) : 12288;
-  if (tiles_cap < nt_min_tiles)
-    LB_E16V(false, grid);
+  const int grid = (int)(g < 8 ? 8 : (g > 256 ? 256 : g));
+  if (small)
+    LB_E16V(false, grid, true);
   else
-    LB_E16V(true, grid);
+    LB_E16V(true, grid, false);
 #undef LB_E16V
-#undef LB_E16V_
 #undef LB_E16V__
   LB_HIP(hipGetLastError());
   return LB_OK;

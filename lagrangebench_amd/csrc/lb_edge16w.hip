@@ -610,38 +610,29 @@ __global__ void __launch_bounds__(WPS * 256, 1) k_edge16w(lb_edge16_args a) {
 //   last layer (no store): everything deferred              215 - 219 us against 227.
 #ifndef EW_NO_LAUNCHER
 int lbk_edge16w(lb_engine* e, const lb_edge16_args& a) {
-  static const int ticket_env = getenv("LB_EDGE_TICKET") ? atoi(getenv("LB_EDGE_TICKET")) : -1;
+  // one trajectory (< 12288 capacity tiles): LDS tile tickets, plain accesses; batches: static walk, nontemporal streams
+  // (lbk_edge16v has the measurements)
   const int64_t tiles_cap = ((int64_t)e->e_cap * e->g.B + 15) / 16;
-  const bool ticket = ticket_env >= 0 ? ticket_env != 0 : tiles_cap < 12288;
+  const bool small = tiles_cap < 12288;
   int64_t g = (tiles_cap + 7) / 8;
   g = (g + 7) / 8 * 8;
-  static const int grid_cap = getenv("LB_EDGE_GRID") ? atoi(getenv("LB_EDGE_GRID")) : 256;
-  const int grid = (int)(g < 8 ? 8 : (g > grid_cap ? grid_cap : g));
-  static const int64_t nt_min_tiles = getenv("LB_EDGE_NT_MIN_TILES") ? atoll(getenv("LB_EDGE_NT_MIN_TILES")) : 12288;
-  const bool nt = tiles_cap >= nt_min_tiles;
+  const int grid = (int)(g < 8 ? 8 : (g > 256 ? 256 : g));
   const bool guard = e->math_auto && !e->guard_sampled;
 #define LB_EW4(SK, NT_, GU, TK) \
   LB_LAUNCH_TIMED(e, (k_edge16w<SK, NT_, GU, TK, (SK ? 2 : 0)>), dim3(grid), dim3(512), a)
-#define LB_EW3(SK, NT_, GU)  \
+#define LB_EW2(SK, NT_, TK)  \
   do {                       \
-    if (ticket)              \
-      LB_EW4(SK, NT_, GU, true);  \
+    if (guard)               \
+      LB_EW4(SK, NT_, 1, TK);\
     else                     \
-      LB_EW4(SK, NT_, GU, false); \
+      LB_EW4(SK, NT_, 0, TK);\
   } while (0)
-#define LB_EW2(SK, NT_)  \
-  do {                   \
-    if (guard)           \
-      LB_EW3(SK, NT_, 1);\
-    else                 \
-      LB_EW3(SK, NT_, 0);\
-  } while (0)
-#define LB_EW1(SK)       \
-  do {                   \
-    if (nt)              \
-      LB_EW2(SK, true);  \
-    else                 \
-      LB_EW2(SK, false); \
+#define LB_EW1(SK)              \
+  do {                          \
+    if (small)                  \
+      LB_EW2(SK, false, true);  \
+    else                        \
+      LB_EW2(SK, true, false);  \
   } while (0)
   if (a.skip_elat_store)
     LB_EW1(true);
@@ -649,7 +640,6 @@ int lbk_edge16w(lb_engine* e, const lb_edge16_args& a) {
     LB_EW1(false);
 #undef LB_EW1
 #undef LB_EW2
-#undef LB_EW3
 #undef LB_EW4
   LB_HIP(hipGetLastError());
   return LB_OK;

@@ -298,26 +298,25 @@ int lbk_segment_sum(lb_engine* e, const float* msg, float* out, int D) {
 // the node kernel beats the LDS-ring kernels up to the 16 k-node mark where lb_node16s takes over (TGV2D-2.5k 15.4 ->
 // 9.4 us, LDC3D-8k 19.3 -> 15.5 us per launch); the edge kernels win on the 2D graphs (TGV2D 13.3 -> 13.0, RPF2D) but
 // repeat the per-tile index / segment arithmetic in each of their four waves, so from ~3 k tiles the wave-per-tile
-// kernel is faster (LDC3D-8k: 38 vs 44 us).  LB_MSPLIT=0 / 1 forces the choice for all of them,
-// LB_MS_MAX_TILES / LB_MS_MAX_NODES move the thresholds.
+// kernel is faster (LDC3D-8k: 38 vs 44 us).  LB_MSPLIT=0 / 1 forces the choice for all of them.
 static int lb_msplit_env() {
   static const int env = getenv("LB_MSPLIT") ? atoi(getenv("LB_MSPLIT")) : -1;
   return env;
 }
 static bool lb_use_msplit_edge(const lb_engine* e) {
-  static const int64_t max_tiles = getenv("LB_MS_MAX_TILES") ? atoll(getenv("LB_MS_MAX_TILES")) : 3072;
+  const int64_t max_tiles = 3072;
   const int env = lb_msplit_env();
   if (!e->f16x2 || !e->fused_agg || env == 0) return false;
   if (env == 1) return true;
   return ((int64_t)e->e_cap * e->g.B + 15) / 16 <= max_tiles;
 }
 static bool lb_use_edge_w(const lb_engine* e) {
-  static const bool edge_w = !(getenv("LB_EDGE_W") && getenv("LB_EDGE_W")[0] == '0');
-  return edge_w && !e->guard_full && e->aggpart_bytes < ((int64_t)1 << 31) &&
+  // (k_edge16v stays for LB_GUARD=full engines and for graphs beyond 32-bit byte offsets)
+  return !e->guard_full && e->aggpart_bytes < ((int64_t)1 << 31) &&
          (int64_t)(e->e_alloc + 32) * 512 < ((int64_t)1 << 32) && e->BN * 1024 < ((int64_t)1 << 32);  // 32-bit byte offsets
 }
 static bool lb_use_msplit_node(const lb_engine* e) {
-  static const int64_t max_nodes = getenv("LB_MS_MAX_NODES") ? atoll(getenv("LB_MS_MAX_NODES")) : 16384;
+  const int64_t max_nodes = 16384;
   const int env = lb_msplit_env();
   if (!e->f16x2 || env == 0) return false;
   if (env == 1) return true;
@@ -502,7 +501,7 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       b.aggpart_bytes = e->aggpart_bytes;
       b.skip_elat_store = skip;
       // round 5: k_edge16w (deferred epilogue: the previous tile's scan / aggregate stores ride in the MFMA slots) unless
-      // LB_EDGE_W=0, the engine range-tests every k-group (LB_GUARD=full: k_edge16v's GUARD 2), or agg | part >= 2 GiB
+      // the engine range-tests every k-group (LB_GUARD=full: k_edge16v's GUARD 2), or agg | part >= 2 GiB
       if (e->f16x2 && e->fused_agg)
         rc = lb_use_edge_w(e) ? lbk_edge16w(e, b) : lbk_edge16v(e, b);
       else
@@ -516,8 +515,8 @@ int lbk_gns_forward(lb_engine* e, lb_gns* g) {
       lb_toc(e);
       if (rc) return rc;
     }
-    // M-split node kernel on the last layer: the decoder rides along (LB_MS_DEC=0: separate k_decoder16 launch)
-    static const bool ms_dec_ok = !(getenv("LB_MS_DEC") && getenv("LB_MS_DEC")[0] == '0');
+    // M-split node kernel on the last layer: the decoder rides along (LB_SMALL_FUSED=0: separate k_decoder16 launch)
+    const bool ms_dec_ok = lb_fused_launches();
     const bool with_dec = ms_pn && ms_dec_ok && k == L - 1 && e->f16x2 && g->desc.out_dim <= 4;
     lb_tic_single(e, LB_T_NODE_MLP);
     rc = node_mlp(g->proc_node[k], e->nlat, 16, true, true, k + 1, g->ms_proc_node[k], g->proc_node_w0_h[k],

@@ -1,6 +1,7 @@
 // lb_internal.h - engine object, device control block and kernel launchers shared by the
 // translation units of liblbhip.so.  gfx950 only (wave64, MFMA f32 32x32x2).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -334,6 +335,13 @@ static inline int lb_alloc(T** p, size_t n) {
     if (_rc) return _rc;   \
   } while (0)
 
+// LB_SMALL_FUSED=0 (one switch since round 6; tests/test_switches_gpu.py): every launch-saving fusion off - the single-launch
+// cell binning / neighbor builds / degree scan + compaction, node features and integrator riding with other launches, the
+// decoder inside the last M-split node launch - i.e. the general multi-launch paths that big or dense problems take anyway.
+static inline bool lb_fused_launches() {
+  static const bool ok = !(getenv("LB_SMALL_FUSED") && getenv("LB_SMALL_FUSED")[0] == '0');
+  return ok;
+}
 void lb_tic(lb_engine* e, int cls);
 void lb_toc(lb_engine* e);
 // Timer classes that consist of ONE kernel (processor edge / node MLP): between lb_tic_single and lb_toc

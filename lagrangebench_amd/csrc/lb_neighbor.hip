@@ -1953,12 +1953,12 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   hipStream_t s = e->stream;
   const int frozen = e->e_cap > 0;
 
-  // LB_SMALL_FUSED=0: always the multi-launch bookkeeping
-  static const bool small_ok = !(getenv("LB_SMALL_FUSED") && getenv("LB_SMALL_FUSED")[0] == '0');
+  // LB_SMALL_FUSED=0: always the multi-launch bookkeeping (lb_fused_launches, lb_internal.h)
+  const bool small_ok = lb_fused_launches();
   const bool small_rows = small_ok && BN <= LB_SMALL_N;
   const bool small_cells = small_rows && ncell_tot <= LB_SMALL_N;
   // one trajectory of <= 4096 particles on the update path: the whole build is ONE launch (k_nl_small)
-  static const bool one_ok = !(getenv("LB_NL_ONE") && getenv("LB_NL_ONE")[0] == '0');
+  const bool one_ok = small_ok;
   const int nls_npad = (int)((BN + 63) / 64 * 64);
   const int nls_waves = (int)std::min<int64_t>(NLS_WAVES, std::max<int64_t>(1, (BN + 255) / 256));
   const int64_t nls_tab = g.use_cell_list ? (int64_t)(g.ncell[0] + g.ncell[1] + (g.dim == 3 ? g.ncell[2] : 0)) * (nls_npad / 64) : 0;
@@ -2036,7 +2036,7 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
     const int npad_m = (int)((BN + 63) / 64 * 64);
     const int64_t tab_m = (int64_t)(g.ncell[0] + g.ncell[1] + (g.dim == 3 ? g.ncell[2] : 0)) * (npad_m / 64);
     const size_t lds_m = 8 * (size_t)tab_m + sizeof(int) * ((size_t)npad_m + NLM_WAVES * NLM_ROWBUF + 48);
-    static const bool mid_ok = !(getenv("LB_NL_MID") && getenv("LB_NL_MID")[0] == '0');
+    const bool mid_ok = small_ok;
     if (mid_ok && one_ok && small_ok && frozen && g.B == 1 && BN > LB_SMALL_N && BN <= NLM_N && g.use_cell_list &&
         (g.dim == 2 || g.dim == 3) && !e->nl_dense && !e->nl_one_off && lds_m <= 150 * 1024 &&
         (int64_t)e->cell_capacity * g.nstencil <= NLM_ROWBUF - LB_MAX_ROW * (NLM_RPW - 1) && e->nl_wg_sum && g.ncell[0] < 2048 &&
@@ -2085,10 +2085,10 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   }
   lb_tic(e, LB_T_CELLS);
   // (one mid-size trajectory that the single-launch builds above refused, e.g. DAM2D: binning still in one launch)
-  static const bool cells1_ok = !(getenv("LB_CELLS_ONE") && getenv("LB_CELLS_ONE")[0] == '0');
+  const bool cells1_ok = small_ok;
   const bool mid_cells = cells1_ok && small_ok && frozen && g.B == 1 && BN <= LB_CELLS1_N && ncell_tot <= LB_CELLS1_NCELL;
-  // batches: one workgroup per trajectory, one launch (LB_CELLS_TRAJ=0: the five-launch counting sort)
-  static const bool cells_traj_ok = !(getenv("LB_CELLS_TRAJ") && getenv("LB_CELLS_TRAJ")[0] == '0');
+  // batches: one workgroup per trajectory, one launch (LB_SMALL_FUSED=0: the five-launch counting sort)
+  const bool cells_traj_ok = small_ok;
   // (measured, profiles/r04_ab_cells_traj.txt: 2.5 k particles x 8 23.1 -> 17.5 us, 5.7 k x 8 27.7 -> 22.7 us, 8 k x 8 30.8 -> 32.5 us -
   // one workgroup per trajectory is bound by its scattered stores from ONE CU; above 6 k particles the five launches stay)
   const bool traj_cells = cells_traj_ok && frozen && !small_cells && g.B > 1 && g.use_cell_list && g.N <= 6144 &&
@@ -2160,8 +2160,8 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   } else {
     lb_launch_nl<NL_COUNT>(e, small, a);
   }
-  // update path of a small batch: scan + finish + compaction in one launch (LB_NL_CSCAN=0: the separate launches)
-  static const bool cscan_ok = !(getenv("LB_NL_CSCAN") && getenv("LB_NL_CSCAN")[0] == '0');
+  // update path of a small batch: scan + finish + compaction in one launch (LB_SMALL_FUSED=0: the separate launches)
+  const bool cscan_ok = small_ok;
   if (rows && cscan_ok && small_ok && BN <= LB_CSCAN_N && g.B <= 64) {
     hipLaunchKernelGGL(k_nl_compact_scan, dim3((int)((BN + 15) / 16)), dim3(256), 0, s, g, BN, e->ctrl, e->deg, e->row_ptr,
                        e->maxd, e->tmp_send, e->tmp_feat, want_efeat64 ? e->tmp_feat64 : (const double*)nullptr,

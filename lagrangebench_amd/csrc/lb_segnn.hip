@@ -543,9 +543,8 @@ extern "C" int lb_segnn_create(lb_engine* e, const lb_segnn_desc* d, const float
   {
     const char* f = getenv("LB_SEGNN_FUSED");
     m->fused_msg = (B == 2) && !(f && f[0] == '0');
-    // LB_SEGNN_NODE=0: node prep / embedding / readout / integrator as round 3's separate launches
-    const char* fn = getenv("LB_SEGNN_NODE");
-    m->fused_node = m->fused_msg && node_ok && !(fn && fn[0] == '0');
+    // LB_SMALL_FUSED=0: node prep / embedding / readout / integrator as round 3's separate launches
+    m->fused_node = m->fused_msg && node_ok && lb_fused_launches();
     if (node_ok) {
       m->embed_image = m->blob + embed_off;
       m->readout_image = m->blob + readout_off;

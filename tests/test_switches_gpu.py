@@ -1,7 +1,7 @@
-"""Every environment switch that selects another kernel family or schedule and SURVIVED the round-5 clean-up must stay
-correct: the forward / rollout parity subset of tests/test_gpu_parity.py is re-run in a subprocess under each GROUP of
-compatible switches (the switches are read once per process; round 5 grouped them - one subprocess per switch cost the
-GPU suite ~8 minutes).  INTEGRATION.md section 3 lists them."""
+"""Every environment switch that selects another kernel family or schedule and SURVIVED the round-6 clean-up (11 left in the
+library; INTEGRATION.md section 3 lists them) must stay correct: the forward / rollout parity subset of
+tests/test_gpu_parity.py is re-run in a subprocess under each GROUP of compatible switches (the switches are read once per
+process).  LB_TRAIN_MATH / LB_TRAIN_SORT are covered by tests/test_train.py, LB_GUARD_MAX_FALLBACKS by the guard-loop tests."""
 import os
 import subprocess
 import sys
@@ -13,21 +13,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SWITCHES = [
     {"LB_MATH": "f32"},                                   # exact-fp32 MFMA kernels (the range guard's fall-back)
     {"LB_FUSED_AGG": "0"},                                # stand-alone jraph.segment_sum
-    {"LB_MSPLIT": "0", "LB_GUARD": "full", "LB_EDGE_TICKET": "1"},   # wave-per-tile kernels also on small graphs, every tile
-                                                          # range-tested, LDS tile tickets at any size
-    {"LB_MSPLIT": "0", "LB_EDGE_TICKET": "0", "LB_EDGE_NT_MIN_TILES": "0"},  # ... static strided walk, nontemporal streams
+    {"LB_MSPLIT": "0", "LB_GUARD": "full"},               # wave-per-tile kernels also on small graphs (k_edge16v: every k-group
+                                                          # of every tile range-tested)
+    {"LB_MSPLIT": "0"},                                   # ... k_edge16w + k_node16s on small graphs
     {"LB_MSPLIT": "1"},                                   # M-split kernels also on large graphs
     {"LB_NL_KERNEL": "cell", "LB_GRAPH": "1"},            # workgroup-per-cell search; hipGraph replay of the step
+    {"LB_NL_KERNEL": "nlc"},                              # wave-per-cell search (round 6) also for 3^2-cell stencils
     {"LB_GUARD": "sampled"},                              # rounds 2-3 guard: first tile of every wave only
     # every launch-fusion of rounds 2-4 switched off together (each unfused path is also the default at larger sizes):
     # multi-launch cell binning / neighbor build / degree scan + compaction, wave-per-receiver search, decoder and
     # node features / integrator as launches of their own
-    {"LB_SMALL_FUSED": "0", "LB_NL_KERNEL": "wave", "LB_CELLS_TRAJ": "0", "LB_CELLS_ONE": "0", "LB_NL_ONE": "0",
-     "LB_NL_MID": "0", "LB_NL_CSCAN": "0", "LB_MS_DEC": "0", "LB_STEP_FUSE": "0"},
+    {"LB_SMALL_FUSED": "0", "LB_NL_KERNEL": "wave"},
 ]
 
 SEGNN_SWITCHES = [
-    {"LB_SEGNN_NODE": "0"},                               # node prep / embedding / readout / integrator as separate launches
+    {"LB_SMALL_FUSED": "0"},                              # node prep / embedding / readout / integrator as separate launches
     {"LB_SEGNN_FUSED": "0"},                              # one kernel per tensor-product block + stand-alone segment_sum
 ]
 
