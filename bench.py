@@ -287,7 +287,7 @@ def main():
                         "achieved": last_bytes / (us_last * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": last_bytes / (us_last * 1e-6) / 1e9 / HBM_PEAK_GBS,
                         "note": "half the bytes, nearly the same time: this launch is bound by instruction issue / LDS "
-                                "weight reads, not by HBM (DESIGN.md section 5)"}
+                                "weight reads, not by HBM (DESIGN.md section 4.3)"}
     if math_mode == "f16x2":
         roof = {"kernel": kern, "bound": "hbm", "achieved": gbs_edge, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs_edge / HBM_PEAK_GBS, "last_layer_variant": last_variant,

@@ -21,7 +21,7 @@
 //     into the registers the node-latent half just released, the projection runs as two 128-wide
 //     halves, the residual re-reads the node row (L2 hit) instead of keeping it for the whole pass;
 //   * the inner block loop / split / LayerNorm are the ones of lb_edge16v.hip (lb_f16x2.h).
-// Measured 52-54 us per launch; where the time goes: profiles/r02_node16s_ablation.txt, DESIGN.md section 4.
+// Measured 52-54 us per launch; where the time goes: profiles/r02_node16s_ablation.txt, DESIGN.md section 4.4 / profiles/HISTORY.md.
 #include <stdlib.h>
 
 #include "lb_f16x2.h"
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (NS_SLOTS == 4 ? 1 : 2) : 4
 #undef NS_REFILL
 
 // (round 5: the two measured-slower variants of this kernel left the tree - k_node16s2, two tiles per wave and weight chunk,
-// 55 - 57 vs 50.5 us per launch, profiles/r02_node16s_ablation.txt / DESIGN.md section 4; k_node16q, a four-slot ring of
+// 55 - 57 vs 50.5 us per launch, profiles/r02_node16s_ablation.txt / profiles/HISTORY.md section 4; k_node16q, a four-slot ring of
 // 16 KiB chunks with exact in-order vmcnt waits, 51.4 vs 50.6 us, profiles/r04_node_q_ab.txt.  git history has both.)
 
 int lbk_node16s(lb_engine* e, const lb_node_args& a, const float* w0h, const float* w1h, const float* wph2,

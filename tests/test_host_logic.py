@@ -113,7 +113,7 @@ def test_write_vtk_and_pkl2vtk(tmp_path):
 
 
 def test_mfma_chain_report_tool_runs():
-    """tools/mfma_chain_check.py: compiles a kernel source to gfx950 assembly (no GPU
+    """tools/mfma_chain_check.py (profiles/HISTORY.md section 4): compiles a kernel source to gfx950 assembly (no GPU
     needed) and reports the spacing of dependent MFMA pairs."""
     import os
     import subprocess

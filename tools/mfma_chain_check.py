@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Build-time report of MFMA accumulate-chain spacing.
+"""Build-time report of MFMA accumulate-chain spacing (profiles/HISTORY.md section 4).
 
     python tools/mfma_chain_check.py [file.hip ...]      (default: every f16x2 kernel source)
 

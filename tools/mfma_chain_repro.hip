@@ -1,4 +1,4 @@
-// tools/mfma_chain_repro.hip - reproducer for the "MFMA accumulate-chain hazard" of DESIGN.md section 4.
+// tools/mfma_chain_repro.hip - reproducer for the "MFMA accumulate-chain hazard" of profiles/HISTORY.md section 4.
 //
 // Round 1 observed (building k_sg_msg): a chain acc = v_mfma_f32_16x16x32_f16(a, b, acc) whose dependent
 // links are separated by only ~2 independent MFMAs intermittently LOSES a link's contribution when the
