@@ -5,17 +5,24 @@
 
 A "step" is ONE rollout step (neighbor-list rebuild -> features -> GNS-10-128 -> integrator ->
 prediction store) over one batch of B synthetic trajectories per GPU.  Inputs are resident in
-HBM before the timed region.  Rank 0 prints ONE JSON line:
+HBM before the timed region.  Workload of `value` (config.workload): TGV3D-8k x 8 trajectories whose
+neighbour count is stationary over the rollout (--vel-amp 0.03, round 6); the drifting trajectories
+rounds 1 - 5 quoted `value` on are other_configs[tag = "tgv3d_drifting"].  Rank 0 prints ONE JSON line:
 
   metric/value : rollout particle-steps/s, whole job = n_gpus * B * N_particles * K / max-rank time
+                 (median of --repeats timed regions of exactly K steps)
   roofline     : the dominant kernel (processor edge MLP with the fused aggregation), timed with HIP
-                 events on the engine stream inside this run.  In the default f16x2 arithmetic the
-                 kernel's binding ceiling is HBM (edge latents stream once in, once out per layer);
-                 its MFMA-side utilisation is reported next to it.  With LB_MATH=f32 the kernel is
-                 bound by the fp32 MFMA pipe and the object says so.
+                 events bound to its dispatches inside this run; algorithmic bytes from the mean real
+                 edge count of the timed steps.  `bound` "hbm" in the default f16x2 arithmetic (edge
+                 latents stream once in, once out per layer), `limiter` says what actually holds the
+                 launch: the package power cap (`power`: hwmon sclk / W at 100 Hz over 1.5 s of the
+                 same rollout).  `traffic`: committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes
+                 (profiles/pmc_traffic.json; --pmc re-measures with two nested passes).
+                 With LB_MATH=f32 the kernel is bound by the fp32 MFMA pipe and the object says so.
   roofline_aggregate : the stand-alone jraph.segment_sum kernel (HBM bound) north_star singles out
-  cpu_baseline : the NumPy oracle (reference-shaped: padded E_cap rows, unfused ops) timed on this
-                 host's cores on a bounded sample (rank 0, N=1 only)
+  cpu_baseline : the CPU restatement of the reference's algorithm (oracle/: torch-CPU network + NumPy
+                 neighbor list, padded E_cap rows, unfused ops; kind "port", NOT JAX-CPU) timed on this
+                 host's cores on a bounded sample after all GPU work (rank 0, N=1 only)
 
 Multi-GPU: launched by torch.distributed.run, one rank per GPU; trajectories are independent, so
 there is no data-path collective - RCCL only gathers the per-trajectory MSE vectors and the max
@@ -790,9 +797,10 @@ CPU_PLAN = {
     # config 1 (TGV2D-2.5k, 20 steps) is mandatory; TGV3D-8k (the config the >= 5x target is quoted on)
     # costs ~1.8 s per step on this host: a bounded sample.  One rollout of warm + steps steps, every step timed
     # (the reference's step loop is host driven, rollout.py:125-169); the reported figure is the MEDIAN step.
-    # (round 6: 10 + 4 timed steps instead of 20 + 5, one warm-up step for TGV3D: ~12 s of CPU work, bench wall <= 20 s)
-    "tgv2d": {"steps": 10, "warm": 2},
-    "tgv3d": {"steps": 4, "warm": 1},
+    # (round 6: 8 + 3 timed steps instead of 20 + 5, one warm-up step each: ~12 s of CPU work incl. the leg process's start-up
+    # and list allocation, bench wall <= 20 s)
+    "tgv2d": {"steps": 8, "warm": 1},
+    "tgv3d": {"steps": 3, "warm": 1},
 }
 
 
