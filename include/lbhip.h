@@ -199,7 +199,8 @@ int lb_rollout(lb_engine* eng, lb_gns* gns, const double* traj_dev, int32_t T, i
  * optimiser step run on the device (csrc/lb_train.hip: rocBLAS sgemm for the dense contractions, hand-written HIP
  * kernels for everything else); the graph, features and targets are the engine's (case.preprocess first). */
 typedef struct lb_gns_train lb_gns_train;
-/* weights_host: the flat blob of GNS.flatten (same layout as lb_gns_create); latent 128, two Linears per MLP. */
+/* weights_host: the flat blob of GNS.flatten (same layout as lb_gns_create); latent <= 128 (narrower: zero-padded on the device),
+ * two to eight Linears per MLP (num_mlp_layers, models/utils.py:100-115; round 6). */
 int lb_gns_train_create(lb_engine* eng, const lb_gns_desc* desc, const float* weights_host, int64_t n_floats,
                         lb_gns_train** out);
 void lb_gns_train_destroy(lb_gns_train* t);

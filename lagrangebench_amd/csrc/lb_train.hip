@@ -44,7 +44,8 @@
 #define TD 128  // latent width of the training path (GNS-*-128)
 
 struct lb_train_mlp {
-  int64_t w0, b0, w1, b1, lns, lno;  // float offsets into the blob
+  int64_t w0, b0, w1, b1, lns, lno;  // float offsets into the blob: first Linear, LAST Linear, LayerNorm
+  std::vector<int64_t> wm, bm;       // the num_mlp_layers - 2 Linears between them (128 x 128 each; round 6)
   int in, out;
   bool ln;
 };
@@ -123,6 +124,11 @@ struct lb_gns_train {
   // reductions then add NOTHING, lb_gns_train_loss_grad re-centres the exponents of the calls that fired and repeats the
   // step.  A call whose chunks do not fit one window (it fires again right after a re-centring) switches to per-chunk
   // scaling inside the kernel (dw_xdyn[c]: one more pass over its X slice).
+  // MLP depth (round 6: any num_mlp_layers >= 2, models/utils.py:100-115): a block keeps nlin - 1 hidden activations, the
+  // first at its `a` pointer, the next ones hs_n / hs_e floats further on (node- / edge-sized blocks)
+  int nlin = 2;
+  int64_t hs_n = 0, hs_e = 0;
+  float* da2 = nullptr;         // second d(hidden) buffer: the middle Linears' backward ping-pongs between da and da2
   int32_t* dw_flag = nullptr;   // [1 + LB_DW_CALLS] (bit 4 of [0]: k_sender_transpose met an edge without its transpose)
   int32_t dw_fallbacks = 0;     // steps repeated because of the guard
   int dw_call = 0;              // k_dw_part_h launches of the current step so far
@@ -1043,12 +1049,14 @@ static int64_t red_capacity(const lb_gns_train* t, int64_t cn, int64_t ce) {
   tot += slot(cn, 128) + slot(cn, std::max(128, t->kpad)) + lnp(cn);                             // node encoder
   tot += 2 * slot(ce, 128) + lnp(ce);                                                            // edge encoder
   tot += 2 * slot(cn, 128) + (cn + 127) / 128 * 128 + 64;                                        // decoder (narrow dW, column sums)
+  const int64_t mid = t->nlin - 2;                                                               // middle Linears of every block
+  tot += mid * ((int64_t)L * (slot(ce, 128) + slot(cn, 128)) + 2 * slot(cn, 128) + slot(ce, 128));
   return tot + 4096;
 }
 // dW[K x 128] += X^T dY, db[128] += column sums of dY (k_dw_part + a descriptor for k_part_reduce); false = refused
 // (nb: how many of dY's 128 column sums are added to db - the SEGNN blocks keep only their Ms scalar-output columns)
 static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx, const float* dY, float* dW, float* db,
-                   int nb = 128, const float* tmax = nullptr) {
+                   int nb, const float* tmax) {
   // (every refusal leaves its reason in lb_last_error - ADVICE r05: callers return a bare LB_ERR_STATE)
   if (K > 384 || rows <= 0) {
     (void)lb_fail(LB_ERR_STATE, "dw_acc: K = %d (<= 384) / rows = %lld (> 0) out of range", K, (long long)rows);
@@ -1106,12 +1114,34 @@ static int colsum_add(lb_gns_train* t, const float* x, int64_t rows, int cols, i
 static int mlp_fwd_tail(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, float* a, float* z, const float* resid, float* y,
                         float* y2);
 // forward of one MLP block: X (rows x in, ldx) -> a = relu(X W0 + b0) -> z = a W1 + b1 -> [LayerNorm (+ resid)] -> y
+// the middle Linears of a block: a_{m+1} = relu(a_m Wm + bm), hidden m at a + m * stride
+static int mlp_mid_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, float* a, int64_t stride) {
+  for (size_t m = 0; m < p.wm.size(); ++m)
+    LB_TRY(gemm_nn(t, rows, TD, TD, a + m * stride, TD, t->w + p.wm[m], a + (m + 1) * stride, TD, 0.f, t->w + p.bm[m], 1));
+  return LB_OK;
+}
+// ... and their backward.  In: t->da = d(last hidden), ReLU-masked; out: t->da = d(first hidden), masked (the two buffers swap)
+static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx, const float* dY, float* dW, float* db,
+                   int nb = 128, const float* tmax = nullptr);
+static int mlp_mid_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* a, int64_t stride) {
+  for (size_t m = p.wm.size(); m-- > 0;) {
+    const float* ain = a + m * stride;  // input of middle Linear m
+    LB_TRY(gemm_nt(t, rows, TD, TD, t->da, t->w + p.wm[m], t->da2, TD, 0.f, 0, ain, TD, t->tmax));  // ReLU mask of ain
+    if (!dw_acc(t, rows, TD, ain, TD, t->da, t->g + p.wm[m], t->g + p.bm[m], 128, t->tmax_ok ? t->tmax : nullptr))
+      return lb_fail(LB_ERR_STATE, "dw_acc refused a middle Linear");
+    std::swap(t->da, t->da2);
+  }
+  t->tmax_ok = false;
+  return LB_OK;
+}
 static int mlp_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* X, int ldx, float* a, float* z,
-                   const float* resid, float* y) {
+                   const float* resid, float* y, int64_t stride) {
   hipStream_t s = t->eng->stream;
   (void)s;
   LB_TRY(gemm_nn(t, rows, TD, p.in, X, ldx, t->w + p.w0, a, TD, 0.f, t->w + p.b0, 1));  // bias + ReLU in the epilogue
-  return resid ? mlp_fwd_tail(t, p, rows, a, z, resid, nullptr, y) : mlp_fwd_tail(t, p, rows, a, z, nullptr, y, nullptr);
+  LB_TRY(mlp_mid_fwd(t, p, rows, a, stride));
+  float* al = a + p.wm.size() * stride;
+  return resid ? mlp_fwd_tail(t, p, rows, al, z, resid, nullptr, y) : mlp_fwd_tail(t, p, rows, al, z, nullptr, y, nullptr);
 }
 // forward of the edge block (gns.py:86-101) without the concatenated input (see k_edge_dP's comment)
 // y = e' = LN(MLP([n_s | n_r | e])) (the message), el_next = e + e' (the next edge latent)
@@ -1128,7 +1158,8 @@ static int edge_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t E, int64_t B
     g.bias = t->w + p.b0; g.gat1 = Ps; g.gidx1 = e->senders; g.gat2 = Pr; g.gidx2 = e->receivers;
     LB_TRY(lin32(t, g, t->w + p.w0 + (size_t)2 * TD * TD, TD, 0));
   }
-  return mlp_fwd_tail(t, p, E, a, z, el, y, el_next);
+  LB_TRY(mlp_mid_fwd(t, p, E, a, t->hs_e));
+  return mlp_fwd_tail(t, p, E, a + p.wm.size() * t->hs_e, z, el, y, el_next);
 }
 // y = LN(...) (may be null), y2 = resid + y (may be null); without LayerNorm (decoder): y = a W1 + b1
 static int mlp_fwd_tail(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, float* a, float* z, const float* resid,
@@ -1170,9 +1201,10 @@ static int mlp_bwd_head(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, co
   return LB_OK;
 }
 static int mlp_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* X, int ldx, const float* a,
-                   const float* z, const float* dy, float* dX) {
+                   const float* z, const float* dy, float* dX, int64_t stride) {
   if (rows == 0) return LB_OK;
-  LB_TRY(mlp_bwd_head(t, p, rows, a, z, dy));
+  LB_TRY(mlp_bwd_head(t, p, rows, a + p.wm.size() * stride, z, dy));
+  LB_TRY(mlp_mid_bwd(t, p, rows, a, stride));
   t->tmax_ok = false;
   if (dX) LB_TRY(gemm_nt(t, rows, TD, p.in, t->da, t->w + p.w0, dX, ldx, 0.f, 0, nullptr, 0, t->tmax));
   if (!dw_acc(t, rows, p.in, X, ldx, t->da, t->g + p.w0, t->g + p.b0, 128, t->tmax_ok ? t->tmax : nullptr))
@@ -1187,7 +1219,8 @@ static int edge_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t E, int64_t B
   hipStream_t s = t->eng->stream;
   lb_engine* e = t->eng;
   // e' feeds agg (gather of dagg over the receivers) and e_{k+1} = e_k + e' (de): d e' = de + dagg[rcv], formed in the load
-  LB_TRY(mlp_bwd_head(t, p, E, a, z, de, dagg, e->receivers));  // -> t->da (E x 128)
+  LB_TRY(mlp_bwd_head(t, p, E, a + p.wm.size() * t->hs_e, z, de, dagg, e->receivers));  // -> t->da (E x 128)
+  LB_TRY(mlp_mid_bwd(t, p, E, a, t->hs_e));
   const float *Ws = t->w + p.w0, *Wr = Ws + (size_t)TD * TD, *We = Wr + (size_t)TD * TD;
   float *gWs = t->g + p.w0, *gWr = gWs + (size_t)TD * TD, *gWe = gWr + (size_t)TD * TD;
   // edge rows: dW_e += e^T da, db0 += column sums of da, de += da W_e^T
@@ -1215,30 +1248,34 @@ static int train_ensure(lb_gns_train* t, int64_t BN, int64_t E) {
   if (BN <= t->cap_n && E <= t->cap_e && t->xnode) return LB_OK;
   LB_HIP(hipStreamSynchronize(t->eng->stream));
   const int64_t cn = std::max(BN, t->cap_n), ce = std::max(E + E / 8 + 1024, t->cap_e);
+  const size_t nh = (size_t)(t->nlin - 1);   // hidden activations kept per block
+  t->hs_n = cn * TD;
+  t->hs_e = ce * TD;
   LB_TRY(tr_alloc(&t->xnode, (size_t)cn * t->kpad));
-  LB_TRY(tr_alloc(&t->a_en, (size_t)cn * TD));
+  LB_TRY(tr_alloc(&t->a_en, nh * cn * TD));
   LB_TRY(tr_alloc(&t->z_en, (size_t)cn * TD));
-  LB_TRY(tr_alloc(&t->a_ee, (size_t)ce * TD));
+  LB_TRY(tr_alloc(&t->a_ee, nh * ce * TD));
   LB_TRY(tr_alloc(&t->z_ee, (size_t)ce * TD));
   for (int k = 0; k <= L; ++k) {
     LB_TRY(tr_alloc(&t->nlat[k], (size_t)cn * TD));
     LB_TRY(tr_alloc(&t->elat[k], (size_t)ce * TD));
   }
   for (int k = 0; k < L; ++k) {
-    LB_TRY(tr_alloc(&t->ae[k], (size_t)ce * TD));
+    LB_TRY(tr_alloc(&t->ae[k], nh * ce * TD));
     LB_TRY(tr_alloc(&t->ze[k], (size_t)ce * TD));
     LB_TRY(tr_alloc(&t->xn[k], (size_t)cn * 2 * TD));
-    LB_TRY(tr_alloc(&t->an[k], (size_t)cn * TD));
+    LB_TRY(tr_alloc(&t->an[k], nh * cn * TD));
     LB_TRY(tr_alloc(&t->zn[k], (size_t)cn * TD));
   }
   const int64_t cm = std::max(cn, ce);
-  LB_TRY(tr_alloc(&t->a_d, (size_t)cn * TD));
+  LB_TRY(tr_alloc(&t->a_d, nh * cn * TD));
   LB_TRY(tr_alloc(&t->pred, (size_t)cn * 4));
   LB_TRY(tr_alloc(&t->dn, (size_t)cn * TD));
   LB_TRY(tr_alloc(&t->de, (size_t)ce * TD));
   LB_TRY(tr_alloc(&t->dy, (size_t)cm * TD));
   LB_TRY(tr_alloc(&t->dz, (size_t)cm * TD));
   LB_TRY(tr_alloc(&t->da, (size_t)cm * TD));
+  if (t->nlin > 2) LB_TRY(tr_alloc(&t->da2, (size_t)cm * TD));
   LB_TRY(tr_alloc(&t->dx, (size_t)cn * std::max(3 * TD, t->kpad)));
   LB_TRY(tr_alloc(&t->dagg, (size_t)cn * TD));
   LB_TRY(tr_alloc(&t->agg, (size_t)cn * TD));
@@ -1348,8 +1385,8 @@ static int train_sender_sort(lb_gns_train* t, int64_t E, int64_t BN) {
 extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const float* w, int64_t n_floats,
                                    lb_gns_train** out) {
   if (!e || !d || !w || !out) return lb_fail(LB_ERR_ARG, "null argument");
-  if (d->latent_size < 4 || d->latent_size > TD || d->blocks_per_step != 2)
-    return lb_fail(LB_ERR_UNSUPPORTED, "training path: latent_size <= 128 and num_mlp_layers 2 are built");
+  if (d->latent_size < 4 || d->latent_size > TD || d->blocks_per_step < 2 || d->blocks_per_step > 8)
+    return lb_fail(LB_ERR_UNSUPPORTED, "training path: latent_size <= 128 and 2 <= num_mlp_layers <= 8 are built");
   if (d->out_dim != e->g.dim || d->node_in != e->g.node_in || d->edge_in != e->g.dim + 1)
     return lb_fail(LB_ERR_ARG, "model widths do not match the case");
   const int L = d->num_mp_steps;
@@ -1358,6 +1395,8 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
   lb_gns_train* t = new lb_gns_train();
   t->desc = *d;
   t->eng = e;
+  t->nlin = d->blocks_per_step;
+  const int nmid = t->nlin - 2;
   t->nin = d->node_in + emb;
   t->kpad = (t->nin + 31) / 32 * 32;
   int64_t o = 0;
@@ -1370,6 +1409,10 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
     p.ln = ln;
     p.w0 = o; o += (int64_t)in * TD;
     p.b0 = o; o += TD;
+    for (int m = 0; m < nmid; ++m) {   // GNS.flatten order: linear_0, linear_1, ..., LayerNorm
+      p.wm.push_back(o); o += (int64_t)TD * TD;
+      p.bm.push_back(o); o += TD;
+    }
     p.w1 = o; o += (int64_t)TD * outw;
     p.b1 = o; o += outw;
     if (ln) {
@@ -1402,6 +1445,11 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
         for (int c = 0; c < lat; ++c) t->cmap.push_back(p.w0 + (int64_t)rp * TD + c);
       }
       for (int c = 0; c < lat; ++c) t->cmap.push_back(p.b0 + c);
+      for (size_t m = 0; m < p.wm.size(); ++m) {
+        for (int r = 0; r < lat; ++r)
+          for (int c = 0; c < lat; ++c) t->cmap.push_back(p.wm[m] + (int64_t)r * TD + c);
+        for (int c = 0; c < lat; ++c) t->cmap.push_back(p.bm[m] + c);
+      }
       for (int r = 0; r < lat; ++r)
         for (int c = 0; c < out_c; ++c) t->cmap.push_back(p.w1 + (int64_t)r * p.out + c);
       for (int c = 0; c < out_c; ++c) t->cmap.push_back(p.b1 + c);
@@ -1410,7 +1458,8 @@ extern "C" int lb_gns_train_create(lb_engine* e, const lb_gns_desc* d, const flo
         for (int c = 0; c < out_c; ++c) t->cmap.push_back(p.lno + c);
       }
     }
-    oc += (int64_t)in_c * lat + lat + (int64_t)lat * out_c + out_c + (p.ln ? 2 * out_c : 0);
+    oc += (int64_t)in_c * lat + lat + (int64_t)p.wm.size() * ((int64_t)lat * lat + lat) + (int64_t)lat * out_c + out_c +
+          (p.ln ? 2 * out_c : 0);
   };
   map_mlp(t->enc_node, t->nin, 0, lat);
   map_mlp(t->enc_edge, d->edge_in, 0, lat);
@@ -1463,7 +1512,7 @@ extern "C" void lb_gns_train_destroy(lb_gns_train* t) {
   sgt_free(t);
   std::vector<void*> bufs = {t->w, t->g, t->m, t->v, t->xnode, t->a_en, t->z_en, t->a_ee, t->z_ee, t->a_d, t->pred,
                              t->dn, t->de, t->dy, t->dz, t->da, t->dx, t->dagg, t->agg, t->dwpart, t->red_dev, t->proj, t->node_w,
-                             t->loss_dev, t->dw_flag, t->loss_part, t->cnt_dev, t->snd_key, t->snd_perm, t->iota, t->snd_ptr, t->sort_tmp,
+                             t->loss_dev, t->dw_flag, t->da2, t->loss_part, t->cnt_dev, t->snd_key, t->snd_perm, t->iota, t->snd_ptr, t->sort_tmp,
                              t->wpack, t->pack_dev, t->pack_dev_h, t->wsc, t->tmax};
   for (auto* v : {&t->nlat, &t->elat, &t->ae, &t->ze, &t->xn, &t->an, &t->zn})
     for (float* p : *v) bufs.push_back(p);
@@ -1558,33 +1607,33 @@ static int gns_train_loss_grad_once(lb_gns_train* t, const float* target_dev, fl
   e->g.kpad = kpad_saved;
   if (rc) return rc;
   // ---- forward
-  LB_TRY(mlp_fwd(t, t->enc_node, BN, t->xnode, t->kpad, t->a_en, t->z_en, nullptr, t->nlat[0]));
-  LB_TRY(mlp_fwd(t, t->enc_edge, E, e->efeat, 8, t->a_ee, t->z_ee, nullptr, t->elat[0]));
+  LB_TRY(mlp_fwd(t, t->enc_node, BN, t->xnode, t->kpad, t->a_en, t->z_en, nullptr, t->nlat[0], t->hs_n));
+  LB_TRY(mlp_fwd(t, t->enc_edge, E, e->efeat, 8, t->a_ee, t->z_ee, nullptr, t->elat[0], t->hs_e));
   for (int k = 0; k < L; ++k) {
     // e' = LN(MLP([n_s | n_r | e])) is both the message and (plus e) the next edge latent: keep e' in dy, then residual
     LB_TRY(edge_fwd(t, t->pe[k], E, BN, t->nlat[k], t->elat[k], t->ae[k], t->ze[k], t->dy, t->elat[k + 1]));
     hipLaunchKernelGGL(k_seg_sum, GRID1(BN * 32), 0, s, e->row_ptr, t->dy, t->agg, BN, E, t->nlat[k], t->xn[k]);
-    LB_TRY(mlp_fwd(t, t->pn[k], BN, t->xn[k], 2 * TD, t->an[k], t->zn[k], t->nlat[k], t->nlat[k + 1]));
+    LB_TRY(mlp_fwd(t, t->pn[k], BN, t->xn[k], 2 * TD, t->an[k], t->zn[k], t->nlat[k], t->nlat[k + 1], t->hs_n));
   }
-  LB_TRY(mlp_fwd(t, t->dec, BN, t->nlat[L], TD, t->a_d, nullptr, nullptr, t->pred));
+  LB_TRY(mlp_fwd(t, t->dec, BN, t->nlat[L], TD, t->a_d, nullptr, nullptr, t->pred, t->hs_n));
   if (pred_out_dev) LB_HIP(hipMemcpyAsync(pred_out_dev, t->pred, sizeof(float) * BN * dim, hipMemcpyDeviceToDevice, s));
   // ---- loss and d loss / d pred, the sender-sorted view of this step's edge list
   LB_TRY(train_loss(t, t->pred, target_dev, loss_weight, t->dy));
   LB_TRY(train_sender_sort(t, E, BN));
   // ---- backward
-  LB_TRY(mlp_bwd(t, t->dec, BN, t->nlat[L], TD, t->a_d, nullptr, t->dy, t->dn));  // dn = d loss / d n_L
+  LB_TRY(mlp_bwd(t, t->dec, BN, t->nlat[L], TD, t->a_d, nullptr, t->dy, t->dn, t->hs_n));  // dn = d loss / d n_L
   LB_HIP(hipMemsetAsync(t->de, 0, sizeof(float) * std::max<int64_t>(E, 1) * TD, s));  // e_L has no reader
   for (int k = L - 1; k >= 0; --k) {
     // node block: n_{k+1} = n_k + LN(MLP([n_k | agg_k])): dy = dn (also flows to n_k through the residual)
     // d [n_k | agg_k] = da W0^T lands where it is used: the n_k half is added to dn, the agg_k half is dagg (round 4 wrote
     // the 256-wide product and split it in a pass of its own).  dn was consumed (LayerNorm backward) before it is updated.
-    LB_TRY(mlp_bwd(t, t->pn[k], BN, t->xn[k], 2 * TD, t->an[k], t->zn[k], t->dn, nullptr));
+    LB_TRY(mlp_bwd(t, t->pn[k], BN, t->xn[k], 2 * TD, t->an[k], t->zn[k], t->dn, nullptr, t->hs_n));
     LB_TRY(gemm_nt(t, BN, TD, TD, t->da, t->w + t->pn[k].w0, t->dn, TD, 1.f));
     LB_TRY(gemm_nt(t, BN, TD, TD, t->da, t->w + t->pn[k].w0 + (size_t)TD * TD, t->dagg, TD));
     LB_TRY(edge_bwd(t, t->pe[k], E, BN, t->nlat[k], t->elat[k], t->ae[k], t->ze[k], t->dagg, t->de, t->dn));
   }
-  LB_TRY(mlp_bwd(t, t->enc_edge, E, e->efeat, 8, t->a_ee, t->z_ee, t->de, nullptr));
-  LB_TRY(mlp_bwd(t, t->enc_node, BN, t->xnode, t->kpad, t->a_en, t->z_en, t->dn, has_emb ? t->dx : nullptr));
+  LB_TRY(mlp_bwd(t, t->enc_edge, E, e->efeat, 8, t->a_ee, t->z_ee, t->de, nullptr, t->hs_e));
+  LB_TRY(mlp_bwd(t, t->enc_node, BN, t->xnode, t->kpad, t->a_en, t->z_en, t->dn, has_emb ? t->dx : nullptr, t->hs_n));
   if (has_emb)
     hipLaunchKernelGGL(k_embed_grad, dim3(t->desc.num_particle_types), dim3(1024), 0, s, t->dx, t->kpad, t->desc.node_in, emb,
                        e->ptype, t->desc.num_particle_types, BN, t->g + t->off_embed, t->dw_flag);

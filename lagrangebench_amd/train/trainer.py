@@ -17,7 +17,7 @@ block's scale; gradients within 1e-4 per leaf of float64 autograd), with a range
 activation operand that repeats a step on the exact-fp32 MFMA kernels; ``LB_TRAIN_MATH=f32`` in the environment when the
 handle is created selects the exact kernels throughout (1.7x slower).
 torch is used for the noise / sampling random streams and as the tensor container only.  Trainable: GNS (latent <= 128,
-two Linears per MLP) and, since round 5, SEGNN (lmax 1, hidden <= 32x0e+32x1o: ``lb_segnn_train_loss_grad``,
+two to eight Linears per MLP) and, since round 5, SEGNN (lmax 1, hidden <= 32x0e+32x1o: ``lb_segnn_train_loss_grad``,
 csrc/lb_train_segnn.h - the loop below is the reference's model-agnostic one); wandb logging is not wired (stdout).
 """
 from __future__ import annotations
@@ -62,11 +62,11 @@ class _ShuffledLoader:
 class Trainer:
     def __init__(self, model: GNS, case, data_train, data_valid, cfg_train=None, cfg_eval=None, cfg_logging=None,
                  input_seq_length: int = defaults.model.input_seq_length, seed: int = defaults.seed):
-        if isinstance(model, GNS) and (not 4 <= model._latent_size <= 128 or model._blocks_per_step != 2):
+        if isinstance(model, GNS) and (not 4 <= model._latent_size <= 128 or not 2 <= model._blocks_per_step <= 8):
             # fail HERE, before datasets and neighbor lists are set up (csrc/lb_train.hip: the training step runs on
-            # 128-wide rows - narrower latents are zero-padded - and two Linears per MLP)
+            # 128-wide rows - narrower latents are zero-padded - with two to eight Linears per MLP)
             raise NotImplementedError(
-                f"training is built for GNS with latent_size <= 128 and num_mlp_layers 2 (got latent_size "
+                f"training is built for GNS with latent_size <= 128 and 2 <= num_mlp_layers <= 8 (got latent_size "
                 f"{model._latent_size}, num_mlp_layers {model._blocks_per_step}); inference runs every size")
         if getattr(model, "generic", False):
             raise NotImplementedError("training is built for SEGNN in the shipped configuration (scalar_units 64, lmax_hidden = "

@@ -39,7 +39,7 @@ def feature_widths(ds, isl=None):
     return node_in, dim + 1
 
 
-def make_params(ds, num_mp_steps=10, seed=1234, decoder_scale=0.01, random_affine=True, latent_size=128):
+def make_params(ds, num_mp_steps=10, seed=1234, decoder_scale=0.01, random_affine=True, latent_size=128, blocks_per_step=2):
     """Haiku-default weights from default_rng(seed); decoder output layer scaled so a random
     net does not blow the neighbor count up.  random_affine additionally randomises biases and
     LayerNorm scale/offset so those code paths are exercised (defaults are 0 / 1 / 0)."""
@@ -47,13 +47,13 @@ def make_params(ds, num_mp_steps=10, seed=1234, decoder_scale=0.01, random_affin
     dim = len(ds.box)
     rng = np.random.default_rng(seed)
     p = O.gns_init(rng, node_in=node_in, edge_in=edge_in, particle_dimension=dim, latent_size=latent_size,
-                   num_mp_steps=num_mp_steps, decoder_scale=decoder_scale)
+                   blocks_per_step=blocks_per_step, num_mp_steps=num_mp_steps, decoder_scale=decoder_scale)
     if random_affine:
         r2 = np.random.default_rng(seed + 1)
         for k, v in p.items():
             if "b" in v:
                 v["b"] = (0.1 * r2.standard_normal(v["b"].shape)).astype(np.float32)
-                if k == "decoder/linear_1":
+                if k == f"decoder/linear_{blocks_per_step - 1}":
                     v["b"] *= np.float32(decoder_scale)
             if "scale" in v:
                 v["scale"] = (1.0 + 0.2 * r2.standard_normal(v["scale"].shape)).astype(np.float32)

@@ -151,15 +151,17 @@ def test_torch_forward_on_engine_graph_equals_hip_forward():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,scale,L,B,latent", [("small2d", 1.0, 3, 2, 128), ("small3d", 1.0, 2, 1, 128),
-                                                   ("tgv2d", 0.6, 10, 2, 128), ("ldc3d", 0.4, 2, 2, 128),
-                                                   ("small2d", 1.0, 5, 2, 64), ("small3d", 1.0, 2, 2, 40)])
-def test_hip_gradients_match_torch_autograd(name, scale, L, B, latent):
+@pytest.mark.parametrize("name,scale,L,B,latent,depth", [("small2d", 1.0, 3, 2, 128, 2), ("small3d", 1.0, 2, 1, 128, 2),
+                                                         ("tgv2d", 0.6, 10, 2, 128, 2), ("ldc3d", 0.4, 2, 2, 128, 2),
+                                                         ("small2d", 1.0, 5, 2, 64, 2), ("small3d", 1.0, 2, 2, 40, 2),
+                                                         ("small3d", 1.0, 2, 2, 128, 3), ("small2d", 1.0, 3, 2, 48, 4)])
+def test_hip_gradients_match_torch_autograd(name, scale, L, B, latent, depth):
     """the hand-written backward (csrc/lb_train.hip: lb_gns_train_loss_grad) against torch
     autograd of the checker network (oracle/gns_torch.py, itself checked against the oracle and finite differences
     above) on engine-built graphs: loss and every parameter gradient of _mse (trainer.py:35-60), gradients summed and
     loss averaged over the batch (trainer.py:63-89), within 1e-4 relative per leaf; then one AdamW step against
-    torch.optim.AdamW."""
+    torch.optim.AdamW.  depth = num_mlp_layers (Linears per MLP, models/utils.py:100-115): 2 in every shipped config; 3 and 4
+    exercise the middle Linears of the training step (round 6)."""
     from lagrangebench_amd.data import make_case
     from lagrangebench_amd.models import GNS
     from oracle.gns_torch import gns_apply_torch, gns_inputs_from_features, params_to_torch
@@ -171,8 +173,8 @@ def test_hip_gradients_match_torch_autograd(name, scale, L, B, latent):
     pos = np.stack([ds[b][0] for b in range(B)])
     pt = np.stack([ds[b][1] for b in range(B)])
     # latent < 128 (round 4: GNS-5-64 of the reference's baselines): the device step runs 128-wide with zero padding
-    params = make_params(ds, num_mp_steps=L, decoder_scale=1.0, latent_size=latent)
-    model = GNS(dim, latent, 2, L, 16)
+    params = make_params(ds, num_mp_steps=L, decoder_scale=1.0, latent_size=latent, blocks_per_step=depth)
+    model = GNS(dim, latent, depth, L, 16)
     feats, _ = hcase.allocate_eval((pos[:, :, :isl], pt))
     eng = feats.engine
     target = torch.randn((B, pos.shape[1], dim), generator=torch.Generator().manual_seed(5))
@@ -199,7 +201,7 @@ def test_hip_gradients_match_torch_autograd(name, scale, L, B, latent):
     losses = []
     for b in range(B):
         node, edge, snd, rcv, ptt = gns_inputs_from_features(feats, torch.as_tensor(pt), b)
-        pred = gns_apply_torch(pt_t, node.double(), edge.double(), snd, rcv, ptt, L)
+        pred = gns_apply_torch(pt_t, node.double(), edge.double(), snd, rcv, ptt, L, depth)
         assert float((pred.detach() - pred_h[b]).abs().max() / pred.detach().abs().max()) < 1e-5
         nk = ~get_kinematic_mask(ptt)
         tot = ((pred - target[b].to(dev)) ** 2).sum(dim=-1)
