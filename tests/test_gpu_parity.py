@@ -224,6 +224,84 @@ def test_single_trajectory_update_path_bitexact(name, scale):
     assert int(eng.nl_flags()[0]) == 1
 
 
+def _batched_update_check(ds, B, pos, pt, shifts=(1, 2)):
+    """Edge lists, counts and edge features of the batched UPDATE path against the oracle's preprocess_eval, bit for bit."""
+    ocase, hcase = oracle_case(ds), hip_case(ds)
+    isl = ds.input_seq_length
+    N = pos.shape[1]
+    _, nbrs = hcase.allocate_eval((pos[:, :, :isl], pt))
+    ons = [ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))[1] for b in range(B)]
+    for b in range(B):   # the allocation itself (count + fill sweeps)
+        want = O.canonical_edges(ons[b].idx, N)
+        assert int(_np(nbrs.n_edges)[b]) == want.shape[1] and (_np(nbrs.idx)[b][:, :want.shape[1]] == want).all(), ("allocate", b)
+    for shift in shifts:
+        feats, nbrs = hcase.preprocess_eval((pos[:, :, shift:shift + isl], pt), nbrs)
+        assert not bool(nbrs.did_buffer_overflow.any())
+        idx_all, ne_all = _np(nbrs.idx), _np(nbrs.n_edges)
+        rd, rdist = _np(feats["rel_disp"]), _np(feats["rel_dist"])
+        for b in range(B):
+            of, ons[b] = ocase.preprocess_eval((pos[b][:, shift:shift + isl].astype(np.float64), pt[b]), ons[b])
+            assert not bool(ons[b].did_buffer_overflow)
+            want = O.canonical_edges(ons[b].idx, N)
+            ne = want.shape[1]
+            assert int(ne_all[b]) == ne and (idx_all[b][:, :ne] == want).all(), f"b={b} shift={shift}"
+            real = ons[b].idx[0] < N
+            order = np.lexsort((ons[b].idx[1][real], ons[b].idx[0][real]))
+            assert np.array_equal(rd[b][:ne], of["rel_disp"][real][order])
+            assert np.array_equal(rdist[b][:ne], of["rel_dist"][real][order])
+    return hcase
+
+
+@pytest.mark.parametrize("name,scale,B", [("tgv3d", 0.6, 3), ("ldc3d", 0.5, 3)])
+def test_batched_update_path_3d_wave_per_cell_bitexact(name, scale, B):
+    """Round 6: batches with 3^3-cell stencils run the wave-per-cell search (k_nlc: float pre-filter in front of the fp64
+    predicate, hits of all a cell's receivers emitted together).  Allocation (count + fill modes) and update (per-node rows
+    + compaction) against the oracle, bit for bit: periodic (TGV3D) and walled (LDC3D) boxes."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    ds = make_case(name, n_trajs=B, extra_seq_length=3, scale=scale)
+    pos = np.stack([ds[b][0] for b in range(B)])
+    pt = np.stack([ds[b][1] for b in range(B)])
+    _batched_update_check(ds, B, pos, pt)
+
+
+@pytest.mark.parametrize("kind", ["clumped", "on_the_cutoff"])
+def test_wave_per_cell_search_hard_cases_bitexact(kind):
+    """k_nlc's two slow paths.  `clumped`: a sub-cube compressed by 2 (8x the density: ~30 particles per cell, ~800 stencil
+    candidates, ~110 neighbours - below the 256 of the dense fall-back) sends cells through the chunked sweep (more than 256
+    candidates do not stay in registers) with the exact predicate.  `on_the_cutoff`: 200 pairs placed at (1 + d) r_c for
+    d = 0, +-1e-16 .. +-1e-5 - inside the band where the float pre-filter must not decide - take the exact fp64 re-evaluation;
+    whether such a pair is an edge is the reference's fp64 arithmetic's call, and the engine must make the same one."""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    B = 2
+    ds = make_case("tgv3d", n_trajs=B, extra_seq_length=3, scale=0.6)
+    pos = np.stack([ds[b][0] for b in range(B)]).copy()
+    pt = np.stack([ds[b][1] for b in range(B)])
+    box = np.asarray(ds.box, np.float64)
+    rc = float(ds.metadata["default_connectivity_radius"])
+    rng = np.random.default_rng(11)
+    N = pos.shape[1]
+    if kind == "clumped":
+        c = 0.5 * box
+        for b in range(B):
+            inside = np.all(np.abs(pos[b][:, 0] - c) < 0.3 * box, axis=-1)
+            pos[b][inside] = c + 0.5 * (pos[b][inside] - c)    # every frame alike: the velocities shrink with the positions
+    else:
+        ds_ = [0.0] + [sgn * 10.0 ** e for e in (-16, -13, -10, -8, -7, -6, -5) for sgn in (1, -1)]
+        for b in range(B):
+            src = rng.choice(N // 2, 200, replace=False) * 2
+            for q, i in enumerate(src):
+                u = rng.standard_normal(3)
+                u /= np.linalg.norm(u)
+                off = rc * (1.0 + ds_[q % len(ds_)]) * u
+                pos[b][i + 1] = np.mod(pos[b][i] + off, box)   # same offset in every frame
+    hcase = _batched_update_check(ds, B, pos, pt)
+    if kind == "clumped":
+        st = hcase.engine(B).stats()
+        assert st["n_edges_total"] / (B * N) > 20, st
+
+
 @pytest.mark.parametrize("name,scale,B", [("tgv2d", 1.0, 3), ("dam2d", 1.0, 2), ("rpf2d", 1.0, 4)])
 def test_batched_update_path_bitexact(name, scale, B):
     """Batches of mid-size trajectories (more than 4096 particles in total, at most 6144 each): the UPDATE path bins every
