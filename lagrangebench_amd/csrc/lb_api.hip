@@ -225,6 +225,7 @@ extern "C" int lb_engine_create(const lb_case_desc* d, void* hip_stream, lb_engi
   A(lb_alloc(&e->row_ptr, (size_t)BN + 1));
   A(lb_alloc(&e->scan_part, (size_t)((BN > (int64_t)nc ? BN : (int64_t)nc) / 2048 + 2)));
   A(lb_alloc(&e->cpos, (size_t)d->dim * BN));
+  e->cell_slots = BN;
   A(lb_alloc(&e->overflow, (size_t)g.B));
   A(lb_alloc(&e->nedges_b, (size_t)g.B));
   A(lb_alloc(&e->acc, (size_t)BN * 4));

@@ -156,7 +156,9 @@ struct lb_engine {
   unsigned long long* nl_wg_sum = nullptr;  // [BN / 8 + 2] k_nl_small: epoch-tagged words of the workgroups
   int32_t* row_ptr;    // [BN+1]
   int32_t* scan_part;  // partial sums of the two-level scans
-  double* cpos;        // [dim][BN] newest-frame positions in cell-sorted order
+  double* cpos;        // [dim][cell_slots] newest-frame positions in cell-sorted order (CSR: BN slots; fixed-stride: cells * cap)
+  int64_t cell_slots = 0;      // slots allocated for cell_part / cpos (>= BN)
+  bool cells_strided = false;  // this build binned into fixed-stride slots (lb_neighbor.hip: k_cell_bin)
   bool nl_dense = false;  // sticky: the density exceeded the staged kernel's limits once -> wave-per-receiver kernel
   int32_t row_cap = 0;    // its LDS row buffer (entries per wave), sized from the largest degree seen
   int32_t maxd;        // per-node slot count of the single-sweep update path (0 = not sized)

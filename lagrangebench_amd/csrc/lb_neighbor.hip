@@ -152,6 +152,54 @@ __global__ void k_cell_fill(lb_geom g, int64_t BN, const double* __restrict__ wi
   for (int d = 0; d < g.dim; ++d) cpos[(int64_t)d * BN + slot] = lb_pos(win, g, BN, step, g.isl - 1, d, gi);
 }
 
+// Frozen update path, fixed-stride cells (round 6): cell c owns the slots [c * cap, (c + 1) * cap) of cell_part / cpos - jax-md's
+// own layout.  Binning is two launches (zero the counters + the per-build maxima; one returning atomic per particle) instead
+// of five (memset, count, two scan passes, fill).  A cell that receives more than `cap` particles drops the surplus and raises
+// max_cell_occ above the capacity: did_buffer_overflow, the caller re-allocates (the CSR path keeps them and flags the same).
+__global__ void k_cell_zero(lb_ctrl* __restrict__ ctrl, int32_t* __restrict__ cell_count, int n) {
+  if (ctrl->overflow_step >= 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {   // per-build maxima: only kernels launched AFTER this one write them
+    ctrl->max_cell_occ = 0;
+    ctrl->max_deg = 0;
+    ctrl->row_overflow = 0;
+  }
+  if (i < n) cell_count[i] = 0;
+}
+__global__ void __launch_bounds__(256) k_cell_bin(lb_geom g, int64_t BN, const double* __restrict__ win,
+                                                  lb_ctrl* __restrict__ ctrl, int32_t* __restrict__ cell_of,
+                                                  int32_t* __restrict__ cell_count, int32_t* __restrict__ cell_part,
+                                                  double* __restrict__ cpos, int32_t cap, int64_t cstride) {
+  if (ctrl->overflow_step >= 0) return;
+  const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int step = ctrl->step;
+  int occ = 0;
+  if (gi < BN) {
+    const int b = (int)(gi / g.N);
+    int h = 0, mult = 1;
+    double p[3] = {0, 0, 0};
+    for (int d = 0; d < g.dim; ++d) {
+      p[d] = lb_pos(win, g, BN, step, g.isl - 1, d, gi);
+      int c = __double2int_rz(lb_r(p[d] / g.cell_size[d], g.f32));  // jnp.array(position / cell_size, dtype=i32)
+      c = c < 0 ? 0 : (c >= g.ncell[d] ? g.ncell[d] - 1 : c);
+      h += c * mult;
+      mult *= g.ncell[d];
+    }
+    const int gc = b * g.ncells + h;
+    cell_of[gi] = gc;
+    const int slot = atomicAdd(&cell_count[gc], 1);
+    occ = slot + 1;
+    if (slot < cap) {
+      const int64_t idx = (int64_t)gc * cap + slot;
+      cell_part[idx] = (int32_t)gi;
+      for (int d = 0; d < g.dim; ++d) cpos[(int64_t)d * cstride + idx] = p[d];
+    }
+  }
+  // largest occupancy: wave maximum, one atomic per wave
+  for (int o = 32; o > 0; o >>= 1) occ = max(occ, __shfl_xor(occ, o));
+  if ((threadIdx.x & 63) == 0 && occ > 0) atomicMax(&ctrl->max_cell_occ, occ);
+}
+
 // Small problems (<= LB_SMALL_N = 4096 particles and cells in the whole batch; measured: TGV2D-2.5k 0.423 -> 0.415,
 // RPF2D-3.2k 0.532 -> 0.517 ms per step, but slower than the multi-launch path from ~8 k particles): cell binning in ONE single-workgroup
 // launch instead of memset + count + two scan passes + fill (each ~4-5 us of launch floor on a 2.5 k-particle
@@ -421,7 +469,13 @@ struct lb_nl_args {
   const int32_t* cell_of;   // [BN] global cell id of each particle
   const int32_t* cell_start;
   const int32_t* cell_part;
-  const double* cpos;       // [dim][BN] positions in cell-sorted order
+  const double* cpos;       // [dim][cstride] positions in cell-sorted order
+  // cell ranges: CSR (cell_cap 0: [cell_start[c], cell_start[c + 1]), cstride = BN) or, on the frozen update path (round 6),
+  // FIXED-STRIDE slots (cell c owns slots [c * cell_cap, c * cell_cap + min(cell_cnt[c], cell_cap)), cstride = cells * cap:
+  // jax-md's own layout; binning is one atomic per particle, no scan)
+  const int32_t* cell_cnt;
+  int32_t cell_cap;
+  int64_t cstride;
   int32_t* deg;             // [BN]
   const int32_t* row_ptr;   // NL_FILL
   int32_t* senders;         // NL_FILL: CSR arrays; NL_ROWS: per-node slots [BN][maxd]
@@ -436,6 +490,10 @@ struct lb_nl_args {
   int32_t nb_search;        // k_nl: workgroups of the search proper; the ones behind them write feature rows (0: none)
 };
 #define NL_FEAT_ROWS 8      // feature rows per wave of a k_nl feature workgroup
+__device__ __forceinline__ int lb_cell_begin(const lb_nl_args& a, int gc) { return a.cell_cap ? gc * a.cell_cap : a.cell_start[gc]; }
+__device__ __forceinline__ int lb_cell_size(const lb_nl_args& a, int gc, int begin) {
+  return a.cell_cap ? min(a.cell_cnt[gc], a.cell_cap) : a.cell_start[gc + 1] - begin;
+}
 
 template <int MODE, int NL_THREADS, int MAXC, bool F32 = false>
 __global__ void __launch_bounds__(NL_THREADS)
@@ -459,8 +517,8 @@ __global__ void __launch_bounds__(NL_THREADS)
   const int tid = threadIdx.x;
   const int gc = blockIdx.x;
   const int b = gc / g.ncells, h = gc % g.ncells;
-  const int own_start = a.cell_start[gc];
-  const int own_cnt = a.cell_start[gc + 1] - own_start;
+  const int own_start = lb_cell_begin(a, gc);
+  const int own_cnt = lb_cell_size(a, gc, own_start);
   if (own_cnt == 0) return;
 
   // stencil cells: start + count, exclusive prefix of the counts with a wave scan
@@ -481,9 +539,9 @@ __global__ void __launch_bounds__(NL_THREADS)
         }
       }
       const int ngc = b * g.ncells + nh;
-      const int st = a.cell_start[ngc];
+      const int st = lb_cell_begin(a, ngc);
       s_cstart[tid] = st;
-      cnt = a.cell_start[ngc + 1] - st;
+      cnt = lb_cell_size(a, ngc, st);
     }
     int incl = cnt;
 #pragma unroll
@@ -516,7 +574,7 @@ __global__ void __launch_bounds__(NL_THREADS)
     }
     const int src = s_cstart[lo] + (j - s_coff[lo]);
     s_id[j] = a.cell_part[src];
-    for (int d = 0; d < g.dim; ++d) s_p[d][j] = a.cpos[(int64_t)d * BN + src];
+    for (int d = 0; d < g.dim; ++d) s_p[d][j] = a.cpos[(int64_t)d * a.cstride + src];
   }
   __syncthreads();
 
@@ -672,9 +730,9 @@ __global__ void __launch_bounds__(64 * NLW_WAVES)
         }
       }
       const int ngc = b * g.ncells + nh;
-      const int st = a.cell_start[ngc];
+      const int st = lb_cell_begin(a, ngc);
       s_cstart[wave][lane] = st;
-      cnt = a.cell_start[ngc + 1] - st;
+      cnt = lb_cell_size(a, ngc, st);
     }
     int incl = cnt;
 #pragma unroll
@@ -688,7 +746,7 @@ __global__ void __launch_bounds__(64 * NLW_WAVES)
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   const int M = s_coff[wave][g.nstencil];
   double pr[3] = {0, 0, 0};
-  for (int d = 0; d < g.dim; ++d) pr[d] = a.cpos[(int64_t)d * BN + r];
+  for (int d = 0; d < g.dim; ++d) pr[d] = a.cpos[(int64_t)d * a.cstride + r];
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   auto slot_of = [&](int j) -> int {  // candidate j -> slot in the cell-sorted arrays
     int lo = 0, hi = g.nstencil;      // largest k with s_coff[k] <= j
@@ -709,7 +767,7 @@ __global__ void __launch_bounds__(64 * NLW_WAVES)
       double dd = lb_disp1(a.cpos[src], pr[0], g.box[0], g.half_box[0], g.periodic, F32);
       double d2 = lb_r(dd * dd, F32);
       for (int d = 1; d < g.dim; ++d) {
-        dd = lb_disp1(a.cpos[(int64_t)d * BN + src], pr[d], g.box[d], g.half_box[d], g.periodic, F32);
+        dd = lb_disp1(a.cpos[(int64_t)d * a.cstride + src], pr[d], g.box[d], g.half_box[d], g.periodic, F32);
         d2 = lb_r(d2 + lb_r(dd * dd, F32), F32);
       }
       ok = d2 < g.rc2;  // strict <
@@ -765,7 +823,7 @@ __global__ void __launch_bounds__(64 * NLW_WAVES)
       double rd[3] = {0, 0, 0};
       double s2 = 0.0;
       for (int d = 0; d < g.dim; ++d) {
-        rd[d] = lb_r(lb_disp1(pr[d], a.cpos[(int64_t)d * BN + src], g.box[d], g.half_box[d], g.periodic, F32) / g.rc, F32);
+        rd[d] = lb_r(lb_disp1(pr[d], a.cpos[(int64_t)d * a.cstride + src], g.box[d], g.half_box[d], g.periodic, F32) / g.rc, F32);
         s2 = (d == 0) ? lb_r(rd[d] * rd[d], F32) : lb_r(s2 + lb_r(rd[d] * rd[d], F32), F32);
       }
       const double dist = s2 > 0.0 ? lb_r(sqrt(s2), F32) : 0.0;
@@ -822,8 +880,8 @@ __global__ void __launch_bounds__(64 * NLC_WAVES, 5)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int gc = __builtin_amdgcn_readfirstlane((int)blockIdx.x * NLC_WAVES + wave);
   if (gc >= g.B * g.ncells) return;
-  const int own_start = a.cell_start[gc];
-  const int own_cnt = a.cell_start[gc + 1] - own_start;
+  const int own_start = lb_cell_begin(a, gc);
+  const int own_cnt = lb_cell_size(a, gc, own_start);
   if (own_cnt <= 0) return;
   int* const s_cstart = s_cstart_[wave];
   int* const s_coff = s_coff_[wave];
@@ -849,9 +907,9 @@ __global__ void __launch_bounds__(64 * NLC_WAVES, 5)
         }
       }
       const int ngc = b * g.ncells + nh;
-      const int st = a.cell_start[ngc];
+      const int st = lb_cell_begin(a, ngc);
       s_cstart[lane] = st;
-      cnt = a.cell_start[ngc + 1] - st;
+      cnt = lb_cell_size(a, ngc, st);
     }
     int incl = cnt;
 #pragma unroll
@@ -898,8 +956,8 @@ __global__ void __launch_bounds__(64 * NLC_WAVES, 5)
       double pr[DIM], sp[DIM];
 #pragma unroll
       for (int d = 0; d < DIM; ++d) {
-        pr[d] = a.cpos[(int64_t)d * BN + rslot];
-        sp[d] = a.cpos[(int64_t)d * BN + src];
+        pr[d] = a.cpos[(int64_t)d * a.cstride + rslot];
+        sp[d] = a.cpos[(int64_t)d * a.cstride + src];
       }
       if (!act) continue;
       const int64_t base = (MODE == NL_ROWS) ? (int64_t)gr * a.maxd : (int64_t)a.row_ptr[gr];
@@ -957,12 +1015,12 @@ __global__ void __launch_bounds__(64 * NLC_WAVES, 5)
     bool bad = false;
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
-      const double org = a.cpos[(int64_t)d * BN + own_start];
+      const double org = a.cpos[(int64_t)d * a.cstride + own_start];
       float lim = 8.f * (float)g.rc;
       if (g.periodic) lim = fminf(lim, 0.5f * (float)(g.box[d] - 1.001 * g.rc));
       _Pragma("unroll") for (int s = 0; s < NLC_S; ++s) {
         if (64 * s >= M) continue;
-        q[s][d] = (float)lb_disp1(a.cpos[(int64_t)d * BN + cj[s]], org, g.box[d], g.half_box[d], g.periodic, 0);
+        q[s][d] = (float)lb_disp1(a.cpos[(int64_t)d * a.cstride + cj[s]], org, g.box[d], g.half_box[d], g.periodic, 0);
         bad = bad || !(fabsf(q[s][d]) <= lim);
       }
     }
@@ -1014,7 +1072,7 @@ __global__ void __launch_bounds__(64 * NLC_WAVES, 5)
       if (exact) {
         double pr[DIM];
 #pragma unroll
-        for (int d = 0; d < DIM; ++d) pr[d] = a.cpos[(int64_t)d * BN + own_start + k];
+        for (int d = 0; d < DIM; ++d) pr[d] = a.cpos[(int64_t)d * a.cstride + own_start + k];
 #pragma unroll
         for (int s = 0; s < NLC_S; ++s) {
           if (c0 + 64 * s >= M) continue;
@@ -1022,7 +1080,7 @@ __global__ void __launch_bounds__(64 * NLC_WAVES, 5)
           double dd = lb_disp1(a.cpos[cj[s]], pr[0], g.box[0], g.half_box[0], g.periodic, F32);
           double d2 = lb_r(dd * dd, F32);
           _Pragma("unroll") for (int d = 1; d < DIM; ++d) {
-            dd = lb_disp1(a.cpos[(int64_t)d * BN + cj[s]], pr[d], g.box[d], g.half_box[d], g.periodic, F32);
+            dd = lb_disp1(a.cpos[(int64_t)d * a.cstride + cj[s]], pr[d], g.box[d], g.half_box[d], g.periodic, F32);
             d2 = lb_r(d2 + lb_r(dd * dd, F32), F32);
           }
           ok[s] = (c0 + 64 * s + lane < M) && (d2 < g.rc2);  // strict <
@@ -1857,21 +1915,26 @@ __global__ void __launch_bounds__(64 * NLM_WAVES) k_nl_mid(lb_geom g, lb_ctrl* _
 // NL_SMALL_MAXC), or 0 for the 256-thread / 2048-candidate variant.  The LDS footprint of the
 // staged stencil (28 B per candidate) sets how many cells a CU keeps in flight - the search is
 // latency bound, so the smallest variant that holds cell_capacity * 3^dim candidates is used.
+// which search kernel a build uses: 0 = k_nl (workgroup per cell, staged stencil), 1 = k_nlw (wave per receiver), 2 = k_nlc
+// (wave per cell).  Measured (MI355X, B = 8): 3^3-cell stencils favour the per-wave kernels (TGV3D 0.28 -> 0.18 -> 0.12 ms per
+// step), 3^2-cell stencils the staged per-cell kernel (DAM2D 0.11 vs 0.15 ms).  LB_NL_KERNEL=cell|wave|nlc overrides.
+static int lb_nl_kernel_kind(const lb_engine* e) {
+  static const char* force = getenv("LB_NL_KERNEL");
+  // dense fall-back (e->nl_dense, sticky): the staged per-cell kernel is bounded by LB_MAX_STENCIL_CAND candidates and
+  // LB_MAX_ROW neighbors; beyond that the wave-per-receiver kernel with a row buffer sized from the largest degree runs
+  // (the reference re-allocates for ANY occupancy, rollout.py:134-151)
+  const bool per_wave = e->nl_dense || e->g.f32 || (force ? force[0] == 'w' : e->g.nstencil == 27);
+  const bool cell_wave = e->g.use_cell_list && !e->nl_dense && (e->g.dim == 2 || e->g.dim == 3) && (force ? force[0] == 'n' : per_wave);
+  return cell_wave ? 2 : (per_wave ? 1 : 0);
+}
 template <int MODE>
 static void lb_launch_nl(lb_engine* e, int small, const lb_nl_args& a) {
-  // measured (MI355X, B = 8): 3^3-cell stencils favour the wave-per-receiver kernel (TGV3D 0.28 ->
-  // 0.18 ms per step), 3^2-cell stencils the staged per-cell kernel (DAM2D 0.11 vs 0.15 ms)
-  static const char* force = getenv("LB_NL_KERNEL");  // "cell" | "wave": ablation override
-  // dense fall-back (e->nl_dense, sticky): the staged per-cell kernel is bounded by LB_MAX_STENCIL_CAND candidates
-  // and LB_MAX_ROW neighbors; beyond that the wave-per-receiver kernel with a row buffer sized from the largest
-  // degree runs (the reference re-allocates for ANY occupancy, rollout.py:134-151)
-  const bool per_wave = e->nl_dense || e->g.f32 || (force ? force[0] == 'w' : e->g.nstencil == 27);
+  const int kind = lb_nl_kernel_kind(e);
+  const bool per_wave = kind == 1;
   // NL_ROWS in a rollout step: every search wave also writes the node-feature row of its receiver
   const bool ride = MODE == NL_ROWS && e->feat_job.xnode && !a.efeat64;
   if (ride) e->feat_done = true;
-  // round 6: one wave per CELL (k_nlc) wherever the wave-per-receiver kernel ran on a cell list that is not dense;
-  // LB_NL_KERNEL=wave keeps k_nlw, =nlc sends the 3^2-cell stencils to k_nlc as well
-  const bool cell_wave = e->g.use_cell_list && !e->nl_dense && (e->g.dim == 2 || e->g.dim == 3) && (force ? force[0] == 'n' : per_wave);
+  const bool cell_wave = kind == 2;   // round 6: one wave per CELL
   if (cell_wave) {
     const int ncell_all = e->g.B * e->g.ncells;
     const int nb_s = (ncell_all + NLC_WAVES - 1) / NLC_WAVES;
@@ -2093,7 +2156,31 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   // one workgroup per trajectory is bound by its scattered stores from ONE CU; above 6 k particles the five launches stay)
   const bool traj_cells = cells_traj_ok && frozen && !small_cells && g.B > 1 && g.use_cell_list && g.N <= 6144 &&
                           g.ncells <= LB_CELLS1_NCELL;
-  if (small_cells) {
+  // frozen capacities + a search kernel that walks CELLS: fixed-stride slots, two launches (k_cell_zero, k_cell_bin)
+  const int64_t strided_slots = (int64_t)ncell_tot * e->cell_capacity;
+#ifdef LB_NO_STRIDED   // (A/B builds: tools/build_variant.sh csr -DLB_NO_STRIDED)
+  const bool strided = false;
+#else
+  const bool strided = small_ok && frozen && g.use_cell_list && e->cell_capacity > 0 && lb_nl_kernel_kind(e) != 1 &&
+                       strided_slots < ((int64_t)1 << 30);
+#endif
+  e->cells_strided = strided;
+  if (strided) {
+    if (strided_slots > e->cell_slots) {   // (first build after an allocation: never inside a graph capture)
+      LB_HIP(hipStreamSynchronize(s));
+      if (e->cell_part) (void)hipFree(e->cell_part);
+      if (e->cpos) (void)hipFree(e->cpos);
+      e->cell_part = nullptr;
+      e->cpos = nullptr;
+      e->cell_slots = strided_slots + strided_slots / 4;
+      LB_HIP(hipMalloc((void**)&e->cell_part, sizeof(int32_t) * (size_t)e->cell_slots));
+      LB_HIP(hipMalloc((void**)&e->cpos, sizeof(double) * (size_t)g.dim * (size_t)e->cell_slots));
+    }
+    e->cells_traj_ready = false;   // (cell_count is rewritten: k_cells_traj's occupancy slots must be zeroed again after this)
+    hipLaunchKernelGGL(k_cell_zero, dim3((ncell_tot + 255) / 256), dim3(256), 0, s, e->ctrl, e->cell_count, ncell_tot);
+    hipLaunchKernelGGL(k_cell_bin, dim3((unsigned)((BN + 255) / 256)), dim3(256), 0, s, g, BN, e->win, e->ctrl, e->cell_of,
+                       e->cell_count, e->cell_part, e->cpos, e->cell_capacity, strided_slots);
+  } else if (small_cells) {
     hipLaunchKernelGGL((k_cells_small<LB_SMALL_N / LB_SMALL_T>), dim3(1), dim3(LB_SMALL_T), sizeof(int) * (size_t)ncell_tot, s, g,
                        BN, e->win, e->ctrl, e->cell_of, e->cell_start, e->cell_part, e->cpos, ncell_tot);
   } else if (traj_cells) {
@@ -2148,6 +2235,9 @@ int lbk_nl_build(lb_engine* e, bool want_efeat64) {
   a.cell_start = e->cell_start;
   a.cell_part = e->cell_part;
   a.cpos = e->cpos;
+  a.cell_cnt = e->cell_count;
+  a.cell_cap = strided ? e->cell_capacity : 0;
+  a.cstride = strided ? strided_slots : BN;
   a.deg = e->deg;
   a.row_ptr = e->row_ptr;
   a.e_alloc = e->e_alloc;
