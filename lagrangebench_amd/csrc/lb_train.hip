@@ -56,7 +56,7 @@ struct lb_red_ent {
   int64_t stride;   // floats between the partials of consecutive g
   int64_t dst0, dst1;  // float offsets into the gradient blob (dst1 unused when n1 == 0)
   int G, n0, n1, off1;
-  int blk0, pad;    // first block of this reduction in the flat grid (64 outputs per block)
+  int blk0, pad;    // first block of this reduction in the flat grid (RED_OUT = 256 outputs per block)
 };
 
 // LB_TRAIN_MATH=f32: the exact-fp32 product kernels (k_lin32f); default: f16x2 (k_lin32h)
@@ -491,14 +491,19 @@ __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, 
   }
 }
 // Ordered sum of partials: out e < n0: dst0[e] += sum_g part[g * stride + e]; n0 <= e < n0 + n1: dst1[e - n0] += sum_g
-// part[g * stride + off1 + e - n0].  A 1024-thread block owns 64 outputs x 16 ranges of g (four loads in flight per thread,
-// added in ascending g), the 16 range sums are combined in range order through LDS: the result does not depend on timing.
+// part[g * stride + off1 + e - n0].  A 1024-thread block owns 256 outputs x 16 ranges of g: a lane owns four consecutive outputs
+// (one 16-byte load per partial, four in flight; the round-5 kernel read 4 bytes per lane and partial - 256-byte
+// requests 66 KB apart, 2.1 TB/s on 350 MB of partials = 165 us of a 2.4 ms TGV2D step), each added in ascending g, the
+// 16 range sums are combined in range order through LDS: the result does not depend on timing (and equals the round-5
+// kernel's bit for bit: the order per output is the same).  A quad that straddles n0 / the end, or whose source is not
+// 16-byte aligned (k_dw_narrow's K x M slots), takes the same sums with scalar loads.
 // Round 5: ONE launch per training step for all reductions (88 of them: every weight / bias / LayerNorm gradient) - each
 // producer writes its partials into a slot of its own and leaves a descriptor; a flat grid, each block finds its descriptor by bisection.  (One
 // launch per producer before: 0.5 ms of a 7 ms TGV3D step, 0.4 ms of a 3.5 ms TGV2D step, mostly launch latency.)
+#define RED_OUT 256   // outputs per block of k_part_reduce (red_push counts its blocks with the same number)
 __global__ void __launch_bounds__(1024) k_part_reduce(const float* __restrict__ part_base, const lb_red_ent* __restrict__ tab,
                                                       int n_ent, float* __restrict__ grad, const int32_t* __restrict__ skip) {
-  __shared__ float s_red[16][64];
+  __shared__ f32x4 s_red[16][64];
   if (skip && *skip) return;   // k_dw_part_h's range guard fired: this step adds nothing, the host repeats it in fp32
   int lo = 0, hi = n_ent - 1;  // the last descriptor with blk0 <= blockIdx.x
   while (lo < hi) {
@@ -508,30 +513,56 @@ __global__ void __launch_bounds__(1024) k_part_reduce(const float* __restrict__ 
   const lb_red_ent d = tab[lo];
   const int bx = (int)blockIdx.x - d.blk0;
   const float* part = part_base + d.part;
-  const int G = d.G, n0 = d.n0;
+  const int G = d.G, n0 = d.n0, n_all = d.n0 + d.n1;
   const int64_t stride = d.stride;
   const int c = threadIdx.x & 63, seg = threadIdx.x >> 6;
-  const int e = bx * 64 + c;
-  const bool ok = e < n0 + d.n1;
-  const int64_t src = e < n0 ? e : (int64_t)d.off1 + (e - n0);
+  const int e0 = bx * RED_OUT + 4 * c;
   const int per = (G + 15) / 16, g0 = seg * per, g1 = g0 + per < G ? g0 + per : G;
-  float s = 0.f;
-  if (ok) {
+  // source of output e0 + j; a quad is "whole" when its four outputs are consecutive floats of one region
+  const bool in0 = e0 + 3 < n0, in1 = e0 >= n0 && e0 + 3 < n_all;
+  const int64_t src0 = e0 < n0 ? e0 : (int64_t)d.off1 + (e0 - n0);
+  const bool vec = (in0 || in1) && ((src0 | stride | d.part) & 3) == 0;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (vec) {
+    const float* p = part + src0;
     int g = g0;
     for (; g + 4 <= g1; g += 4) {
-      const float v0 = part[(int64_t)g * stride + src], v1 = part[(int64_t)(g + 1) * stride + src];
-      const float v2 = part[(int64_t)(g + 2) * stride + src], v3 = part[(int64_t)(g + 3) * stride + src];
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (int64_t)g * stride);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (int64_t)(g + 1) * stride);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (int64_t)(g + 2) * stride);
+      const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (int64_t)(g + 3) * stride);
       s = (((s + v0) + v1) + v2) + v3;
     }
-    for (; g < g1; ++g) s += part[(int64_t)g * stride + src];
+    for (; g < g1; ++g) s = s + *reinterpret_cast<const f32x4*>(p + (int64_t)g * stride);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = e0 + j;
+      if (e >= n_all) continue;
+      const int64_t src = e < n0 ? e : (int64_t)d.off1 + (e - n0);
+      float sj = 0.f;
+      int g = g0;
+      for (; g + 4 <= g1; g += 4) {
+        const float v0 = part[(int64_t)g * stride + src], v1 = part[(int64_t)(g + 1) * stride + src];
+        const float v2 = part[(int64_t)(g + 2) * stride + src], v3 = part[(int64_t)(g + 3) * stride + src];
+        sj = (((sj + v0) + v1) + v2) + v3;
+      }
+      for (; g < g1; ++g) sj += part[(int64_t)g * stride + src];
+      s[j] = sj;
+    }
   }
   s_red[seg][c] = s;
   __syncthreads();
-  if (seg == 0 && ok) {
-    float v = s_red[0][c];
+  if (seg == 0 && e0 < n_all) {
+    f32x4 v = s_red[0][c];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) v += s_red[k][c];
-    if (e < n0) grad[d.dst0 + e] += v; else grad[d.dst1 + (e - n0)] += v;
+    for (int k = 1; k < 16; ++k) v = v + s_red[k][c];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = e0 + j;
+      if (e < n0) grad[d.dst0 + e] += v[j];
+      else if (e < n_all) grad[d.dst1 + (e - n0)] += v[j];
+    }
   }
 }
 // ---- tall-skinny products without the library (round 5): k_pack_w / k_lin32 / k_lin32f of lb_lin32.h
@@ -1023,7 +1054,7 @@ static void red_push(lb_gns_train* t, int64_t part, int G, int64_t stride, int n
   d.dst1 = dst1 ? dst1 - t->g : 0;
   d.blk0 = t->red_blocks;
   t->red_tab.push_back(d);
-  t->red_blocks += (n0 + n1 + 63) / 64;
+  t->red_blocks += (n0 + n1 + RED_OUT - 1) / RED_OUT;
 }
 static int red_flush(lb_gns_train* t) {
   const size_t n = t->red_tab.size();
@@ -1284,7 +1315,7 @@ static int train_ensure(lb_gns_train* t, int64_t BN, int64_t E) {
   LB_TRY(tr_alloc(&t->dwpart, (size_t)t->red_cap));
   if (!t->red_dev) {
     LB_TRY(lb_alloc(&t->red_dev, (size_t)LB_RED_MAX));
-    LB_HIP(hipHostMalloc((void**)&t->red_host, sizeof(lb_red_ent) * LB_RED_MAX));
+    LB_HIP(hipHostMalloc((void**)&t->red_host, sizeof(lb_red_ent) * (LB_RED_MAX + 1)));   // (+ the step's status words)
   }
   LB_TRY(tr_alloc(&t->proj, (size_t)cn * 2 * TD));
   LB_TRY(tr_alloc(&t->node_w, (size_t)cn));
@@ -1533,6 +1564,11 @@ static int segnn_train_loss_grad_once(lb_gns_train* t, const float* target_dev, 
 // [2^-8, 2^15) (bits 1 | 2), or k_sender_transpose an edge without its transpose (bit 4), the reductions have added nothing
 // (k_part_reduce / k_embed_grad read the flag) and the step runs again - with X scaled per chunk from now on, or with
 // the radix sort for this step.
+// the step's loss and guard flag come back through pinned words behind the descriptor table (ONE stream synchronisation per
+// step: round 5 took the loss and the flag with a pageable copy each)
+static_assert(sizeof(lb_red_ent) >= sizeof(double) + sizeof(int32_t), "status words live in one spare descriptor");
+static double* status_loss(lb_gns_train* t) { return reinterpret_cast<double*>(t->red_host + LB_RED_MAX); }
+static int32_t* status_flag(lb_gns_train* t) { return reinterpret_cast<int32_t*>(status_loss(t) + 1); }
 static int train_loss_grad_guarded(lb_gns_train* t, const float* target_dev, float loss_weight, double* loss_out,
                                    float* pred_out_dev) {
   auto once = [&]() {
@@ -1547,9 +1583,9 @@ static int train_loss_grad_guarded(lb_gns_train* t, const float* target_dev, flo
     t->dw_call = 0;
     rc = once();
     if (rc) break;
-    int32_t flag = 0;
-    LB_HIP(hipMemcpyAsync(&flag, t->dw_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    LB_HIP(hipStreamSynchronize(s));
+    LB_HIP(hipMemcpyAsync(status_flag(t), t->dw_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    LB_HIP(hipStreamSynchronize(s));   // (also delivers the loss the attempt left in status_loss)
+    const int32_t flag = *status_flag(t);
     if (!flag) break;
     // the reductions of this attempt added nothing (k_part_reduce / k_embed_grad saw the flag): repeat with what it asks for
     if (attempt == 3) { rc = lb_fail(LB_ERR_STATE, "training: the step's guard flag (%d) does not clear", flag); break; }
@@ -1573,6 +1609,7 @@ static int train_loss_grad_guarded(lb_gns_train* t, const float* target_dev, flo
     }
   }
   t->cub_sort = false;
+  if (!rc && loss_out) *loss_out = *status_loss(t);
   return rc;
 }
 extern "C" int32_t lb_gns_train_math_fallbacks(lb_gns_train* t) { return t ? t->dw_fallbacks : -1; }
@@ -1639,10 +1676,8 @@ static int gns_train_loss_grad_once(lb_gns_train* t, const float* target_dev, fl
                        e->ptype, t->desc.num_particle_types, BN, t->g + t->off_embed, t->dw_flag);
   LB_TRY(red_flush(t));  // every weight / bias / LayerNorm gradient: partials -> gradient blob, one launch
   LB_HIP(hipGetLastError());
-  if (loss_out) {
-    LB_HIP(hipMemcpyAsync(loss_out, t->loss_dev, sizeof(double), hipMemcpyDeviceToHost, s));
-    LB_HIP(hipStreamSynchronize(s));
-  }
+  if (loss_out)   // (train_loss_grad_guarded synchronises and hands it over)
+    LB_HIP(hipMemcpyAsync(status_loss(t), t->loss_dev, sizeof(double), hipMemcpyDeviceToHost, s));
   return LB_OK;
 }
 

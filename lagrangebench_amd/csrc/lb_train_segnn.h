@@ -285,7 +285,7 @@ static int sgt_ensure(lb_gns_train* t, int64_t BN, int64_t E) {
   LB_TRY(tr_alloc(&t->dwpart, (size_t)t->red_cap));
   if (!t->red_dev) {
     LB_TRY(lb_alloc(&t->red_dev, (size_t)LB_RED_MAX));
-    LB_HIP(hipHostMalloc((void**)&t->red_host, sizeof(lb_red_ent) * LB_RED_MAX));
+    LB_HIP(hipHostMalloc((void**)&t->red_host, sizeof(lb_red_ent) * (LB_RED_MAX + 1)));   // (+ the step's status words)
   }
   LB_TRY(tr_alloc(&t->pred, (size_t)cn * 4));
   LB_TRY(tr_alloc(&t->dy, (size_t)cn * 4));
@@ -571,9 +571,7 @@ static int segnn_train_loss_grad_once(lb_gns_train* t, const float* target_dev, 
   if (bi != 0) return lb_fail(LB_ERR_STATE, "segnn training: block bookkeeping");
   LB_TRY(red_flush(t));
   LB_HIP(hipGetLastError());
-  if (loss_out) {
-    LB_HIP(hipMemcpyAsync(loss_out, t->loss_dev, sizeof(double), hipMemcpyDeviceToHost, s));
-    LB_HIP(hipStreamSynchronize(s));
-  }
+  if (loss_out)   // (train_loss_grad_guarded synchronises and hands it over)
+    LB_HIP(hipMemcpyAsync(status_loss(t), t->loss_dev, sizeof(double), hipMemcpyDeviceToHost, s));
   return LB_OK;
 }
