@@ -58,11 +58,16 @@ struct lb_lin_args {
   // k_lin32h: if not null, receives the largest |X| of every 16-row tile (the kernel finds the rows' maxima anyway): the
   // weight-gradient kernel that contracts the same X as its dY operand scales by it instead of scanning X again
   float* tmax;
+  // k_lin32h: floats between the 128-column chunks of an X row (0 = 128: one contiguous row).  The stacked product
+  // dn += [dPs | dPr] [Ws | Wr]^T reads its two chunks from two arrays BN * 128 floats apart.
+  int64_t xcs;
 };
 
 struct lb_pack_ent {    // one operand matrix of k_pack_w
   int64_t src, dst;     // float offsets into the weight blob / the packed blob
   int NR, NO, ldw, trans;  // trans = 0: Wop[k][m] = W[k * ldw + m]; 1: Wop[k][m] = W[m * ldw + k]
+                           // (k_pack_wh only) 2: Wop[k][m] = W[((k >> 7) * NO + m) * ldw + (k & 127)] - the transposes of
+                           // NR / 128 consecutive NO x 128 row blocks stacked along k
   int NJ, NOB;
 };
 
@@ -364,7 +369,8 @@ __global__ void __launch_bounds__(256) k_pack_wh(const float* __restrict__ w, fl
   // the matrix' largest magnitude (every block of the entry computes it for itself: <= 49 k elements)
   float m = 0.f;
   {   // in memory order (the maximum does not care which way the matrix is read): rows of ldw floats, `cols` used
-    const int rows_m = e.trans ? e.NO : e.NR, cols = e.trans ? e.NR : e.NO;
+    const int rows_m = e.trans == 2 ? (e.NR >> 7) * e.NO : (e.trans ? e.NO : e.NR);
+    const int cols = e.trans == 2 ? 128 : (e.trans ? e.NR : e.NO);
     const int tpr = cols >= 256 ? 256 : (cols >= 128 ? 128 : (cols >= 64 ? 64 : 32)), rpi = 256 / tpr;
     const int c0 = threadIdx.x % tpr, r0 = threadIdx.x / tpr;
     for (int c = c0; c < cols; c += tpr) {
@@ -397,7 +403,9 @@ __global__ void __launch_bounds__(256) k_pack_wh(const float* __restrict__ w, fl
     const int mb = q % e.NOB, p = q / e.NOB, g = ln >> 4;
     const int k = 32 * p + (i < 4 ? 4 * g + i : 16 + 4 * g + (i - 4)), c = 16 * mb + (ln & 15);
     float v = 0.f;
-    if (k < e.NR && c < e.NO) v = (e.trans ? src[(int64_t)c * e.ldw + k] : src[(int64_t)k * e.ldw + c]) * s;
+    if (k < e.NR && c < e.NO)
+      v = (e.trans == 2 ? src[((int64_t)(k >> 7) * e.NO + c) * e.ldw + (k & 127)]
+                        : (e.trans ? src[(int64_t)c * e.ldw + k] : src[(int64_t)k * e.ldw + c])) * s;
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (float)hi);
     const size_t base = ((size_t)(p * e.NOB + mb) * 2) * 64;
@@ -406,9 +414,15 @@ __global__ void __launch_bounds__(256) k_pack_wh(const float* __restrict__ w, fl
   }
 }
 
+// Paired launches (round 6): gridDim.y = 2 runs two products of the same shape and epilogue class in ONE launch, job b on
+// blockIdx.y = 1 (the sender / receiver projections of the edge block, the two halves of d [n | agg]): node-sized products
+// are latency chains of ~6 us, and two of them side by side cost one.  EPI 2 honours the job's own `accum` flag, so an
+// accumulating product pairs with a storing one.
 template <int EPI>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lin32h(lb_lin_args a) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lin32h(lb_lin_args a_job, lb_lin_args b_job) {
+  const lb_lin_args& a = blockIdx.y ? b_job : a_job;
   constexpr int NOB = 8;
+  const int64_t xcs = a.xcs ? a.xcs : 128;
   extern __shared__ f32x4 sWl[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, kq = lane >> 4;
@@ -495,7 +509,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
       for (int p = 0; p < 4; ++p) lb_split8v(ring[2 * p] * s, ring[2 * p + 1] * s, hi[p], lo[p]);
       // the ring is free: the next chunk (or the next tile's first) is requested before the first MFMA of this one
-      const float* nx = jc + 1 < nch ? xr + 128 * (jc + 1) : xnext;
+      const float* nx = jc + 1 < nch ? xr + xcs * (jc + 1) : xnext;
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) ring[jj] = *reinterpret_cast<const f32x4*>(nx + 16 * jj);
       f32x4 part[NOB];
@@ -585,7 +599,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) y[jj] = ep[mb][jj] > 0.f ? y[jj] : 0.f;
           } else if (EPI == 2) {
-            y = ep[mb] + y;
+            if (a.accum) y = ep[mb] + y;
           }
           if (EPI == 4) {
             y = ((acc[mb] + ep[mb]) + ep2[mb]) + sv[4 * mb];

@@ -265,8 +265,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 __global__ void __launch_bounds__(512) k_dw_part_h(const float* __restrict__ X, int ldx, int K, const float* __restrict__ dY,
                                                    int64_t rows, int64_t chunk, float* __restrict__ part,
                                                    const float* __restrict__ tmax, int32_t* __restrict__ xflag,
-                                                   int32_t* __restrict__ xslot, int xexp, int xscale) {
+                                                   int32_t* __restrict__ xslot, int xexp, int xscale,
+                                                   const float* __restrict__ dY_b, float* __restrict__ part_b) {
   __shared__ h8 sAB[2][2][1024];   // [buffer][A | B][(tile * 2 + part) * 64 + lane]: 64 KiB
+  // blockIdx.z = 1: the second product of a paired launch - the same X against another dY (dw_acc_pair: the sender / receiver
+  // halves of the edge block's first Linear share the node latents; two node-sized launches of ~6 us were two latency chains)
+  if (blockIdx.z) {
+    dY = dY_b;
+    part = part_b;
+  }
   float* red = reinterpret_cast<float*>(&sAB[0][0][0]);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = tid & 127, g = tid >> 7;
@@ -944,8 +951,27 @@ static void pack_all(lb_gns_train* t) {
                        t->pack_dev_h);
 }
 // Y[rows x NO] = X[rows x NR] * Wop (+ epilogue) on k_lin32 / k_lin32f; a.Wp is filled in here
-static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int trans) {
+// b / Wb: a second product of the same shape (rows, NR, NO) and epilogue class to run in the same launch (k_lin32h only:
+// the other kernels get two launches); an accumulating job may pair with a storing one (both run the accumulate variant)
+static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int trans, const lb_lin_args* b = nullptr,
+                 const float* Wb = nullptr) {
   if (a.rows == 0) return LB_OK;
+  if (b) {
+    const bool same = b->rows == a.rows && b->NR == a.NR && b->NO == a.NO && b->ldx == a.ldx && b->ldy == a.ldy &&
+                      !a.mask && !b->mask && !a.ln_scale && !b->ln_scale && !a.gat1 && !b->gat1 && !a.tmax && !b->tmax &&
+                      !a.bias == !b->bias && a.relu == b->relu;
+    const bool fast_pair = a.NO == 128 && (a.NR & 127) == 0 && (a.ldx & 3) == 0 && (a.ldy & 3) == 0 &&
+                           (((uintptr_t)a.bias | (uintptr_t)b->bias) & 15) == 0;
+#ifdef LB_NO_PAIR   // (tools/build_variant.sh A/B: every product a launch of its own)
+    const bool pair_ok = false;
+#else
+    const bool pair_ok = true;
+#endif
+    if (!(pair_ok && same && fast_pair && t->f16x2)) {
+      LB_TRY(lin32(t, a, W, ldw, trans));
+      return lin32(t, *b, Wb, ldw, trans);
+    }
+  }
   if (a.NR > 256 || a.NO > 128) return lb_fail(LB_ERR_UNSUPPORTED, "k_lin32: %d x %d operand", a.NR, a.NO);
   const int nob = a.NO <= 16 ? 1 : (a.NO <= 64 ? 4 : 8);  // 16-column output blocks per wave (generic kernel)
   a.NJ = (a.NR + 15) / 16;
@@ -956,10 +982,19 @@ static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int tr
   const bool fast = a.NO == 128 && (a.NR & 127) == 0 && (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && (!a.mask || (a.ldm & 3) == 0) &&
                     !(a.mask && a.accum) && (((uintptr_t)a.bias | (uintptr_t)a.ln_scale | (uintptr_t)a.ln_offset) & 15) == 0;
   const bool half = fast && t->f16x2;
+  if ((trans == 2 || a.xcs) && !half) return lb_fail(LB_ERR_UNSUPPORTED, "k_lin32: stacked operands run on k_lin32h only");
   t->tmax_ok = half && a.tmax;
   if (!half) a.tmax = nullptr;
   if (half) LB_TRY(pack_lookup_h(t, W, a.NR, a.NO, ldw, trans, &a.Wp, &a.wsc));
   else LB_TRY(pack_lookup(t, W, a.NR, a.NO, ldw, trans, nob, &a.Wp));
+  lb_lin_args b2 = a;   // (single launches pass their own job twice: blockIdx.y is 0)
+  if (b) {
+    b2 = *b;
+    b2.NJ = a.NJ;
+    LB_TRY(pack_lookup_h(t, Wb, b2.NR, b2.NO, ldw, trans, &b2.Wp, &b2.wsc));
+  }
+  const unsigned gy = b ? 2u : 1u;
+  const bool pair_accum = b && (a.accum || b->accum);
   if (a.gat1 && (!fast || a.mask || a.accum || a.ln_scale || !a.bias))
     return lb_fail(LB_ERR_UNSUPPORTED, "k_lin32: gather epilogue on a %d x %d operand", a.NR, a.NO);
   if (a.ln_scale && (!fast || a.mask || a.accum || a.relu))
@@ -974,12 +1009,21 @@ static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int tr
     }                                                                                                                        \
     hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(512), lds, s, a);                                                            \
   } while (0)
+#define LB_LIN_GO2(KERNEL)                                                                                                   \
+  do {                                                                                                                       \
+    static bool raised = false;                                                                                              \
+    if (!raised) {                                                                                                           \
+      (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                \
+      raised = true;                                                                                                         \
+    }                                                                                                                        \
+    hipLaunchKernelGGL(KERNEL, dim3(grid, gy), dim3(512), lds, s, a, b2);                                                    \
+  } while (0)
   if (half) {
-    if (a.gat1) LB_LIN_GO(k_lin32h<4>);
-    else if (a.ln_scale) LB_LIN_GO(k_lin32h<3>);
-    else if (a.mask) LB_LIN_GO(k_lin32h<1>);
-    else if (a.accum) LB_LIN_GO(k_lin32h<2>);
-    else LB_LIN_GO(k_lin32h<0>);
+    if (a.gat1) LB_LIN_GO2(k_lin32h<4>);
+    else if (a.ln_scale) LB_LIN_GO2(k_lin32h<3>);
+    else if (a.mask) LB_LIN_GO2(k_lin32h<1>);
+    else if (a.accum || pair_accum) LB_LIN_GO2(k_lin32h<2>);
+    else LB_LIN_GO2(k_lin32h<0>);
   } else if (fast) {
     if (a.gat1) LB_LIN_GO(k_lin32f<4>);
     else if (a.ln_scale) LB_LIN_GO(k_lin32f<3>);
@@ -990,6 +1034,7 @@ static int lin32(lb_gns_train* t, lb_lin_args a, const float* W, int ldw, int tr
   else if (nob == 4) LB_LIN_GO(k_lin32<4>);
   else LB_LIN_GO(k_lin32<8>);
 #undef LB_LIN_GO
+#undef LB_LIN_GO2
   LB_HIP(hipGetLastError());
   return LB_OK;
 }
@@ -1020,6 +1065,39 @@ static int gemm_nt(lb_gns_train* t, int64_t rows, int M, int K, const float* dY,
     LB_TRY(lin32(t, a, W + (size_t)c0 * M, M, 1));
   }
   return LB_OK;
+}
+// two products of one shape in ONE launch (k_lin32h's paired form; lin32 falls back to two launches where it does not apply):
+// Ya = X Wa, Yb = X Wb (K x 128 operands, no epilogue) ...
+static int gemm_nn_pair(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx, const float* Wa, float* Ya, const float* Wb,
+                        float* Yb, int ldy) {
+  lb_lin_args a{};
+  a.X = X; a.ldx = ldx; a.NR = K; a.Y = Ya; a.ldy = ldy; a.NO = TD; a.rows = rows;
+  lb_lin_args b = a;
+  b.Y = Yb;
+  return lin32(t, a, Wa, TD, 0, &b, Wb);
+}
+// ... and dXa = dY Wa^T (+ beta_a dXa), dXb = dY Wb^T (+ beta_b dXb) for 128 x 128 operands
+static int gemm_nt_pair(lb_gns_train* t, int64_t rows, const float* dY, const float* Wa, float* dXa, float beta_a, const float* Wb,
+                        float* dXb, float beta_b) {
+  lb_lin_args a{};
+  a.X = dY; a.ldx = TD; a.NR = TD; a.Y = dXa; a.ldy = TD; a.NO = TD; a.rows = rows; a.accum = beta_a != 0.f;
+  lb_lin_args b = a;
+  b.Y = dXb; b.accum = beta_b != 0.f;
+  return lin32(t, a, Wa, TD, 1, &b, Wb);
+}
+// dX += dYa Wa^T + dYb Wb^T for two 128 x 128 operands that are consecutive row blocks of one matrix (Wb = Wa + 128 * 128)
+// and two dY arrays `gap` floats apart: ONE product with a 256-deep reduction (k_lin32h reads its two chunks from the two
+// arrays, k_pack_wh stacks the two transposes: trans = 2) - the two accumulating launches it replaces were serialised by dX
+static int gemm_nt_stack2(lb_gns_train* t, int64_t rows, const float* dYa, int64_t gap, const float* Wa, float* dX) {
+#ifndef LB_NO_PAIR
+  if (t->f16x2) {
+    lb_lin_args a{};
+    a.X = dYa; a.ldx = TD; a.NR = 2 * TD; a.xcs = gap; a.Y = dX; a.ldy = TD; a.NO = TD; a.rows = rows; a.accum = 1;
+    return lin32(t, a, Wa, TD, 2);
+  }
+#endif
+  LB_TRY(gemm_nt(t, rows, TD, TD, dYa, Wa, dX, TD, 1.f));
+  return gemm_nt(t, rows, TD, TD, dYa + gap, Wa + (size_t)TD * TD, dX, TD, 1.f);
 }
 // ---- the step's gradient reductions: producers take a slot for their partials and leave a descriptor, red_flush sums all
 // of them in one launch (lb_red_ent / k_part_reduce)
@@ -1086,8 +1164,9 @@ static int64_t red_capacity(const lb_gns_train* t, int64_t cn, int64_t ce) {
 }
 // dW[K x 128] += X^T dY, db[128] += column sums of dY (k_dw_part + a descriptor for k_part_reduce); false = refused
 // (nb: how many of dY's 128 column sums are added to db - the SEGNN blocks keep only their Ms scalar-output columns)
+// dY_b / dW_b (dw_acc_pair): a second product X^T dY_b -> dW_b (no bias) in the same launch - f16x2 kernel only
 static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx, const float* dY, float* dW, float* db,
-                   int nb, const float* tmax) {
+                   int nb, const float* tmax, const float* dY_b, float* dW_b) {
   // (every refusal leaves its reason in lb_last_error - ADVICE r05: callers return a bare LB_ERR_STATE)
   if (K > 384 || rows <= 0) {
     (void)lb_fail(LB_ERR_STATE, "dw_acc: K = %d (<= 384) / rows = %lld (> 0) out of range", K, (long long)rows);
@@ -1102,20 +1181,40 @@ static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx
   }
   float* part = red_slot(t, (int64_t)G * (K + 1) * 128, &off);
   if (!part) return false;  // (red_slot said why)
+  int64_t off_b = 0;
+  float* part_b = nullptr;
+  if (dY_b) {
+    if (!(t->f16x2 && K >= 32)) {
+      (void)lb_fail(LB_ERR_STATE, "dw_acc: paired products run on the f16x2 kernel only");
+      return false;
+    }
+    part_b = red_slot(t, (int64_t)G * (K + 1) * 128, &off_b);
+    if (!part_b) return false;
+  }
 #define DW_GO(NA, DEPTH) hipLaunchKernelGGL((k_dw_part<NA, DEPTH>), dim3(G), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part)
   const bool deep = chunk >= 192;
   if (t->f16x2 && K >= 32) {   // (narrower operands - the encoders' raw features - stay on the fp32 kernel)
     const int c = std::min(t->dw_call++, LB_DW_CALLS - 1);
     if ((int)t->dw_xexp.size() <= c) { t->dw_xexp.resize(c + 1, 0); t->dw_xdyn.resize(c + 1, 0); }
-    hipLaunchKernelGGL(k_dw_part_h, dim3((unsigned)G, (unsigned)((K + 127) / 128)), dim3(512), 0, s, X, ldx, K, dY, rows, chunk, part,
-                       tmax, t->dw_flag, t->dw_flag + 1 + c, (int)t->dw_xexp[c], (int)t->dw_xdyn[c]);
+    hipLaunchKernelGGL(k_dw_part_h, dim3((unsigned)G, (unsigned)((K + 127) / 128), part_b ? 2u : 1u), dim3(512), 0, s, X, ldx, K, dY,
+                       rows, chunk, part, tmax, t->dw_flag, t->dw_flag + 1 + c, (int)t->dw_xexp[c], (int)t->dw_xdyn[c], dY_b, part_b);
   }
   else if (K <= 128) { if (deep) DW_GO(1, 12); else DW_GO(1, 6); }
   else if (K <= 256) { if (deep) DW_GO(2, 8); else DW_GO(2, 6); }
   else DW_GO(3, 4);
 #undef DW_GO
   red_push(t, off, G, (int64_t)(K + 1) * 128, K * 128, db ? nb : 0, K * 128, dW, db);
+  if (part_b) red_push(t, off_b, G, (int64_t)(K + 1) * 128, K * 128, 0, K * 128, dW_b, nullptr);
   return true;
+}
+// dW_a += X^T dY_a and dW_b += X^T dY_b: one launch on the f16x2 kernel, two otherwise
+static bool dw_acc_pair(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx, const float* dY_a, float* dW_a,
+                        const float* dY_b, float* dW_b) {
+#ifndef LB_NO_PAIR
+  if (t->f16x2 && K >= 32) return dw_acc(t, rows, K, X, ldx, dY_a, dW_a, nullptr, 128, nullptr, dY_b, dW_b);
+#endif
+  return dw_acc(t, rows, K, X, ldx, dY_a, dW_a, nullptr, 128, nullptr, nullptr, nullptr) &&
+         dw_acc(t, rows, K, X, ldx, dY_b, dW_b, nullptr, 128, nullptr, nullptr, nullptr);
 }
 // dW[K x M] += X^T dY for M <= 4 (k_dw_narrow + the ordered reduce)
 static int dw_narrow(lb_gns_train* t, int64_t rows, int M, int K, const float* X, int ldx, const float* dY, int ldy, float* dW) {
@@ -1153,7 +1252,9 @@ static int mlp_mid_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, flo
 }
 // ... and their backward.  In: t->da = d(last hidden), ReLU-masked; out: t->da = d(first hidden), masked (the two buffers swap)
 static bool dw_acc(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx, const float* dY, float* dW, float* db,
-                   int nb = 128, const float* tmax = nullptr);
+                   int nb = 128, const float* tmax = nullptr, const float* dY_b = nullptr, float* dW_b = nullptr);
+static bool dw_acc_pair(lb_gns_train* t, int64_t rows, int K, const float* X, int ldx, const float* dY_a, float* dW_a,
+                        const float* dY_b, float* dW_b);
 static int mlp_mid_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t rows, const float* a, int64_t stride) {
   for (size_t m = p.wm.size(); m-- > 0;) {
     const float* ain = a + m * stride;  // input of middle Linear m
@@ -1181,8 +1282,7 @@ static int edge_fwd(lb_gns_train* t, const lb_train_mlp& p, int64_t E, int64_t B
   hipStream_t s = t->eng->stream;
   lb_engine* e = t->eng;
   float *Ps = t->proj, *Pr = t->proj + (size_t)BN * TD;
-  LB_TRY(gemm_nn(t, BN, TD, TD, n, TD, t->w + p.w0, Ps, TD));
-  LB_TRY(gemm_nn(t, BN, TD, TD, n, TD, t->w + p.w0 + (size_t)TD * TD, Pr, TD));
+  LB_TRY(gemm_nn_pair(t, BN, TD, n, TD, t->w + p.w0, Ps, t->w + p.w0 + (size_t)TD * TD, Pr, TD));
   {  // a = relu(e W_e + Ps[snd] + Pr[rcv] + b0): the gathers and the bias ride in the product's epilogue
     lb_lin_args g{};
     g.X = el; g.ldx = TD; g.NR = TD; g.Y = a; g.ldy = TD; g.NO = TD; g.rows = E;
@@ -1261,11 +1361,9 @@ static int edge_bwd(lb_gns_train* t, const lb_train_mlp& p, int64_t E, int64_t B
   // node rows: dP = transpose of the two gathers, then dW_s += n^T dPs, dW_r += n^T dPr, dn += dPs W_s^T + dPr W_r^T
   float *dPs = t->proj, *dPr = t->proj + (size_t)BN * TD;
   hipLaunchKernelGGL(k_edge_dP, GRID1(BN * 32), 0, s, t->da, t->snd_ptr, t->snd_perm, e->row_ptr, dPs, dPr, BN, E);
-  if (!dw_acc(t, BN, TD, n, TD, dPs, gWs, nullptr) || !dw_acc(t, BN, TD, n, TD, dPr, gWr, nullptr))
-    return lb_fail(LB_ERR_STATE, "dw_acc refused the edge block");
-  LB_TRY(gemm_nt(t, BN, TD, TD, dPs, Ws, dn, TD, 1.f));
-  LB_TRY(gemm_nt(t, BN, TD, TD, dPr, Wr, dn, TD, 1.f));
-  return LB_OK;
+  if (!dw_acc_pair(t, BN, TD, n, TD, dPs, gWs, dPr, gWr)) return lb_fail(LB_ERR_STATE, "dw_acc refused the edge block");
+  (void)Wr;
+  return gemm_nt_stack2(t, BN, dPs, (int64_t)BN * TD, Ws, dn);
 }
 
 template <typename T>
@@ -1665,8 +1763,7 @@ static int gns_train_loss_grad_once(lb_gns_train* t, const float* target_dev, fl
     // d [n_k | agg_k] = da W0^T lands where it is used: the n_k half is added to dn, the agg_k half is dagg (round 4 wrote
     // the 256-wide product and split it in a pass of its own).  dn was consumed (LayerNorm backward) before it is updated.
     LB_TRY(mlp_bwd(t, t->pn[k], BN, t->xn[k], 2 * TD, t->an[k], t->zn[k], t->dn, nullptr, t->hs_n));
-    LB_TRY(gemm_nt(t, BN, TD, TD, t->da, t->w + t->pn[k].w0, t->dn, TD, 1.f));
-    LB_TRY(gemm_nt(t, BN, TD, TD, t->da, t->w + t->pn[k].w0 + (size_t)TD * TD, t->dagg, TD));
+    LB_TRY(gemm_nt_pair(t, BN, t->da, t->w + t->pn[k].w0, t->dn, 1.f, t->w + t->pn[k].w0 + (size_t)TD * TD, t->dagg, 0.f));
     LB_TRY(edge_bwd(t, t->pe[k], E, BN, t->nlat[k], t->elat[k], t->ae[k], t->ze[k], t->dagg, t->de, t->dn));
   }
   LB_TRY(mlp_bwd(t, t->enc_edge, E, e->efeat, 8, t->a_ee, t->z_ee, t->de, nullptr, t->hs_e));

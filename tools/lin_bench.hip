@@ -98,11 +98,11 @@ int main(int argc, char** argv) {
     auto go = [&] {
       if (fast == 2) hipLaunchKernelGGL(k_lin32g, dim3(grid), dim3(512), lds, 0, a);
       else if (fast == 3) {
-        if (mode == 5) hipLaunchKernelGGL((k_lin32h<4>), dim3(grid), dim3(512), lds, 0, a);
-        else if (mode == 4) hipLaunchKernelGGL((k_lin32h<3>), dim3(grid), dim3(512), lds, 0, a);
-        else if (mode == 2) hipLaunchKernelGGL((k_lin32h<1>), dim3(grid), dim3(512), lds, 0, a);
-        else if (mode == 3) hipLaunchKernelGGL((k_lin32h<2>), dim3(grid), dim3(512), lds, 0, a);
-        else hipLaunchKernelGGL((k_lin32h<0>), dim3(grid), dim3(512), lds, 0, a);
+        if (mode == 5) hipLaunchKernelGGL((k_lin32h<4>), dim3(grid), dim3(512), lds, 0, a, a);
+        else if (mode == 4) hipLaunchKernelGGL((k_lin32h<3>), dim3(grid), dim3(512), lds, 0, a, a);
+        else if (mode == 2) hipLaunchKernelGGL((k_lin32h<1>), dim3(grid), dim3(512), lds, 0, a, a);
+        else if (mode == 3) hipLaunchKernelGGL((k_lin32h<2>), dim3(grid), dim3(512), lds, 0, a, a);
+        else hipLaunchKernelGGL((k_lin32h<0>), dim3(grid), dim3(512), lds, 0, a, a);
       } else if (fast) {
         if (mode == 5) hipLaunchKernelGGL((k_lin32f<4>), dim3(grid), dim3(512), lds, 0, a);
         else if (mode == 4) hipLaunchKernelGGL((k_lin32f<3>), dim3(grid), dim3(512), lds, 0, a);
