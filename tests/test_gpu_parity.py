@@ -224,13 +224,16 @@ def test_single_trajectory_update_path_bitexact(name, scale):
     assert int(eng.nl_flags()[0]) == 1
 
 
-def _batched_update_check(ds, B, pos, pt, shifts=(1, 2)):
-    """Edge lists, counts and edge features of the batched UPDATE path against the oracle's preprocess_eval, bit for bit."""
-    ocase, hcase = oracle_case(ds), hip_case(ds)
+def _batched_update_check(ds, B, pos, pt, shifts=(1, 2), f32=False):
+    """Edge lists, counts and edge features of the batched UPDATE path against the oracle's preprocess_eval, bit for bit.
+    f32: both sides in float32 geometry (case.py:169; the engine keeps float32 VALUES in its fp64 containers)."""
+    ocase, hcase = (oracle_case(ds, dtype=np.float32), hip_case(ds, dtype="float32")) if f32 else (oracle_case(ds), hip_case(ds))
+    odt = np.float32 if f32 else np.float64
+    cast = (lambda x: x.astype(np.float32)) if f32 else (lambda x: x)
     isl = ds.input_seq_length
     N = pos.shape[1]
     _, nbrs = hcase.allocate_eval((pos[:, :, :isl], pt))
-    ons = [ocase.allocate_eval((pos[b][:, :isl].astype(np.float64), pt[b]))[1] for b in range(B)]
+    ons = [ocase.allocate_eval((pos[b][:, :isl].astype(odt), pt[b]))[1] for b in range(B)]
     for b in range(B):   # the allocation itself (count + fill sweeps)
         want = O.canonical_edges(ons[b].idx, N)
         assert int(_np(nbrs.n_edges)[b]) == want.shape[1] and (_np(nbrs.idx)[b][:, :want.shape[1]] == want).all(), ("allocate", b)
@@ -240,16 +243,29 @@ def _batched_update_check(ds, B, pos, pt, shifts=(1, 2)):
         idx_all, ne_all = _np(nbrs.idx), _np(nbrs.n_edges)
         rd, rdist = _np(feats["rel_disp"]), _np(feats["rel_dist"])
         for b in range(B):
-            of, ons[b] = ocase.preprocess_eval((pos[b][:, shift:shift + isl].astype(np.float64), pt[b]), ons[b])
+            of, ons[b] = ocase.preprocess_eval((pos[b][:, shift:shift + isl].astype(odt), pt[b]), ons[b])
             assert not bool(ons[b].did_buffer_overflow)
             want = O.canonical_edges(ons[b].idx, N)
             ne = want.shape[1]
             assert int(ne_all[b]) == ne and (idx_all[b][:, :ne] == want).all(), f"b={b} shift={shift}"
             real = ons[b].idx[0] < N
             order = np.lexsort((ons[b].idx[1][real], ons[b].idx[0][real]))
-            assert np.array_equal(rd[b][:ne], of["rel_disp"][real][order])
-            assert np.array_equal(rdist[b][:ne], of["rel_dist"][real][order])
+            assert np.array_equal(cast(rd[b][:ne]), of["rel_disp"][real][order])
+            assert np.array_equal(cast(rdist[b][:ne]), of["rel_dist"][real][order])
     return hcase
+
+
+@pytest.mark.parametrize("name,scale,B", [("tgv3d", 0.6, 3), ("tgv2d", 0.8, 3), ("dam2d", 0.5, 2)])
+def test_batched_update_path_float32_geometry_bitexact(name, scale, B):
+    """dtype=float32 batches: every float32 engine searches with one wave per cell (k_nlc<.., F32>, 2D and 3D) - allocation
+    and the per-step update path (node rows + compaction) against the float32 oracle, bit for bit.  (The single-trajectory
+    float32 test above only reaches the allocation sweeps.)"""
+    _need_gpu()
+    from lagrangebench_amd.data import make_case
+    ds = make_case(name, n_trajs=B, extra_seq_length=3, scale=scale)
+    pos = np.stack([ds[b][0] for b in range(B)])
+    pt = np.stack([ds[b][1] for b in range(B)])
+    _batched_update_check(ds, B, pos, pt, f32=True)
 
 
 @pytest.mark.parametrize("name,scale,B", [("tgv3d", 0.6, 3), ("ldc3d", 0.5, 3)])
