@@ -29,6 +29,7 @@
 #include <cmath>
 #include <complex>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "lb_internal.h"
@@ -161,22 +162,30 @@ __global__ void __launch_bounds__(SGG_NT) k_sgg_tp(sgg_args a) {
     {
       const float* xrow = xin + rr * a.xin_stride;
       const float* Mrow = Mt + rr * ((a.ms + 3) & ~3);
-      for (int k = rc; k < O.K4; k += TPR) {
-        const int kx = kmap[2 * k], ki = kmap[2 * k + 1];
-        const int d1 = (ki >> 12) & 15, cs = ki & 0xfff;
-        const float* xr = xrow + kx;
-        const float* Mr = Mrow + (ki >> 16);   // [m1][m3]
-        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int m1 = 0; m1 < d1; ++m1) {
-          const float x1 = xr[m1 * cs];
+      // 2 l3 + 1 as a compile-time constant (round 6: five predicated multiply-adds per m1 whatever the output irrep was -
+      // a third of a forward's time went into this loop)
+      auto form = [&](auto d3c) {
+        constexpr int D3 = decltype(d3c)::value;
+        for (int k = rc; k < O.K4; k += TPR) {
+          const int kx = kmap[2 * k], ki = kmap[2 * k + 1];
+          const int d1 = (ki >> 12) & 15, cs = ki & 0xfff;
+          const float* xr = xrow + kx;
+          const float* Mr = Mrow + (ki >> 16);   // [m1][m3]
+          float acc[D3];
 #pragma unroll
-          for (int m3 = 0; m3 < 5; ++m3)
-            if (m3 < d3) acc[m3] += Mr[m1 * d3 + m3] * x1;
+          for (int m3 = 0; m3 < D3; ++m3) acc[m3] = 0.f;
+          for (int m1 = 0; m1 < d1; ++m1) {
+            const float x1 = xr[m1 * cs];
+#pragma unroll
+            for (int m3 = 0; m3 < D3; ++m3) acc[m3] += Mr[m1 * D3 + m3] * x1;
+          }
+#pragma unroll
+          for (int m3 = 0; m3 < D3; ++m3) X[(m3 * 16 + rr) * a.xs + (k & 3) * ps + (k >> 2)] = acc[m3];   // plane k mod 4, position k / 4
         }
-#pragma unroll
-        for (int m3 = 0; m3 < 5; ++m3)
-          if (m3 < d3) X[(m3 * 16 + rr) * a.xs + (k & 3) * ps + (k >> 2)] = acc[m3];   // plane k mod 4, position k / 4
-      }
+      };
+      if (d3 == 1) form(std::integral_constant<int, 1>{});
+      else if (d3 == 3) form(std::integral_constant<int, 3>{});
+      else form(std::integral_constant<int, 5>{});
     }
     __syncthreads();
     for (int t = wave; t < T; t += SGG_NT / 64) {
