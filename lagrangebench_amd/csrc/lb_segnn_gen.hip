@@ -129,12 +129,44 @@ __global__ void __launch_bounds__(SGG_NT) k_sgg_tp(sgg_args a) {
       Mt[r * ms4 + el] = t;
     }
   }
-  for (int o = 0; o < a.n_op; ++o) {
-    const int s4 = a.op[o].stride >> 2;
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.op[o].x);
-    const f32x4* srow = src + (int64_t)sidx[o * 16 + rr] * s4;
-    float* drow = xin + rr * a.xin_stride + a.op[o].lds_off;
-    for (int c = rc; c < s4; c += TPR) *reinterpret_cast<f32x4*>(drow + 4 * c) = srow[c];
+  {   // the operands' rows: every load of every operand is out before the first LDS store (round 5 staged operand after operand:
+      // up to three dependent memory round trips in a workgroup whose life is a chain of them)
+    constexpr int MAXL = 4;   // 16-byte pieces per thread and operand: rows of up to MAXL * TPR * 4 floats
+    f32x4 buf[3][MAXL];
+    bool wide = false;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      if (o < a.n_op) {
+        const int s4 = a.op[o].stride >> 2;
+        wide |= s4 > MAXL * TPR;
+        const f32x4* srow = reinterpret_cast<const f32x4*>(a.op[o].x) + (int64_t)sidx[o * 16 + rr] * s4;
+#pragma unroll
+        for (int u = 0; u < MAXL; ++u) {
+          const int c = rc + u * TPR;
+          buf[o][u] = srow[c < s4 ? c : 0];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      if (o < a.n_op) {
+        const int s4 = a.op[o].stride >> 2;
+        float* drow = xin + rr * a.xin_stride + a.op[o].lds_off;
+#pragma unroll
+        for (int u = 0; u < MAXL; ++u) {
+          const int c = rc + u * TPR;
+          if (c < s4) *reinterpret_cast<f32x4*>(drow + 4 * c) = buf[o][u];
+        }
+      }
+    }
+    if (wide) {   // (rows wider than the register staging covers: the remaining pieces, operand after operand)
+      for (int o = 0; o < a.n_op; ++o) {
+        const int s4 = a.op[o].stride >> 2;
+        const f32x4* srow = reinterpret_cast<const f32x4*>(a.op[o].x) + (int64_t)sidx[o * 16 + rr] * s4;
+        float* drow = xin + rr * a.xin_stride + a.op[o].lds_off;
+        for (int c = rc + MAXL * TPR; c < s4; c += TPR) *reinterpret_cast<f32x4*>(drow + 4 * c) = srow[c];
+      }
+    }
   }
 
   for (int oi = 0; oi < a.n_out; ++oi) {
