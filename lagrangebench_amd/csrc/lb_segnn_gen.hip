@@ -430,6 +430,16 @@ __global__ void __launch_bounds__(256) k_sgg_bn_part(sgg_bn_args a, int pass) {
     f32x4 mu = {0.f, 0.f, 0.f, 0.f};
     if (pass) mu = reinterpret_cast<const f32x4*>(a.mean)[b * S4 + c4];
     int64_t r = q0 + rl;
+    for (; r + 7 * RL < q1; r += 8 * RL) {   // eight rows in flight per lane (round 6: four - a chunk was ~11 dependent round trips)
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = x4[(r + u * RL) * S4 + c4] - mu;
+      if (pass) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = v[u] * v[u];
+      }
+      s = s + (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+    }
     for (; r + 3 * RL < q1; r += 4 * RL) {
       f32x4 v0 = x4[r * S4 + c4] - mu, v1 = x4[(r + RL) * S4 + c4] - mu, v2 = x4[(r + 2 * RL) * S4 + c4] - mu,
             v3 = x4[(r + 3 * RL) * S4 + c4] - mu;
@@ -459,7 +469,19 @@ __global__ void __launch_bounds__(256) k_sgg_bn_fin(sgg_bn_args a, int pass) {
   const float n = (float)((r1 - r0) > 1 ? (r1 - r0) : 1);
   for (int c = threadIdx.x; c < a.stride; c += 256) {
     float s = 0.f;
-    for (int g = 0; g < a.G; ++g) s += a.part[((int64_t)b * a.G + g) * a.stride + c];
+    {   // the G partials in chunk order, eight loads in flight (round 5: one dependent load per addition - this single-block
+        // launch was the slowest of the five)
+      const float* pp = a.part + (int64_t)b * a.G * a.stride + c;
+      int g = 0;
+      for (; g + 8 <= a.G; g += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pp[(int64_t)(g + u) * a.stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; g < a.G; ++g) s += pp[(int64_t)g * a.stride];
+    }
     if (!pass) {
       bool scalar = false;
       for (int q = 0; q < a.n_chunk; ++q)
